@@ -1,0 +1,145 @@
+/*
+ * memhip.h -- C ABI of libmemhip.so: the MI355X (gfx950) kernels behind the
+ * MEM (tum-vision/mem) pretraining hot path.
+ *
+ * The reference has no FFI of its own (it is pure Python):
+ * the drop-in boundary is its Python surface, mirrored in the mem_amd package, and
+ * THIS header is what that mirror binds with ctypes.  Each entry point cites
+ * the reference code it replaces (paths relative to /root/reference).
+ *
+ * Conventions (all entry points):
+ *   - plain pointers + sizes only; pointers are caller-owned DEVICE buffers
+ *     (tensor.data_ptr()) unless a parameter is documented "host".
+ *   - no allocation, no host synchronisation, no global mutable state inside;
+ *     scratch comes in through (workspace, workspace_bytes); work is enqueued
+ *     on `stream` (a hipStream_t passed as void*; NULL = default stream).
+ *   - return 0 on success, a negative MEMHIP_E* code on failure; a message is
+ *     available from memhip_last_error() (thread-local).  No C++ exception
+ *     crosses the boundary.
+ *   - "rows_pad": token-major activation matrices are allocated with their row
+ *     count rounded up to a multiple of 128 and zero-filled once; kernels never
+ *     write rows >= rows.
+ */
+#ifndef MEMHIP_H
+#define MEMHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MEMHIP_ABI_VERSION 1
+
+#define MEMHIP_OK 0
+#define MEMHIP_EINVAL (-1)   /* bad argument (shape / alignment / null) */
+#define MEMHIP_EWORKSPACE (-2) /* workspace too small */
+#define MEMHIP_ELAUNCH (-3)  /* hip launch / runtime error */
+#define MEMHIP_EUNSUPPORTED (-4)
+
+typedef void* memhip_stream_t;
+
+int memhip_abi_version(void);
+const char* memhip_last_error(void);
+/* Name of the device code object this library was built for ("gfx950"). */
+const char* memhip_arch(void);
+
+/* ------------------------------------------------------------------------
+ * Event stream -> voxel/histogram image
+ * replaces EventArrToImg.__call__            mem/datasets.py:566-595
+ * ------------------------------------------------------------------------
+ * ev        f64 [n_total, 4] rows [x, y, t, p] (the reference's (N,4) float64
+ *           layout, mem/dataset_folder.py:275-302), samples concatenated
+ * offsets   i64 [B+1] CSR row offsets of each sample inside ev
+ * out       u8  [B, 3, H, W] planar [pos, tss, neg] (the reference returns the
+ *           same bytes viewed as (H, W, 3); the Python mirror transposes)
+ * status    i32 [B]  out: number of events of sample b whose flat pixel index
+ *           x + W*y fell outside [-H*W, H*W) (the reference raises IndexError)
+ * workspace u32 [B, 3, H*W] (memhip_rasterize_workspace)
+ * Semantics: x,y truncated toward zero; only p == +1 / p == -1 count; counts
+ * are exact mod 256; NumPy negative-index wrap kept; time surface (optional)
+ * = (t - tmin) / (tmax - tmin) * 255 truncated to u8, last event in array
+ * order wins.
+ */
+size_t memhip_rasterize_workspace(int B, int H, int W);
+int memhip_rasterize_f64(const double* ev, const int64_t* offsets, int B, int H, int W,
+                         int time_surface, uint8_t* out, int32_t* status,
+                         void* workspace, size_t workspace_bytes, memhip_stream_t stream);
+
+/* Event-level augmentations fused into the rasterizer's single read of the
+ * events (no intermediate (N',4) arrays):
+ * replaces ReshapeScaleXandY  mem/datasets.py:464-485   x*=scale_x, y*=scale_y
+ *          RandomTimeFlip     mem/datasets.py:598-609   reverse order, t<-t_last-t, p<- -p
+ *          Aug_FlipEvsAlongX  mem/datasets.py:501-521   x <- flip_w-1-x
+ *          Aug_RandomShiftEvs mem/datasets.py:524-549   x+=shift_x, y+=shift_y, keep
+ *                                                       0<=x<filt_w and 0<=y<filt_h
+ * applied per event in exactly that order, in float64 like the reference.
+ * (SliceRandomMaxEvs, datasets.py:488-498, is a contiguous window: express it
+ * through `offsets`.)  The random draws stay with the caller (host), so parity
+ * is draw for draw.  aug = device array of B records, or NULL for none.
+ */
+typedef struct memhip_event_aug {
+  double scale_x, scale_y;   /* 1.0 = off */
+  int32_t time_flip;         /* 0/1 */
+  int32_t flip_x;            /* 0/1 */
+  int64_t flip_w;            /* W used by the x flip */
+  int32_t shift_x, shift_y;
+  int32_t do_filter;         /* 0/1: apply the bounds filter of Aug_RandomShiftEvs */
+  int32_t filt_w, filt_h;
+  int32_t pad_;
+} memhip_event_aug_t;
+int memhip_rasterize_aug_f64(const double* ev, const int64_t* offsets, const memhip_event_aug_t* aug,
+                             int B, int H, int W, int time_surface, uint8_t* out, int32_t* status,
+                             void* workspace, size_t workspace_bytes, memhip_stream_t stream);
+
+/* Per-sample extent of the (augmented) events, for the reference's data-dependent
+ * canvas "W = xs.max()+1" (mem/datasets.py:516,538-540,572-575).
+ * extent   f64 [B,4] out: max x, max y, min x, min y after `aug` (NULL = raw)
+ *          and the bounds filter; rows of empty samples are (-inf,-inf,+inf,+inf). */
+int memhip_events_extent(const double* ev, const int64_t* offsets, const memhip_event_aug_t* aug,
+                         int B, double* extent, memhip_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * Tensor-level event transforms, fused
+ * replaces ToTensor (/255), RemoveTimesurface, RemoveHotPixels, LogTransform,
+ * GammaTransform, NormalizeEvent            mem/transforms.py:200-275
+ * in the order of build_transformNPY        mem/datasets.py:637-653
+ * ------------------------------------------------------------------------
+ * in        u8 [B,3,H,W] (in_is_u8=1: value/255 first) or f32 [B,3,H,W]
+ * out       f32 [B, out_chans, H, W]; out_chans = 3 keeps [pos,tss,neg],
+ *           out_chans = 2 keeps [pos,neg] (= x[:, 0::2], the "2-bin voxel")
+ * flags     bit0 remove_timesurface, bit1 remove_hot_pixels, bit2 log,
+ *           bit3 gamma, bit4 normalize
+ */
+#define MEMHIP_EV_RM_TS 1
+#define MEMHIP_EV_HOTPIX 2
+#define MEMHIP_EV_LOG 4
+#define MEMHIP_EV_GAMMA 8
+#define MEMHIP_EV_NORMALIZE 16
+int memhip_event_norm(const void* in, int in_is_u8, int B, int H, int W, int flags,
+                      float num_stds, float gamma, float* out, int out_chans,
+                      memhip_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * Mask generators (HOST code: bit-exact CPython `random` semantics need
+ * glibc exp/log/sqrt and a sequential MT19937 stream)
+ * replaces MaskingGenerator.__call__         mem/masking_generator.py:44-81
+ *          MaskingGeneratorRandomLocation    mem/masking_generator.py:106-116
+ * ------------------------------------------------------------------------
+ * mt_state  host u32 [625]: the 624 MT19937 words + position, exactly the
+ *           tuple random.getstate()[1]; updated in place.
+ * out       host u8 [n_masks, H, W] (0/1)
+ */
+int memhip_mt_seed(uint32_t* mt_state, const uint32_t* key, int key_len);
+double memhip_mt_random(uint32_t* mt_state);
+int memhip_mask_blockwise(uint32_t* mt_state, int H, int W, int num_masking_patches,
+                          int min_num_patches, int max_num_patches, double log_aspect_lo,
+                          double log_aspect_hi, int n_masks, uint8_t* out);
+int memhip_mask_random_location(uint32_t* mt_state, int H, int W, int num_masking_patches,
+                                int n_masks, uint8_t* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MEMHIP_H */

@@ -1,0 +1,37 @@
+// Shared host-side helpers for libmemhip.so (gfx950 only; no CUDA paths).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdint>
+#include "../../include/memhip.h"
+
+namespace memhip {
+
+extern thread_local char g_err[512];
+
+inline int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+inline int check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(MEMHIP_ELAUNCH, "%s: %s", what, hipGetErrorString(e));
+  return MEMHIP_OK;
+}
+
+inline hipStream_t as_stream(memhip_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+}  // namespace memhip
+
+#define MEMHIP_REQUIRE(cond, ...) \
+  do { if (!(cond)) return memhip::fail(MEMHIP_EINVAL, __VA_ARGS__); } while (0)
+#define MEMHIP_HIP(call) \
+  do { hipError_t e_ = (call); if (e_ != hipSuccess) \
+    return memhip::fail(MEMHIP_ELAUNCH, "%s: %s", #call, hipGetErrorString(e_)); } while (0)

@@ -1,0 +1,250 @@
+// Event stream -> [pos, tss, neg] uint8 voxel image (reference: mem/datasets.py:566-595).
+//
+// HBM-bound scatter: every event (32 B, the reference's (N,4) float64 row) is read exactly
+// once with two 16-B loads per lane (a wave covers 2 KiB contiguous), binned with u32 atomics
+// that resolve in the XCD L2 / memory side, and a second streaming pass folds the u32 bins to
+// the reference's wrap-around uint8 counts.  Algorithmic bytes: 32*N + 3*H*W per sample.
+#include "common.h"
+
+static_assert(sizeof(memhip_event_aug_t) == 56, "memhip_event_aug_t ABI layout");
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kEvPerThread = 8;
+
+// order-preserving map double -> u64 (so integer atomic max == fp max)
+__device__ __forceinline__ unsigned long long enc_f64(double v) {
+  unsigned long long b = (unsigned long long)__double_as_longlong(v);
+  return (b & 0x8000000000000000ull) ? ~b : (b | 0x8000000000000000ull);
+}
+__device__ __forceinline__ double dec_f64(unsigned long long e) {
+  unsigned long long b = (e & 0x8000000000000000ull) ? (e & 0x7fffffffffffffffull) : ~e;
+  return __longlong_as_double((long long)b);
+}
+
+// workspace layout: bins u32 [B][3][HW] (0: pos count, 1: last event position + 1, 2: neg
+// count), then tstat u64 [B][2] (max enc(t), max ~enc(t)).
+
+struct Ev { double x, y, t, p; long long pos; bool keep; };
+
+// One event through the reference's augmentation chain (datasets.py:464-549, 598-609), in
+// float64 and in the reference's order.  `i` is the index inside the sample's window of n events.
+__device__ __forceinline__ Ev load_event(const double* __restrict__ ev, long long beg, long long n,
+                                         long long i, const memhip_event_aug_t* __restrict__ a,
+                                         double t_last) {
+  const double2 xy = reinterpret_cast<const double2*>(ev)[2 * (beg + i)];
+  const double2 tp = reinterpret_cast<const double2*>(ev)[2 * (beg + i) + 1];
+  Ev e{xy.x, xy.y, tp.x, tp.y, i, true};
+  if (a) {
+    e.x *= a->scale_x;
+    e.y *= a->scale_y;
+    if (a->time_flip) { e.pos = n - 1 - i; e.t = t_last - e.t; e.p = -e.p; }
+    if (a->flip_x) e.x = (double)(a->flip_w - 1) - e.x;
+    e.x += (double)a->shift_x;
+    e.y += (double)a->shift_y;
+    if (a->do_filter)
+      e.keep = (e.x >= 0.0) & (e.x < (double)a->filt_w) & (e.y >= 0.0) & (e.y < (double)a->filt_h);
+  }
+  return e;
+}
+
+__global__ __launch_bounds__(kThreads) void raster_count(
+    const double* __restrict__ ev, const int64_t* __restrict__ offsets,
+    const memhip_event_aug_t* __restrict__ augs, int H, int W,
+    int time_surface, unsigned int* __restrict__ bins, unsigned long long* __restrict__ tstat,
+    int32_t* __restrict__ status) {
+  const int b = blockIdx.y;
+  const long long beg = offsets[b], end = offsets[b + 1];
+  const long long HW = (long long)H * W;
+  unsigned int* pos = bins + (size_t)b * 3 * HW;
+  unsigned int* tss = pos + HW;
+  unsigned int* neg = tss + HW;
+  unsigned long long tmax = 0ull, tmin_inv = 0ull;
+  int bad = 0;
+  const long long n = end - beg;
+  const memhip_event_aug_t* a = augs ? augs + b : nullptr;
+  const double t_last = (a && a->time_flip && n > 0) ? ev[4 * (end - 1) + 2] : 0.0;
+  const long long chunk = (long long)kThreads * kEvPerThread;
+  for (long long base = (long long)blockIdx.x * chunk; base < n;
+       base += (long long)gridDim.x * chunk) {
+#pragma unroll
+    for (int k = 0; k < kEvPerThread; ++k) {
+      const long long i = base + (long long)k * kThreads + threadIdx.x;
+      if (i >= n) break;
+      const Ev e = load_event(ev, beg, n, i, a, t_last);
+      if (!e.keep) continue;
+      const long long xi = (long long)e.x;   // trunc toward zero == ndarray.astype(int)
+      const long long yi = (long long)e.y;
+      long long flat = xi + (long long)W * yi;
+      if (flat < -HW || flat >= HW) { ++bad; continue; }   // reference: IndexError
+      if (flat < 0) flat += HW;                             // NumPy negative index
+      if (e.p == 1.0) atomicAdd(pos + flat, 1u);
+      else if (e.p == -1.0) atomicAdd(neg + flat, 1u);
+      if (time_surface) {
+        atomicMax(tss + flat, (unsigned int)e.pos + 1u);    // last in (augmented) array order
+        const unsigned long long q = enc_f64(e.t);
+        tmax = q > tmax ? q : tmax;
+        tmin_inv = (~q) > tmin_inv ? (~q) : tmin_inv;
+      }
+    }
+  }
+  if (time_surface) {
+    for (int o = 32; o > 0; o >>= 1) {
+      unsigned long long a = __shfl_xor(tmax, o), c = __shfl_xor(tmin_inv, o);
+      tmax = a > tmax ? a : tmax;
+      tmin_inv = c > tmin_inv ? c : tmin_inv;
+    }
+    if ((threadIdx.x & 63) == 0) {
+      atomicMax(tstat + 2 * b, tmax);
+      atomicMax(tstat + 2 * b + 1, tmin_inv);
+    }
+  }
+  if (bad) atomicAdd(status + b, bad);
+}
+
+__global__ __launch_bounds__(kThreads) void raster_finalize(
+    const double* __restrict__ ev, const int64_t* __restrict__ offsets,
+    const memhip_event_aug_t* __restrict__ augs, int H, int W,
+    int time_surface, const unsigned int* __restrict__ bins,
+    const unsigned long long* __restrict__ tstat, uint8_t* __restrict__ out) {
+  const int b = blockIdx.y;
+  const long long HW = (long long)H * W;
+  const unsigned int* pos = bins + (size_t)b * 3 * HW;
+  const unsigned int* tss = pos + HW;
+  const unsigned int* neg = tss + HW;
+  uint8_t* o = out + (size_t)b * 3 * HW;
+  double tmin = 0.0, trange = 0.0;
+  if (time_surface) {
+    const double tmax = dec_f64(tstat[2 * b]);
+    tmin = dec_f64(~tstat[2 * b + 1]);
+    trange = tmax - tmin;            // == (ts - ts.min()).max()
+  }
+  const long long beg = offsets[b], n = offsets[b + 1] - beg;
+  const bool tflip = augs && augs[b].time_flip;
+  const double t_last = (tflip && n > 0) ? ev[4 * (beg + n - 1) + 2] : 0.0;
+  for (long long p = (long long)blockIdx.x * kThreads + threadIdx.x; p < HW;
+       p += (long long)gridDim.x * kThreads) {
+    o[p] = (uint8_t)(pos[p] & 0xFFu);
+    o[2 * HW + p] = (uint8_t)(neg[p] & 0xFFu);
+    uint8_t tv = 0;
+    if (time_surface) {
+      const unsigned int last = tss[p];
+      if (last) {
+        const long long j = (long long)last - 1;           // position in augmented order
+        double t = ev[4 * (beg + (tflip ? n - 1 - j : j)) + 2];
+        if (tflip) t = t_last - t;
+        const double v = (t - tmin) / trange * 255.0;   // same op order as the reference
+        tv = (v == v) ? (uint8_t)v : (uint8_t)0;         // NaN (single timestamp) -> 0
+      }
+    }
+    o[HW + p] = tv;
+  }
+}
+
+}  // namespace
+
+extern "C" size_t memhip_rasterize_workspace(int B, int H, int W) {
+  size_t bins = (size_t)B * 3 * H * W * sizeof(unsigned int);
+  bins = (bins + 15) & ~(size_t)15;
+  return bins + (size_t)B * 2 * sizeof(unsigned long long);
+}
+
+extern "C" int memhip_rasterize_aug_f64(const double* ev, const int64_t* offsets,
+                                        const memhip_event_aug_t* aug, int B, int H, int W,
+                                        int time_surface, uint8_t* out, int32_t* status,
+                                        void* workspace, size_t workspace_bytes,
+                                        memhip_stream_t stream) {
+  MEMHIP_REQUIRE(B >= 0 && H > 0 && W > 0, "rasterize: bad shape B=%d H=%d W=%d", B, H, W);
+  if (B == 0) return MEMHIP_OK;
+  MEMHIP_REQUIRE(ev && offsets && out && status && workspace, "rasterize: null pointer");
+  MEMHIP_REQUIRE(((uintptr_t)ev & 15) == 0, "rasterize: ev must be 16-byte aligned");
+  const size_t need = memhip_rasterize_workspace(B, H, W);
+  if (workspace_bytes < need)
+    return memhip::fail(MEMHIP_EWORKSPACE, "rasterize: workspace %zu < %zu", workspace_bytes, need);
+  hipStream_t s = memhip::as_stream(stream);
+  size_t bins_bytes = ((size_t)B * 3 * H * W * sizeof(unsigned int) + 15) & ~(size_t)15;
+  unsigned int* bins = (unsigned int*)workspace;
+  unsigned long long* tstat = (unsigned long long*)((char*)workspace + bins_bytes);
+  MEMHIP_HIP(hipMemsetAsync(workspace, 0, need, s));
+  MEMHIP_HIP(hipMemsetAsync(status, 0, (size_t)B * sizeof(int32_t), s));
+  // enough blocks per sample to fill the chip at small B, grid-stride beyond
+  int bx = B >= 256 ? 8 : (B >= 32 ? 32 : 256);
+  dim3 g1(bx, B);
+  hipLaunchKernelGGL(raster_count, g1, dim3(kThreads), 0, s, ev, offsets, aug, H, W, time_surface,
+                     bins, tstat, status);
+  long long HW = (long long)H * W;
+  int fx = (int)((HW + kThreads - 1) / kThreads);
+  if (fx > 64) fx = 64;
+  dim3 g2(fx, B);
+  hipLaunchKernelGGL(raster_finalize, g2, dim3(kThreads), 0, s, ev, offsets, aug, H, W,
+                     time_surface, bins, tstat, out);
+  return memhip::check_launch("rasterize");
+}
+
+extern "C" int memhip_rasterize_f64(const double* ev, const int64_t* offsets, int B, int H, int W,
+                                    int time_surface, uint8_t* out, int32_t* status,
+                                    void* workspace, size_t workspace_bytes,
+                                    memhip_stream_t stream) {
+  return memhip_rasterize_aug_f64(ev, offsets, nullptr, B, H, W, time_surface, out, status,
+                                  workspace, workspace_bytes, stream);
+}
+
+namespace {
+__global__ __launch_bounds__(kThreads) void extent_init(double* __restrict__ ext, int B) {
+  const int i = blockIdx.x * kThreads + threadIdx.x;
+  if (i < 4 * B) reinterpret_cast<unsigned long long*>(ext)[i] = 0ull;
+}
+// ext holds, during accumulation, u64 maxima of enc(x), enc(y), ~enc(x), ~enc(y)
+__global__ __launch_bounds__(kThreads) void extent_accum(
+    const double* __restrict__ ev, const int64_t* __restrict__ offsets,
+    const memhip_event_aug_t* __restrict__ augs, unsigned long long* __restrict__ ext) {
+  const int b = blockIdx.y;
+  const long long beg = offsets[b], n = offsets[b + 1] - beg;
+  const memhip_event_aug_t* a = augs ? augs + b : nullptr;
+  unsigned long long m[4] = {0ull, 0ull, 0ull, 0ull};
+  for (long long i = (long long)blockIdx.x * kThreads + threadIdx.x; i < n;
+       i += (long long)gridDim.x * kThreads) {
+    const Ev e = load_event(ev, beg, n, i, a, 0.0);
+    if (!e.keep) continue;
+    const unsigned long long ex = enc_f64(e.x), ey = enc_f64(e.y);
+    m[0] = ex > m[0] ? ex : m[0];
+    m[1] = ey > m[1] ? ey : m[1];
+    m[2] = (~ex) > m[2] ? (~ex) : m[2];
+    m[3] = (~ey) > m[3] ? (~ey) : m[3];
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    for (int o = 32; o > 0; o >>= 1) {
+      unsigned long long v = __shfl_xor(m[k], o);
+      m[k] = v > m[k] ? v : m[k];
+    }
+    if ((threadIdx.x & 63) == 0 && m[k]) atomicMax(ext + 4 * b + k, m[k]);
+  }
+}
+__global__ __launch_bounds__(kThreads) void extent_decode(double* __restrict__ ext, int B) {
+  const int i = blockIdx.x * kThreads + threadIdx.x;
+  if (i >= 4 * B) return;
+  const unsigned long long v = reinterpret_cast<unsigned long long*>(ext)[i];
+  const int k = i & 3;
+  double d;
+  if (v == 0ull) d = (k < 2) ? -INFINITY : INFINITY;
+  else d = dec_f64(k < 2 ? v : ~v);
+  ext[i] = d;
+}
+}  // namespace
+
+extern "C" int memhip_events_extent(const double* ev, const int64_t* offsets,
+                                    const memhip_event_aug_t* aug, int B, double* extent,
+                                    memhip_stream_t stream) {
+  MEMHIP_REQUIRE(B >= 0, "events_extent: bad B");
+  if (B == 0) return MEMHIP_OK;
+  MEMHIP_REQUIRE(ev && offsets && extent, "events_extent: null pointer");
+  hipStream_t s = memhip::as_stream(stream);
+  const int nb = memhip::cdiv(4LL * B, kThreads);
+  hipLaunchKernelGGL(extent_init, dim3(nb), dim3(kThreads), 0, s, extent, B);
+  hipLaunchKernelGGL(extent_accum, dim3(B >= 64 ? 8 : 64, B), dim3(kThreads), 0, s, ev, offsets, aug,
+                     reinterpret_cast<unsigned long long*>(extent));
+  hipLaunchKernelGGL(extent_decode, dim3(nb), dim3(kThreads), 0, s, extent, B);
+  return memhip::check_launch("events_extent");
+}

@@ -1,0 +1,129 @@
+"""-m "not gpu": the oracle restatement reproduces the committed reference goldens
+(tests/golden/*, generated from the imported reference by oracle/gen_golden.py)."""
+import json
+import os
+import random
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN
+from oracle import events_np as E
+from oracle import masking_py as MP
+from oracle import transforms_t as T
+from oracle import vit_ref as V
+
+
+def test_rasterizer_goldens():
+    g = np.load(os.path.join(GOLDEN, "events_raster.npz"))
+    meta = json.load(open(os.path.join(GOLDEN, "events_raster.json")))
+    assert len(meta) >= 12
+    for m in meta:
+        img = E.event_arr_to_img(g[m["name"] + "__ev"], m["H"], m["W"], m["timesurface"])
+        assert img.dtype == np.uint8 and np.array_equal(img, g[m["name"] + "__img"]), m["name"]
+    ev = g["wrap256__ev"]                                      # uint8 wrap-around is exercised
+    hits = int(((ev[:, 0] == 7) & (ev[:, 1] == 5) & (ev[:, 3] == 1)).sum())
+    assert hits > 255 and g["wrap256__img"][5, 7, 0] == hits % 256
+    with pytest.raises(IndexError):
+        E.event_arr_to_img(g["oob__ev"], 100, 120, False)
+
+
+def test_event_aug_goldens():
+    g = np.load(os.path.join(GOLDEN, "events_augs.npz"))
+    small = g["small__in"]
+    assert np.array_equal(E.slice_random_max_evs(g["slice__in"], 30000, int(g["slice__start"])), g["slice__out"])
+    for tag in ("flip", "noflip"):
+        u = float(g[f"timeflip_{tag}__u"])
+        assert np.array_equal(E.random_time_flip(small.copy(), u), g[f"timeflip_{tag}__out"])
+        assert np.array_equal(E.flip_along_x(small, u), g[f"flipx_{tag}__out"])
+        assert np.array_equal(E.flip_along_x(small, u, W=300), g[f"flipx300_{tag}__out"])
+    for tag, HW in (("a", (None, None)), ("b", (180, 240)), ("c", (None, None))):
+        xs, ys = g[f"shift_{tag}__xy"]
+        assert np.array_equal(E.random_shift(small, xs, ys, HW[0], HW[1]), g[f"shift_{tag}__out"])
+    for tr in (0, 1):
+        assert np.array_equal(E.reshape_scale_xy(g[f"rescale_{tr}__in"], 224, 224, 480, 640, bool(tr)),
+                              g[f"rescale_{tr}__out"])
+
+
+def test_ncaltech_decode_golden():
+    g = np.load(os.path.join(GOLDEN, "ncaltech_records.npz"))
+    assert np.array_equal(E.decode_ncaltech101(g["raw"].tobytes()), g["events"])
+
+
+def test_transform_goldens():
+    g = np.load(os.path.join(GOLDEN, "transforms.npz"))
+    for name in ("s32", "s224", "zeros"):
+        x = torch.from_numpy(g[name + "__in"])
+        r = T.remove_timesurface(x)
+        assert np.array_equal(r.numpy(), g[name + "__rm_ts"])
+        assert np.array_equal(T.remove_hot_pixels(r, 10.0).numpy(), g[name + "__hot10"])
+        assert np.array_equal(T.remove_hot_pixels(r, 3.0).numpy(), g[name + "__hot3"])
+        n = T.normalize_event(T.remove_hot_pixels(r, 10.0))
+        assert np.array_equal(n.numpy(), g[name + "__norm"])
+        assert np.array_equal(T.event_chain(x).numpy(), g[name + "__norm"])
+        assert np.array_equal(T.log_transform(r).numpy(), g[name + "__log"])
+        assert np.array_equal(T.gamma_transform(r, 0.5).numpy(), g[name + "__gamma"])
+        assert np.array_equal(T.to_uint8(n).numpy(), g[name + "__u8"])
+        assert np.array_equal(T.to_float32(T.to_uint8(n)).numpy(), g[name + "__f32"])
+    assert (g["s224__hot3"] != g["s224__rm_ts"]).any()           # the hot-pixel branch fires
+
+
+def test_mask_goldens():
+    g = np.load(os.path.join(GOLDEN, "masks.npz"))
+    meta = json.load(open(os.path.join(GOLDEN, "masks.json")))
+    for c in meta["cfgs"]:
+        for s in meta["seeds"][:3]:
+            random.seed(s)
+            o = MP.BlockMaskOracle(tuple(c["size"]), c["n"], min_num_patches=c["lo"], max_num_patches=c["hi"])
+            got = np.stack([o() for _ in range(meta["per_seed"])])
+            want = np.unpackbits(g[f"{c['tag']}__s{s}"], axis=1)[:, :got[0].size].reshape(got.shape)
+            assert np.array_equal(got, want), (c, s)
+    random.seed(12345)
+    assert np.array_equal(np.array([random.random() for _ in range(16)]), g["mt__random_s12345"])
+
+
+def test_schedule_goldens():
+    g = np.load(os.path.join(GOLDEN, "schedules.npz"))
+    s = V.cosine_scheduler(5e-4, 1e-5, 3000, 8, warmup_epochs=5, warmup_steps=1000)
+    assert np.array_equal(s[:1200], g["lr_ncaltech_head"]) and np.array_equal(s[-200:], g["lr_ncaltech_tail"])
+    assert np.array_equal(V.cosine_scheduler(5e-4, 1e-5, 2, 10, warmup_epochs=5, warmup_steps=4), g["lr_small"])
+
+
+TINY = dict(img_size=(64, 64), patch_size=(16, 16), in_chans=3, vocab_size=512, embed_dim=128, depth=2,
+            num_heads=2, mlp_ratio=4, drop_path_rate=0.0, use_shared_rel_pos_bias=True,
+            use_abs_pos_emb=False, init_values=0.1)
+
+
+def test_vit_tiny_fwdbwd_golden():
+    torch.set_num_threads(1)
+    g = np.load(os.path.join(GOLDEN, "vit_tiny_fwdbwd.npz"))
+    meta = json.load(open(os.path.join(GOLDEN, "vit_meta.json")))
+    m = V.RefViT(**TINY)
+    assert list(m.state_dict().keys()) == meta["tiny_state_keys"]
+    m.load_state_dict(V.fill_by_name(m.state_dict(), seed=0))
+    x, mask, labels = torch.from_numpy(g["x"]), torch.from_numpy(g["mask"]), torch.from_numpy(g["labels"])
+    lo = m(x, mask)
+    loss = torch.nn.CrossEntropyLoss()(lo, labels)
+    loss.backward()
+    assert np.array_equal(lo.detach().numpy(), g["fp32__logits"])
+    assert np.array_equal(loss.detach().numpy(), g["fp32__loss"])
+    for k, p in m.named_parameters():
+        assert np.array_equal(p.grad.numpy(), g[f"fp32__grad__{k}"]), k
+    _, names = V.param_groups(m)
+    assert names["no_decay"] == meta["tiny_groups"]["no_decay"] and names["decay"] == meta["tiny_groups"]["decay"]
+    assert "mask_token" in names["decay"] and "cls_token" in names["no_decay"]
+
+
+def test_vit_tiny_train_golden():
+    """First 20 of the 100 golden steps (the full 100 are checked against the HIP path on the GPU)."""
+    torch.set_num_threads(1)
+    from oracle.gen_golden import vit_inputs
+    g = np.load(os.path.join(GOLDEN, "vit_tiny_train100.npz"))
+    m = V.RefViT(**TINY)
+    m.load_state_dict(V.fill_by_name(m.state_dict(), seed=0))
+    opt = V.make_optimizer(m)
+    for it in range(20):
+        xb, mb, lb = vit_inputs(TINY, 4, 1000 + it % 8, 6)
+        loss, gn, acc = V.train_step(m, opt, xb, mb, lb, it, g["lr"], g["wd"], clip_grad=30.0)
+        assert loss == g["fp32__loss"][it] and gn == g["fp32__gnorm"][it], it
