@@ -139,6 +139,41 @@ int memhip_mask_blockwise(uint32_t* mt_state, int H, int W, int num_masking_patc
 int memhip_mask_random_location(uint32_t* mt_state, int H, int W, int num_masking_patches,
                                 int n_masks, uint8_t* out);
 
+/* ------------------------------------------------------------------------
+ * bf16 MFMA GEMM  C[M,N] = A[M,K] * B[N,K]^T  (+ fused epilogue)
+ * replaces every F.linear / nn.Linear / nn.Conv2d(k=s=patch) of the ViT:
+ *   patch embed  mem/modeling_finetune.py:203,209   qkv  :132-133   proj :155
+ *   fc1+GELU     :61-68    fc2 :69    lm_head  mem/modeling_pretrain.py:59,126
+ * and their dgrad / wgrad products in backward.
+ * ------------------------------------------------------------------------
+ * A, B are bf16 row-major with the reduction dimension contiguous (lda, ldb in
+ * elements, multiples of 8; K a multiple of 64).  fp32 accumulate.  Output
+ * rows >= M / cols >= N are never written.
+ */
+#define MEMHIP_EPI_BIAS_BF16 0   /* out0 bf16 = bf16(acc+bias); cols < colscale_n then *= colscale (q*scale, :137) */
+#define MEMHIP_EPI_BIAS_GELU 1   /* out0 bf16 = h = bf16(acc+bias); out1 bf16 = gelu(h)       (:66-68) */
+#define MEMHIP_EPI_RESIDUAL 2    /* y=bf16(acc+bias) -> out0 (may be NULL); resid f32 += drop_path(vec1*y) (:187-188) */
+#define MEMHIP_EPI_DGELU 3       /* out0 bf16 = bf16(acc) * gelu'(aux bf16)                   (GELU backward) */
+#define MEMHIP_EPI_F32 4         /* out0 f32 (+)= acc                                         (weight gradients) */
+#define MEMHIP_EPI_PATCH_EMBED 5 /* resid f32[b*(L+1)+1+p] = bf16(acc+bias)*(1-w) + vec1*w    (modeling_pretrain.py:101-108) */
+typedef struct memhip_gemm_args {
+  const void* A; const void* B;
+  int64_t lda, ldb;
+  int32_t M, N, K, epilogue;
+  void* out0; int64_t ldo0;
+  void* out1; int64_t ldo1;
+  const float* bias;      /* [N] fp32 or NULL */
+  const float* vec1;      /* RESIDUAL: layer-scale gamma [N] (NULL = none); PATCH_EMBED: mask_token [N] */
+  float* resid; int64_t ldr;   /* fp32 residual stream */
+  const void* aux; int64_t ldaux; /* DGELU: pre-activation bf16 [M,N]; PATCH_EMBED: mask u8 [M] */
+  const float* rowmask;   /* RESIDUAL: stochastic-depth keep mask per sample (0/1), NULL = off */
+  float keep_prob;        /* RESIDUAL: 1 - drop_prob */
+  float colscale; int32_t colscale_n;
+  int32_t rows_per_sample;  /* RESIDUAL: tokens per sample; PATCH_EMBED: patches per sample */
+  int32_t accumulate;     /* F32: 1 = out0 += acc */
+} memhip_gemm_args_t;
+int memhip_gemm_bf16_nt(const memhip_gemm_args_t* args, memhip_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -6,6 +6,10 @@ missing or a symbol cannot be resolved, importing this module raises.
 import ctypes as C
 import os
 
+# torch first: its bundled HIP runtime (libamdhip64) must be the one already loaded when
+# libmemhip.so resolves its dependency, so that streams / device pointers are shared.
+import torch  # noqa: F401
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmemhip.so")
 

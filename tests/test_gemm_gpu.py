@@ -1,0 +1,125 @@
+"""-m gpu: bf16 MFMA GEMM + fused epilogues vs plain torch fp32 references of the same op."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _rand(shape, seed, scale=1.0):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    return (torch.randn(shape, generator=g, device="cuda") * scale)
+
+
+def test_exact_integer_layout():
+    """A = I-like / small integers, asymmetric B: every product is exact in bf16/fp32, so any
+    fragment-layout or swizzle mistake shows up as a hard mismatch (not a tolerance issue)."""
+    from mem_amd import ops
+    M, N, K = 256, 384, 128
+    g = torch.Generator(device="cuda").manual_seed(0)
+    A = torch.randint(-3, 4, (M, K), generator=g, device="cuda").float()
+    B = torch.randint(-3, 4, (N, K), generator=g, device="cuda").float()
+    B += torch.arange(N, device="cuda").view(N, 1) % 5            # asymmetric
+    C = torch.zeros((M, N), dtype=torch.float32, device="cuda")
+    ops.gemm_nt(A.bfloat16(), B.bfloat16(), M, N, K, ops.EPI_F32, out0=C)
+    torch.testing.assert_close(C, A @ B.t(), rtol=0, atol=0)
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (394, 768, 768), (50, 200, 64), (1000, 2304, 768),
+                                   (333, 3072, 768), (394, 768, 3072), (196 * 3, 128, 768), (7, 512, 128)])
+def test_bias_bf16_and_edges(M, N, K):
+    from mem_amd import ops
+    A = _rand((M, K), 1).bfloat16()
+    B = _rand((N, K), 2, 0.05).bfloat16()
+    bias = _rand((N,), 3)
+    out = torch.full((M + 3, N), 7.0, dtype=torch.bfloat16, device="cuda")       # guard rows
+    ops.gemm_nt(A, B, M, N, K, ops.EPI_BIAS_BF16, out0=out, bias=bias, colscale=0.125, colscale_n=N // 3)
+    ref = (A.float() @ B.float().t() + bias).bfloat16()
+    ref[:, : N // 3] = (ref[:, : N // 3].float() * 0.125).bfloat16()
+    torch.testing.assert_close(out[:M].float(), ref.float(), rtol=2e-2, atol=2e-2)
+    # fp32-accumulate quality: compare against the fp64 product at bf16 resolution
+    ref64 = (A.double() @ B.double().t() + bias.double())
+    ref64[:, : N // 3] *= 0.125
+    err = (out[:M].double() - ref64).abs().max().item()
+    assert err < 0.02 * max(1.0, ref64.abs().max().item())
+    assert (out[M:] == 7.0).all()                                                # rows >= M untouched
+
+
+def test_gelu_epilogue():
+    from mem_amd import ops
+    M, N, K = 300, 512, 256
+    A, B, bias = _rand((M, K), 4).bfloat16(), _rand((N, K), 5, 0.08).bfloat16(), _rand((N,), 6, 0.1)
+    h = torch.zeros((M, N), dtype=torch.bfloat16, device="cuda")
+    a = torch.zeros_like(h)
+    ops.gemm_nt(A, B, M, N, K, ops.EPI_BIAS_GELU, out0=h, out1=a, bias=bias)
+    href = (A.float() @ B.float().t() + bias).bfloat16()
+    torch.testing.assert_close(h.float(), href.float(), rtol=2e-2, atol=2e-2)
+    # GELU is applied to the kernel's own rounded h: must match torch's exact-erf GELU on that h
+    torch.testing.assert_close(a.float(), torch.nn.functional.gelu(h.float()).bfloat16().float(), rtol=1e-2, atol=1e-3)
+
+
+def test_residual_epilogue_with_droppath():
+    from mem_amd import ops
+    T, Bn, N, K = 17, 9, 256, 128
+    M = T * Bn
+    A, B, bias = _rand((M, K), 7).bfloat16(), _rand((N, K), 8, 0.08).bfloat16(), _rand((N,), 9, 0.1)
+    gamma = _rand((N,), 10, 0.1)
+    x0 = _rand((M, N), 11)
+    keep = (torch.arange(Bn, device="cuda") % 3 != 0).float()
+    for mask, kp in ((None, 1.0), (keep, 0.9)):
+        x = x0.clone()
+        y = torch.zeros((M, N), dtype=torch.bfloat16, device="cuda")
+        ops.gemm_nt(A, B, M, N, K, ops.EPI_RESIDUAL, out0=y, bias=bias, vec1=gamma, resid=x, rowmask=mask,
+                    keep_prob=kp, rows_per_sample=T)
+        t = gamma * y.float()
+        if mask is not None:
+            t = t.div(kp) * mask.repeat_interleave(T).view(-1, 1)
+        torch.testing.assert_close(x, x0 + t, rtol=0, atol=0)          # fp32 tail is exact given y
+        torch.testing.assert_close(y.float(), (A.float() @ B.float().t() + bias).bfloat16().float(), rtol=2e-2, atol=2e-2)
+
+
+def test_dgelu_and_f32_accumulate():
+    from mem_amd import ops
+    M, N, K = 260, 384, 192
+    A, B = _rand((M, K), 12).bfloat16(), _rand((N, K), 13, 0.08).bfloat16()
+    h = _rand((M, N), 14).bfloat16()
+    out = torch.zeros((M, N), dtype=torch.bfloat16, device="cuda")
+    ops.gemm_nt(A, B, M, N, K, ops.EPI_DGELU, out0=out, aux=h)
+    da = (A.float() @ B.float().t()).bfloat16().float()
+    hh = h.float().requires_grad_(True)
+    torch.nn.functional.gelu(hh).backward(torch.ones_like(hh))
+    ref = (da * hh.grad).bfloat16().float()
+    torch.testing.assert_close(out.float(), ref, rtol=3e-2, atol=3e-2)
+    C = torch.ones((M, N), dtype=torch.float32, device="cuda")
+    ops.gemm_nt(A, B, M, N, K, ops.EPI_F32, out0=C, accumulate=True)
+    torch.testing.assert_close(C, 1.0 + A.float() @ B.float().t(), rtol=1e-4, atol=1e-3)
+
+
+def test_patch_embed_epilogue():
+    from mem_amd import ops
+    Bn, L, N, K = 5, 16, 128, 768
+    M = Bn * L
+    A, Wt, bias = _rand((M, K), 15).bfloat16(), _rand((N, K), 16, 0.05).bfloat16(), _rand((N,), 17, 0.1)
+    mt = _rand((N,), 18)
+    mask = (torch.rand((M,), device="cuda") < 0.4).to(torch.uint8)
+    x = torch.full((Bn * (L + 1), N), -5.0, device="cuda")
+    ops.gemm_nt(A, Wt, M, N, K, ops.EPI_PATCH_EMBED, bias=bias, vec1=mt, resid=x, aux=mask, rows_per_sample=L)
+    y = (A.float() @ Wt.float().t() + bias).bfloat16().float()
+    w = mask.float().view(-1, 1)
+    ref = (y * (1 - w) + mt * w).view(Bn, L, N)
+    got = x.view(Bn, L + 1, N)
+    torch.testing.assert_close(got[:, 1:], ref, rtol=2e-2, atol=2e-2)
+    assert (got[:, 0] == -5.0).all()                                  # cls rows untouched
+
+
+def test_vitb_shapes_throughput_sanity():
+    """Full BASELINE M (256*197) on the three ViT-B weight shapes: finite + spot-check rows."""
+    from mem_amd import ops
+    M = 256 * 197
+    for N, K in ((2304, 768), (3072, 768), (768, 3072)):
+        A, B = _rand((M, K), 20).bfloat16(), _rand((N, K), 21, 0.03).bfloat16()
+        out = torch.empty((M, N), dtype=torch.bfloat16, device="cuda")
+        ops.gemm_nt(A, B, M, N, K, ops.EPI_BIAS_BF16, out0=out)
+        rows = torch.tensor([0, 1, 127, 128, 25000, M - 1], device="cuda")
+        ref = (A[rows].float() @ B.float().t()).bfloat16().float()
+        torch.testing.assert_close(out[rows].float(), ref, rtol=2e-2, atol=2e-2)
+        assert torch.isfinite(out.float()).all()
