@@ -174,6 +174,98 @@ typedef struct memhip_gemm_args {
 } memhip_gemm_args_t;
 int memhip_gemm_bf16_nt(const memhip_gemm_args_t* args, memhip_stream_t stream);
 
+/* ------------------------------------------------------------------------
+ * LayerNorm (eps 1e-6) forward / backward          mem/modeling_pretrain.py:132,
+ * mem/modeling_finetune.py:166,172,184-188; final norm mem/modeling_pretrain.py:117
+ * ------------------------------------------------------------------------
+ * x fp32 [*, D] (residual stream), y bf16 [R, D] (what the next Linear consumes
+ * under autocast), mean/rstd fp32 [R].  row_idx (i32 [R], may be NULL) selects
+ * the input row of output row r: the final norm + `x[:,1:][bool_masked_pos]`
+ * (modeling_pretrain.py:121-126) is one gathered LayerNorm over the masked rows.
+ * backward: dres[row] (+)= dx, dgamma/dbeta fp32 [D] are ACCUMULATED.
+ */
+int memhip_layernorm_fwd(const float* x, int64_t ldx, const int32_t* row_idx, int R, int D,
+                         const float* gamma, const float* beta, float eps, void* y_bf16, int64_t ldy,
+                         float* mean, float* rstd, memhip_stream_t stream);
+int memhip_layernorm_bwd(const void* dy_bf16, int64_t lddy, const float* x, int64_t ldx,
+                         const int32_t* row_idx, int R, int D, const float* gamma, const float* mean,
+                         const float* rstd, float* dres, int64_t lddres, int accumulate, float* dgamma,
+                         float* dbeta, memhip_stream_t stream);
+
+/* Backward of `x = x + drop_path(gamma * y)` (mem/modeling_finetune.py:187-188):
+ * dy bf16 = bf16(dt * gamma), dgamma += sum_m dt*y, dbias += sum_m dy with
+ * dt = dx * rowmask[m / rows_per_sample] / keep_prob.  gamma/rowmask/dgamma/dbias may be NULL. */
+int memhip_branch_bwd(const float* dx, int64_t lddx, const void* y_bf16, int64_t ldy, const float* gamma,
+                      const float* rowmask, float keep_prob, int rows_per_sample, int M, int D,
+                      void* dy_bf16, int64_t lddy, float* dgamma, float* dbias, memhip_stream_t stream);
+
+/* Backward of the token assembly (mem/modeling_pretrain.py:101-108): dcls += dx[cls rows],
+ * dmask_token += sum dx*w, dy bf16 [B*L, D] = bf16(dx*(1-w)); mask u8 [B*L]. */
+int memhip_embed_bwd(const float* dx, int64_t lddx, const uint8_t* mask, int B, int L, int D,
+                     void* dy_bf16, int64_t lddy, float* dcls, float* dmask_token, memhip_stream_t stream);
+
+/* nn.CrossEntropyLoss()(logits, labels) + mlm_acc  (mem/engine_for_pretraining.py:152,233).
+ * logits bf16 [M, V] (in place -> dlogits = (softmax - onehot) * grad_scale when write_grad);
+ * row_loss f32 [M], row_correct i32 [M] scratch; out2 f32 [2] = {mean loss, accuracy}. */
+int memhip_cross_entropy(void* logits_bf16, int64_t ld, const int64_t* labels, int M, int V,
+                         float grad_scale, float* row_loss, int32_t* row_correct, int write_grad,
+                         float* out2, memhip_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * Fused attention with shared relative position bias, head_dim 64, <= 256 tokens
+ * replaces Attention.forward q*scale .. (attn@v)   mem/modeling_finetune.py:137-154
+ *          RelativePositionBias.forward              mem/modeling_finetune.py:242-247
+ * ------------------------------------------------------------------------
+ * qkv   bf16 [B*T, 3D] token-major, columns [q*scale | k | v], head h at h*64
+ * bias  f32 [heads, TP, TP], TP = memhip_attn_tokens_padded(T) (zero padding)
+ * out   bf16 [B*T, D];  lse f32 [B, heads, TP] (saved for backward)
+ * bwd:  dqkv bf16 [B*T, 3D] (dq already multiplied by `scale`);
+ *       dtable f32 [num_rel, heads] += bias gradient bucketed through
+ *       relidx_pad i32 [TP, TP] (-1 in the padding); NULL skips it.
+ */
+int memhip_attn_tokens_padded(int T);
+int memhip_relpos_gather(const float* table, const int32_t* index /*[T*T]*/, int T, int TP, int heads,
+                         float* bias_pad, memhip_stream_t stream);
+int memhip_attn_fwd(const void* qkv, int64_t ldqkv, int B, int T, int D, int heads, const float* bias_pad,
+                    void* out, int64_t ldo, float* lse, memhip_stream_t stream);
+int memhip_attn_bwd(const void* qkv, int64_t ldqkv, const void* dout, const void* out, int64_t ldo,
+                    const float* lse, const float* bias_pad, const int32_t* relidx_pad, int num_rel,
+                    int B, int T, int D, int heads, float scale, void* dqkv, int64_t lddqkv, float* dtable,
+                    memhip_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * Layout / dtype movers
+ * ------------------------------------------------------------------------ */
+int memhip_cast_f32_bf16(const float* in, void* out_bf16, int64_t n, memhip_stream_t stream);
+/* out bf16 [Cc, ldout] = in f32 [R, Cc]^T (the [in,out]-major copy of a Linear weight used by dgrad) */
+int memhip_transpose_cast_f32_bf16(const float* in, int64_t ldin, int R, int Cc, void* out_bf16,
+                                   int64_t ldout, memhip_stream_t stream);
+/* out bf16 [Cc, ldout] = in bf16 [R, Cc]^T, columns [R, R_pad) zero-filled (R_pad % 64 == 0);
+ * optional fused column sums of `in` (Linear bias gradients) over two column ranges. */
+int memhip_transpose_bf16(const void* in, int64_t ldin, int R, int Cc, void* out, int64_t ldout, int R_pad,
+                          float* colsum0, int c0_begin, int c0_end, float* colsum1, int c1_begin,
+                          int c1_end, memhip_stream_t stream);
+/* im2col of the k=s=patch conv (mem/modeling_finetune.py:203-209): x f32 [B,C,H,W] ->
+ * bf16 [B*L, C*ph*pw], k = c*ph*pw + py*pw + px */
+int memhip_im2col_bf16(const float* x, int B, int C, int H, int W, int ph, int pw, void* out_bf16,
+                       memhip_stream_t stream);
+/* x[b*T, :] = cls_token (mem/modeling_pretrain.py:101,108) */
+int memhip_fill_cls(float* x, int64_t ldx, int B, int T, int D, const float* cls, memhip_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * Optimizer step on flat fp32 buffers (tensors padded to 1024 elements)
+ * replaces clip_grad_norm_ / get_grad_norm_   mem/utils.py:360-366,380-392
+ *          optim.AdamW(betas=(0.9,0.95))      mem/optim_factory.py:121,132-133
+ * ------------------------------------------------------------------------ */
+size_t memhip_grad_norm_workspace(void);
+int memhip_grad_norm(const float* g, int64_t n, float* norm_out, void* workspace, size_t workspace_bytes,
+                     memhip_stream_t stream);
+/* wd_flag_per_chunk u8 [n/1024]: 1 = weight decay applies to that chunk.  gnorm (device scalar) and
+ * max_norm > 0 fold gradient clipping into the update; step >= 1 is the AdamW step count. */
+int memhip_adamw(float* p, const float* g, float* m, float* v, int64_t n, const uint8_t* wd_flag_per_chunk,
+                 double lr, double beta1, double beta2, double eps, double weight_decay, int step,
+                 const float* gnorm, double max_norm, memhip_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

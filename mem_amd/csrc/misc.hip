@@ -1,0 +1,183 @@
+// Layout / dtype movers around the GEMMs: fp32 master -> bf16 shadow weights (plain and
+// transposed), bf16 transposes that give the weight-gradient contraction its K-contiguous
+// operands (with the Linear bias gradient = column sums fused in), im2col for the k=s=16
+// patch-embed conv (mem/modeling_finetune.py:203-209), cls-token rows and the shared relative
+// position bias gather (mem/modeling_finetune.py:242-247).  All HBM-bound, 16-B lane accesses.
+#include "common.h"
+
+namespace {
+
+using namespace memhip;
+
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+
+__global__ __launch_bounds__(256) void cast_kernel(const float* __restrict__ in, __bf16* __restrict__ out,
+                                                   long long n4) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+    const float4 v = reinterpret_cast<const float4*>(in)[i];
+    bf16x4 o;
+    o[0] = (__bf16)v.x; o[1] = (__bf16)v.y; o[2] = (__bf16)v.z; o[3] = (__bf16)v.w;
+    reinterpret_cast<bf16x4*>(out)[i] = o;
+  }
+}
+
+// 64x64 tile transpose through LDS.  IN = float (cast to bf16) or bf16.
+// out[c][r] = in[r][c]; rows r in [R, R_pad) of the transposed output are zero-filled.
+template <typename IN>
+__global__ __launch_bounds__(256) void transpose_kernel(const IN* __restrict__ in, long long ldin, int R,
+                                                        int Cc, __bf16* __restrict__ out, long long ldout,
+                                                        int R_pad, float* __restrict__ cs0, int c0b, int c0e,
+                                                        float* __restrict__ cs1, int c1b, int c1e) {
+  __shared__ __bf16 tile[64][66];
+  const int r0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+  const int t = threadIdx.x;
+  // load: 8 threads per row (8 elements each), 32 rows per pass
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    const int rl = (t >> 3) + pass * 32, cl = (t & 7) * 8;
+    const int r = r0 + rl;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int c = c0 + cl + k;
+      __bf16 v = (__bf16)0.f;
+      if (r < R && c < Cc) v = (__bf16)(float)in[(long long)r * ldin + c];
+      tile[rl][cl + k] = v;
+    }
+  }
+  __syncthreads();
+  // store: output row = input column; 8 threads per output row, 8 consecutive r each
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    const int cl = (t >> 3) + pass * 32, rl = (t & 7) * 8;
+    const int c = c0 + cl;
+    bf16x8 o;
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { o[k] = tile[rl + k][cl]; s += (float)o[k]; }
+    if (c < Cc && r0 + rl < R_pad)
+      *reinterpret_cast<bf16x8*>(out + (long long)c * ldout + r0 + rl) = o;
+    if (cs0 || cs1) {
+      s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4);
+      if ((t & 7) == 0 && c < Cc) {
+        if (cs0 && c >= c0b && c < c0e) atomicAdd(cs0 + (c - c0b), s);
+        if (cs1 && c >= c1b && c < c1e) atomicAdd(cs1 + (c - c1b), s);
+      }
+    }
+  }
+}
+
+// x f32 [B,C,H,W] -> patches bf16 [B*L, C*ph*pw], k = c*ph*pw + py*pw + px (Conv2d weight order)
+__global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ x, int B, int C, int H, int W,
+                                                     int ph, int pw, __bf16* __restrict__ out) {
+  const int gw = W / pw, gh = H / ph;
+  const int K = C * ph * pw, K8 = K >> 3;
+  const long long total = (long long)B * gh * gw * K8;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int k8 = (int)(i % K8);
+    const long long row = i / K8;
+    const int k = k8 * 8;
+    const int c = k / (ph * pw), rem = k - c * ph * pw, py = rem / pw, px = rem - py * pw;
+    const int gx = (int)(row % gw);
+    const long long t = row / gw;
+    const int gy = (int)(t % gh), b = (int)(t / gh);
+    const float* src = x + (((long long)b * C + c) * H + gy * ph + py) * W + gx * pw + px;
+    const float4 a = reinterpret_cast<const float4*>(src)[0], d = reinterpret_cast<const float4*>(src)[1];
+    bf16x8 o;
+    o[0] = (__bf16)a.x; o[1] = (__bf16)a.y; o[2] = (__bf16)a.z; o[3] = (__bf16)a.w;
+    o[4] = (__bf16)d.x; o[5] = (__bf16)d.y; o[6] = (__bf16)d.z; o[7] = (__bf16)d.w;
+    reinterpret_cast<bf16x8*>(out)[i] = o;
+  }
+}
+
+__global__ __launch_bounds__(256) void fill_cls_kernel(float* __restrict__ x, long long ldx, int B, int T, int D,
+                                                       const float* __restrict__ cls) {
+  const int b = blockIdx.x;
+  for (int c = threadIdx.x; c < D; c += 256) x[(long long)b * T * ldx + c] = cls[c];
+}
+
+// bias[h][q][k] = table[idx[q*T+k]][h] for q,k < T, 0 in the padding (TP >= T)
+__global__ __launch_bounds__(256) void relpos_gather_kernel(const float* __restrict__ table,
+                                                            const int* __restrict__ idx, int T, int TP, int Hh,
+                                                            float* __restrict__ bias) {
+  const long long total = (long long)Hh * TP * TP;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int k = (int)(i % TP);
+    const long long t = i / TP;
+    const int q = (int)(t % TP), h = (int)(t / TP);
+    float v = 0.f;
+    if (q < T && k < T) v = table[(long long)idx[q * T + k] * Hh + h];
+    bias[i] = v;
+  }
+}
+
+}  // namespace
+
+extern "C" int memhip_cast_f32_bf16(const float* in, void* out, int64_t n, memhip_stream_t stream) {
+  MEMHIP_REQUIRE(n >= 0 && n % 4 == 0, "cast: n must be a multiple of 4");
+  if (n == 0) return MEMHIP_OK;
+  MEMHIP_REQUIRE(in && out, "cast: null pointer");
+  const long long n4 = n / 4;
+  int blocks = (int)((n4 + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(cast_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), in, (__bf16*)out, n4);
+  return check_launch("cast_f32_bf16");
+}
+
+extern "C" int memhip_transpose_cast_f32_bf16(const float* in, int64_t ldin, int R, int Cc, void* out,
+                                              int64_t ldout, memhip_stream_t stream) {
+  MEMHIP_REQUIRE(R > 0 && Cc > 0 && in && out, "transpose_cast: bad arguments");
+  MEMHIP_REQUIRE(ldout % 8 == 0 && ldout >= R, "transpose_cast: ldout");
+  const int R_pad = (int)(ldout < (int64_t)cdiv(R, 64) * 64 ? ldout : (int64_t)cdiv(R, 64) * 64);
+  hipLaunchKernelGGL(transpose_kernel<float>, dim3(cdiv(R, 64), cdiv(Cc, 64)), dim3(256), 0, as_stream(stream), in,
+                     (long long)ldin, R, Cc, (__bf16*)out, (long long)ldout, R_pad, (float*)nullptr, 0, 0,
+                     (float*)nullptr, 0, 0);
+  return check_launch("transpose_cast");
+}
+
+extern "C" int memhip_transpose_bf16(const void* in, int64_t ldin, int R, int Cc, void* out, int64_t ldout,
+                                     int R_pad, float* colsum0, int c0_begin, int c0_end, float* colsum1,
+                                     int c1_begin, int c1_end, memhip_stream_t stream) {
+  MEMHIP_REQUIRE(R >= 0 && Cc > 0 && in && out, "transpose: bad arguments");
+  MEMHIP_REQUIRE(R_pad >= R && R_pad % 64 == 0 && ldout >= R_pad && ldout % 8 == 0,
+                 "transpose: R_pad=%d must be a multiple of 64 and <= ldout", R_pad);
+  if (R_pad == 0) return MEMHIP_OK;
+  hipLaunchKernelGGL(transpose_kernel<__bf16>, dim3(R_pad / 64, cdiv(Cc, 64)), dim3(256), 0, as_stream(stream),
+                     (const __bf16*)in, (long long)ldin, R, Cc, (__bf16*)out, (long long)ldout, R_pad, colsum0,
+                     c0_begin, c0_end, colsum1, c1_begin, c1_end);
+  return check_launch("transpose_bf16");
+}
+
+extern "C" int memhip_im2col_bf16(const float* x, int B, int C, int H, int W, int ph, int pw, void* out,
+                                  memhip_stream_t stream) {
+  MEMHIP_REQUIRE(B >= 0 && C > 0 && ph > 0 && pw > 0 && H % ph == 0 && W % pw == 0, "im2col: bad shape");
+  MEMHIP_REQUIRE(pw % 8 == 0 && W % 4 == 0, "im2col: patch width must be a multiple of 8");
+  if (B == 0) return MEMHIP_OK;
+  MEMHIP_REQUIRE(x && out, "im2col: null pointer");
+  const long long total = (long long)B * (H / ph) * (W / pw) * (C * ph * pw / 8);
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(im2col_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), x, B, C, H, W, ph, pw,
+                     (__bf16*)out);
+  return check_launch("im2col");
+}
+
+extern "C" int memhip_fill_cls(float* x, int64_t ldx, int B, int T, int D, const float* cls,
+                               memhip_stream_t stream) {
+  MEMHIP_REQUIRE(B >= 0 && T > 0 && D > 0, "fill_cls: bad shape");
+  if (B == 0) return MEMHIP_OK;
+  MEMHIP_REQUIRE(x && cls, "fill_cls: null pointer");
+  hipLaunchKernelGGL(fill_cls_kernel, dim3(B), dim3(256), 0, as_stream(stream), x, (long long)ldx, B, T, D, cls);
+  return check_launch("fill_cls");
+}
+
+extern "C" int memhip_relpos_gather(const float* table, const int32_t* index, int T, int TP, int heads,
+                                    float* bias, memhip_stream_t stream) {
+  MEMHIP_REQUIRE(T > 0 && TP >= T && heads > 0 && table && index && bias, "relpos_gather: bad arguments");
+  const long long total = (long long)heads * TP * TP;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(relpos_gather_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), table, index, T, TP,
+                     heads, bias);
+  return check_launch("relpos_gather");
+}

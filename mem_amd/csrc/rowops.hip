@@ -1,0 +1,411 @@
+// Row-wise / column-reducing kernels of the ViT block that sit between the MFMA GEMMs.
+// All of them are HBM-bound: one wave per token row with 16-byte lane accesses (LayerNorm,
+// cross-entropy), or column-owning threads sweeping a band of rows (the reductions that produce
+// layer-scale / bias / LayerNorm-affine gradients), finished with one fp32 atomic per column per
+// workgroup.  Reference ops: nn.LayerNorm(eps=1e-6) (mem/modeling_pretrain.py:132), the layer-scale
+// + DropPath residual (mem/modeling_finetune.py:187-188), nn.CrossEntropyLoss + argmax accuracy
+// (mem/engine_for_pretraining.py:152,233).
+#include "common.h"
+
+namespace {
+
+using namespace memhip;
+
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+
+__device__ __forceinline__ float wsum(float v) {
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ float wmax(float v) {
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+
+constexpr int kMaxChunks = 8;   // float4 chunks per lane: D <= 64*4*8 = 2048
+
+// ---------------------------------------------------------------- LayerNorm forward
+// one wave per output row; x fp32 (row via row_idx), y bf16, mean/rstd saved for backward
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, long long ldx,
+                                                     const int* __restrict__ row_idx, int R, int D,
+                                                     const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, float eps,
+                                                     __bf16* __restrict__ y, long long ldy,
+                                                     float* __restrict__ mean, float* __restrict__ rstd) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= R) return;
+  const long long src = row_idx ? row_idx[r] : r;
+  const float4* xr = reinterpret_cast<const float4*>(x + src * ldx);
+  const int nch = D >> 2;
+  float4 v[kMaxChunks];
+  float s = 0.f;
+#pragma unroll
+  for (int c = 0; c < kMaxChunks; ++c) {
+    const int i = lane + c * 64;
+    if (i < nch) { v[c] = xr[i]; s += (v[c].x + v[c].y) + (v[c].z + v[c].w); }
+  }
+  const float mu = wsum(s) / (float)D;
+  float q = 0.f;
+#pragma unroll
+  for (int c = 0; c < kMaxChunks; ++c) {
+    const int i = lane + c * 64;
+    if (i < nch) {
+      const float a = v[c].x - mu, b = v[c].y - mu, cc = v[c].z - mu, d = v[c].w - mu;
+      q += (a * a + b * b) + (cc * cc + d * d);
+    }
+  }
+  const float var = wsum(q) / (float)D;          // biased, as nn.LayerNorm
+  const float rs = 1.0f / sqrtf(var + eps);
+  if (lane == 0) { mean[r] = mu; rstd[r] = rs; }
+  const float4* g4 = reinterpret_cast<const float4*>(gamma);
+  const float4* b4 = reinterpret_cast<const float4*>(beta);
+  bf16x4* yr = reinterpret_cast<bf16x4*>(y + (long long)r * ldy);
+#pragma unroll
+  for (int c = 0; c < kMaxChunks; ++c) {
+    const int i = lane + c * 64;
+    if (i < nch) {
+      const float4 g = g4[i], b = b4[i];
+      bf16x4 o;
+      o[0] = (__bf16)((v[c].x - mu) * rs * g.x + b.x);
+      o[1] = (__bf16)((v[c].y - mu) * rs * g.y + b.y);
+      o[2] = (__bf16)((v[c].z - mu) * rs * g.z + b.z);
+      o[3] = (__bf16)((v[c].w - mu) * rs * g.w + b.w);
+      yr[i] = o;
+    }
+  }
+}
+
+// ---------------------------------------------------------------- LayerNorm backward
+// workgroup = 4 waves x kRowsPerWave rows; dx per row (wave reductions), dgamma/dbeta per lane
+// column accumulated in registers over the workgroup's rows, then LDS -> one atomic per column.
+constexpr int kLnRowsPerWave = 8;
+
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const __bf16* __restrict__ dy, long long lddy,
+                                                     const float* __restrict__ x, long long ldx,
+                                                     const int* __restrict__ row_idx, int R, int D,
+                                                     const float* __restrict__ gamma,
+                                                     const float* __restrict__ mean,
+                                                     const float* __restrict__ rstd,
+                                                     float* __restrict__ dres, long long lddres,
+                                                     int accumulate, float* __restrict__ dgamma,
+                                                     float* __restrict__ dbeta) {
+  extern __shared__ float red[];   // [4][2][D]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nch = D >> 2;
+  const float4* g4 = reinterpret_cast<const float4*>(gamma);
+  float4 ag[kMaxChunks], ab[kMaxChunks];
+#pragma unroll
+  for (int c = 0; c < kMaxChunks; ++c) { ag[c] = float4{0, 0, 0, 0}; ab[c] = float4{0, 0, 0, 0}; }
+  const int r0 = (blockIdx.x * 4 + wave) * kLnRowsPerWave;
+  for (int rr = 0; rr < kLnRowsPerWave; ++rr) {
+    const int r = r0 + rr;
+    if (r >= R) break;
+    const long long src = row_idx ? row_idx[r] : r;
+    const float4* xr = reinterpret_cast<const float4*>(x + src * ldx);
+    const bf16x4* dyr = reinterpret_cast<const bf16x4*>(dy + (long long)r * lddy);
+    const float mu = mean[r], rs = rstd[r];
+    float4 xh[kMaxChunks], gg[kMaxChunks];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < kMaxChunks; ++c) {
+      const int i = lane + c * 64;
+      if (i < nch) {
+        const float4 xv = xr[i];
+        const bf16x4 d4 = dyr[i];
+        const float4 g = g4[i];
+        const float d0 = (float)d4[0], d1 = (float)d4[1], d2 = (float)d4[2], d3 = (float)d4[3];
+        xh[c] = float4{(xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs};
+        gg[c] = float4{d0 * g.x, d1 * g.y, d2 * g.z, d3 * g.w};
+        s1 += (gg[c].x + gg[c].y) + (gg[c].z + gg[c].w);
+        s2 += (gg[c].x * xh[c].x + gg[c].y * xh[c].y) + (gg[c].z * xh[c].z + gg[c].w * xh[c].w);
+        ag[c].x += d0 * xh[c].x; ag[c].y += d1 * xh[c].y; ag[c].z += d2 * xh[c].z; ag[c].w += d3 * xh[c].w;
+        ab[c].x += d0; ab[c].y += d1; ab[c].z += d2; ab[c].w += d3;
+      }
+    }
+    const float m1 = wsum(s1) / (float)D, m2 = wsum(s2) / (float)D;
+    float4* o = reinterpret_cast<float4*>(dres + src * lddres);
+#pragma unroll
+    for (int c = 0; c < kMaxChunks; ++c) {
+      const int i = lane + c * 64;
+      if (i < nch) {
+        float4 d{rs * (gg[c].x - m1 - xh[c].x * m2), rs * (gg[c].y - m1 - xh[c].y * m2),
+                 rs * (gg[c].z - m1 - xh[c].z * m2), rs * (gg[c].w - m1 - xh[c].w * m2)};
+        if (accumulate) { const float4 p = o[i]; d.x += p.x; d.y += p.y; d.z += p.z; d.w += p.w; }
+        o[i] = d;
+      }
+    }
+  }
+  float4* rg = reinterpret_cast<float4*>(red + (size_t)wave * 2 * D);
+  float4* rb = reinterpret_cast<float4*>(red + (size_t)wave * 2 * D + D);
+#pragma unroll
+  for (int c = 0; c < kMaxChunks; ++c) {
+    const int i = lane + c * 64;
+    if (i < nch) { rg[i] = ag[c]; rb[i] = ab[c]; }
+  }
+  __syncthreads();
+  for (int n = threadIdx.x; n < D; n += 256) {
+    float a = 0.f, b = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) { a += red[(size_t)w * 2 * D + n]; b += red[(size_t)w * 2 * D + D + n]; }
+    atomicAdd(dgamma + n, a);
+    atomicAdd(dbeta + n, b);
+  }
+}
+
+// ---------------------------------------------------------------- residual-branch backward
+// forward (modeling_finetune.py:187-188):  x += (gamma * y / keep) * mask[b]
+// backward: dt = (dx * mask[b]) / keep ; dgamma += sum_m dt * y ; dy = bf16(dt * gamma) ;
+//           dbias += sum_m dy   (the Linear that produced y)
+constexpr int kBrRows = 32;
+
+__global__ __launch_bounds__(256) void branch_bwd_kernel(const float* __restrict__ dx, long long lddx,
+                                                         const __bf16* __restrict__ y, long long ldy,
+                                                         const float* __restrict__ gamma,
+                                                         const float* __restrict__ rowmask, float keep,
+                                                         int rps, int M, int D, __bf16* __restrict__ dyo,
+                                                         long long lddy, float* __restrict__ dgamma,
+                                                         float* __restrict__ dbias) {
+  const int m0 = blockIdx.x * kBrRows;
+  const int m1 = min(M, m0 + kBrRows);
+  for (int c = threadIdx.x * 4; c < D; c += 256 * 4) {
+    float4 g = gamma ? *reinterpret_cast<const float4*>(gamma + c) : float4{1.f, 1.f, 1.f, 1.f};
+    float4 ag{0, 0, 0, 0}, ab{0, 0, 0, 0};
+    for (int m = m0; m < m1; ++m) {
+      float4 d = *reinterpret_cast<const float4*>(dx + (long long)m * lddx + c);
+      if (rowmask) {
+        const float k = rowmask[m / rps];
+        d.x = __fdiv_rn(d.x * k, keep); d.y = __fdiv_rn(d.y * k, keep);
+        d.z = __fdiv_rn(d.z * k, keep); d.w = __fdiv_rn(d.w * k, keep);
+      }
+      const bf16x4 yv = *reinterpret_cast<const bf16x4*>(y + (long long)m * ldy + c);
+      ag.x += d.x * (float)yv[0]; ag.y += d.y * (float)yv[1];
+      ag.z += d.z * (float)yv[2]; ag.w += d.w * (float)yv[3];
+      bf16x4 o;
+      o[0] = (__bf16)(d.x * g.x); o[1] = (__bf16)(d.y * g.y);
+      o[2] = (__bf16)(d.z * g.z); o[3] = (__bf16)(d.w * g.w);
+      *reinterpret_cast<bf16x4*>(dyo + (long long)m * lddy + c) = o;
+      ab.x += (float)o[0]; ab.y += (float)o[1]; ab.z += (float)o[2]; ab.w += (float)o[3];
+    }
+    if (dgamma) {
+      atomicAdd(dgamma + c, ag.x); atomicAdd(dgamma + c + 1, ag.y);
+      atomicAdd(dgamma + c + 2, ag.z); atomicAdd(dgamma + c + 3, ag.w);
+    }
+    if (dbias) {
+      atomicAdd(dbias + c, ab.x); atomicAdd(dbias + c + 1, ab.y);
+      atomicAdd(dbias + c + 2, ab.z); atomicAdd(dbias + c + 3, ab.w);
+    }
+  }
+}
+
+// ---------------------------------------------------------------- patch-embed / token backward
+// forward (modeling_pretrain.py:101-108): row b*(L+1) = cls ; row b*(L+1)+1+p = y*(1-w) + mask_token*w
+// backward: dcls += dx[cls rows]; dmask_token += sum dx*w; dy = bf16(dx*(1-w))
+__global__ __launch_bounds__(256) void embed_bwd_kernel(const float* __restrict__ dx, long long lddx,
+                                                        const unsigned char* __restrict__ mask, int B,
+                                                        int L, int D, __bf16* __restrict__ dy,
+                                                        long long lddy, float* __restrict__ dcls,
+                                                        float* __restrict__ dmask) {
+  const int b = blockIdx.x;
+  for (int c = threadIdx.x * 4; c < D; c += 256 * 4) {
+    const float4 dc = *reinterpret_cast<const float4*>(dx + (long long)b * (L + 1) * lddx + c);
+    atomicAdd(dcls + c, dc.x); atomicAdd(dcls + c + 1, dc.y);
+    atomicAdd(dcls + c + 2, dc.z); atomicAdd(dcls + c + 3, dc.w);
+    float4 am{0, 0, 0, 0};
+    for (int p = 0; p < L; ++p) {
+      const float4 d = *reinterpret_cast<const float4*>(dx + ((long long)b * (L + 1) + 1 + p) * lddx + c);
+      const float w = (float)mask[(long long)b * L + p];
+      am.x += d.x * w; am.y += d.y * w; am.z += d.z * w; am.w += d.w * w;
+      const float u = 1.0f - w;
+      bf16x4 o;
+      o[0] = (__bf16)(d.x * u); o[1] = (__bf16)(d.y * u); o[2] = (__bf16)(d.z * u); o[3] = (__bf16)(d.w * u);
+      *reinterpret_cast<bf16x4*>(dy + ((long long)b * L + p) * lddy + c) = o;
+    }
+    atomicAdd(dmask + c, am.x); atomicAdd(dmask + c + 1, am.y);
+    atomicAdd(dmask + c + 2, am.z); atomicAdd(dmask + c + 3, am.w);
+  }
+}
+
+// ---------------------------------------------------------------- softmax cross-entropy
+// one 256-thread workgroup per masked-token row; logits bf16 (the lm_head output under autocast),
+// statistics in fp32.  Writes the row loss, "argmax == label" and (in place) dlogits = (softmax -
+// onehot) * grad_scale as bf16.
+template <int VPT>   // bf16x8 chunks per thread
+__global__ __launch_bounds__(256) void ce_kernel(__bf16* __restrict__ logits, long long ld,
+                                                 const long long* __restrict__ labels, int V,
+                                                 float grad_scale, float* __restrict__ row_loss,
+                                                 int* __restrict__ row_correct, int write_grad) {
+  __shared__ float sm[4];
+  __shared__ int si[4];
+  __shared__ float bc[2];
+  const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  bf16x8* row = reinterpret_cast<bf16x8*>(logits + (long long)r * ld);
+  const int nch = V >> 3;
+  float v[VPT][8];
+  float mx = -INFINITY;
+  int amax = 0x7fffffff;
+#pragma unroll
+  for (int c = 0; c < VPT; ++c) {
+    const int i = tid + c * 256;
+    if (i < nch) {
+      const bf16x8 t = row[i];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        v[c][k] = (float)t[k];
+        if (v[c][k] > mx) { mx = v[c][k]; amax = i * 8 + k; }   // first index of the max in this thread
+      }
+    }
+  }
+  // (max, smallest index) reduction == torch.max(-1) on CPU (first occurrence)
+  for (int o = 32; o > 0; o >>= 1) {
+    const float om = __shfl_xor(mx, o);
+    const int oi = __shfl_xor(amax, o);
+    if (om > mx || (om == mx && oi < amax)) { mx = om; amax = oi; }
+  }
+  if (lane == 0) { sm[wave] = mx; si[wave] = amax; }
+  __syncthreads();
+  if (tid == 0) {
+    float m = sm[0]; int a = si[0];
+    for (int w = 1; w < 4; ++w) if (sm[w] > m || (sm[w] == m && si[w] < a)) { m = sm[w]; a = si[w]; }
+    bc[0] = m; si[0] = a;
+  }
+  __syncthreads();
+  mx = bc[0];
+  amax = si[0];
+  float s = 0.f;
+#pragma unroll
+  for (int c = 0; c < VPT; ++c) {
+    const int i = tid + c * 256;
+    if (i < nch) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { v[c][k] = __expf(v[c][k] - mx); s += v[c][k]; }
+    }
+  }
+  s = wsum(s);
+  __syncthreads();
+  if (lane == 0) sm[wave] = s;
+  __syncthreads();
+  if (tid == 0) bc[1] = (sm[0] + sm[1]) + (sm[2] + sm[3]);
+  __syncthreads();
+  const float sum = bc[1];
+  const long long lab = labels[r];
+  if (tid == 0) {
+    const float zl = (float)logits[(long long)r * ld + lab];
+    row_loss[r] = (mx + __logf(sum)) - zl;        // -log_softmax[label]
+    row_correct[r] = (amax == (int)lab) ? 1 : 0;
+  }
+  if (write_grad) {
+    const float inv = 1.0f / sum;
+    __syncthreads();                              // tid 0 has read logits[label] before it is overwritten
+#pragma unroll
+    for (int c = 0; c < VPT; ++c) {
+      const int i = tid + c * 256;
+      if (i < nch) {
+        bf16x8 o;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          float p = v[c][k] * inv;
+          if ((long long)(i * 8 + k) == lab) p -= 1.0f;
+          o[k] = (__bf16)(p * grad_scale);
+        }
+        row[i] = o;
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void ce_reduce_kernel(const float* __restrict__ row_loss,
+                                                        const int* __restrict__ row_correct, int M,
+                                                        float* __restrict__ out) {
+  __shared__ double sd[4];
+  __shared__ int sc[4];
+  double s = 0.0;
+  int c = 0;
+  for (int i = threadIdx.x; i < M; i += 256) { s += (double)row_loss[i]; c += row_correct[i]; }
+  for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o); c += __shfl_xor(c, o); }
+  if ((threadIdx.x & 63) == 0) { sd[threadIdx.x >> 6] = s; sc[threadIdx.x >> 6] = c; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const double t = (sd[0] + sd[1]) + (sd[2] + sd[3]);
+    const int k = sc[0] + sc[1] + sc[2] + sc[3];
+    out[0] = (float)(t / (double)M);          // nn.CrossEntropyLoss(reduction="mean")
+    out[1] = (float)k / (float)M;             // mlm_acc
+  }
+}
+
+}  // namespace
+
+extern "C" int memhip_layernorm_fwd(const float* x, int64_t ldx, const int32_t* row_idx, int R, int D,
+                                    const float* gamma, const float* beta, float eps, void* y,
+                                    int64_t ldy, float* mean, float* rstd, memhip_stream_t stream) {
+  MEMHIP_REQUIRE(R >= 0 && D > 0 && D % 4 == 0 && D <= 64 * 4 * kMaxChunks, "layernorm_fwd: bad R=%d D=%d", R, D);
+  if (R == 0) return MEMHIP_OK;
+  MEMHIP_REQUIRE(x && gamma && beta && y && mean && rstd, "layernorm_fwd: null pointer");
+  MEMHIP_REQUIRE(ldx % 4 == 0 && ldy % 4 == 0, "layernorm_fwd: ld must be a multiple of 4");
+  hipLaunchKernelGGL(ln_fwd_kernel, dim3(cdiv(R, 4)), dim3(256), 0, as_stream(stream), x, (long long)ldx,
+                     row_idx, R, D, gamma, beta, eps, (__bf16*)y, (long long)ldy, mean, rstd);
+  return check_launch("layernorm_fwd");
+}
+
+extern "C" int memhip_layernorm_bwd(const void* dy, int64_t lddy, const float* x, int64_t ldx,
+                                    const int32_t* row_idx, int R, int D, const float* gamma,
+                                    const float* mean, const float* rstd, float* dres, int64_t lddres,
+                                    int accumulate, float* dgamma, float* dbeta, memhip_stream_t stream) {
+  MEMHIP_REQUIRE(R >= 0 && D > 0 && D % 4 == 0 && D <= 64 * 4 * kMaxChunks, "layernorm_bwd: bad R=%d D=%d", R, D);
+  if (R == 0) return MEMHIP_OK;
+  MEMHIP_REQUIRE(dy && x && gamma && mean && rstd && dres && dgamma && dbeta, "layernorm_bwd: null pointer");
+  MEMHIP_REQUIRE(ldx % 4 == 0 && lddy % 4 == 0 && lddres % 4 == 0, "layernorm_bwd: ld must be a multiple of 4");
+  const int rows_per_block = 4 * kLnRowsPerWave;
+  hipLaunchKernelGGL(ln_bwd_kernel, dim3(cdiv(R, rows_per_block)), dim3(256), (size_t)8 * D * sizeof(float),
+                     as_stream(stream), (const __bf16*)dy, (long long)lddy, x, (long long)ldx, row_idx, R, D,
+                     gamma, mean, rstd, dres, (long long)lddres, accumulate, dgamma, dbeta);
+  return check_launch("layernorm_bwd");
+}
+
+extern "C" int memhip_branch_bwd(const float* dx, int64_t lddx, const void* y, int64_t ldy,
+                                 const float* gamma, const float* rowmask, float keep_prob,
+                                 int rows_per_sample, int M, int D, void* dy, int64_t lddy,
+                                 float* dgamma, float* dbias, memhip_stream_t stream) {
+  MEMHIP_REQUIRE(M >= 0 && D > 0 && D % 4 == 0, "branch_bwd: bad M=%d D=%d", M, D);
+  if (M == 0) return MEMHIP_OK;
+  MEMHIP_REQUIRE(dx && y && dy, "branch_bwd: null pointer");
+  MEMHIP_REQUIRE(lddx % 4 == 0 && ldy % 4 == 0 && lddy % 4 == 0, "branch_bwd: ld must be a multiple of 4");
+  hipLaunchKernelGGL(branch_bwd_kernel, dim3(cdiv(M, kBrRows)), dim3(256), 0, as_stream(stream), dx,
+                     (long long)lddx, (const __bf16*)y, (long long)ldy, gamma, rowmask, keep_prob,
+                     rows_per_sample > 0 ? rows_per_sample : 1, M, D, (__bf16*)dy, (long long)lddy, dgamma, dbias);
+  return check_launch("branch_bwd");
+}
+
+extern "C" int memhip_embed_bwd(const float* dx, int64_t lddx, const uint8_t* mask, int B, int L, int D,
+                                void* dy, int64_t lddy, float* dcls, float* dmask_token,
+                                memhip_stream_t stream) {
+  MEMHIP_REQUIRE(B >= 0 && L > 0 && D > 0 && D % 4 == 0, "embed_bwd: bad shape");
+  if (B == 0) return MEMHIP_OK;
+  MEMHIP_REQUIRE(dx && mask && dy && dcls && dmask_token, "embed_bwd: null pointer");
+  hipLaunchKernelGGL(embed_bwd_kernel, dim3(B), dim3(256), 0, as_stream(stream), dx, (long long)lddx, mask, B,
+                     L, D, (__bf16*)dy, (long long)lddy, dcls, dmask_token);
+  return check_launch("embed_bwd");
+}
+
+extern "C" int memhip_cross_entropy(void* logits, int64_t ld, const int64_t* labels, int M, int V,
+                                    float grad_scale, float* row_loss, int32_t* row_correct,
+                                    int write_grad, float* out2, memhip_stream_t stream) {
+  MEMHIP_REQUIRE(M >= 0 && V > 0 && V % 8 == 0 && V <= 256 * 8 * 8, "cross_entropy: V=%d unsupported", V);
+  if (M == 0) return MEMHIP_OK;
+  MEMHIP_REQUIRE(logits && labels && row_loss && row_correct && out2, "cross_entropy: null pointer");
+  MEMHIP_REQUIRE(ld % 8 == 0, "cross_entropy: ld must be a multiple of 8");
+  hipStream_t s = as_stream(stream);
+  const int nch = V / 8, vpt = cdiv(nch, 256);
+  __bf16* lg = (__bf16*)logits;
+  const long long* lab = (const long long*)labels;
+#define CE_LAUNCH(N) hipLaunchKernelGGL(ce_kernel<N>, dim3(M), dim3(256), 0, s, lg, (long long)ld, lab, V, \
+                                        grad_scale, row_loss, row_correct, write_grad)
+  if (vpt <= 1) CE_LAUNCH(1);
+  else if (vpt <= 2) CE_LAUNCH(2);
+  else if (vpt <= 4) CE_LAUNCH(4);
+  else CE_LAUNCH(8);
+#undef CE_LAUNCH
+  hipLaunchKernelGGL(ce_reduce_kernel, dim3(1), dim3(256), 0, s, row_loss, row_correct, M, out2);
+  return check_launch("cross_entropy");
+}

@@ -50,3 +50,105 @@ def gemm_nt(A, B, M, N, K, epi, out0=None, out1=None, bias=None, vec1=None, resi
     a.keep_prob, a.colscale, a.colscale_n = keep_prob, colscale, colscale_n
     a.rows_per_sample, a.accumulate = rows_per_sample, int(accumulate)
     check(lib.memhip_gemm_bf16_nt(C.byref(a), stream_ptr()), "gemm_bf16_nt")
+
+
+f64 = C.c_double
+declare({
+    "memhip_layernorm_fwd": (i32, [vp, i64, vp, i32, i32, vp, vp, f32, vp, i64, vp, vp, vp]),
+    "memhip_layernorm_bwd": (i32, [vp, i64, vp, i64, vp, i32, i32, vp, vp, vp, vp, i64, i32, vp, vp, vp]),
+    "memhip_branch_bwd": (i32, [vp, i64, vp, i64, vp, vp, f32, i32, i32, i32, vp, i64, vp, vp, vp]),
+    "memhip_embed_bwd": (i32, [vp, i64, vp, i32, i32, i32, vp, i64, vp, vp, vp]),
+    "memhip_cross_entropy": (i32, [vp, i64, vp, i32, i32, f32, vp, vp, i32, vp, vp]),
+    "memhip_attn_tokens_padded": (i32, [i32]),
+    "memhip_relpos_gather": (i32, [vp, vp, i32, i32, i32, vp, vp]),
+    "memhip_attn_fwd": (i32, [vp, i64, i32, i32, i32, i32, vp, vp, i64, vp, vp]),
+    "memhip_attn_bwd": (i32, [vp, i64, vp, vp, i64, vp, vp, vp, i32, i32, i32, i32, i32, f32, vp, i64, vp, vp]),
+    "memhip_cast_f32_bf16": (i32, [vp, vp, i64, vp]),
+    "memhip_transpose_cast_f32_bf16": (i32, [vp, i64, i32, i32, vp, i64, vp]),
+    "memhip_transpose_bf16": (i32, [vp, i64, i32, i32, vp, i64, i32, vp, i32, i32, vp, i32, i32, vp]),
+    "memhip_im2col_bf16": (i32, [vp, i32, i32, i32, i32, i32, i32, vp, vp]),
+    "memhip_fill_cls": (i32, [vp, i64, i32, i32, i32, vp, vp]),
+    "memhip_grad_norm_workspace": (sz, []),
+    "memhip_grad_norm": (i32, [vp, i64, vp, vp, sz, vp]),
+    "memhip_adamw": (i32, [vp, vp, vp, vp, i64, vp, f64, f64, f64, f64, f64, i32, vp, f64, vp]),
+})
+
+
+def layernorm_fwd(x, gamma, beta, y, mean, rstd, R, D, eps=1e-6, row_idx=None):
+    check(lib.memhip_layernorm_fwd(ptr(x), x.stride(0), ptr(row_idx), R, D, ptr(gamma), ptr(beta), eps,
+                                   ptr(y), y.stride(0), ptr(mean), ptr(rstd), stream_ptr()), "layernorm_fwd")
+
+
+def layernorm_bwd(dy, x, gamma, mean, rstd, dres, dgamma, dbeta, R, D, accumulate=True, row_idx=None):
+    check(lib.memhip_layernorm_bwd(ptr(dy), dy.stride(0), ptr(x), x.stride(0), ptr(row_idx), R, D, ptr(gamma),
+                                   ptr(mean), ptr(rstd), ptr(dres), dres.stride(0), int(accumulate),
+                                   ptr(dgamma), ptr(dbeta), stream_ptr()), "layernorm_bwd")
+
+
+def branch_bwd(dx, y, gamma, dy, dgamma, dbias, M, D, rowmask=None, keep_prob=1.0, rows_per_sample=1):
+    check(lib.memhip_branch_bwd(ptr(dx), dx.stride(0), ptr(y), y.stride(0), ptr(gamma), ptr(rowmask), keep_prob,
+                                rows_per_sample, M, D, ptr(dy), dy.stride(0), ptr(dgamma), ptr(dbias),
+                                stream_ptr()), "branch_bwd")
+
+
+def embed_bwd(dx, mask_u8, B, L, D, dy, dcls, dmask_token):
+    check(lib.memhip_embed_bwd(ptr(dx), dx.stride(0), ptr(mask_u8), B, L, D, ptr(dy), dy.stride(0), ptr(dcls),
+                               ptr(dmask_token), stream_ptr()), "embed_bwd")
+
+
+def cross_entropy(logits, labels, M, V, grad_scale, row_loss, row_correct, out2, write_grad=True):
+    check(lib.memhip_cross_entropy(ptr(logits), logits.stride(0), ptr(labels), M, V, grad_scale, ptr(row_loss),
+                                   ptr(row_correct), int(write_grad), ptr(out2), stream_ptr()), "cross_entropy")
+
+
+def attn_tokens_padded(T):
+    return lib.memhip_attn_tokens_padded(T)
+
+
+def relpos_gather(table, index_i32, T, TP, heads, bias_pad):
+    check(lib.memhip_relpos_gather(ptr(table), ptr(index_i32), T, TP, heads, ptr(bias_pad), stream_ptr()),
+          "relpos_gather")
+
+
+def attn_fwd(qkv, B, T, D, heads, bias_pad, out, lse):
+    check(lib.memhip_attn_fwd(ptr(qkv), qkv.stride(0), B, T, D, heads, ptr(bias_pad), ptr(out), out.stride(0),
+                              ptr(lse), stream_ptr()), "attn_fwd")
+
+
+def attn_bwd(qkv, dout, out, lse, bias_pad, relidx_pad, num_rel, B, T, D, heads, scale, dqkv, dtable):
+    check(lib.memhip_attn_bwd(ptr(qkv), qkv.stride(0), ptr(dout), ptr(out), out.stride(0), ptr(lse),
+                              ptr(bias_pad), ptr(relidx_pad), num_rel, B, T, D, heads, scale, ptr(dqkv),
+                              dqkv.stride(0), ptr(dtable), stream_ptr()), "attn_bwd")
+
+
+def cast_f32_bf16(src, dst, n):
+    check(lib.memhip_cast_f32_bf16(ptr(src), ptr(dst), n, stream_ptr()), "cast")
+
+
+def transpose_cast(src_f32, R, Cc, dst_bf16, ldout=None):
+    check(lib.memhip_transpose_cast_f32_bf16(ptr(src_f32), src_f32.stride(0), R, Cc, ptr(dst_bf16),
+                                             dst_bf16.stride(0) if ldout is None else ldout, stream_ptr()),
+          "transpose_cast")
+
+
+def transpose_bf16(src, R, Cc, dst, R_pad, colsum0=None, c0=(0, 0), colsum1=None, c1=(0, 0)):
+    check(lib.memhip_transpose_bf16(ptr(src), src.stride(0), R, Cc, ptr(dst), dst.stride(0), R_pad, ptr(colsum0),
+                                    c0[0], c0[1], ptr(colsum1), c1[0], c1[1], stream_ptr()), "transpose_bf16")
+
+
+def im2col(x, B, Cc, H, W, ph, pw, out):
+    check(lib.memhip_im2col_bf16(ptr(x), B, Cc, H, W, ph, pw, ptr(out), stream_ptr()), "im2col")
+
+
+def fill_cls(x, B, T, D, cls):
+    check(lib.memhip_fill_cls(ptr(x), x.stride(0), B, T, D, ptr(cls), stream_ptr()), "fill_cls")
+
+
+def grad_norm(g, n, norm_out, ws):
+    check(lib.memhip_grad_norm(ptr(g), n, ptr(norm_out), ptr(ws), ws.numel() * ws.element_size(), stream_ptr()),
+          "grad_norm")
+
+
+def adamw(p, g, m, v, n, wd_flags, lr, beta1, beta2, eps, wd, step, gnorm=None, max_norm=0.0):
+    check(lib.memhip_adamw(ptr(p), ptr(g), ptr(m), ptr(v), n, ptr(wd_flags), lr, beta1, beta2, eps, wd, step,
+                           ptr(gnorm), max_norm if max_norm else 0.0, stream_ptr()), "adamw")

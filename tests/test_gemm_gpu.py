@@ -72,7 +72,8 @@ def test_residual_epilogue_with_droppath():
                     keep_prob=kp, rows_per_sample=T)
         t = gamma * y.float()
         if mask is not None:
-            t = t.div(kp) * mask.repeat_interleave(T).view(-1, 1)
+            # true division like the CPU reference (torch-GPU multiplies by a reciprocal instead)
+            t = (t.cpu().div(kp) * mask.cpu().repeat_interleave(T).view(-1, 1)).cuda()
         torch.testing.assert_close(x, x0 + t, rtol=0, atol=0)          # fp32 tail is exact given y
         torch.testing.assert_close(y.float(), (A.float() @ B.float().t() + bias).bfloat16().float(), rtol=2e-2, atol=2e-2)
 

@@ -1,0 +1,231 @@
+"""-m gpu: every non-GEMM ViT kernel against a plain torch fp32 reference of the same op."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _rand(shape, seed, scale=1.0):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    return torch.randn(shape, generator=g, device="cuda") * scale
+
+
+@pytest.mark.parametrize("R,D", [(394, 768), (50, 128), (197 * 3 + 1, 1024)])
+def test_layernorm_fwd_bwd(R, D):
+    from mem_amd import ops
+    x = _rand((R + 5, D), 1, 2.0) + 0.5
+    gamma, beta = 1 + _rand((D,), 2, 0.1), _rand((D,), 3, 0.1)
+    y = torch.zeros((R, D), dtype=torch.bfloat16, device="cuda")
+    mean, rstd = torch.zeros(R, device="cuda"), torch.zeros(R, device="cuda")
+    ops.layernorm_fwd(x, gamma, beta, y, mean, rstd, R, D)
+    xr = x[:R].clone().requires_grad_(True)
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    ref = F.layer_norm(xr, (D,), gr, br, 1e-6)
+    torch.testing.assert_close(y.float(), ref.bfloat16().float(), rtol=1e-2, atol=1e-2)
+    torch.testing.assert_close(mean, x[:R].mean(1), rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(rstd, 1 / torch.sqrt(x[:R].var(1, unbiased=False) + 1e-6), rtol=1e-4, atol=1e-5)
+    dy = _rand((R, D), 4).bfloat16()
+    ref.backward(dy.float())
+    dres0 = _rand((R + 5, D), 5)
+    dres = dres0.clone()
+    dg, db = torch.zeros(D, device="cuda"), torch.zeros(D, device="cuda")
+    ops.layernorm_bwd(dy, x, gamma, mean, rstd, dres, dg, db, R, D, accumulate=True)
+    torch.testing.assert_close(dres[:R] - dres0[:R], xr.grad, rtol=1e-3, atol=2e-4)
+    assert torch.equal(dres[R:], dres0[R:])
+    torch.testing.assert_close(dg, gr.grad, rtol=2e-3, atol=2e-3)
+    torch.testing.assert_close(db, br.grad, rtol=2e-3, atol=2e-3)
+
+
+def test_layernorm_gathered_rows():
+    from mem_amd import ops
+    Rin, D = 400, 256
+    x = _rand((Rin, D), 6)
+    gamma, beta = 1 + _rand((D,), 7, 0.1), _rand((D,), 8, 0.1)
+    idx = torch.tensor([3, 399, 17, 18, 250, 1], dtype=torch.int32, device="cuda")
+    R = idx.numel()
+    y = torch.zeros((R, D), dtype=torch.bfloat16, device="cuda")
+    mean, rstd = torch.zeros(R, device="cuda"), torch.zeros(R, device="cuda")
+    ops.layernorm_fwd(x, gamma, beta, y, mean, rstd, R, D, row_idx=idx)
+    ref = F.layer_norm(x[idx.long()], (D,), gamma, beta, 1e-6)
+    torch.testing.assert_close(y.float(), ref.bfloat16().float(), rtol=1e-2, atol=1e-2)
+    dy = _rand((R, D), 9).bfloat16()
+    dres = torch.zeros((Rin, D), device="cuda")
+    dg, db = torch.zeros(D, device="cuda"), torch.zeros(D, device="cuda")
+    ops.layernorm_bwd(dy, x, gamma, mean, rstd, dres, dg, db, R, D, accumulate=False, row_idx=idx)
+    xr = x.clone().requires_grad_(True)
+    F.layer_norm(xr[idx.long()], (D,), gamma, beta, 1e-6).backward(dy.float())
+    torch.testing.assert_close(dres, xr.grad, rtol=1e-3, atol=2e-4)
+
+
+def test_branch_bwd():
+    from mem_amd import ops
+    T, Bn, D = 17, 7, 256
+    M = T * Bn
+    dx, y, gamma = _rand((M, D), 10), _rand((M, D), 11).bfloat16(), _rand((D,), 12, 0.2)
+    keep = (torch.arange(Bn, device="cuda") % 2 == 0).float()
+    for mask, kp in ((None, 1.0), (keep, 0.8)):
+        dy = torch.zeros((M, D), dtype=torch.bfloat16, device="cuda")
+        dg, db = torch.zeros(D, device="cuda"), torch.zeros(D, device="cuda")
+        ops.branch_bwd(dx, y, gamma, dy, dg, db, M, D, rowmask=mask, keep_prob=kp, rows_per_sample=T)
+        dt = dx if mask is None else dx * mask.repeat_interleave(T).view(-1, 1) / kp
+        torch.testing.assert_close(dy.float(), (dt * gamma).bfloat16().float(), rtol=1e-2, atol=1e-3)
+        torch.testing.assert_close(dg, (dt * y.float()).sum(0), rtol=1e-3, atol=1e-3)
+        torch.testing.assert_close(db, dy.float().sum(0), rtol=1e-3, atol=1e-3)
+
+
+def test_embed_bwd_and_fill_cls_and_im2col():
+    from mem_amd import ops
+    Bn, L, D = 4, 16, 128
+    dx = _rand((Bn * (L + 1), D), 13)
+    mask = (torch.rand((Bn * L,), device="cuda") < 0.5).to(torch.uint8)
+    dy = torch.zeros((Bn * L, D), dtype=torch.bfloat16, device="cuda")
+    dcls, dmt = torch.zeros(D, device="cuda"), torch.zeros(D, device="cuda")
+    ops.embed_bwd(dx, mask, Bn, L, D, dy, dcls, dmt)
+    d3 = dx.view(Bn, L + 1, D)
+    w = mask.float().view(Bn, L, 1)
+    torch.testing.assert_close(dcls, d3[:, 0].sum(0), rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(dmt, (d3[:, 1:] * w).sum((0, 1)), rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(dy.float().view(Bn, L, D), (d3[:, 1:] * (1 - w)).bfloat16().float(), rtol=0, atol=0)
+    x = torch.zeros((Bn * (L + 1), D), device="cuda")
+    cls = _rand((D,), 14)
+    ops.fill_cls(x, Bn, L + 1, D, cls)
+    assert torch.equal(x.view(Bn, L + 1, D)[:, 0], cls.expand(Bn, D)) and x.view(Bn, L + 1, D)[:, 1:].abs().sum() == 0
+    img = _rand((3, 2, 64, 48), 15)
+    out = torch.zeros((3 * 4 * 3, 2 * 256), dtype=torch.bfloat16, device="cuda")
+    ops.im2col(img, 3, 2, 64, 48, 16, 16, out)
+    ref = F.unfold(img, kernel_size=16, stride=16).transpose(1, 2).reshape(3 * 12, 512)
+    torch.testing.assert_close(out.float(), ref.bfloat16().float(), rtol=0, atol=0)
+
+
+@pytest.mark.parametrize("M,V", [(600, 8192), (37, 512), (5, 1024)])
+def test_cross_entropy(M, V):
+    from mem_amd import ops
+    logits = (_rand((M, V), 16, 2.0)).bfloat16()
+    labels = torch.randint(0, V, (M,), device="cuda")
+    logits[0, labels[0]] = 30.0            # a surely-correct row
+    lg = logits.clone()
+    row_loss, row_ok = torch.zeros(M, device="cuda"), torch.zeros(M, dtype=torch.int32, device="cuda")
+    out2 = torch.zeros(2, device="cuda")
+    ops.cross_entropy(lg, labels, M, V, 1.0 / M, row_loss, row_ok, out2)
+    lr_ = logits.float().requires_grad_(True)
+    loss = F.cross_entropy(lr_, labels)
+    loss.backward()
+    torch.testing.assert_close(out2[0], loss.detach(), rtol=1e-5, atol=1e-5)
+    acc = (logits.float().cpu().max(-1)[1] == labels.cpu()).float().mean()
+    assert abs(out2[1].item() - acc.item()) < 1e-6
+    torch.testing.assert_close(lg.float(), lr_.grad.bfloat16().float(), rtol=2e-2, atol=1e-7)
+
+
+def _attn_ref(qkv, bias, B, T, D, H, scale):
+    """reference attention in fp32 with the autocast rounding points (bf16 matmul outputs)."""
+    q, k, v = qkv.float().view(B, T, 3, H, 64).permute(2, 0, 3, 1, 4)
+    s = (q @ k.transpose(-2, -1)).bfloat16().float() + bias
+    p = s.softmax(-1)
+    o = (p.bfloat16().float() @ v).bfloat16()
+    return o.transpose(1, 2).reshape(B * T, D), p
+
+
+@pytest.mark.parametrize("B,T,H", [(3, 197, 12), (2, 17, 2), (2, 65, 4), (1, 256, 2)])
+def test_attention_fwd_bwd(B, T, H):
+    from mem_amd import ops
+    from oracle.vit_ref import rel_pos_index
+    D = 64 * H
+    scale = 0.125
+    TP = ops.attn_tokens_padded(T)
+    qkv = _rand((B * T, 3 * D), 20, 1.0)
+    qkv[:, :D] *= scale
+    qkv = qkv.bfloat16()
+    side = int(math.isqrt(T - 1))
+    if side * side == T - 1:
+        idx, nrd = rel_pos_index((side, side))
+        idx = idx.cuda()
+    else:
+        nrd = 50
+        idx = torch.randint(0, nrd, (T, T), device="cuda")
+    table = _rand((nrd, H), 21, 0.5)
+    bias_pad = torch.zeros((H, TP, TP), device="cuda")
+    ops.relpos_gather(table, idx.int().contiguous(), T, TP, H, bias_pad)
+    bias = table[idx.view(-1)].view(T, T, H).permute(2, 0, 1).contiguous()
+    assert torch.equal(bias_pad[:, :T, :T], bias) and bias_pad[:, T:].abs().sum() == 0
+    out = torch.zeros((B * T, D), dtype=torch.bfloat16, device="cuda")
+    lse = torch.zeros((B, H, TP), device="cuda")
+    ops.attn_fwd(qkv, B, T, D, H, bias_pad, out, lse)
+    ref, p = _attn_ref(qkv, bias, B, T, D, H, scale)
+    torch.testing.assert_close(out.float(), ref.float(), rtol=2e-2, atol=2e-2)
+    q, k, _ = qkv.float().view(B, T, 3, H, 64).permute(2, 0, 3, 1, 4)
+    s = (q @ k.transpose(-2, -1)).bfloat16().float() + bias
+    torch.testing.assert_close(lse[:, :, :T], torch.logsumexp(s, -1), rtol=1e-4, atol=1e-4)
+    # ---- backward against autograd through the same rounded-op reference
+    dout = _rand((B * T, D), 22, 1.0).bfloat16()
+    qf = qkv.float().requires_grad_(True)
+    tb = table.clone().requires_grad_(True)
+    bb = tb[idx.view(-1)].view(T, T, H).permute(2, 0, 1)
+    q, k, v = qf.view(B, T, 3, H, 64).permute(2, 0, 3, 1, 4)
+    o = ((q @ k.transpose(-2, -1)) + bb).softmax(-1) @ v
+    o.transpose(1, 2).reshape(B * T, D).backward(dout.float())
+    dqkv = torch.zeros((B * T, 3 * D), dtype=torch.bfloat16, device="cuda")
+    dtable = torch.zeros((nrd, H), device="cuda")
+    relidx_pad = torch.full((TP, TP), -1, dtype=torch.int32, device="cuda")
+    relidx_pad[:T, :T] = idx.int()
+    ops.attn_bwd(qkv, dout, out, lse, bias_pad, relidx_pad, nrd, B, T, D, H, scale, dqkv, dtable)
+    g = qf.grad.clone()
+    g[:, :D] *= scale          # kernel returns d(q_lin) = d(q') * scale
+    err = (dqkv.float() - g).abs().max().item()
+    assert err < 0.05 * g.abs().max().item() + 1e-3, err
+    rel = (dqkv.float() - g).norm() / g.norm()
+    assert rel < 2e-2, rel
+    relb = (dtable - tb.grad).norm() / tb.grad.norm()
+    assert relb < 2e-2, relb
+
+
+def test_cast_and_transposes():
+    from mem_amd import ops
+    w = _rand((2304, 768), 30)
+    flat = torch.zeros(2304 * 768, dtype=torch.bfloat16, device="cuda")
+    ops.cast_f32_bf16(w, flat, w.numel())
+    assert torch.equal(flat.view(2304, 768), w.bfloat16())
+    wt = torch.zeros((768, 2304), dtype=torch.bfloat16, device="cuda")
+    ops.transpose_cast(w, 2304, 768, wt)
+    assert torch.equal(wt, w.bfloat16().t().contiguous())
+    R, Cc = 394, 2304
+    Rp = 448
+    a = _rand((R, Cc), 31).bfloat16()
+    at = torch.full((Cc, Rp), 9.0, dtype=torch.bfloat16, device="cuda")
+    cs0, cs1 = torch.zeros(768, device="cuda"), torch.zeros(768, device="cuda")
+    ops.transpose_bf16(a, R, Cc, at, Rp, cs0, (0, 768), cs1, (1536, 2304))
+    assert torch.equal(at[:, :R], a.t().contiguous()) and at[:, R:].abs().sum() == 0
+    torch.testing.assert_close(cs0, a[:, :768].float().sum(0), rtol=1e-4, atol=1e-3)
+    torch.testing.assert_close(cs1, a[:, 1536:].float().sum(0), rtol=1e-4, atol=1e-3)
+
+
+def test_grad_norm_and_adamw_match_torch():
+    from mem_amd import ops
+    n = 1024 * 37
+    p0, g = _rand((n,), 40), _rand((n,), 41, 3.0)
+    flags = torch.zeros(n // 1024, dtype=torch.uint8, device="cuda")
+    flags[::2] = 1
+    ws = torch.zeros(1024, dtype=torch.float64, device="cuda")
+    norm = torch.zeros(1, device="cuda")
+    ops.grad_norm(g, n, norm, ws)
+    torch.testing.assert_close(norm[0], g.double().norm().float(), rtol=1e-6, atol=0)
+    # torch reference on CPU (true-division semantics), two param groups
+    pc = p0.cpu().clone()
+    dec = flags.cpu().bool().repeat_interleave(1024)
+    pa, pb = torch.nn.Parameter(pc[dec].clone()), torch.nn.Parameter(pc[~dec].clone())
+    opt = torch.optim.AdamW([{"params": [pa], "weight_decay": 0.05}, {"params": [pb], "weight_decay": 0.0}],
+                            lr=5e-4, betas=(0.9, 0.95), eps=1e-8)
+    p, m, v = p0.clone(), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    for step in range(1, 4):
+        gs = g * step
+        ops.grad_norm(gs, n, norm, ws)
+        ops.adamw(p, gs, m, v, n, flags, 5e-4, 0.9, 0.95, 1e-8, 0.05, step, gnorm=norm, max_norm=30.0)
+        gc = gs.cpu()
+        pa.grad, pb.grad = gc[dec].clone(), gc[~dec].clone()
+        torch.nn.utils.clip_grad_norm_([pa, pb], 30.0)
+        opt.step()
+    got = p.cpu()
+    torch.testing.assert_close(got[dec], pa.detach(), rtol=2e-6, atol=2e-7)
+    torch.testing.assert_close(got[~dec], pb.detach(), rtol=2e-6, atol=2e-7)
