@@ -152,7 +152,7 @@ int memhip_mask_random_location(uint32_t* mt_state, int H, int W, int num_maskin
  */
 #define MEMHIP_EPI_BIAS_BF16 0   /* out0 bf16 = bf16(acc+bias); cols < colscale_n then *= colscale (q*scale, :137) */
 #define MEMHIP_EPI_BIAS_GELU 1   /* out0 bf16 = h = bf16(acc+bias); out1 bf16 = gelu(h)       (:66-68) */
-#define MEMHIP_EPI_RESIDUAL 2    /* y=bf16(acc+bias) -> out0 (may be NULL); resid f32 += drop_path(vec1*y) (:187-188) */
+#define MEMHIP_EPI_RESIDUAL 2    /* y=bf16(acc+bias) -> out0 (may be NULL); resid f32 = (aux f32 or resid) + drop_path(vec1*y) (:187-188) */
 #define MEMHIP_EPI_DGELU 3       /* out0 bf16 = bf16(acc) * gelu'(aux bf16)                   (GELU backward) */
 #define MEMHIP_EPI_F32 4         /* out0 f32 (+)= acc                                         (weight gradients) */
 #define MEMHIP_EPI_PATCH_EMBED 5 /* resid f32[b*(L+1)+1+p] = bf16(acc+bias)*(1-w) + vec1*w    (modeling_pretrain.py:101-108) */
@@ -165,7 +165,8 @@ typedef struct memhip_gemm_args {
   const float* bias;      /* [N] fp32 or NULL */
   const float* vec1;      /* RESIDUAL: layer-scale gamma [N] (NULL = none); PATCH_EMBED: mask_token [N] */
   float* resid; int64_t ldr;   /* fp32 residual stream */
-  const void* aux; int64_t ldaux; /* DGELU: pre-activation bf16 [M,N]; PATCH_EMBED: mask u8 [M] */
+  const void* aux; int64_t ldaux; /* DGELU: pre-activation bf16 [M,N]; PATCH_EMBED: mask u8 [M];
+                                     RESIDUAL: residual INPUT f32 [M,N] (NULL = resid in place) */
   const float* rowmask;   /* RESIDUAL: stochastic-depth keep mask per sample (0/1), NULL = off */
   float keep_prob;        /* RESIDUAL: 1 - drop_prob */
   float colscale; int32_t colscale_n;

@@ -52,8 +52,10 @@ __device__ __forceinline__ void epilogue(const GemmArgs& p, int m, int n, float 
     if (p.out0) reinterpret_cast<__bf16*>(p.out0)[(long long)m * p.ldo0 + n] = y;
     float t = p.vec1 ? __fmul_rn(vec_n, (float)y) : (float)y;            // gamma * branch
     if (p.rowmask) t = __fmul_rn(__fdiv_rn(t, p.keep_prob), p.rowmask[m / p.rows_per_sample]);
-    float* x = p.resid + (long long)m * p.ldr + n;
-    *x = __fadd_rn(*x, t);
+    // residual input: aux (fp32, ldaux) when given, else in place
+    const float xin = p.aux ? reinterpret_cast<const float*>(p.aux)[(long long)m * p.ldaux + n]
+                            : p.resid[(long long)m * p.ldr + n];
+    p.resid[(long long)m * p.ldr + n] = __fadd_rn(xin, t);
   } else if constexpr (EPI == MEMHIP_EPI_DGELU) {
     const float da = bf16_round(acc);
     const float h = (float)reinterpret_cast<const __bf16*>(p.aux)[(long long)m * p.ldaux + n];

@@ -1,0 +1,351 @@
+"""ViTEngine -- the fused HIP forward/backward pipeline behind
+VisionTransformerForMaskedImageModeling (reference arithmetic: mem/modeling_pretrain.py:97-126 +
+mem/modeling_finetune.py:128-189 + nn.CrossEntropyLoss, mem/engine_for_pretraining.py:152).
+
+MI355X-first structure (not an autograd graph):
+  * all parameters live in ONE flat fp32 buffer (tensors padded to 1024 elements, laid out in
+    reverse-layer order so gradient buckets become ready -- and can be all-reduced over RCCL --
+    in the order backward produces them); gradients and both Adam moments are flat twins.
+    nn.Parameter objects are views into it, so state_dict()/checkpoints keep the reference keys.
+  * bf16 shadow weights (plus [in,out]-major copies for dgrad) are re-derived from the fp32
+    masters once per step by a streaming cast.
+  * activations are pre-allocated per batch size (288 GB of HBM: ~1.6 GB per ViT-B block at
+    B=256), every op is a hand-written HIP kernel from libmemhip.so enqueued on the current
+    stream; there is no host synchronisation inside forward/backward.
+  * precision policy == the reference under autocast: bf16 GEMM operands with fp32 accumulate,
+    fp32 residual stream / LayerNorm statistics / softmax / loss / optimizer.
+"""
+import math
+
+import torch
+
+from . import ops
+
+ALIGN = 1024
+
+
+def _pad(n, a):
+    return (n + a - 1) // a * a
+
+
+class ViTEngine:
+    def __init__(self, model):
+        self.model = model
+        p0 = next(model.parameters())
+        assert p0.is_cuda, "mem_amd runs on the GPU only: move the model to cuda first (no CPU fallback)"
+        self.dev = p0.device
+        pe = model.patch_embed
+        self.C = pe.proj.weight.shape[1]
+        self.ph, self.pw = pe.patch_size
+        self.H, self.W = pe.img_size
+        self.L = pe.num_patches
+        self.T = self.L + 1
+        self.D = model.embed_dim
+        self.depth = len(model.blocks)
+        self.heads = model.blocks[0].attn.num_heads
+        self.scale = float(model.blocks[0].attn.scale)
+        self.hidden = model.blocks[0].mlp.fc1.weight.shape[0]
+        self.V = model.lm_head.weight.shape[0]
+        self.Kpe = self.C * self.ph * self.pw
+        assert self.D % 64 == 0 and self.hidden % 64 == 0 and self.Kpe % 64 == 0, "GEMM K dims must be multiples of 64"
+        assert model.pos_embed is None, "use_abs_pos_emb is off in every pretraining config; not in the fused path"
+        assert model.rel_pos_bias is not None, "fused attention expects the shared relative position bias"
+        self.TP = ops.attn_tokens_padded(self.T)
+        self.nrd = model.rel_pos_bias.num_relative_distance
+        self._pack_parameters()
+        self._build_static()
+        self.B = 0
+        self.step_masks = None
+        self.weights_dirty = True
+        self.grad_hook = None            # called as grad_hook(bucket_index) when a bucket's grads are final
+
+    # ------------------------------------------------------------------ parameter packing
+    def _pack_parameters(self):
+        m = self.model
+        named = dict(m.named_parameters())
+        skip = m.no_weight_decay()
+        order = []                                    # (bucket, [names]) in reverse-layer order
+        order.append(("head", ["lm_head.weight", "lm_head.bias", "norm.weight", "norm.bias"]))
+        for i in reversed(range(self.depth)):
+            pre = f"blocks.{i}."
+            names = [pre + n for n in ("mlp.fc2.weight", "mlp.fc2.bias", "gamma_2", "mlp.fc1.weight", "mlp.fc1.bias",
+                                       "norm2.weight", "norm2.bias", "attn.proj.weight", "attn.proj.bias", "gamma_1",
+                                       "attn.qkv.weight", "QKVBIAS", "norm1.weight", "norm1.bias")]
+            order.append((f"block{i}", names))
+        order.append(("embed", ["rel_pos_bias.relative_position_bias_table", "patch_embed.proj.weight",
+                                "patch_embed.proj.bias", "mask_token", "cls_token"]))
+        segs, off = {}, 0
+        buckets, flags = [], []
+        for bname, names in order:
+            b0 = off
+            for n in names:
+                if n.endswith("QKVBIAS"):
+                    pre = n[: -len("QKVBIAS")]
+                    D = self.D
+                    segs[pre + "attn.q_bias"] = (off, D)
+                    segs[pre + "attn.v_bias"] = (off + 2 * D, D)
+                    segs[pre + "attn.qkvbias3"] = (off, 3 * D)          # [q_bias | 0 | v_bias]
+                    size = _pad(3 * D, ALIGN)
+                    flags += [0] * (size // ALIGN)
+                    off += size
+                    continue
+                if n not in named:
+                    continue                                           # gamma_* absent when layer scale is off
+                p = named[n]
+                segs[n] = (off, p.numel())
+                size = _pad(p.numel(), ALIGN)
+                decay = not (p.ndim == 1 or n.endswith(".bias") or n in skip)   # optim_factory.py:63
+                flags += [1 if decay else 0] * (size // ALIGN)
+                off += size
+            buckets.append((bname, b0, off))
+        missing = [n for n in named if n not in segs]
+        assert not missing, f"parameters not placed in the flat buffer: {missing}"
+        self.nflat = off
+        self.segs, self.buckets = segs, buckets
+        self.flat_p = torch.zeros(off, dtype=torch.float32, device=self.dev)
+        self.flat_g = torch.zeros(off, dtype=torch.float32, device=self.dev)
+        self.flat_w16 = torch.zeros(off, dtype=torch.bfloat16, device=self.dev)
+        self.wd_flags = torch.tensor(flags, dtype=torch.uint8, device=self.dev)
+        self.decay_names = [n for n, p in named.items() if not (p.ndim == 1 or n.endswith(".bias") or n in skip)]
+        self.no_decay_names = [n for n in named if n not in set(self.decay_names)]
+        for n, p in named.items():
+            o, k = segs[n]
+            view = self.flat_p[o:o + k].view(p.shape)
+            view.copy_(p.data)
+            p.data = view
+            p.grad = self.flat_g[o:o + k].view(p.shape)
+        self.named = named
+
+    def attach_grads(self):
+        """Re-point p.grad at the flat gradient buffer (zero_grad(set_to_none=True) drops them)."""
+        for n, p in self.named.items():
+            o, k = self.segs[n]
+            g = p.grad
+            if g is None or g.data_ptr() != self.flat_g.data_ptr() + 4 * o:
+                p.grad = self.flat_g[o:o + k].view(p.shape)
+
+    def P(self, name):           # fp32 master view
+        o, k = self.segs[name]
+        return self.flat_p[o:o + k]
+
+    def G(self, name):           # fp32 gradient view
+        o, k = self.segs[name]
+        return self.flat_g[o:o + k]
+
+    def W16(self, name, rows, cols):   # bf16 shadow as a [rows, cols] matrix
+        o, k = self.segs[name]
+        return self.flat_w16[o:o + k].view(rows, cols)
+
+    def _build_static(self):
+        D, Hd, V, dev = self.D, self.hidden, self.V, self.dev
+        bf = torch.bfloat16
+        self.wT = {}
+        for i in range(self.depth):
+            self.wT[i] = dict(qkv=torch.empty((D, 3 * D), dtype=bf, device=dev),
+                              proj=torch.empty((D, D), dtype=bf, device=dev),
+                              fc1=torch.empty((D, Hd), dtype=bf, device=dev),
+                              fc2=torch.empty((Hd, D), dtype=bf, device=dev))
+        self.wT_lm = torch.empty((D, V), dtype=bf, device=dev)
+        idx = self.model.rel_pos_bias.relative_position_index.to(dev)
+        self.relidx = idx.to(torch.int32).contiguous()
+        self.relidx_pad = torch.full((self.TP, self.TP), -1, dtype=torch.int32, device=dev)
+        self.relidx_pad[: self.T, : self.T] = self.relidx
+        self.bias_pad = torch.zeros((self.heads, self.TP, self.TP), dtype=torch.float32, device=dev)
+        self.gn_ws = torch.zeros(1024, dtype=torch.float64, device=dev)
+        self.gnorm = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.loss_acc = torch.zeros(2, dtype=torch.float32, device=dev)
+
+    # ------------------------------------------------------------------ buffers per batch size
+    def ensure_batch(self, B, Mm_max):
+        if B <= self.B and Mm_max <= getattr(self, "Mm_cap", 0):
+            return
+        B = max(B, self.B)
+        Mm_cap = max(Mm_max, getattr(self, "Mm_cap", 0))
+        dev, bf, f32 = self.dev, torch.bfloat16, torch.float32
+        D, Hd, T, V = self.D, self.hidden, self.T, self.V
+        M = B * T
+        Mp = _pad(M, 64)
+        e = lambda *s, dt=bf: torch.empty(s, dtype=dt, device=dev)   # noqa: E731
+        self.patches = e(B * self.L, self.Kpe)
+        self.x = [torch.zeros((M, D), dtype=f32, device=dev) for _ in range(2 * self.depth + 1)]
+        self.act = []
+        for _ in range(self.depth):
+            self.act.append(dict(h1=e(M, D), qkv=e(M, 3 * D), ao=e(M, D), y1=e(M, D), h2=e(M, D), hpre=e(M, Hd),
+                                 a=e(M, Hd), y2=e(M, D), lse=e(B, self.heads, self.TP, dt=f32),
+                                 mean1=e(M, dt=f32), rstd1=e(M, dt=f32), mean2=e(M, dt=f32), rstd2=e(M, dt=f32)))
+        # head
+        self.hN = e(Mm_cap, D)
+        self.meanN, self.rstdN = e(Mm_cap, dt=f32), e(Mm_cap, dt=f32)
+        self.logits = e(Mm_cap, V)
+        self.row_loss, self.row_ok = e(Mm_cap, dt=f32), torch.empty(Mm_cap, dtype=torch.int32, device=dev)
+        self.dhN = e(Mm_cap, D)
+        # backward temporaries (shared by all blocks)
+        self.dx = torch.zeros((M, D), dtype=f32, device=dev)
+        self.dY, self.dh_small = e(M, D), e(M, D)
+        self.dbig = e(M, Hd)
+        self.dqkv = e(M, 3 * D)
+        self.dao = e(M, D)
+        self.dYpe = e(B * self.L, D)
+        Mmp = _pad(Mm_cap, 64)
+        BLp = _pad(B * self.L, 64)
+        self.tA = e(max(max(Hd, 3 * D) * Mp, V * Mmp, D * BLp))
+        self.tB = e(max(Hd * Mp, D * Mmp, self.Kpe * BLp))
+        self.B, self.Mm_cap = B, Mm_cap
+
+    # ------------------------------------------------------------------ weights
+    def sync_weights(self):
+        """fp32 masters -> bf16 shadows (+ [in,out]-major copies for the dgrad GEMMs)."""
+        ops.cast_f32_bf16(self.flat_p, self.flat_w16, self.nflat)
+        D, Hd = self.D, self.hidden
+        for i in range(self.depth):
+            pre = f"blocks.{i}."
+            ops.transpose_cast(self.P(pre + "attn.qkv.weight").view(3 * D, D), 3 * D, D, self.wT[i]["qkv"])
+            ops.transpose_cast(self.P(pre + "attn.proj.weight").view(D, D), D, D, self.wT[i]["proj"])
+            ops.transpose_cast(self.P(pre + "mlp.fc1.weight").view(Hd, D), Hd, D, self.wT[i]["fc1"])
+            ops.transpose_cast(self.P(pre + "mlp.fc2.weight").view(D, Hd), D, Hd, self.wT[i]["fc2"])
+        ops.transpose_cast(self.P("lm_head.weight").view(self.V, D), self.V, D, self.wT_lm)
+        self.weights_dirty = False
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, x, mask_u8, rows_idx, labels=None, dp_masks=None, all_tokens=False):
+        """x f32 [B,C,H,W]; mask_u8 u8 [B*L]; rows_idx i32 [Mm] (token rows b*T+1+p of the masked
+        patches, or of ALL patches when all_tokens); labels i64 [Mm] or None.
+        dp_masks: f32 [2*depth, B] stochastic-depth keep masks (0/1) or None.
+        Leaves logits (bf16 [Mm,V]) in self.logits; with labels also loss/acc in self.loss_acc and
+        dlogits (in place of the logits)."""
+        assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous()
+        B = x.shape[0]
+        assert tuple(x.shape[1:]) == (self.C, self.H, self.W), \
+            f"Input image size ({x.shape[2]}*{x.shape[3]}) doesn't match model ({self.H}*{self.W})."
+        Mm = rows_idx.numel()
+        self.ensure_batch(B, Mm)
+        if self.weights_dirty:
+            self.sync_weights()
+        D, Hd, T, L, V = self.D, self.hidden, self.T, self.L, self.V
+        M = B * T
+        self.cur = dict(B=B, M=M, Mm=Mm, mask=mask_u8, rows=rows_idx, dp=dp_masks, labels=labels)
+        ops.im2col(x, B, self.C, self.H, self.W, self.ph, self.pw, self.patches)
+        x0 = self.x[0]
+        ops.fill_cls(x0, B, T, D, self.P("cls_token"))
+        ops.gemm_nt(self.patches, self.W16("patch_embed.proj.weight", D, self.Kpe), B * L, D, self.Kpe,
+                    ops.EPI_PATCH_EMBED, bias=self.P("patch_embed.proj.bias"), vec1=self.P("mask_token"),
+                    resid=x0, aux=mask_u8, rows_per_sample=L, ldaux=0)
+        ops.relpos_gather(self.P("rel_pos_bias.relative_position_bias_table"), self.relidx, T, self.TP, self.heads,
+                          self.bias_pad)
+        for i in range(self.depth):
+            pre = f"blocks.{i}."
+            a = self.act[i]
+            blk = self.model.blocks[i]
+            keep = 1.0 - blk.drop_prob
+            use_dp = dp_masks is not None and blk.drop_prob > 0.0
+            xin, xmid, xout = self.x[2 * i], self.x[2 * i + 1], self.x[2 * i + 2]
+            g1 = self.P(pre + "gamma_1") if (pre + "gamma_1") in self.segs else None
+            g2 = self.P(pre + "gamma_2") if (pre + "gamma_2") in self.segs else None
+            ops.layernorm_fwd(xin, self.P(pre + "norm1.weight"), self.P(pre + "norm1.bias"), a["h1"], a["mean1"],
+                              a["rstd1"], M, D)
+            ops.gemm_nt(a["h1"], self.W16(pre + "attn.qkv.weight", 3 * D, D), M, 3 * D, D, ops.EPI_BIAS_BF16,
+                        out0=a["qkv"], bias=self.P(pre + "attn.qkvbias3"), colscale=self.scale, colscale_n=D)
+            ops.attn_fwd(a["qkv"], B, T, D, self.heads, self.bias_pad, a["ao"], a["lse"])
+            ops.gemm_nt(a["ao"], self.W16(pre + "attn.proj.weight", D, D), M, D, D, ops.EPI_RESIDUAL, out0=a["y1"],
+                        bias=self.P(pre + "attn.proj.bias"), vec1=g1, resid=xmid, aux=xin, ldaux=D,
+                        rowmask=dp_masks[2 * i] if use_dp else None, keep_prob=keep, rows_per_sample=T)
+            ops.layernorm_fwd(xmid, self.P(pre + "norm2.weight"), self.P(pre + "norm2.bias"), a["h2"], a["mean2"],
+                              a["rstd2"], M, D)
+            ops.gemm_nt(a["h2"], self.W16(pre + "mlp.fc1.weight", Hd, D), M, Hd, D, ops.EPI_BIAS_GELU, out0=a["hpre"],
+                        out1=a["a"], bias=self.P(pre + "mlp.fc1.bias"))
+            ops.gemm_nt(a["a"], self.W16(pre + "mlp.fc2.weight", D, Hd), M, D, Hd, ops.EPI_RESIDUAL, out0=a["y2"],
+                        bias=self.P(pre + "mlp.fc2.bias"), vec1=g2, resid=xout, aux=xmid, ldaux=D,
+                        rowmask=dp_masks[2 * i + 1] if use_dp else None, keep_prob=keep, rows_per_sample=T)
+        xl = self.x[2 * self.depth]
+        # final norm on exactly the rows that reach the head (x[:,1:][bool_masked_pos])
+        ops.layernorm_fwd(xl, self.P("norm.weight"), self.P("norm.bias"), self.hN, self.meanN, self.rstdN, Mm, D,
+                          row_idx=rows_idx)
+        ops.gemm_nt(self.hN, self.W16("lm_head.weight", V, D), Mm, V, D, ops.EPI_BIAS_BF16, out0=self.logits,
+                    bias=self.P("lm_head.bias"))
+        if labels is not None:
+            ops.cross_entropy(self.logits, labels, Mm, V, 1.0 / Mm, self.row_loss, self.row_ok, self.loss_acc,
+                              write_grad=True)
+        return self.logits[:Mm]
+
+    # ------------------------------------------------------------------ backward
+    def _wgrad(self, dY, X, R, n_out, n_in, gname, colsum0=None, c0=(0, 0), colsum1=None, c1=(0, 0)):
+        """grad[gname] [n_out, n_in] = dY[R, n_out]^T @ X[R, n_in]  (+ fused column sums of dY)."""
+        Rp = _pad(R, 64)
+        dYt = self.tA[: n_out * Rp].view(n_out, Rp)
+        Xt = self.tB[: n_in * Rp].view(n_in, Rp)
+        ops.transpose_bf16(dY, R, n_out, dYt, Rp, colsum0, c0, colsum1, c1)
+        ops.transpose_bf16(X, R, n_in, Xt, Rp)
+        ops.gemm_nt(dYt, Xt, n_out, n_in, Rp, ops.EPI_F32, out0=self.G(gname).view(n_out, n_in))
+
+    def backward(self, dlogits=None):
+        """Gradients of mean-CE (dlogits already in self.logits after forward(labels=...)) or of a
+        caller-supplied dlogits (bf16 [Mm,V]) w.r.t. every parameter, into the flat grad buffer."""
+        c = self.cur
+        B, M, Mm = c["B"], c["M"], c["Mm"]
+        D, Hd, T, L, V = self.D, self.hidden, self.T, self.L, self.V
+        dp_masks = c["dp"]
+        if dlogits is not None:
+            self.logits[:Mm].copy_(dlogits)
+        self.flat_g.zero_()
+        dx = self.dx
+        dx[:M].zero_()
+        dl = self.logits
+        # ---- head
+        ops.gemm_nt(dl, self.wT_lm, Mm, D, V, ops.EPI_BIAS_BF16, out0=self.dhN)
+        self._wgrad(dl, self.hN, Mm, V, D, "lm_head.weight", colsum0=self.G("lm_head.bias"), c0=(0, V))
+        ops.layernorm_bwd(self.dhN, self.x[2 * self.depth], self.P("norm.weight"), self.meanN, self.rstdN, dx,
+                          self.G("norm.weight"), self.G("norm.bias"), Mm, D, accumulate=False, row_idx=c["rows"])
+        if self.grad_hook:
+            self.grad_hook(0)
+        dtable = self.G("rel_pos_bias.relative_position_bias_table")
+        for i in reversed(range(self.depth)):
+            pre = f"blocks.{i}."
+            a = self.act[i]
+            blk = self.model.blocks[i]
+            keep = 1.0 - blk.drop_prob
+            use_dp = dp_masks is not None and blk.drop_prob > 0.0
+            xin, xmid = self.x[2 * i], self.x[2 * i + 1]
+            has_g = (pre + "gamma_1") in self.segs
+            # -- MLP branch
+            ops.branch_bwd(dx, a["y2"], self.P(pre + "gamma_2") if has_g else None, self.dY,
+                           self.G(pre + "gamma_2") if has_g else None, self.G(pre + "mlp.fc2.bias"), M, D,
+                           rowmask=dp_masks[2 * i + 1] if use_dp else None, keep_prob=keep, rows_per_sample=T)
+            ops.gemm_nt(self.dY, self.wT[i]["fc2"], M, Hd, D, ops.EPI_DGELU, out0=self.dbig, aux=a["hpre"])
+            self._wgrad(self.dY, a["a"], M, D, Hd, pre + "mlp.fc2.weight")
+            self._wgrad(self.dbig, a["h2"], M, Hd, D, pre + "mlp.fc1.weight", colsum0=self.G(pre + "mlp.fc1.bias"),
+                        c0=(0, Hd))
+            ops.gemm_nt(self.dbig, self.wT[i]["fc1"], M, D, Hd, ops.EPI_BIAS_BF16, out0=self.dh_small)
+            ops.layernorm_bwd(self.dh_small, xmid, self.P(pre + "norm2.weight"), a["mean2"], a["rstd2"], dx,
+                              self.G(pre + "norm2.weight"), self.G(pre + "norm2.bias"), M, D, accumulate=True)
+            # -- attention branch
+            ops.branch_bwd(dx, a["y1"], self.P(pre + "gamma_1") if has_g else None, self.dY,
+                           self.G(pre + "gamma_1") if has_g else None, self.G(pre + "attn.proj.bias"), M, D,
+                           rowmask=dp_masks[2 * i] if use_dp else None, keep_prob=keep, rows_per_sample=T)
+            ops.gemm_nt(self.dY, self.wT[i]["proj"], M, D, D, ops.EPI_BIAS_BF16, out0=self.dao)
+            self._wgrad(self.dY, a["ao"], M, D, D, pre + "attn.proj.weight")
+            ops.attn_bwd(a["qkv"], self.dao, a["ao"], a["lse"], self.bias_pad, self.relidx_pad, self.nrd, B, T, D,
+                         self.heads, self.scale, self.dqkv, dtable)
+            self._wgrad(self.dqkv, a["h1"], M, 3 * D, D, pre + "attn.qkv.weight",
+                        colsum0=self.G(pre + "attn.q_bias"), c0=(0, D), colsum1=self.G(pre + "attn.v_bias"),
+                        c1=(2 * D, 3 * D))
+            ops.gemm_nt(self.dqkv, self.wT[i]["qkv"], M, D, 3 * D, ops.EPI_BIAS_BF16, out0=self.dh_small)
+            ops.layernorm_bwd(self.dh_small, xin, self.P(pre + "norm1.weight"), a["mean1"], a["rstd1"], dx,
+                              self.G(pre + "norm1.weight"), self.G(pre + "norm1.bias"), M, D, accumulate=True)
+            if self.grad_hook:
+                self.grad_hook(self.depth - i)
+        # ---- embedding
+        ops.embed_bwd(dx, c["mask"], B, L, D, self.dYpe, self.G("cls_token"), self.G("mask_token"))
+        self._wgrad(self.dYpe, self.patches, B * L, D, self.Kpe, "patch_embed.proj.weight",
+                    colsum0=self.G("patch_embed.proj.bias"), c0=(0, D))
+        if self.grad_hook:
+            self.grad_hook(self.depth + 1)
+
+    # ------------------------------------------------------------------ optimizer primitives
+    def grad_norm(self):
+        ops.grad_norm(self.flat_g, self.nflat, self.gnorm, self.gn_ws)
+        return self.gnorm
+
+    def adamw_step(self, m, v, lr, wd, step, betas=(0.9, 0.95), eps=1e-8, max_norm=0.0):
+        ops.adamw(self.flat_p, self.flat_g, m, v, self.nflat, self.wd_flags, lr, betas[0], betas[1], eps, wd, step,
+                  gnorm=self.gnorm, max_norm=max_norm or 0.0)
+        self.weights_dirty = True

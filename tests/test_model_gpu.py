@@ -1,0 +1,150 @@
+"""-m gpu: the fused HIP ViT (mem_amd.modeling_pretrain) against the reference goldens
+(tests/golden/vit_*.npz, produced by the imported reference on CPU) and the oracle.
+
+Tolerances (stated, per dtype): the product computes like the reference under bf16 autocast
+(bf16 GEMM operands, fp32 accumulate); against the reference's own bf16-autocast CPU run the
+remaining differences are accumulation order and a few fused roundings:
+  logits  |d| <= 0.03 abs (bf16 resolution at |logit|~2-4 is 0.016)
+  loss    |d| <= 2e-3      (vs bf16 golden)   /  <= 1e-2 (vs fp32 golden)
+  grads   relative L2 error per tensor <= 3e-2 (vs bf16 golden), global cosine >= 0.999
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+TINY = dict(img_size=(64, 64), patch_size=(16, 16), in_chans=3, vocab_size=512, embed_dim=128, depth=2,
+            num_heads=2, mlp_ratio=4, drop_path_rate=0.0, use_shared_rel_pos_bias=True,
+            use_abs_pos_emb=False, init_values=0.1)
+
+
+def _tiny_model():
+    from mem_amd.modeling_pretrain import pt_vit
+    from oracle.vit_ref import fill_by_name
+    m = pt_vit(**TINY)
+    m.load_state_dict(fill_by_name(m.state_dict(), seed=0))
+    return m.cuda().train()
+
+
+def test_state_dict_surface_and_init_parity():
+    """Same keys/shapes as the reference and -- same torch seed -- the same initial weights."""
+    from mem_amd.modeling_pretrain import create_model
+    from oracle.vit_ref import RefViT
+    meta = json.load(open(os.path.join(GOLDEN, "vit_meta.json")))
+    torch.manual_seed(0)
+    m = create_model("pt_vit", pretrained=False, drop_block_rate=None, **TINY)
+    assert list(m.state_dict().keys()) == meta["tiny_state_keys"]
+    assert {k: list(v.shape) for k, v in m.state_dict().items()} == meta["tiny_state_shapes"]
+    torch.manual_seed(0)
+    o = RefViT(**TINY)
+    for (k, a), (_, b) in zip(m.state_dict().items(), o.state_dict().items()):
+        assert torch.equal(a, b), k
+    assert m.get_num_layers() == 2 and m.no_weight_decay() == {"pos_embed", "cls_token"}
+    assert m.patch_embed.patch_size == (16, 16) and m.patch_embed.patch_shape == (4, 4)
+
+
+def test_tiny_forward_backward_vs_reference_golden():
+    g = np.load(os.path.join(GOLDEN, "vit_tiny_fwdbwd.npz"))
+    m = _tiny_model()
+    x, mask, labels = torch.from_numpy(g["x"]).cuda(), torch.from_numpy(g["mask"]).cuda(), torch.from_numpy(g["labels"]).cuda()
+    # --- API path: logits with autograd, loss outside (like the reference engine does)
+    logits = m(x, mask)
+    assert logits.shape == tuple(g["bf16__logits"].shape)
+    d = (logits.detach().float().cpu().numpy() - g["bf16__logits"])
+    assert np.abs(d).max() <= 0.03, np.abs(d).max()
+    loss = torch.nn.CrossEntropyLoss()(logits.float(), labels)
+    assert abs(loss.item() - float(g["bf16__loss"])) <= 2e-3
+    assert abs(loss.item() - float(g["fp32__loss"])) <= 1e-2
+    loss.backward()
+    api_grads = {k: p.grad.detach().clone() for k, p in m.named_parameters()}
+    # --- fused path: loss + dlogits inside the pipeline
+    la = m.forward_loss(x, mask, labels)
+    assert abs(la[0].item() - float(g["bf16__loss"])) <= 2e-3
+    m.backward()
+    num = den = 0.0
+    for k, p in m.named_parameters():
+        ref = torch.from_numpy(g[f"bf16__grad__{k}"]).cuda()
+        for got in (p.grad, api_grads[k]):
+            rel = (got - ref).norm() / (ref.norm() + 1e-12)
+            assert rel <= 3e-2, (k, rel.item())
+        num += (p.grad * ref).sum().item()
+        den += (p.grad.norm() ** 2).item() ** 0.5 * 0 + 0
+    flat_g = torch.cat([p.grad.flatten() for _, p in m.named_parameters()])
+    flat_r = torch.cat([torch.from_numpy(g[f"bf16__grad__{k}"]).flatten() for k, _ in m.named_parameters()]).cuda()
+    cos = torch.nn.functional.cosine_similarity(flat_g, flat_r, dim=0).item()
+    assert cos >= 0.999, cos
+    flat_r32 = torch.cat([torch.from_numpy(g[f"fp32__grad__{k}"]).flatten() for k, _ in m.named_parameters()]).cuda()
+    assert torch.nn.functional.cosine_similarity(flat_g, flat_r32, dim=0).item() >= 0.995
+    # --- return_all_tokens
+    m.eval()
+    with torch.no_grad():
+        allt = m(x, mask, return_all_tokens=True)
+    assert allt.shape == tuple(g["bf16__logits_all"].shape)
+    assert np.abs(allt.float().cpu().numpy() - g["bf16__logits_all"]).max() <= 0.03
+
+
+def test_drop_path_masks_vs_oracle():
+    """Stochastic depth with the keep masks fed in: product vs the CPU oracle under bf16 autocast."""
+    from mem_amd.modeling_pretrain import pt_vit
+    from oracle.gen_golden import vit_inputs
+    from oracle.vit_ref import RefViT, fill_by_name
+    cfg = dict(TINY, drop_path_rate=0.3)
+    m = pt_vit(**cfg)
+    w = fill_by_name(m.state_dict(), seed=0)
+    m.load_state_dict(w)
+    m = m.cuda().train()
+    o = RefViT(**cfg)
+    o.load_state_dict(w)
+    x, mask, labels = vit_inputs(cfg, 6, 5, 6)
+    masks = (torch.rand(4, 6, generator=torch.Generator().manual_seed(1)) > 0.4).float()
+    keep = [(masks[2 * i], masks[2 * i + 1]) for i in range(2)]
+    with torch.autocast("cpu", dtype=torch.bfloat16):
+        lo = o(x, mask, keep=keep)
+        lref = torch.nn.CrossEntropyLoss()(lo, labels)
+    lref.backward()
+    la = m.forward_loss(x.cuda(), mask.cuda(), labels.cuda(), drop_path_masks=masks.cuda())
+    m.backward()
+    assert abs(la[0].item() - lref.item()) <= 3e-3
+    for (k, p), (_, q) in zip(m.named_parameters(), o.named_parameters()):
+        rel = (p.grad.cpu() - q.grad).norm() / (q.grad.norm() + 1e-12)
+        assert rel <= 4e-2, (k, rel.item())
+
+
+@pytest.mark.parametrize("C", [3, 2])
+def test_vit_base_vs_reference_golden(C):
+    """ViT-B/16 224^2 (BASELINE shapes), B=2: loss, sampled logits and per-parameter gradient norms."""
+    from mem_amd.modeling_pretrain import pt_vit
+    from oracle.gen_golden import BASE, vit_inputs
+    from oracle.vit_ref import fill_by_name
+    g = np.load(os.path.join(GOLDEN, f"vit_base_c{C}.npz"))
+    meta = json.load(open(os.path.join(GOLDEN, "vit_meta.json")))
+    cfg = dict(BASE, in_chans=C)
+    m = pt_vit(**cfg)
+    assert sum(p.numel() for p in m.parameters()) == meta[f"base_c{C}_nparams"]
+    m.load_state_dict(fill_by_name(m.state_dict(), seed=1))
+    m = m.cuda().train()
+    x, mask, labels = vit_inputs(cfg, 2, 77, 98)
+    la = m.forward_loss(x.cuda(), mask.cuda(), labels.cuda())
+    assert abs(la[0].item() - float(g["bf16__loss"])) <= 5e-3, (la[0].item(), float(g["bf16__loss"]))
+    assert abs(la[0].item() - float(g["fp32__loss"])) <= 2e-2
+    m.eval()
+    with torch.no_grad():
+        lo = m(x.cuda(), mask.cuda())
+    m.train()
+    samp = lo.float().cpu()[::7, ::97].numpy()
+    assert np.abs(samp - g["bf16__logits_sample"]).max() <= 0.06
+    m.forward_loss(x.cuda(), mask.cuda(), labels.cuda())
+    m.backward()
+    names = meta[f"base_c{C}_param_names"]
+    gn = np.array([dict(m.named_parameters())[k].grad.norm().item() for k in names])
+    ref = g["bf16__gradnorms"]
+    big = ref > 1e-6
+    assert np.abs(gn[big] / ref[big] - 1).max() <= 0.08, np.abs(gn[big] / ref[big] - 1).max()
+    tot = np.sqrt((gn ** 2).sum()) / np.sqrt((ref ** 2).sum())
+    assert abs(tot - 1) <= 0.02, tot
