@@ -1,0 +1,200 @@
+#!/usr/bin/env python
+"""bench.py -- MEM pretraining throughput on MI355X (BASELINE.json metric: pretrain samples/sec,
+ViT-B/16, 224^2 2-bin event voxels, bf16, B=256 per GPU).
+
+One "step" = one pass of the hot path over one synthetic batch that is already resident in HBM:
+  events f64 (N,4) x256 -> fused augment+rasterize -> fused event_norm -> block-wise masks (host
+  MT19937, overlapped) -> ViT-B masked forward + CE -> backward (RCCL all-reduce overlapped when
+  N>1) -> grad-norm/clip + AdamW.
+Launch:  python bench.py [--gpus N --steps K --warmup W]
+         (N>1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FLOP_PER_SAMPLE = {2: 108.85e9, 3: 109.08e9}      # BASELINE.md section 2 (GEMMs only, fwd+bwd)
+PEAK_BF16_TFLOPS = 2500.0                          # MI355X dense bf16 (MI355X_MICROARCH.md)
+
+
+def cpu_baseline(batch=8, budget_s=15.0, max_threads=32):
+    """The oracle (CPU restatement of the reference, proven equal to it in the build container)
+    timed on this box's host cores: fp32 eager PyTorch ViT-B fwd + CE + bwd + clip + AdamW.
+    Bounded sample: steps are run until ~budget_s of CPU work has been spent (>= 1 timed step).
+    Thread count is capped: eager CPU PyTorch at batch 8 gets slower, not faster, beyond a few
+    dozen threads (256 threads measured 75 s/step on the GPU box)."""
+    import torch
+    from oracle import vit_ref as V
+    from oracle.gen_golden import BASE, vit_inputs
+    threads = max(1, min(os.cpu_count() or 1, max_threads))
+    torch.set_num_threads(threads)
+    cfg = dict(BASE, in_chans=2, drop_path_rate=0.0)
+    m = V.RefViT(**cfg)
+    opt = V.make_optimizer(m)
+    x, mask, labels = vit_inputs(cfg, batch, 7, 98)
+    V.train_step(m, opt, x, mask, labels, 0, clip_grad=30.0)            # warm-up
+    t0 = time.time()
+    steps = 0
+    while steps < 1 or (time.time() - t0 < budget_s and steps < 50):
+        V.train_step(m, opt, x, mask, labels, steps + 1, clip_grad=30.0)
+        steps += 1
+    dt = time.time() - t0
+    return {"value": round(batch * steps / dt, 3), "unit": "samples/sec", "cores": threads,
+            "kind": "port", "sample": f"ViT-B/16 C=2 fp32 eager CPU (oracle/vit_ref.py), batch {batch}, {steps} steps "
+                                      f"after 1 warm-up in {dt:.1f} s, {threads} threads of {os.cpu_count()} cores"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=256, help="per-GPU batch (BASELINE config: 256)")
+    ap.add_argument("--events", type=int, default=30000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-gemm-timer", action="store_true")
+    a = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", 0))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl")
+
+    from mem_amd import datasets as D, ops
+    from mem_amd.masking_generator import MaskingGenerator
+    from mem_amd.modeling_pretrain import pt_vit
+    from mem_amd.optim_factory import FlatAdamW, get_parameter_groups
+    from mem_amd.parallel import GradReducer
+    from mem_amd.utils import cosine_scheduler
+
+    B, NE, H, W, C = a.batch, a.events, 224, 224, 2
+    torch.manual_seed(1234 + rank)
+    model = pt_vit(img_size=(H, W), patch_size=(16, 16), in_chans=C, vocab_size=8192, embed_dim=768, depth=12,
+                   num_heads=12, mlp_ratio=4, drop_path_rate=0.1, use_shared_rel_pos_bias=True,
+                   use_abs_pos_emb=False, init_values=0.1).cuda().train()
+    eng = model.engine
+    import contextlib, io
+    with contextlib.redirect_stdout(io.StringIO()):
+        groups = get_parameter_groups(model, 0.05, model.no_weight_decay())
+        lr_sched = cosine_scheduler(5e-4, 1e-5, 3000, 1000, warmup_epochs=5, warmup_steps=1000)
+    opt = FlatAdamW(model, groups, lr=5e-4)
+    opt.max_norm = 30.0
+    reducer = None
+    if world > 1:
+        reducer = GradReducer(eng.flat_g, eng.buckets, flat_p=eng.flat_p)
+        eng.grad_hook = reducer
+        eng.weights_dirty = True
+
+    # ---- synthetic batch, resident in HBM (SURVEY.md section 8d recipe)
+    g = np.random.default_rng(1234 + rank)
+    ev = np.empty((B * NE, 4), dtype=np.float64)
+    ev[:, 0] = g.integers(0, W, B * NE)
+    ev[:, 1] = g.integers(0, H, B * NE)
+    ev[:, 2] = np.sort(g.integers(0, 300000, (B, NE)), axis=1).reshape(-1)
+    ev[:, 3] = g.integers(0, 2, B * NE) * 2 - 1
+    ev_dev = torch.from_numpy(ev).cuda()
+    offsets = (torch.arange(B + 1, dtype=torch.int64) * NE).cuda()
+    pipe = D.EventBatchPipeline(H, W, out_chans=C, time_surface=False, train_augs=False)
+    masker = MaskingGenerator((14, 14), 98, min_num_patches=16, seed=1234 + rank)
+    label_pool = torch.randint(0, 8192, (B * 98,), generator=torch.Generator().manual_seed(1234 + rank)).cuda()
+    T = eng.T
+
+    def step(it):
+        for grp in opt.param_groups:
+            grp["lr"] = lr_sched[it]
+        x = pipe(ev_dev, offsets)                                     # rasterize + event_norm (HIP)
+        m = masker.batch_u8(B).reshape(B, -1)                         # host MT19937 (bit-exact CPython stream)
+        bi, pi = np.nonzero(m)
+        rows = torch.from_numpy((bi * T + 1 + pi).astype(np.int32)).cuda(non_blocking=True)
+        mask_u8 = torch.from_numpy(m.reshape(-1)).cuda(non_blocking=True)
+        labels = label_pool[: rows.numel()]
+        la = model.forward_loss(x, None, labels, rows=rows, mask_u8=mask_u8)
+        model.backward()
+        if reducer is not None:
+            reducer.finish()
+        eng.grad_norm()
+        opt.step()
+        return la
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for it in range(a.warmup):
+        step(it)
+    fence()
+    if not a.no_gemm_timer:
+        ops.GEMM_TIMER = []
+    t0 = time.perf_counter()
+    for it in range(a.steps):
+        la = step(a.warmup + it)
+    fence()
+    dt = time.perf_counter() - t0
+    timer, ops.GEMM_TIMER = ops.GEMM_TIMER, None
+    loss_last = float(la[0].item())
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        ms = dt / a.steps * 1e3
+        value = world * B * a.steps / dt
+        roof = None
+        if timer:
+            tot_ms, tot_fl, per = 0.0, 0.0, {}
+            for e0, e1, fl, epi in timer:
+                d = e0.elapsed_time(e1)
+                tot_ms += d
+                tot_fl += fl
+                k = per.setdefault(int(epi), [0, 0.0, 0.0])
+                k[0] += 1; k[1] += d; k[2] += fl
+            ach = tot_fl / (tot_ms * 1e-3) / 1e12
+            traffic = None
+            tpath = os.path.join(ROOT, "profiles", "gemm_traffic.json")
+            if os.path.exists(tpath):
+                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+            roof = {"bound": "mfma", "kernel": "gemm_nt_kernel<EPI> (bf16 MFMA GEMM, all epilogues)",
+                    "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
+                    "launches": len(timer), "avg_launch_us": round(tot_ms / len(timer) * 1e3, 2),
+                    "gemm_share_of_step": round(tot_ms / (dt * 1e3), 3),
+                    "per_epilogue": {str(k): {"launches": v[0], "avg_us": round(v[1] / v[0] * 1e3, 2),
+                                              "tflops": round(v[2] / (v[1] * 1e-3) / 1e12, 1)} for k, v in sorted(per.items())}}
+        out = {"metric": "pretrain samples/sec (ViT-B, 224^2 event voxels)", "value": round(value, 1),
+               "unit": "samples/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+               "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": "bf16", "data": "synthetic",
+               "config": {"workload": "MEM pretrain ViT-Base/16, 224^2 2-bin event voxels, bf16, batch 256 per GPU "
+                                      "(BASELINE configs[1]); step = rasterize 256x30k events + event_norm + masks "
+                                      "+ ViT fwd/CE/bwd + clip + AdamW",
+                          "global_batch": world * B, "events_per_sample": NE, "parallelism": f"dp{world}",
+                          "model_flops_frac_of_peak": round(value / world * FLOP_PER_SAMPLE[C] / (PEAK_BF16_TFLOPS * 1e12), 4),
+                          "last_loss": round(loss_last, 4)},
+               "roofline": roof}
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,123 @@
+"""Pretraining loop -- mirror of /root/reference/mem/engine_for_pretraining.py
+(train_one_epoch :108-287, evaluate :289-366; the plotting / wandb-image helpers :28-105 are out
+of scope).
+
+Arithmetic per step is the reference's (:123-162): schedule assignment, tokenizer labels,
+masked-token cross-entropy, backward, clip, AdamW -- but the loss and its gradient are fused into
+the HIP pipeline (``model.forward_loss`` / ``model.backward``), the data-parallel all-reduce is
+overlapped with backward (parallel.GradReducer) and the four per-step host synchronisations of
+the reference (:156,:165,:230,:233) are replaced by ONE read-back every ``print_freq`` steps: the
+logged values are the same, they just reach the meters in batches.  Works for any device the
+model supports; the shipped loop's CUDA-only crash sites (:163,:165) have no equivalent here.
+"""
+import math
+import sys
+from typing import Iterable
+
+import torch
+
+from . import utils
+
+
+def _prep_batch(batch, device, model, d_vae):
+    samples, images, bool_masked_pos = batch
+    images = images.to(device, non_blocking=True)
+    samples = samples.to(device, non_blocking=True)
+    bool_masked_pos = bool_masked_pos.to(device, non_blocking=True)
+    with torch.no_grad():
+        bool_masked_pos = bool_masked_pos.flatten(1).to(torch.bool)
+        input_ids = d_vae.get_codebook_indices(images).flatten(1)       # (B, 14*14)
+        labels = input_ids[bool_masked_pos]                              # (numMasked)
+    in_chans = model.patch_embed.proj.weight.shape[1]
+    if samples.shape[1] == 3 and in_chans == 2:
+        samples = samples[:, 0::2].contiguous()      # the 2-bin voxel view (engine_for_finetuning.py:228)
+    return samples, images, bool_masked_pos, labels
+
+
+def _flush(pending, metric_logger, log_writer, optimizer, run):
+    """One device->host transfer for all steps since the last flush."""
+    if not pending:
+        return
+    vals = torch.stack([torch.cat([la, gn]) for la, gn, _ in pending]).tolist()     # [[loss, acc, gnorm], ...]
+    for (loss_value, mlm_acc, grad_norm), (_, _, meta) in zip(vals, pending):
+        if not math.isfinite(loss_value):
+            print("Loss is {}, stopping training".format(loss_value))
+            sys.exit(1)
+        metric_logger.update(mlm_acc=mlm_acc)
+        metric_logger.update(loss=loss_value)
+        metric_logger.update(loss_scale=meta["loss_scale"])
+        metric_logger.update(lr=meta["max_lr"])
+        metric_logger.update(min_lr=meta["min_lr"])
+        metric_logger.update(weight_decay=meta["wd"])
+        metric_logger.update(grad_norm=grad_norm)
+        if log_writer is not None:
+            log_writer.update(mlm_acc=mlm_acc, head="loss")
+            log_writer.update(loss=loss_value, head="loss")
+            log_writer.update(loss_scale=meta["loss_scale"], head="opt")
+            log_writer.update(lr=meta["max_lr"], head="opt")
+            log_writer.update(min_lr=meta["min_lr"], head="opt")
+            log_writer.update(weight_decay=meta["wd"], head="opt")
+            log_writer.update(grad_norm=grad_norm, head="opt")
+            log_writer.set_step()
+    pending.clear()
+
+
+def train_one_epoch(model: torch.nn.Module, d_vae: torch.nn.Module, data_loader: Iterable, optimizer,
+                    device: torch.device, epoch: int, loss_scaler, max_norm: float = 0, log_writer=None,
+                    lr_scheduler=None, start_steps=None, lr_schedule_values=None, wd_schedule_values=None,
+                    run=None, args=None, plotting=False, MAE=False):
+    if MAE:
+        raise NotImplementedError("--mae 1 (modeling_mae.py) is outside this round (SURVEY.md section 8 row f4)")
+    model.train()
+    metric_logger = utils.MetricLogger(delimiter="  ")
+    metric_logger.add_meter("lr", utils.SmoothedValue(window_size=1, fmt="{value:.6f}"))
+    metric_logger.add_meter("min_lr", utils.SmoothedValue(window_size=1, fmt="{value:.6f}"))
+    header = "Epoch: [{}]".format(epoch)
+    print_freq = 10
+    start_steps = start_steps or 0
+    reducer = getattr(model, "_reducer", None)
+    pending = []
+    for step, (batch, _) in enumerate(metric_logger.log_every(data_loader, print_freq, header)):
+        it = start_steps + step
+        if lr_schedule_values is not None or wd_schedule_values is not None:
+            for param_group in optimizer.param_groups:
+                if lr_schedule_values is not None:
+                    param_group["lr"] = lr_schedule_values[it] * param_group["lr_scale"]
+                if wd_schedule_values is not None and param_group["weight_decay"] > 0:
+                    param_group["weight_decay"] = wd_schedule_values[it]
+        samples, images, bool_masked_pos, labels = _prep_batch(batch, device, model, d_vae)
+        loss_acc = model.forward_loss(samples, bool_masked_pos, labels)
+        model._fused_loss_pending = True
+        grad_norm = loss_scaler(loss_acc, optimizer, clip_grad=max_norm, parameters=model.parameters(),
+                                model=model, reducer=reducer)
+        lrs = [g["lr"] for g in optimizer.param_groups]
+        wds = [g["weight_decay"] for g in optimizer.param_groups if g["weight_decay"] > 0]
+        pending.append((loss_acc.clone(), grad_norm.clone(),
+                        dict(loss_scale=loss_scaler.state_dict()["scale"], max_lr=max(lrs), min_lr=min(lrs),
+                             wd=wds[-1] if wds else None)))
+        if (step + 1) % print_freq == 0:
+            _flush(pending, metric_logger, log_writer, optimizer, run)
+        if lr_scheduler is not None:
+            lr_scheduler.step_update(start_steps + step)
+    _flush(pending, metric_logger, log_writer, optimizer, run)
+    metric_logger.synchronize_between_processes()
+    print("Averaged stats:", metric_logger)
+    return {k: meter.global_avg for k, meter in metric_logger.meters.items()}
+
+
+@torch.no_grad()
+def evaluate(data_loader, model, d_vae, device, args, plotting=False, MAE=False):
+    if MAE:
+        raise NotImplementedError("--mae 1 is outside this round (SURVEY.md section 8 row f4)")
+    metric_logger = utils.MetricLogger(delimiter="  ")
+    header = "Test:"
+    model.eval()
+    for batch in metric_logger.log_every(data_loader, 10, header):
+        samples, images, bool_masked_pos, labels = _prep_batch(batch[0], device, model, d_vae)
+        la = model.forward_loss(samples, bool_masked_pos, labels).tolist()
+        metric_logger.update(loss=la[0])
+        metric_logger.meters["mlm_acc"].update(la[1])
+    metric_logger.synchronize_between_processes()
+    print("* mlm_acc {mlm_acc.global_avg:.3f} loss {losses.global_avg:.3f}".format(
+        mlm_acc=metric_logger.mlm_acc, losses=metric_logger.loss))
+    return {k: meter.global_avg for k, meter in metric_logger.meters.items()}

@@ -29,6 +29,11 @@ def _p(t):
     return None if t is None else t.data_ptr()
 
 
+# Optional live timing of every GEMM launch with HIP events on the launch stream (bench.py's
+# roofline leg): set GEMM_TIMER to a list; entries are (start_event, end_event, flops, epilogue).
+GEMM_TIMER = None
+
+
 def gemm_nt(A, B, M, N, K, epi, out0=None, out1=None, bias=None, vec1=None, resid=None, aux=None,
             rowmask=None, keep_prob=1.0, colscale=1.0, colscale_n=0, rows_per_sample=1, accumulate=False,
             lda=None, ldb=None, ldo0=None, ldo1=None, ldr=None, ldaux=None):
@@ -49,7 +54,14 @@ def gemm_nt(A, B, M, N, K, epi, out0=None, out1=None, bias=None, vec1=None, resi
     a.rowmask = _p(rowmask)
     a.keep_prob, a.colscale, a.colscale_n = keep_prob, colscale, colscale_n
     a.rows_per_sample, a.accumulate = rows_per_sample, int(accumulate)
-    check(lib.memhip_gemm_bf16_nt(C.byref(a), stream_ptr()), "gemm_bf16_nt")
+    if GEMM_TIMER is None:
+        check(lib.memhip_gemm_bf16_nt(C.byref(a), stream_ptr()), "gemm_bf16_nt")
+    else:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        check(lib.memhip_gemm_bf16_nt(C.byref(a), stream_ptr()), "gemm_bf16_nt")
+        e1.record()
+        GEMM_TIMER.append((e0, e1, 2.0 * M * N * K, epi))
 
 
 f64 = C.c_double

@@ -1,0 +1,121 @@
+"""Optimizer factory -- mirror of /root/reference/mem/optim_factory.py:56-133.
+
+``get_parameter_groups`` keeps the reference's decay / no_decay rule (ndim==1, ``.bias``, the
+model's ``no_weight_decay()`` skip list) and ``create_optimizer`` keeps its AdamW with betas
+hard-set to (0.9, 0.95) (:121).  Only ``--opt adamw`` -- the one optimizer every config uses -- is
+implemented; the update itself is one streaming HIP kernel over the model's flat parameter /
+gradient / moment buffers (csrc/optim.hip), with gradient clipping folded in.
+"""
+import json
+
+import torch
+
+
+def get_parameter_groups(model, weight_decay=1e-5, skip_list=(), get_num_layer=None, get_layer_scale=None):
+    assert get_num_layer is None and get_layer_scale is None, "layer-decay groups belong to finetuning"
+    names = {}
+    groups = {}
+    for name, param in model.named_parameters():
+        if not param.requires_grad:
+            continue
+        if len(param.shape) == 1 or name.endswith(".bias") or name in skip_list:
+            gname, wd = "no_decay", 0.0
+        else:
+            gname, wd = "decay", weight_decay
+        if gname not in groups:
+            names[gname] = {"weight_decay": wd, "params": [], "lr_scale": 1.0}
+            groups[gname] = {"weight_decay": wd, "params": [], "lr_scale": 1.0}
+        groups[gname]["params"].append(param)
+        names[gname]["params"].append(name)
+    print("Param groups = %s" % json.dumps(names, indent=2))
+    return list(groups.values())
+
+
+class FlatAdamW:
+    """torch.optim.AdamW-shaped optimizer over the engine's flat buffers.
+
+    ``param_groups`` (lr / weight_decay / lr_scale, as engine_for_pretraining.py:126-130 mutates
+    them every step), ``zero_grad``, ``step``, ``state_dict`` / ``load_state_dict`` (torch's
+    per-parameter layout, so reference checkpoints interchange)."""
+
+    def __init__(self, model, param_groups, lr, betas=(0.9, 0.95), eps=1e-8):
+        self.engine = model.engine
+        self.defaults = dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=0.0)
+        self.param_groups = []
+        for g in param_groups:
+            g = dict(g)
+            g.setdefault("lr", lr)
+            g.setdefault("betas", tuple(betas))
+            g.setdefault("eps", eps)
+            self.param_groups.append(g)
+        assert all(g.get("lr_scale", 1.0) == 1.0 for g in self.param_groups), "pretraining uses lr_scale 1"
+        e = self.engine
+        self.exp_avg = torch.zeros(e.nflat, dtype=torch.float32, device=e.dev)
+        self.exp_avg_sq = torch.zeros(e.nflat, dtype=torch.float32, device=e.dev)
+        self.steps = 0
+        self.is_second_order = False
+        self.max_norm = 0.0           # set by the scaler (clip folded into the update kernel)
+
+    def zero_grad(self, set_to_none=False):
+        self.engine.flat_g.zero_()
+
+    def step(self):
+        lrs = {g["lr"] for g in self.param_groups}
+        assert len(lrs) == 1, "flat AdamW: one learning rate for all groups (lr_scale == 1)"
+        wds = [g["weight_decay"] for g in self.param_groups if g["weight_decay"] > 0]
+        wd = wds[0] if wds else 0.0
+        g0 = self.param_groups[0]
+        self.steps += 1
+        self.engine.adamw_step(self.exp_avg, self.exp_avg_sq, lrs.pop(), wd, self.steps, betas=g0["betas"],
+                               eps=g0["eps"], max_norm=self.max_norm)
+
+    # ---- torch-format state for checkpoints (utils.save_model / auto_load_model)
+    def _param_list(self):
+        return [p for g in self.param_groups for p in g["params"]]
+
+    def state_dict(self):
+        e = self.engine
+        name_of = {id(p): n for n, p in e.named.items()}
+        state, idx = {}, 0
+        groups = []
+        for g in self.param_groups:
+            ids = []
+            for p in g["params"]:
+                o, k = e.segs[name_of[id(p)]]
+                if self.steps:
+                    state[idx] = {"step": torch.tensor(float(self.steps)),
+                                  "exp_avg": self.exp_avg[o:o + k].view(p.shape).clone(),
+                                  "exp_avg_sq": self.exp_avg_sq[o:o + k].view(p.shape).clone()}
+                ids.append(idx)
+                idx += 1
+            groups.append({**{k: v for k, v in g.items() if k != "params"}, "params": ids})
+        return {"state": state, "param_groups": groups}
+
+    def load_state_dict(self, sd):
+        e = self.engine
+        name_of = {id(p): n for n, p in e.named.items()}
+        params = self._param_list()
+        for g, sg in zip(self.param_groups, sd["param_groups"]):
+            for k, v in sg.items():
+                if k != "params":
+                    g[k] = v
+        for idx, st in sd["state"].items():
+            p = params[int(idx)]
+            o, k = e.segs[name_of[id(p)]]
+            self.exp_avg[o:o + k].copy_(st["exp_avg"].reshape(-1))
+            self.exp_avg_sq[o:o + k].copy_(st["exp_avg_sq"].reshape(-1))
+            self.steps = int(float(st["step"]))
+
+
+def create_optimizer(args, model, get_num_layer=None, get_layer_scale=None, filter_bias_and_bn=True, skip_list=None):
+    opt_lower = args.opt.lower()
+    if opt_lower.split("_")[-1] != "adamw":
+        raise NotImplementedError(f"--opt {args.opt}: the pretraining path uses adamw (every reference config)")
+    weight_decay = args.weight_decay
+    if weight_decay and filter_bias_and_bn:
+        skip = skip_list if skip_list is not None else (model.no_weight_decay() if hasattr(model, "no_weight_decay") else {})
+        parameters = get_parameter_groups(model, weight_decay, skip, get_num_layer, get_layer_scale)
+    else:
+        parameters = [{"params": list(model.parameters()), "weight_decay": weight_decay, "lr_scale": 1.0}]
+    eps = args.opt_eps if getattr(args, "opt_eps", None) is not None else 1e-8
+    return FlatAdamW(model, parameters, lr=args.lr, betas=(0.9, 0.95), eps=eps)   # betas: optim_factory.py:121

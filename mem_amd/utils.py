@@ -1,0 +1,324 @@
+"""Runtime utilities -- mirror of the pretraining-path parts of /root/reference/mem/utils.py:
+SmoothedValue / MetricLogger (:34-183), distributed init (:235-299), NativeScalerWithGradNormCount
+(:351-377), get_grad_norm_ (:380-392), cosine_scheduler (:395-412), save_model / auto_load_model
+(:425-447, :485-519), create_d_vae / get_event_vae (:559-578).
+
+Differences that are deliberate: device-agnostic (the reference hard-codes
+'cuda' / torch.cuda.synchronize), one packed all-reduce for all meters instead of one per meter,
+and a scaler that is a no-op for bf16 (no loss scaling needed) but keeps the checkpoint key.
+"""
+import datetime
+import glob
+import math
+import os
+import time
+from collections import defaultdict, deque
+from pathlib import Path
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+class SmoothedValue(object):
+    def __init__(self, window_size=20, fmt=None):
+        if fmt is None:
+            fmt = "{median:.4f} ({global_avg:.4f})"
+        self.deque = deque(maxlen=window_size)
+        self.total = 0.0
+        self.count = 0
+        self.fmt = fmt
+
+    def update(self, value, n=1):
+        self.deque.append(value)
+        self.count += n
+        self.total += value * n
+
+    def synchronize_between_processes(self):
+        """utils.py:52-63 (count/total only; the deque stays local)."""
+        if not is_dist_avail_and_initialized():
+            return
+        t = _sync_device_tensor([self.count, self.total])
+        self.count, self.total = int(t[0]), t[1]
+
+    @property
+    def median(self):
+        return torch.tensor(list(self.deque)).median().item()
+
+    @property
+    def avg(self):
+        return torch.tensor(list(self.deque), dtype=torch.float32).mean().item()
+
+    @property
+    def global_avg(self):
+        return float("nan") if self.count == 0 else self.total / self.count
+
+    @property
+    def max(self):
+        return float("nan") if len(self.deque) == 0 else max(self.deque)
+
+    @property
+    def value(self):
+        return float("nan") if len(self.deque) == 0 else self.deque[-1]
+
+    def __str__(self):
+        return self.fmt.format(median=self.median, avg=self.avg, global_avg=self.global_avg, max=self.max,
+                               value=self.value)
+
+
+def _sync_device_tensor(values):
+    dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+    t = torch.tensor(values, dtype=torch.float64, device=dev)
+    dist.barrier()
+    dist.all_reduce(t)
+    return t.tolist()
+
+
+class MetricLogger(object):
+    def __init__(self, delimiter="\t"):
+        self.meters = defaultdict(SmoothedValue)
+        self.delimiter = delimiter
+
+    def update(self, **kwargs):
+        for k, v in kwargs.items():
+            if v is None:
+                continue
+            if isinstance(v, torch.Tensor):
+                v = v.item()
+            assert isinstance(v, (float, int))
+            self.meters[k].update(v)
+
+    def __getattr__(self, attr):
+        if attr in self.meters:
+            return self.meters[attr]
+        if attr in self.__dict__:
+            return self.__dict__[attr]
+        raise AttributeError("'{}' object has no attribute '{}'".format(type(self).__name__, attr))
+
+    def __str__(self):
+        return self.delimiter.join("{}: {}".format(n, str(m)) for n, m in self.meters.items())
+
+    def synchronize_between_processes(self):
+        """All meters in ONE packed fp64 all-reduce (the reference issues one per meter)."""
+        if not is_dist_avail_and_initialized():
+            return
+        names = list(self.meters.keys())
+        flat = []
+        for n in names:
+            flat += [self.meters[n].count, self.meters[n].total]
+        t = _sync_device_tensor(flat)
+        for i, n in enumerate(names):
+            self.meters[n].count, self.meters[n].total = int(t[2 * i]), t[2 * i + 1]
+
+    def add_meter(self, name, meter):
+        self.meters[name] = meter
+
+    def log_every(self, iterable, print_freq, header=None):
+        i = 0
+        header = header or ""
+        start_time = time.time()
+        end = time.time()
+        iter_time = SmoothedValue(fmt="{avg:.4f}")
+        data_time = SmoothedValue(fmt="{avg:.4f}")
+        space_fmt = ":" + str(len(str(len(iterable)))) + "d"
+        log_msg = [header, "[{0" + space_fmt + "}/{1}]", "eta: {eta}", "{meters}", "time: {time}", "data: {data}"]
+        if torch.cuda.is_available():
+            log_msg.append("max mem: {memory:.0f}")
+        log_msg = self.delimiter.join(log_msg)
+        MB = 1024.0 * 1024.0
+        for obj in iterable:
+            data_time.update(time.time() - end)
+            yield obj
+            iter_time.update(time.time() - end)
+            if i % print_freq == 0 or i == len(iterable) - 1:
+                eta = str(datetime.timedelta(seconds=int(iter_time.global_avg * (len(iterable) - i))))
+                kw = dict(eta=eta, meters=str(self), time=str(iter_time), data=str(data_time))
+                if torch.cuda.is_available():
+                    kw["memory"] = torch.cuda.max_memory_allocated() / MB
+                print(log_msg.format(i, len(iterable), **kw))
+            i += 1
+            end = time.time()
+        total_time = time.time() - start_time
+        print("{} Total time: {} ({:.4f} s / it)".format(header, str(datetime.timedelta(seconds=int(total_time))),
+                                                         total_time / max(1, len(iterable))))
+
+
+def setup_for_distributed(is_master):
+    import builtins as __builtin__
+    builtin_print = __builtin__.print
+
+    def print(*args, **kwargs):
+        force = kwargs.pop("force", False)
+        if is_master or force:
+            builtin_print(*args, **kwargs)
+
+    __builtin__.print = print
+
+
+def is_dist_avail_and_initialized():
+    return dist.is_available() and dist.is_initialized()
+
+
+def get_world_size():
+    return dist.get_world_size() if is_dist_avail_and_initialized() else 1
+
+
+def get_rank():
+    return dist.get_rank() if is_dist_avail_and_initialized() else 0
+
+
+def is_main_process():
+    return get_rank() == 0
+
+
+def save_on_master(*args, **kwargs):
+    if is_main_process():
+        torch.save(*args, **kwargs)
+
+
+def init_distributed_mode(args):
+    """utils.py:264-294; backend nccl (= RCCL on ROCm) for cuda, gloo for --device cpu."""
+    if getattr(args, "dist_on_itp", False):
+        args.rank = int(os.environ["OMPI_COMM_WORLD_RANK"])
+        args.world_size = int(os.environ["OMPI_COMM_WORLD_SIZE"])
+        args.gpu = int(os.environ["OMPI_COMM_WORLD_LOCAL_RANK"])
+        args.dist_url = "tcp://%s:%s" % (os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"])
+        os.environ["LOCAL_RANK"], os.environ["RANK"], os.environ["WORLD_SIZE"] = str(args.gpu), str(args.rank), str(args.world_size)
+    elif "RANK" in os.environ and "WORLD_SIZE" in os.environ:
+        args.rank = int(os.environ["RANK"])
+        args.world_size = int(os.environ["WORLD_SIZE"])
+        args.gpu = int(os.environ["LOCAL_RANK"])
+    elif "SLURM_PROCID" in os.environ:
+        args.rank = int(os.environ["SLURM_PROCID"])
+        args.gpu = args.rank % max(1, torch.cuda.device_count())
+    else:
+        print("Not using distributed mode")
+        args.distributed = False
+        return
+    args.distributed = True
+    on_gpu = str(getattr(args, "device", "cuda")).startswith("cuda")
+    if on_gpu:
+        torch.cuda.set_device(args.gpu)
+    args.dist_backend = "nccl" if on_gpu else "gloo"
+    print("| distributed init (rank {}): {}, gpu {}".format(args.rank, args.dist_url, args.gpu), flush=True)
+    dist.init_process_group(backend=args.dist_backend, init_method=args.dist_url, world_size=args.world_size,
+                            rank=args.rank)
+    dist.barrier()
+    setup_for_distributed(args.rank == 0)
+
+
+def cleanup_distributed_mode():
+    if is_dist_avail_and_initialized():
+        dist.destroy_process_group()
+
+
+class NativeScalerWithGradNormCount:
+    """utils.py:351-377.  bf16 needs no loss scaling: backward -> (fused) clip -> step; the returned
+    value is the total gradient norm BEFORE clipping, like clip_grad_norm_ / get_grad_norm_.
+    ``loss`` is either an autograd tensor or the model's fused-loss handle (``model.backward``)."""
+    state_dict_key = "amp_scaler"
+
+    def __call__(self, loss, optimizer, clip_grad=None, parameters=None, create_graph=False, update_grad=True,
+                 model=None, reducer=None):
+        if model is not None and getattr(model, "_fused_loss_pending", False):
+            model.backward()
+            model._fused_loss_pending = False
+        else:
+            loss.backward(create_graph=create_graph)
+        if not update_grad:
+            return None
+        if reducer is not None:
+            reducer.finish()
+        norm = optimizer.engine.grad_norm()
+        optimizer.max_norm = float(clip_grad) if clip_grad else 0.0
+        optimizer.step()
+        return norm
+
+    def state_dict(self):
+        return {"scale": 1.0, "growth_factor": 2.0, "backoff_factor": 0.5, "growth_interval": 2000,
+                "_growth_tracker": 0}
+
+    def load_state_dict(self, state_dict):
+        pass
+
+
+def get_grad_norm_(parameters, norm_type: float = 2.0) -> torch.Tensor:
+    """utils.py:380-392 (generic helper, torch plumbing)."""
+    if isinstance(parameters, torch.Tensor):
+        parameters = [parameters]
+    parameters = [p for p in parameters if p.grad is not None]
+    if len(parameters) == 0:
+        return torch.tensor(0.0)
+    device = parameters[0].grad.device
+    if norm_type == math.inf:
+        return max(p.grad.detach().abs().max().to(device) for p in parameters)
+    return torch.norm(torch.stack([torch.norm(p.grad.detach(), norm_type).to(device) for p in parameters]), norm_type)
+
+
+def cosine_scheduler(base_value, final_value, epochs, niter_per_ep, warmup_epochs=0, start_warmup_value=0,
+                     warmup_steps=-1):
+    """utils.py:395-412."""
+    warmup_schedule = np.array([])
+    warmup_iters = warmup_epochs * niter_per_ep
+    if warmup_steps > 0:
+        warmup_iters = warmup_steps
+    print("Set warmup steps = %d" % warmup_iters)
+    if warmup_epochs > 0:
+        warmup_schedule = np.linspace(start_warmup_value, base_value, warmup_iters)
+    iters = np.arange(epochs * niter_per_ep - warmup_iters)
+    schedule = np.array([final_value + 0.5 * (base_value - final_value) * (1 + math.cos(math.pi * i / (len(iters))))
+                         for i in iters])
+    schedule = np.concatenate((warmup_schedule, schedule))
+    assert len(schedule) == epochs * niter_per_ep
+    return schedule
+
+
+def save_model(args, epoch, model, model_without_ddp, optimizer, loss_scaler, model_ema=None):
+    """utils.py:425-447 (torch.amp branch): same file name and keys."""
+    output_dir = Path(args.output_dir)
+    to_save = {"model": model_without_ddp.state_dict(), "optimizer": optimizer.state_dict(), "epoch": epoch,
+               "scaler": loss_scaler.state_dict(), "args": args}
+    save_on_master(to_save, output_dir / ("checkpoint-%s.pth" % str(epoch)))
+
+
+def auto_load_model(args, model, model_without_ddp, optimizer, loss_scaler, model_ema=None):
+    """utils.py:485-519."""
+    output_dir = Path(args.output_dir)
+    if args.auto_resume and len(args.resume) <= 1:
+        latest = -1
+        for ckpt in glob.glob(os.path.join(output_dir, "checkpoint-*.pth")):
+            t = ckpt.split("-")[-1].split(".")[0]
+            if t.isdigit():
+                latest = max(int(t), latest)
+        if latest >= 0:
+            args.resume = os.path.join(output_dir, "checkpoint-%d.pth" % latest)
+        print("Auto resume checkpoint: %s" % args.resume)
+    print(f"Resuming from {args.resume}")
+    if args.resume:
+        checkpoint = torch.load(args.resume, map_location="cpu", weights_only=False)
+        model_without_ddp.load_state_dict(checkpoint["model"], strict=True)
+        print("Resume checkpoint %s" % args.resume)
+        if optimizer is not None and "optimizer" in checkpoint and "epoch" in checkpoint:
+            optimizer.load_state_dict(checkpoint["optimizer"])
+            epoch = checkpoint["epoch"] if checkpoint["epoch"] != "best" else args.epochs
+            args.start_epoch = epoch + 1
+            if "scaler" in checkpoint:
+                loss_scaler.load_state_dict(checkpoint["scaler"])
+            print("With optim & sched!")
+
+
+def create_d_vae(weight_path, d_vae_type, image_size, device):
+    if d_vae_type == "event":
+        return get_event_vae(weight_path, image_size, device)
+    raise NotImplementedError()
+
+
+def get_event_vae(weight_path, image_size, device):
+    """utils.py:571-578: checkpoint {'hparams', 'weights', ...} written by eventvae/train_vae.py:271-290."""
+    from .vae_model import DiscreteVAE
+    loaded_obj = torch.load(weight_path, map_location="cpu", weights_only=False)
+    vae_params, weights = loaded_obj["hparams"], loaded_obj["weights"]
+    vae = DiscreteVAE(**vae_params).to(device)
+    vae.load_state_dict(weights)
+    print(f"loaded event vae from {weight_path}")
+    return vae
