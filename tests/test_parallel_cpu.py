@@ -1,0 +1,60 @@
+"""-m "not gpu": the N>1 data-parallel gradient exchange (parallel.GradReducer) with world_size 2
+on the gloo backend: bucketed async all-reduce == mean of the per-rank gradients, parameters are
+broadcast from rank 0, and the packed metric all-reduce of MetricLogger."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from mem_amd.parallel import GradReducer
+    from mem_amd import utils
+    n = 5 * 1024
+    buckets = [("head", 0, 1024), ("block1", 1024, 3072), ("block0", 3072, 4096), ("embed", 4096, n)]
+    flat_p = torch.full((n,), float(rank + 1))
+    flat_g = torch.arange(n, dtype=torch.float32) * (rank + 1)
+    red = GradReducer(flat_g, buckets, flat_p=flat_p)
+    assert torch.equal(flat_p, torch.ones(n))                    # rank-0 weights everywhere
+    for b in range(len(buckets)):                                # the order backward releases buckets
+        red(b)
+    red.finish()
+    want = torch.arange(n, dtype=torch.float32) * (1 + 2) / 2    # mean over ranks
+    ok = torch.allclose(flat_g, want)
+    ml = utils.MetricLogger()
+    ml.update(loss=float(rank + 1), acc=0.5 * (rank + 1))
+    ml.update(loss=float(rank + 3))
+    ml.synchronize_between_processes()
+    ok = ok and abs(ml.loss.global_avg - (1 + 3 + 2 + 4) / 4) < 1e-12 and ml.loss.count == 4
+    ok = ok and abs(ml.acc.global_avg - (0.5 + 1.0) / 2) < 1e-12
+    q.put((rank, bool(ok)))
+    dist.destroy_process_group()
+
+
+def test_grad_reducer_world2_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(60)
+    assert sorted(res) == [(0, True), (1, True)]
+
+
+def test_reducer_single_process_noop():
+    from mem_amd.parallel import GradReducer
+    g = torch.ones(2048)
+    r = GradReducer(g, [("a", 0, 1024), ("b", 1024, 2048)])
+    r(0); r(1); r.finish()
+    assert torch.equal(g, torch.ones(2048))

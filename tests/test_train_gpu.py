@@ -1,0 +1,81 @@
+"""-m gpu: optimisation-step and loss-curve parity of the HIP path against the reference goldens
+(tests/golden/vit_tiny_train100.npz: reference model + reference create_optimizer, 100 steps, and
+vit_base_c3.npz cfg1: BASELINE config #1 = ViT-B, B=2, 10 steps).
+
+Stated tolerances: the product trains in bf16 (GEMM operands) with fp32 accumulate/residual --
+the reference's autocast policy.  Against the reference's bf16-autocast curve the per-step loss
+differs by accumulation-order noise that compounds slowly over steps:
+   |loss_hip - loss_ref_bf16| <= 0.02 over 100 steps, <= 5e-3 over the first 10;
+   vs the fp32 reference curve <= 0.05;  grad-norm within 5 %.
+(The north-star 1e-4 figure needs an fp32-operand mode that this round does not have: DESIGN.md.)
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(cfg, n_steps, batch_fn, lr, wd, clip, seed_w):
+    from mem_amd.modeling_pretrain import pt_vit
+    from mem_amd.optim_factory import create_optimizer
+    from mem_amd.utils import NativeScalerWithGradNormCount
+    from oracle.vit_ref import fill_by_name
+    import contextlib, io
+
+    class A:
+        opt = "adamw"; weight_decay = 0.05; lr = 5e-4; opt_eps = 1e-8; opt_betas = [0.9, 0.999]; momentum = 0.9
+    m = pt_vit(**cfg)
+    m.load_state_dict(fill_by_name(m.state_dict(), seed=seed_w))
+    m = m.cuda().train()
+    with contextlib.redirect_stdout(io.StringIO()):
+        opt = create_optimizer(A(), m)
+    scaler = NativeScalerWithGradNormCount()
+    rec = []
+    for it in range(n_steps):
+        for g in opt.param_groups:                       # engine_for_pretraining.py:124-130
+            g["lr"] = lr[it] * g["lr_scale"]
+            if g["weight_decay"] > 0:
+                g["weight_decay"] = wd[it]
+        x, mask, labels = batch_fn(it)
+        la = m.forward_loss(x.cuda(), mask.cuda(), labels.cuda())
+        m._fused_loss_pending = True
+        gn = scaler(la, opt, clip_grad=clip, parameters=m.parameters(), model=m)
+        rec.append((la[0].item(), gn.item(), la[1].item()))
+    return m, opt, np.array(rec)
+
+
+def test_tiny_100_steps_vs_reference_curves():
+    from oracle.gen_golden import TINY, vit_inputs
+    g = np.load(os.path.join(GOLDEN, "vit_tiny_train100.npz"))
+    m, opt, rec = _run(TINY, 100, lambda it: vit_inputs(TINY, 4, 1000 + it % 8, 6), g["lr"], g["wd"], 30.0, 0)
+    d16 = np.abs(rec[:, 0] - g["bf16__loss"])
+    d32 = np.abs(rec[:, 0] - g["fp32__loss"])
+    print("max |dloss| vs bf16 ref: first10 %.2e, all %.2e; vs fp32 ref %.2e; step-100 %.2e" %
+          (d16[:10].max(), d16.max(), d32.max(), d16[-1]))
+    assert d16[:10].max() <= 5e-3 and d16.max() <= 2e-2 and d32.max() <= 5e-2
+    assert rec[-1, 0] < rec[0, 0] - 0.5                                    # it actually learns
+    assert np.abs(rec[:, 1] / g["bf16__gnorm"] - 1).max() <= 0.05
+    # checkpoint round trip of the optimizer state in torch's layout
+    sd = opt.state_dict()
+    assert len(sd["state"]) == len(list(m.parameters())) and sd["param_groups"][0]["betas"] == (0.9, 0.95)
+    opt.load_state_dict(sd)
+
+
+def test_vit_base_config1_10_steps():
+    """BASELINE config #1 arithmetic (ViT-B C=3, B=2, 10 steps, ncaltech.conf hyper-parameters) on the
+    GPU against the reference's fp32 CPU curve."""
+    from oracle.gen_golden import BASE, vit_inputs
+    g = np.load(os.path.join(GOLDEN, "vit_base_c3.npz"))
+    cfg = dict(BASE, in_chans=3)
+    from oracle.vit_ref import cosine_scheduler
+    wd10 = cosine_scheduler(0.05, 0.05, 1, 10)
+    _, _, rec = _run(cfg, 10, lambda it: vit_inputs(cfg, 2, 500 + it, 98), g["cfg1__lr"], wd10, 30.0, 1)
+    d = np.abs(rec[:, 0] - g["cfg1__loss"])
+    print("config#1 max |dloss| vs fp32 reference: %.3e" % d.max(), rec[:, 0], g["cfg1__loss"])
+    assert d.max() <= 3e-2
+    assert np.abs(rec[:, 1] / g["cfg1__gnorm"] - 1).max() <= 0.08
