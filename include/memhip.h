@@ -175,6 +175,16 @@ typedef struct memhip_gemm_args {
 } memhip_gemm_args_t;
 int memhip_gemm_bf16_nt(const memhip_gemm_args_t* args, memhip_stream_t stream);
 
+/* Weight-gradient GEMM  out[N,K] (+)= sum_r A[r,N] * B[r,K]  (A = dY, B = X, both token-major
+ * bf16 with the reduction over ROWS): the dY^T @ X that autograd computes for every Linear /
+ * Conv2d weight on the path.  No transposed copies: fragments are read with the transposing LDS
+ * read; split-K over the rows with fp32 atomics.  accumulate=1: add into `out` (pre-zeroed by
+ * the caller); accumulate=0: overwrite. */
+int memhip_gemm_bf16_tn(const void* A, int64_t lda, const void* B, int64_t ldb, int R, int N, int K,
+                        float* out, int64_t ldo, int accumulate, memhip_stream_t stream);
+/* out f32 [C] += column sums of in bf16 [R, C]  (Linear bias gradients = grad_output.sum(0)) */
+int memhip_colsum_bf16(const void* in, int64_t ld, int R, int C, float* out, memhip_stream_t stream);
+
 /* ------------------------------------------------------------------------
  * LayerNorm (eps 1e-6) forward / backward          mem/modeling_pretrain.py:132,
  * mem/modeling_finetune.py:166,172,184-188; final norm mem/modeling_pretrain.py:117

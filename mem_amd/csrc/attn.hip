@@ -16,6 +16,7 @@
 // Rounding points follow the reference under autocast: q k^T and the P V / dO V^T / dS K products
 // are rounded to bf16, bias add + softmax (+ its backward) run in fp32, P and dS are rounded to
 // bf16 when they feed an MFMA.
+#include <cstdlib>
 #include "common.h"
 
 namespace {
@@ -48,38 +49,72 @@ __device__ __forceinline__ bf16x8 acc_frag(const f32x16& x, int s, float mul) {
   return r;
 }
 
-// Stage the transposed copy dst[d][tok] (row stride VS) of a [T][64] head slice that sits at
-// src + tok*ld (tokens >= T are zero-filled up to TP).
-__device__ __forceinline__ void stage_transposed(__bf16* dst, int VS, const __bf16* src, long long ld, int T,
-                                                 int TP) {
-  for (int idx = threadIdx.x; idx < TP * 8; idx += blockDim.x) {
-    const int tok = idx >> 3, dc = idx & 7;
-    bf16x8 v;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) v[i] = (__bf16)0.f;
-    if (tok < T) v = ld16(src + (long long)tok * ld + dc * 8);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) dst[(dc * 8 + i) * VS + tok] = v[i];
+__device__ __attribute__((aligned(256))) unsigned char g_attn_zero_page[128];   // zero-initialised
+
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                   (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
+}
+
+// LDS image of a [TP tokens][64] bf16 head slice: 128-B rows, 16-B chunk c of token t lives at
+// chunk position c ^ ((t >> 1) & 7)  (same XOR as the GEMM tiles: conflict-free ds_read_b128 row
+// fragments; the transposing reads below are 2-way at worst).
+__device__ __forceinline__ int tok_slot(int tok, int chunk) { return tok * 8 + (chunk ^ ((tok >> 1) & 7)); }
+
+// Stage src[tok*ld + 0..63] (tok < T, zero beyond) with LDS-DMA: one wave-instruction = 8 tokens.
+__device__ __forceinline__ void stage_head(char* dst, const __bf16* src, long long ld, int T, int TP) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  for (int inst = wave; inst < TP / 8; inst += nw) {
+    const int tok = inst * 8 + (lane >> 3), cpos = lane & 7;
+    const int chunk = cpos ^ ((tok >> 1) & 7);
+    const void* g = tok < T ? (const void*)(src + (long long)tok * ld + chunk * 8)
+                            : (const void*)(g_attn_zero_page + cpos * 16);
+    glds16(g, dst + inst * 1024);
   }
+}
+
+// row fragment: 8 consecutive head-dim elements (16-B chunk) of one token -> MFMA operand whose
+// lane-row is the token (lane r = tok, k = 16t + 8hh + j)
+__device__ __forceinline__ bf16x8 row_frag(const char* img, int tok, int chunk) {
+  return *reinterpret_cast<const bf16x8*>(img + tok_slot(tok, chunk) * 16);
+}
+
+// column fragment via ds_read_b64_tr_b16: lane (r = l&31 -> d = db*32 + r, hh = l>>5) receives the
+// 8 tokens tokbase+{0..3} and tokbase+8+{0..3} of head-dim column d  (tokbase already holds +4hh)
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+__device__ __forceinline__ bf16x8 col_frag(const char* img, int tokbase, int db, int lane) {
+  const int rhalf = (lane >> 4) & 1, q = (lane >> 2) & 3, p = lane & 3;
+  const int ch = db * 4 + rhalf * 2 + (p >> 1), h8 = (p & 1) * 8;
+  const int t0 = tokbase + q, t1 = t0 + 8;
+  const char* a0 = img + tok_slot(t0, ch) * 16 + h8;
+  const char* a1 = img + tok_slot(t1, ch) * 16 + h8;
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)a0);
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)a1);
+  union { struct { s16x4 l, h; } s; bf16x8 v; } u;
+  u.s.l = lo;
+  u.s.h = hi;
+  return u.v;
 }
 
 #define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
 
 // ------------------------------------------------------------------------------- forward
 template <int NKB>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const __bf16* __restrict__ qkv, long long ldq, int T,
+__global__ __launch_bounds__(512) void attn_fwd_kernel(const __bf16* __restrict__ qkv, long long ldq, int T,
                                                        int D, int H, const float* __restrict__ bias,
                                                        __bf16* __restrict__ out, long long ldo,
                                                        float* __restrict__ lse) {
-  constexpr int TP = NKB * 32, VS = TP + 4;
-  __shared__ __attribute__((aligned(16))) __bf16 Vt[HD * VS];
+  constexpr int TP = NKB * 32;
+  __shared__ __attribute__((aligned(16))) char Ks[TP * 128];
+  __shared__ __attribute__((aligned(16))) char Vs[TP * 128];
   const int b = blockIdx.x / H, h = blockIdx.x % H;
   const __bf16* base = qkv + (long long)b * T * ldq + h * HD;      // q slice of this head
-  stage_transposed(Vt, VS, base + 2 * D, ldq, T, TP);
+  stage_head(Ks, base + D, ldq, T, TP);
+  stage_head(Vs, base + 2 * D, ldq, T, TP);
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 31, hh = lane >> 5;
-  for (int qb = wave; qb < NKB; qb += 4) {
+  for (int qb = wave; qb < NKB; qb += 8) {
     const int q = qb * 32 + r;
     const int qc = q < T ? q : T - 1;
     bf16x8 Qf[4];
@@ -90,13 +125,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const __bf16* __restrict_
     for (int kb = 0; kb < NKB; ++kb) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) s[kb][i] = 0.f;
-      const int kr = kb * 32 + r;
-      const int krc = kr < T ? kr : T - 1;
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const bf16x8 Kf = ld16(base + D + (long long)krc * ldq + 16 * t + 8 * hh);
-        s[kb] = MFMA32(Kf, Qf[t], s[kb]);
-      }
+      for (int t = 0; t < 4; ++t) s[kb] = MFMA32(row_frag(Ks, kb * 32 + r, 2 * t + hh), Qf[t], s[kb]);
     }
     // + bias, key mask, row max  (lane: query q; regs: keys)
     const float* brow = bias + ((long long)h * TP + q) * TP;
@@ -143,10 +173,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const __bf16* __restrict_
         const bf16x8 pf = acc_frag(s[kb], ss, inv);
         const int key0 = kb * 32 + 16 * ss + 4 * hh;
 #pragma unroll
-        for (int db = 0; db < 2; ++db) {
-          const __bf16* vrow = Vt + (db * 32 + r) * VS + key0;
-          o[db] = MFMA32(cat4(vrow, vrow + 8), pf, o[db]);
-        }
+        for (int db = 0; db < 2; ++db) o[db] = MFMA32(col_frag(Vs, key0, db, lane), pf, o[db]);
       }
     }
     if (q < T) {
@@ -166,7 +193,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const __bf16* __restrict_
 
 // ------------------------------------------------------------------------------- backward
 template <int NKB>
-__global__ __launch_bounds__(256) void attn_bwd_kernel(const __bf16* __restrict__ qkv, long long ldq,
+__global__ __launch_bounds__(512) void attn_bwd_kernel(const __bf16* __restrict__ qkv, long long ldq,
                                                        const __bf16* __restrict__ dout,
                                                        const __bf16* __restrict__ out, long long ldo,
                                                        const float* __restrict__ lse,
@@ -174,13 +201,14 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const __bf16* __restrict_
                                                        const int* __restrict__ relidx, int nrd,
                                                        __bf16* __restrict__ dqkv, long long lddq,
                                                        float* __restrict__ dtable, int T, int D, int H,
-                                                       float scale) {
-  constexpr int TP = NKB * 32, VS = TP + 4;
+                                                       float scale, int dbg) {
+  constexpr int TP = NKB * 32;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  __bf16* Qt = reinterpret_cast<__bf16*>(smem_raw);
-  __bf16* dOt = Qt + HD * VS;
-  __bf16* Kt = dOt + HD * VS;
-  float* lseS = reinterpret_cast<float*>(Kt + HD * VS);
+  char* Qs = smem_raw;
+  char* Ks = Qs + TP * 128;
+  char* Vs = Ks + TP * 128;
+  char* dOs = Vs + TP * 128;
+  float* lseS = reinterpret_cast<float*>(dOs + TP * 128);
   float* delS = lseS + TP;
   float* bins = delS + TP;
 
@@ -192,9 +220,10 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const __bf16* __restrict_
   const __bf16* dob = dout + row0 * ldo + h * HD;
   const __bf16* ob = out + row0 * ldo + h * HD;
 
-  stage_transposed(Qt, VS, qb_, ldq, T, TP);
-  stage_transposed(dOt, VS, dob, ldo, T, TP);
-  stage_transposed(Kt, VS, kb_, ldq, T, TP);
+  stage_head(Qs, qb_, ldq, T, TP);
+  stage_head(Ks, kb_, ldq, T, TP);
+  stage_head(Vs, vb_, ldq, T, TP);
+  stage_head(dOs, dob, ldo, T, TP);
   for (int q = threadIdx.x; q < TP; q += blockDim.x) {
     float dl = 0.f, l = 0.f;
     if (q < T) {
@@ -216,14 +245,14 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const __bf16* __restrict_
   const int r = lane & 31, hh = lane >> 5;
 
   // ---- phase A: a wave owns 32 keys, sweeps the queries: dV, dK   (tiles are [q rows][key cols])
-  for (int kb = wave; kb < NKB; kb += 4) {
+  if (!(dbg & 1))
+  for (int kb = wave; kb < NKB; kb += 8) {
     const int key = kb * 32 + r;
-    const int kc = key < T ? key : T - 1;
     bf16x8 Kf[4], Vf[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-      Kf[t] = ld16(kb_ + (long long)kc * ldq + 16 * t + 8 * hh);
-      Vf[t] = ld16(vb_ + (long long)kc * ldq + 16 * t + 8 * hh);
+      Kf[t] = row_frag(Ks, key, 2 * t + hh);
+      Vf[t] = row_frag(Vs, key, 2 * t + hh);
     }
     f32x16 dVt[2], dKt[2];
 #pragma unroll
@@ -232,16 +261,13 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const __bf16* __restrict_
       for (int i = 0; i < 16; ++i) { dVt[db][i] = 0.f; dKt[db][i] = 0.f; }
     for (int qb = 0; qb < NKB; ++qb) {
       const int qr = qb * 32 + r;
-      const int qc = qr < T ? qr : T - 1;
       f32x16 S, dP;
 #pragma unroll
       for (int i = 0; i < 16; ++i) { S[i] = 0.f; dP[i] = 0.f; }
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
-        const bf16x8 Qf = ld16(qb_ + (long long)qc * ldq + 16 * t + 8 * hh);
-        const bf16x8 dOf = ld16(dob + (long long)qc * ldo + 16 * t + 8 * hh);
-        S = MFMA32(Qf, Kf[t], S);
-        dP = MFMA32(dOf, Vf[t], dP);
+        S = MFMA32(row_frag(Qs, qr, 2 * t + hh), Kf[t], S);
+        dP = MFMA32(row_frag(dOs, qr, 2 * t + hh), Vf[t], dP);
       }
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
@@ -257,10 +283,8 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const __bf16* __restrict_
         const int q0 = qb * 32 + 16 * ss + 4 * hh;
 #pragma unroll
         for (int db = 0; db < 2; ++db) {
-          const __bf16* a1 = dOt + (db * 32 + r) * VS + q0;
-          const __bf16* a2 = Qt + (db * 32 + r) * VS + q0;
-          dVt[db] = MFMA32(cat4(a1, a1 + 8), pf, dVt[db]);
-          dKt[db] = MFMA32(cat4(a2, a2 + 8), dsf, dKt[db]);
+          dVt[db] = MFMA32(col_frag(dOs, q0, db, lane), pf, dVt[db]);
+          dKt[db] = MFMA32(col_frag(Qs, q0, db, lane), dsf, dKt[db]);
         }
       }
     }
@@ -280,14 +304,14 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const __bf16* __restrict_
   }
 
   // ---- phase B: a wave owns 32 queries, sweeps the keys: dQ, dBias   (tiles are [key rows][q cols])
-  for (int qb = wave; qb < NKB; qb += 4) {
+  if (!(dbg & 2))
+  for (int qb = wave; qb < NKB; qb += 8) {
     const int q = qb * 32 + r;
-    const int qc = q < T ? q : T - 1;
     bf16x8 Qf[4], dOf[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-      Qf[t] = ld16(qb_ + (long long)qc * ldq + 16 * t + 8 * hh);
-      dOf[t] = ld16(dob + (long long)qc * ldo + 16 * t + 8 * hh);
+      Qf[t] = row_frag(Qs, q, 2 * t + hh);
+      dOf[t] = row_frag(dOs, q, 2 * t + hh);
     }
     const float lq = lseS[q], dq_ = delS[q];
     f32x16 dQt[2];
@@ -299,16 +323,13 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const __bf16* __restrict_
     const int* irow = relidx + (long long)q * TP;
     for (int kb = 0; kb < NKB; ++kb) {
       const int kr = kb * 32 + r;
-      const int kc = kr < T ? kr : T - 1;
       f32x16 St, dPt;
 #pragma unroll
       for (int i = 0; i < 16; ++i) { St[i] = 0.f; dPt[i] = 0.f; }
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
-        const bf16x8 Kf = ld16(kb_ + (long long)kc * ldq + 16 * t + 8 * hh);
-        const bf16x8 Vf = ld16(vb_ + (long long)kc * ldq + 16 * t + 8 * hh);
-        St = MFMA32(Kf, Qf[t], St);
-        dPt = MFMA32(Vf, dOf[t], dPt);
+        St = MFMA32(row_frag(Ks, kr, 2 * t + hh), Qf[t], St);
+        dPt = MFMA32(row_frag(Vs, kr, 2 * t + hh), dOf[t], dPt);
       }
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
@@ -333,10 +354,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const __bf16* __restrict_
         const bf16x8 dsf = acc_frag(dPt, ss, 1.0f);
         const int k0 = kb * 32 + 16 * ss + 4 * hh;
 #pragma unroll
-        for (int db = 0; db < 2; ++db) {
-          const __bf16* a = Kt + (db * 32 + r) * VS + k0;
-          dQt[db] = MFMA32(cat4(a, a + 8), dsf, dQt[db]);
-        }
+        for (int db = 0; db < 2; ++db) dQt[db] = MFMA32(col_frag(Ks, k0, db, lane), dsf, dQt[db]);
       }
     }
     if (q < T) {
@@ -363,8 +381,8 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const __bf16* __restrict_
 
 template <int NKB>
 size_t bwd_smem(int nrd) {
-  constexpr int TP = NKB * 32, VS = TP + 4;
-  return (size_t)3 * HD * VS * 2 + (size_t)2 * TP * 4 + (size_t)nrd * 4 + 16;
+  constexpr int TP = NKB * 32;
+  return (size_t)4 * TP * 128 + (size_t)2 * TP * 4 + (size_t)nrd * 4 + 16;
 }
 
 }  // namespace
@@ -388,7 +406,7 @@ extern "C" int memhip_attn_fwd(const void* qkv, int64_t ldqkv, int B, int T, int
   MEMHIP_REQUIRE(ldqkv % 8 == 0 && ldo % 8 == 0, "attn_fwd: ld must be a multiple of 8");
   hipStream_t s = as_stream(stream);
   const int nkb = (T + 31) / 32;
-#define FWD(N) hipLaunchKernelGGL(attn_fwd_kernel<N>, dim3(B * heads), dim3(256), 0, s, (const __bf16*)qkv, \
+#define FWD(N) hipLaunchKernelGGL(attn_fwd_kernel<N>, dim3(B * heads), dim3(512), 0, s, (const __bf16*)qkv, \
                                   (long long)ldqkv, T, D, heads, bias_pad, (__bf16*)out, (long long)ldo, lse)
   ATTN_DISPATCH(nkb, FWD)
 #undef FWD
@@ -407,14 +425,15 @@ extern "C" int memhip_attn_bwd(const void* qkv, int64_t ldqkv, const void* dout,
   hipStream_t s = as_stream(stream);
   const int nkb = (T + 31) / 32;
   const int nrd = dtable ? num_rel : 0;
+  static const int dbg = getenv("MEMHIP_ATTN_DBG") ? atoi(getenv("MEMHIP_ATTN_DBG")) : 0;
 #define BWD(N)                                                                                         \
   {                                                                                                    \
     const size_t sm = bwd_smem<N>(nrd);                                                                \
     MEMHIP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_kernel<N>),                  \
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm));              \
-    hipLaunchKernelGGL(attn_bwd_kernel<N>, dim3(B * heads), dim3(256), sm, s, (const __bf16*)qkv,      \
+    hipLaunchKernelGGL(attn_bwd_kernel<N>, dim3(B * heads), dim3(512), sm, s, (const __bf16*)qkv,      \
                        (long long)ldqkv, (const __bf16*)dout, (const __bf16*)out, (long long)ldo, lse, \
-                       bias_pad, relidx_pad, nrd, (__bf16*)dqkv, (long long)lddqkv, dtable, T, D, heads, scale); \
+                       bias_pad, relidx_pad, nrd, (__bf16*)dqkv, (long long)lddqkv, dtable, T, D, heads, scale, dbg); \
   }
   ATTN_DISPATCH(nkb, BWD)
 #undef BWD

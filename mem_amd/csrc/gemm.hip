@@ -113,7 +113,35 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_nt_kernel(GemmArgs p) {
     cur ^= 1;
   }
 
-  // epilogue: C/D layout of 16x16 MFMA: col = lane & 15, row = (lane >> 4) * 4 + reg
+  // ---- epilogue.  C/D layout of the 16x16 MFMA: col = lane & 15, row = (lane >> 4) * 4 + reg.
+  // Fast path: each wave transposes its 64x64 fp32 sub-tile through its own 16 KiB slice of the
+  // (now idle) staging LDS, 32 rows at a time, so that a lane owns 8 consecutive columns of one
+  // row and every global access of the fused epilogue is a full 16-byte vector (a row of the
+  // sub-tile = 256 contiguous bytes of fp32 / 128 of bf16).
+  const int mw = m0 + wr * 64, nw = n0 + wc * 64;
+  if (vec_ok(p) && nw + 64 <= p.N) {
+    constexpr int LS = 72;                                  // padded row stride (floats)
+    float* wreg = reinterpret_cast<float*>(smem + wave * 16384);
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+#pragma unroll
+      for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            wreg[(ii * 16 + (lane >> 4) * 4 + r) * LS + j * 16 + (lane & 15)] = acc[half * 2 + ii][j][r];
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int row = it * 8 + (lane >> 3), c8 = (lane & 7) * 8;
+        const int m = mw + half * 32 + row;
+        float v[8];
+        ld8(wreg + row * LS + c8, v);
+        if (m < p.M) epilogue8<EPI>(p, m, nw + c8, v);
+      }
+    }
+    return;
+  }
   float bias_n[4], vec_n[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {

@@ -164,3 +164,27 @@ def grad_norm(g, n, norm_out, ws):
 def adamw(p, g, m, v, n, wd_flags, lr, beta1, beta2, eps, wd, step, gnorm=None, max_norm=0.0):
     check(lib.memhip_adamw(ptr(p), ptr(g), ptr(m), ptr(v), n, ptr(wd_flags), lr, beta1, beta2, eps, wd, step,
                            ptr(gnorm), max_norm if max_norm else 0.0, stream_ptr()), "adamw")
+
+
+declare({
+    "memhip_gemm_bf16_tn": (i32, [vp, i64, vp, i64, i32, i32, i32, vp, i64, i32, vp]),
+    "memhip_colsum_bf16": (i32, [vp, i64, i32, i32, vp, vp]),
+})
+
+
+def gemm_tn(A, B, R, N, K, out, accumulate=True):
+    """out[N,K] (+)= A[R,N]^T @ B[R,K]  (weight gradient; A = dY, B = X, token-major bf16)."""
+    if GEMM_TIMER is None:
+        check(lib.memhip_gemm_bf16_tn(ptr(A), A.stride(0), ptr(B), B.stride(0), R, N, K, ptr(out), out.stride(0),
+                                      int(accumulate), stream_ptr()), "gemm_bf16_tn")
+    else:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        check(lib.memhip_gemm_bf16_tn(ptr(A), A.stride(0), ptr(B), B.stride(0), R, N, K, ptr(out), out.stride(0),
+                                      int(accumulate), stream_ptr()), "gemm_bf16_tn")
+        e1.record()
+        GEMM_TIMER.append((e0, e1, 2.0 * R * N * K, 100))
+
+
+def colsum_bf16(x, R, Cc, out):
+    check(lib.memhip_colsum_bf16(ptr(x), x.stride(0), R, Cc, ptr(out), stream_ptr()), "colsum_bf16")

@@ -186,10 +186,6 @@ class ViTEngine:
         self.dqkv = e(M, 3 * D)
         self.dao = e(M, D)
         self.dYpe = e(B * self.L, D)
-        Mmp = _pad(Mm_cap, 64)
-        BLp = _pad(B * self.L, 64)
-        self.tA = e(max(max(Hd, 3 * D) * Mp, V * Mmp, D * BLp))
-        self.tB = e(max(Hd * Mp, D * Mmp, self.Kpe * BLp))
         self.B, self.Mm_cap = B, Mm_cap
 
     # ------------------------------------------------------------------ weights
@@ -268,14 +264,12 @@ class ViTEngine:
         return self.logits[:Mm]
 
     # ------------------------------------------------------------------ backward
-    def _wgrad(self, dY, X, R, n_out, n_in, gname, colsum0=None, c0=(0, 0), colsum1=None, c1=(0, 0)):
-        """grad[gname] [n_out, n_in] = dY[R, n_out]^T @ X[R, n_in]  (+ fused column sums of dY)."""
-        Rp = _pad(R, 64)
-        dYt = self.tA[: n_out * Rp].view(n_out, Rp)
-        Xt = self.tB[: n_in * Rp].view(n_in, Rp)
-        ops.transpose_bf16(dY, R, n_out, dYt, Rp, colsum0, c0, colsum1, c1)
-        ops.transpose_bf16(X, R, n_in, Xt, Rp)
-        ops.gemm_nt(dYt, Xt, n_out, n_in, Rp, ops.EPI_F32, out0=self.G(gname).view(n_out, n_in))
+    def _wgrad(self, dY, X, R, n_out, n_in, gname, bias_grads=()):
+        """grad[gname] [n_out, n_in] += dY[R, n_out]^T @ X[R, n_in]; bias_grads = ((grad_view, c0, c1), ...)
+        column sums of dY[:, c0:c1] (the Linear bias gradients)."""
+        ops.gemm_tn(dY, X, R, n_out, n_in, self.G(gname).view(n_out, n_in), accumulate=True)
+        for gv, c0, c1 in bias_grads:
+            ops.colsum_bf16(dY[:, c0:c1], R, c1 - c0, gv)
 
     def backward(self, dlogits=None):
         """Gradients of mean-CE (dlogits already in self.logits after forward(labels=...)) or of a
@@ -292,7 +286,7 @@ class ViTEngine:
         dl = self.logits
         # ---- head
         ops.gemm_nt(dl, self.wT_lm, Mm, D, V, ops.EPI_BIAS_BF16, out0=self.dhN)
-        self._wgrad(dl, self.hN, Mm, V, D, "lm_head.weight", colsum0=self.G("lm_head.bias"), c0=(0, V))
+        self._wgrad(dl, self.hN, Mm, V, D, "lm_head.weight", bias_grads=((self.G("lm_head.bias"), 0, V),))
         ops.layernorm_bwd(self.dhN, self.x[2 * self.depth], self.P("norm.weight"), self.meanN, self.rstdN, dx,
                           self.G("norm.weight"), self.G("norm.bias"), Mm, D, accumulate=False, row_idx=c["rows"])
         if self.grad_hook:
@@ -312,8 +306,8 @@ class ViTEngine:
                            rowmask=dp_masks[2 * i + 1] if use_dp else None, keep_prob=keep, rows_per_sample=T)
             ops.gemm_nt(self.dY, self.wT[i]["fc2"], M, Hd, D, ops.EPI_DGELU, out0=self.dbig, aux=a["hpre"])
             self._wgrad(self.dY, a["a"], M, D, Hd, pre + "mlp.fc2.weight")
-            self._wgrad(self.dbig, a["h2"], M, Hd, D, pre + "mlp.fc1.weight", colsum0=self.G(pre + "mlp.fc1.bias"),
-                        c0=(0, Hd))
+            self._wgrad(self.dbig, a["h2"], M, Hd, D, pre + "mlp.fc1.weight",
+                        bias_grads=((self.G(pre + "mlp.fc1.bias"), 0, Hd),))
             ops.gemm_nt(self.dbig, self.wT[i]["fc1"], M, D, Hd, ops.EPI_BIAS_BF16, out0=self.dh_small)
             ops.layernorm_bwd(self.dh_small, xmid, self.P(pre + "norm2.weight"), a["mean2"], a["rstd2"], dx,
                               self.G(pre + "norm2.weight"), self.G(pre + "norm2.bias"), M, D, accumulate=True)
@@ -326,8 +320,7 @@ class ViTEngine:
             ops.attn_bwd(a["qkv"], self.dao, a["ao"], a["lse"], self.bias_pad, self.relidx_pad, self.nrd, B, T, D,
                          self.heads, self.scale, self.dqkv, dtable)
             self._wgrad(self.dqkv, a["h1"], M, 3 * D, D, pre + "attn.qkv.weight",
-                        colsum0=self.G(pre + "attn.q_bias"), c0=(0, D), colsum1=self.G(pre + "attn.v_bias"),
-                        c1=(2 * D, 3 * D))
+                        bias_grads=((self.G(pre + "attn.q_bias"), 0, D), (self.G(pre + "attn.v_bias"), 2 * D, 3 * D)))
             ops.gemm_nt(self.dqkv, self.wT[i]["qkv"], M, D, 3 * D, ops.EPI_BIAS_BF16, out0=self.dh_small)
             ops.layernorm_bwd(self.dh_small, xin, self.P(pre + "norm1.weight"), a["mean1"], a["rstd1"], dx,
                               self.G(pre + "norm1.weight"), self.G(pre + "norm1.bias"), M, D, accumulate=True)
@@ -336,7 +329,7 @@ class ViTEngine:
         # ---- embedding
         ops.embed_bwd(dx, c["mask"], B, L, D, self.dYpe, self.G("cls_token"), self.G("mask_token"))
         self._wgrad(self.dYpe, self.patches, B * L, D, self.Kpe, "patch_embed.proj.weight",
-                    colsum0=self.G("patch_embed.proj.bias"), c0=(0, D))
+                    bias_grads=((self.G("patch_embed.proj.bias"), 0, D),))
         if self.grad_hook:
             self.grad_hook(self.depth + 1)
 

@@ -124,3 +124,28 @@ def test_vitb_shapes_throughput_sanity():
         ref = (A[rows].float() @ B.float().t()).bfloat16().float()
         torch.testing.assert_close(out[rows].float(), ref, rtol=2e-2, atol=2e-2)
         assert torch.isfinite(out.float()).all()
+
+
+@pytest.mark.parametrize("R,N,K", [(256, 128, 128), (394, 768, 768), (50432 // 8, 2304, 768), (1000, 512, 3072),
+                                   (333, 128, 512), (70, 768, 512), (5000, 8192, 768)])
+def test_gemm_tn_weight_gradient(R, N, K):
+    """out[N,K] += A[R,N]^T @ B[R,K] with the transposing LDS read + split-K atomics."""
+    from mem_amd import ops
+    # exact-integer check first (layout / k-permutation / swizzle mistakes are hard failures)
+    g = torch.Generator(device="cuda").manual_seed(R)
+    Ai = torch.randint(-2, 3, (R, N), generator=g, device="cuda").float()
+    Bi = torch.randint(-2, 3, (R, K), generator=g, device="cuda").float() + (torch.arange(K, device="cuda") % 3)
+    out = torch.zeros((N, K), dtype=torch.float32, device="cuda")
+    ops.gemm_tn(Ai.bfloat16(), Bi.bfloat16(), R, N, K, out, accumulate=True)
+    torch.testing.assert_close(out, Ai.t() @ Bi, rtol=0, atol=0)
+    A, B = _rand((R, N), 50).bfloat16(), _rand((R, K), 51).bfloat16()
+    out = torch.full((N, K), 2.0, dtype=torch.float32, device="cuda")
+    ops.gemm_tn(A, B, R, N, K, out, accumulate=True)
+    ref = 2.0 + A.float().t() @ B.float()
+    torch.testing.assert_close(out, ref, rtol=2e-3, atol=2e-2)
+    out2 = torch.full((N, K), 5.0, dtype=torch.float32, device="cuda")
+    ops.gemm_tn(A, B, R, N, K, out2, accumulate=False)
+    torch.testing.assert_close(out2, ref - 2.0, rtol=2e-3, atol=2e-2)
+    cs = torch.zeros(N, device="cuda")
+    ops.colsum_bf16(A, R, N, cs)
+    torch.testing.assert_close(cs, A.float().sum(0), rtol=1e-4, atol=1e-2)
