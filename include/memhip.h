@@ -233,15 +233,19 @@ int memhip_cross_entropy(void* logits_bf16, int64_t ld, const int64_t* labels, i
  * bwd:  dqkv bf16 [B*T, 3D] (dq already multiplied by `scale`);
  *       dtable f32 [num_rel, heads] += bias gradient bucketed through
  *       relidx_pad i32 [TP, TP] (-1 in the padding); NULL skips it.
+ *       dq_bias / dv_bias f32 [D] += column sums of dq / dv (the q_bias / v_bias gradients).
  */
 int memhip_attn_tokens_padded(int T);
 int memhip_relpos_gather(const float* table, const int32_t* index /*[T*T]*/, int T, int TP, int heads,
-                         float* bias_pad, memhip_stream_t stream);
+                         float* bias_pad, float* biasT_pad /*[heads,TP(key),TP(query)] or NULL*/,
+                         memhip_stream_t stream);
 int memhip_attn_fwd(const void* qkv, int64_t ldqkv, int B, int T, int D, int heads, const float* bias_pad,
                     void* out, int64_t ldo, float* lse, memhip_stream_t stream);
 int memhip_attn_bwd(const void* qkv, int64_t ldqkv, const void* dout, const void* out, int64_t ldo,
-                    const float* lse, const float* bias_pad, const int32_t* relidx_pad, int num_rel,
-                    int B, int T, int D, int heads, float scale, void* dqkv, int64_t lddqkv, float* dtable,
+                    const float* lse, const float* bias_pad, const float* biasT_pad,
+                    const int32_t* relidx_pad, int num_rel, int B, int T, int D, int heads, float scale,
+                    void* dqkv, int64_t lddqkv, float* dtable, float* dq_bias /*[D] += or NULL*/,
+                    float* dv_bias /*[D] += or NULL*/, float* delta_ws /*f32 [B,heads,TP] scratch*/,
                     memhip_stream_t stream);
 
 /* ------------------------------------------------------------------------

@@ -99,7 +99,7 @@ __global__ __launch_bounds__(256) void fill_cls_kernel(float* __restrict__ x, lo
 // bias[h][q][k] = table[idx[q*T+k]][h] for q,k < T, 0 in the padding (TP >= T)
 __global__ __launch_bounds__(256) void relpos_gather_kernel(const float* __restrict__ table,
                                                             const int* __restrict__ idx, int T, int TP, int Hh,
-                                                            float* __restrict__ bias) {
+                                                            float* __restrict__ bias, float* __restrict__ biasT) {
   const long long total = (long long)Hh * TP * TP;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
     const int k = (int)(i % TP);
@@ -108,6 +108,7 @@ __global__ __launch_bounds__(256) void relpos_gather_kernel(const float* __restr
     float v = 0.f;
     if (q < T && k < T) v = table[(long long)idx[q * T + k] * Hh + h];
     bias[i] = v;
+    if (biasT) biasT[((long long)h * TP + k) * TP + q] = v;      // [h][key][query] copy for attn_bwd_kv
   }
 }
 
@@ -172,12 +173,12 @@ extern "C" int memhip_fill_cls(float* x, int64_t ldx, int B, int T, int D, const
 }
 
 extern "C" int memhip_relpos_gather(const float* table, const int32_t* index, int T, int TP, int heads,
-                                    float* bias, memhip_stream_t stream) {
+                                    float* bias, float* biasT, memhip_stream_t stream) {
   MEMHIP_REQUIRE(T > 0 && TP >= T && heads > 0 && table && index && bias, "relpos_gather: bad arguments");
   const long long total = (long long)heads * TP * TP;
   int blocks = (int)((total + 255) / 256);
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(relpos_gather_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), table, index, T, TP,
-                     heads, bias);
+                     heads, bias, biasT);
   return check_launch("relpos_gather");
 }

@@ -151,6 +151,7 @@ class ViTEngine:
         self.relidx_pad = torch.full((self.TP, self.TP), -1, dtype=torch.int32, device=dev)
         self.relidx_pad[: self.T, : self.T] = self.relidx
         self.bias_pad = torch.zeros((self.heads, self.TP, self.TP), dtype=torch.float32, device=dev)
+        self.biasT_pad = torch.zeros((self.heads, self.TP, self.TP), dtype=torch.float32, device=dev)
         self.gn_ws = torch.zeros(1024, dtype=torch.float64, device=dev)
         self.gnorm = torch.zeros(1, dtype=torch.float32, device=dev)
         self.loss_acc = torch.zeros(2, dtype=torch.float32, device=dev)
@@ -185,6 +186,7 @@ class ViTEngine:
         self.dbig = e(M, Hd)
         self.dqkv = e(M, 3 * D)
         self.dao = e(M, D)
+        self.delta_ws = e(B, self.heads, self.TP, dt=f32)
         self.dYpe = e(B * self.L, D)
         self.B, self.Mm_cap = B, Mm_cap
 
@@ -227,7 +229,7 @@ class ViTEngine:
                     ops.EPI_PATCH_EMBED, bias=self.P("patch_embed.proj.bias"), vec1=self.P("mask_token"),
                     resid=x0, aux=mask_u8, rows_per_sample=L, ldaux=0)
         ops.relpos_gather(self.P("rel_pos_bias.relative_position_bias_table"), self.relidx, T, self.TP, self.heads,
-                          self.bias_pad)
+                          self.bias_pad, self.biasT_pad)
         for i in range(self.depth):
             pre = f"blocks.{i}."
             a = self.act[i]
@@ -317,10 +319,10 @@ class ViTEngine:
                            rowmask=dp_masks[2 * i] if use_dp else None, keep_prob=keep, rows_per_sample=T)
             ops.gemm_nt(self.dY, self.wT[i]["proj"], M, D, D, ops.EPI_BIAS_BF16, out0=self.dao)
             self._wgrad(self.dY, a["ao"], M, D, D, pre + "attn.proj.weight")
-            ops.attn_bwd(a["qkv"], self.dao, a["ao"], a["lse"], self.bias_pad, self.relidx_pad, self.nrd, B, T, D,
-                         self.heads, self.scale, self.dqkv, dtable)
-            self._wgrad(self.dqkv, a["h1"], M, 3 * D, D, pre + "attn.qkv.weight",
-                        bias_grads=((self.G(pre + "attn.q_bias"), 0, D), (self.G(pre + "attn.v_bias"), 2 * D, 3 * D)))
+            ops.attn_bwd(a["qkv"], self.dao, a["ao"], a["lse"], self.bias_pad, self.biasT_pad, self.relidx_pad,
+                         self.nrd, B, T, D, self.heads, self.scale, self.dqkv, dtable, self.delta_ws,
+                         dq_bias=self.G(pre + "attn.q_bias"), dv_bias=self.G(pre + "attn.v_bias"))
+            self._wgrad(self.dqkv, a["h1"], M, 3 * D, D, pre + "attn.qkv.weight")
             ops.gemm_nt(self.dqkv, self.wT[i]["qkv"], M, D, 3 * D, ops.EPI_BIAS_BF16, out0=self.dh_small)
             ops.layernorm_bwd(self.dh_small, xin, self.P(pre + "norm1.weight"), a["mean1"], a["rstd1"], dx,
                               self.G(pre + "norm1.weight"), self.G(pre + "norm1.bias"), M, D, accumulate=True)

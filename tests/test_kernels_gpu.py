@@ -147,7 +147,8 @@ def test_attention_fwd_bwd(B, T, H):
         idx = torch.randint(0, nrd, (T, T), device="cuda")
     table = _rand((nrd, H), 21, 0.5)
     bias_pad = torch.zeros((H, TP, TP), device="cuda")
-    ops.relpos_gather(table, idx.int().contiguous(), T, TP, H, bias_pad)
+    biasT_pad = torch.zeros_like(bias_pad)
+    ops.relpos_gather(table, idx.int().contiguous(), T, TP, H, bias_pad, biasT_pad)
     bias = table[idx.view(-1)].view(T, T, H).permute(2, 0, 1).contiguous()
     assert torch.equal(bias_pad[:, :T, :T], bias) and bias_pad[:, T:].abs().sum() == 0
     out = torch.zeros((B * T, D), dtype=torch.bfloat16, device="cuda")
@@ -170,7 +171,13 @@ def test_attention_fwd_bwd(B, T, H):
     dtable = torch.zeros((nrd, H), device="cuda")
     relidx_pad = torch.full((TP, TP), -1, dtype=torch.int32, device="cuda")
     relidx_pad[:T, :T] = idx.int()
-    ops.attn_bwd(qkv, dout, out, lse, bias_pad, relidx_pad, nrd, B, T, D, H, scale, dqkv, dtable)
+    delta_ws = torch.zeros((B, H, TP), device="cuda")
+    dqb, dvb = torch.zeros(D, device="cuda"), torch.zeros(D, device="cuda")
+    ops.attn_bwd(qkv, dout, out, lse, bias_pad, biasT_pad, relidx_pad, nrd, B, T, D, H, scale, dqkv, dtable, delta_ws,
+                 dq_bias=dqb, dv_bias=dvb)
+    assert torch.equal(biasT_pad, bias_pad.transpose(1, 2).contiguous())
+    torch.testing.assert_close(dqb, dqkv[:, :D].float().sum(0), rtol=1e-3, atol=1e-2)
+    torch.testing.assert_close(dvb, dqkv[:, 2 * D:].float().sum(0), rtol=1e-3, atol=1e-2)
     g = qf.grad.clone()
     g[:, :D] *= scale          # kernel returns d(q_lin) = d(q') * scale
     err = (dqkv.float() - g).abs().max().item()

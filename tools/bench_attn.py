@@ -9,7 +9,8 @@ qkv = (torch.randn(B * T, 3 * D, device="cuda") * 0.5).bfloat16()
 idx, nrd = rel_pos_index((14, 14)); idx = idx.cuda()
 table = torch.randn(nrd, H, device="cuda") * 0.3
 bias_pad = torch.zeros(H, TP, TP, device="cuda")
-ops.relpos_gather(table, idx.int().contiguous(), T, TP, H, bias_pad)
+biasT_pad = torch.zeros_like(bias_pad)
+ops.relpos_gather(table, idx.int().contiguous(), T, TP, H, bias_pad, biasT_pad)
 out = torch.zeros(B * T, D, dtype=torch.bfloat16, device="cuda"); lse = torch.zeros(B, H, TP, device="cuda")
 dout = torch.randn(B * T, D, device="cuda").bfloat16()
 dqkv = torch.zeros(B * T, 3 * D, dtype=torch.bfloat16, device="cuda"); dtable = torch.zeros(nrd, H, device="cuda")
@@ -19,5 +20,6 @@ def t(f, n=10):
     for _ in range(n): f()
     torch.cuda.synchronize(); return (time.perf_counter() - t0) / n * 1e6
 print("fwd us", t(lambda: ops.attn_fwd(qkv, B, T, D, H, bias_pad, out, lse)))
-print("bwd us (dtable)", t(lambda: ops.attn_bwd(qkv, dout, out, lse, bias_pad, relidx_pad, nrd, B, T, D, H, 0.125, dqkv, dtable)))
-print("bwd us (no dtable)", t(lambda: ops.attn_bwd(qkv, dout, out, lse, bias_pad, relidx_pad, nrd, B, T, D, H, 0.125, dqkv, None)))
+dws = torch.zeros(B, H, TP, device="cuda"); dqb = torch.zeros(D, device="cuda"); dvb = torch.zeros(D, device="cuda")
+print("bwd us (dtable+bias)", t(lambda: ops.attn_bwd(qkv, dout, out, lse, bias_pad, biasT_pad, relidx_pad, nrd, B, T, D, H, 0.125, dqkv, dtable, dws, dqb, dvb)))
+print("bwd us (no dtable)", t(lambda: ops.attn_bwd(qkv, dout, out, lse, bias_pad, biasT_pad, relidx_pad, nrd, B, T, D, H, 0.125, dqkv, None, dws)))
