@@ -198,8 +198,11 @@ extern "C" int memhip_colsum_bf16(const void* in, int64_t ld, int R, int Cc, flo
   MEMHIP_REQUIRE(R >= 0 && Cc > 0 && Cc % 8 == 0 && ld % 8 == 0, "colsum: bad shape");
   if (R == 0) return MEMHIP_OK;
   MEMHIP_REQUIRE(in && out, "colsum: null pointer");
-  const int rows_per_block = 128;
   const int gx = cdiv(Cc, 256 * 8);
+  int gy = 1024 / gx;                                  // ~1024 workgroups in all: few atomics per column
+  if (gy < 1) gy = 1;
+  int rows_per_block = cdiv(R, gy);
+  if (rows_per_block < 16) rows_per_block = 16;
   hipLaunchKernelGGL(colsum_kernel, dim3(gx, cdiv(R, rows_per_block)), dim3(256), 0, as_stream(stream),
                      (const __bf16*)in, (long long)ld, R, Cc, rows_per_block, out);
   return check_launch("colsum_bf16");

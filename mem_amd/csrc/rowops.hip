@@ -80,7 +80,6 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 // ---------------------------------------------------------------- LayerNorm backward
 // workgroup = 4 waves x kRowsPerWave rows; dx per row (wave reductions), dgamma/dbeta per lane
 // column accumulated in registers over the workgroup's rows, then LDS -> one atomic per column.
-constexpr int kLnRowsPerWave = 8;
 
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const __bf16* __restrict__ dy, long long lddy,
                                                      const float* __restrict__ x, long long ldx,
@@ -98,10 +97,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const __bf16* __restrict__ 
   float4 ag[kMaxChunks], ab[kMaxChunks];
 #pragma unroll
   for (int c = 0; c < kMaxChunks; ++c) { ag[c] = float4{0, 0, 0, 0}; ab[c] = float4{0, 0, 0, 0}; }
-  const int r0 = (blockIdx.x * 4 + wave) * kLnRowsPerWave;
-  for (int rr = 0; rr < kLnRowsPerWave; ++rr) {
-    const int r = r0 + rr;
-    if (r >= R) break;
+  // rows are dealt to (workgroup, wave) round-robin: the column accumulators persist over ALL of a
+  // workgroup's rows, so the number of same-address atomics is gridDim.x per column, not R/32
+  for (int r = blockIdx.x * 4 + wave; r < R; r += gridDim.x * 4) {
     const long long src = row_idx ? row_idx[r] : r;
     const float4* xr = reinterpret_cast<const float4*>(x + src * ldx);
     const bf16x4* dyr = reinterpret_cast<const bf16x4*>(dy + (long long)r * lddy);
@@ -158,7 +156,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const __bf16* __restrict__ 
 // forward (modeling_finetune.py:187-188):  x += (gamma * y / keep) * mask[b]
 // backward: dt = (dx * mask[b]) / keep ; dgamma += sum_m dt * y ; dy = bf16(dt * gamma) ;
 //           dbias += sum_m dy   (the Linear that produced y)
-constexpr int kBrRows = 32;
+// one wave per token row (16-byte lane accesses), rows dealt round-robin to a fixed grid so that the
+// column sums cost gridDim.x atomics per column (same-address atomics are the slow part)
+constexpr int kBrMaxChunks = 8;   // float4 chunks per lane: D <= 2048
 
 __global__ __launch_bounds__(256) void branch_bwd_kernel(const float* __restrict__ dx, long long lddx,
                                                          const __bf16* __restrict__ y, long long ldy,
@@ -167,35 +167,56 @@ __global__ __launch_bounds__(256) void branch_bwd_kernel(const float* __restrict
                                                          int rps, int M, int D, __bf16* __restrict__ dyo,
                                                          long long lddy, float* __restrict__ dgamma,
                                                          float* __restrict__ dbias) {
-  const int m0 = blockIdx.x * kBrRows;
-  const int m1 = min(M, m0 + kBrRows);
-  for (int c = threadIdx.x * 4; c < D; c += 256 * 4) {
-    float4 g = gamma ? *reinterpret_cast<const float4*>(gamma + c) : float4{1.f, 1.f, 1.f, 1.f};
-    float4 ag{0, 0, 0, 0}, ab{0, 0, 0, 0};
-    for (int m = m0; m < m1; ++m) {
-      float4 d = *reinterpret_cast<const float4*>(dx + (long long)m * lddx + c);
-      if (rowmask) {
-        const float k = rowmask[m / rps];
-        d.x = __fdiv_rn(d.x * k, keep); d.y = __fdiv_rn(d.y * k, keep);
-        d.z = __fdiv_rn(d.z * k, keep); d.w = __fdiv_rn(d.w * k, keep);
+  extern __shared__ float red[];   // [4][2][D]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nch = D >> 2;
+  float4 g[kBrMaxChunks], ag[kBrMaxChunks], ab[kBrMaxChunks];
+#pragma unroll
+  for (int c = 0; c < kBrMaxChunks; ++c) {
+    const int i = lane + c * 64;
+    g[c] = (gamma && i < nch) ? reinterpret_cast<const float4*>(gamma)[i] : float4{1.f, 1.f, 1.f, 1.f};
+    ag[c] = float4{0, 0, 0, 0};
+    ab[c] = float4{0, 0, 0, 0};
+  }
+  for (int m = blockIdx.x * 4 + wave; m < M; m += gridDim.x * 4) {
+    const float4* dr = reinterpret_cast<const float4*>(dx + (long long)m * lddx);
+    const bf16x4* yr = reinterpret_cast<const bf16x4*>(y + (long long)m * ldy);
+    bf16x4* orow = reinterpret_cast<bf16x4*>(dyo + (long long)m * lddy);
+    const float k = rowmask ? rowmask[m / rps] : 1.f;
+#pragma unroll
+    for (int c = 0; c < kBrMaxChunks; ++c) {
+      const int i = lane + c * 64;
+      if (i < nch) {
+        float4 d = dr[i];
+        if (rowmask) {
+          d.x = __fdiv_rn(d.x * k, keep); d.y = __fdiv_rn(d.y * k, keep);
+          d.z = __fdiv_rn(d.z * k, keep); d.w = __fdiv_rn(d.w * k, keep);
+        }
+        const bf16x4 yv = yr[i];
+        ag[c].x += d.x * (float)yv[0]; ag[c].y += d.y * (float)yv[1];
+        ag[c].z += d.z * (float)yv[2]; ag[c].w += d.w * (float)yv[3];
+        bf16x4 o;
+        o[0] = (__bf16)(d.x * g[c].x); o[1] = (__bf16)(d.y * g[c].y);
+        o[2] = (__bf16)(d.z * g[c].z); o[3] = (__bf16)(d.w * g[c].w);
+        orow[i] = o;
+        ab[c].x += (float)o[0]; ab[c].y += (float)o[1]; ab[c].z += (float)o[2]; ab[c].w += (float)o[3];
       }
-      const bf16x4 yv = *reinterpret_cast<const bf16x4*>(y + (long long)m * ldy + c);
-      ag.x += d.x * (float)yv[0]; ag.y += d.y * (float)yv[1];
-      ag.z += d.z * (float)yv[2]; ag.w += d.w * (float)yv[3];
-      bf16x4 o;
-      o[0] = (__bf16)(d.x * g.x); o[1] = (__bf16)(d.y * g.y);
-      o[2] = (__bf16)(d.z * g.z); o[3] = (__bf16)(d.w * g.w);
-      *reinterpret_cast<bf16x4*>(dyo + (long long)m * lddy + c) = o;
-      ab.x += (float)o[0]; ab.y += (float)o[1]; ab.z += (float)o[2]; ab.w += (float)o[3];
     }
-    if (dgamma) {
-      atomicAdd(dgamma + c, ag.x); atomicAdd(dgamma + c + 1, ag.y);
-      atomicAdd(dgamma + c + 2, ag.z); atomicAdd(dgamma + c + 3, ag.w);
-    }
-    if (dbias) {
-      atomicAdd(dbias + c, ab.x); atomicAdd(dbias + c + 1, ab.y);
-      atomicAdd(dbias + c + 2, ab.z); atomicAdd(dbias + c + 3, ab.w);
-    }
+  }
+  float4* rg = reinterpret_cast<float4*>(red + (size_t)wave * 2 * D);
+  float4* rb = reinterpret_cast<float4*>(red + (size_t)wave * 2 * D + D);
+#pragma unroll
+  for (int c = 0; c < kBrMaxChunks; ++c) {
+    const int i = lane + c * 64;
+    if (i < nch) { rg[i] = ag[c]; rb[i] = ab[c]; }
+  }
+  __syncthreads();
+  for (int n = threadIdx.x; n < D; n += 256) {
+    float a = 0.f, b = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) { a += red[(size_t)w * 2 * D + n]; b += red[(size_t)w * 2 * D + D + n]; }
+    if (dgamma) atomicAdd(dgamma + n, a);
+    if (dbias) atomicAdd(dbias + n, b);
   }
 }
 
@@ -356,8 +377,9 @@ extern "C" int memhip_layernorm_bwd(const void* dy, int64_t lddy, const float* x
   if (R == 0) return MEMHIP_OK;
   MEMHIP_REQUIRE(dy && x && gamma && mean && rstd && dres && dgamma && dbeta, "layernorm_bwd: null pointer");
   MEMHIP_REQUIRE(ldx % 4 == 0 && lddy % 4 == 0 && lddres % 4 == 0, "layernorm_bwd: ld must be a multiple of 4");
-  const int rows_per_block = 4 * kLnRowsPerWave;
-  hipLaunchKernelGGL(ln_bwd_kernel, dim3(cdiv(R, rows_per_block)), dim3(256), (size_t)8 * D * sizeof(float),
+  int grid = cdiv(R, 4);
+  if (grid > 1024) grid = 1024;                      // 4 workgroups per CU, ~50 rows per wave at ViT-B scale
+  hipLaunchKernelGGL(ln_bwd_kernel, dim3(grid), dim3(256), (size_t)8 * D * sizeof(float),
                      as_stream(stream), (const __bf16*)dy, (long long)lddy, x, (long long)ldx, row_idx, R, D,
                      gamma, mean, rstd, dres, (long long)lddres, accumulate, dgamma, dbeta);
   return check_launch("layernorm_bwd");
@@ -371,7 +393,10 @@ extern "C" int memhip_branch_bwd(const float* dx, int64_t lddx, const void* y, i
   if (M == 0) return MEMHIP_OK;
   MEMHIP_REQUIRE(dx && y && dy, "branch_bwd: null pointer");
   MEMHIP_REQUIRE(lddx % 4 == 0 && ldy % 4 == 0 && lddy % 4 == 0, "branch_bwd: ld must be a multiple of 4");
-  hipLaunchKernelGGL(branch_bwd_kernel, dim3(cdiv(M, kBrRows)), dim3(256), 0, as_stream(stream), dx,
+  MEMHIP_REQUIRE(D <= 64 * 4 * kBrMaxChunks, "branch_bwd: D=%d too large", D);
+  int grid = cdiv(M, 4);
+  if (grid > 1024) grid = 1024;
+  hipLaunchKernelGGL(branch_bwd_kernel, dim3(grid), dim3(256), (size_t)8 * D * sizeof(float), as_stream(stream), dx,
                      (long long)lddx, (const __bf16*)y, (long long)ldy, gamma, rowmask, keep_prob,
                      rows_per_sample > 0 ? rows_per_sample : 1, M, D, (__bf16*)dy, (long long)lddy, dgamma, dbias);
   return check_launch("branch_bwd");
