@@ -172,6 +172,8 @@ typedef struct memhip_gemm_args {
   float colscale; int32_t colscale_n;
   int32_t rows_per_sample;  /* RESIDUAL: tokens per sample; PATCH_EMBED: patches per sample */
   int32_t accumulate;     /* F32: 1 = out0 += acc */
+  float* colsum;          /* BIAS_BF16 / DGELU: f32 [N] += column sums of the bf16 output rows < M (the
+                             bias gradient of the Linear whose grad_output this GEMM produces); NULL = off */
 } memhip_gemm_args_t;
 int memhip_gemm_bf16_nt(const memhip_gemm_args_t* args, memhip_stream_t stream);
 

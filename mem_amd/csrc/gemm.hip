@@ -10,6 +10,7 @@
 // through the *source* address (LDS-DMA writes lane-linear) so that every ds_read_b128 fragment
 // read is bank-conflict free.  Workgroup ids are remapped so that the 8 XCDs each walk a
 // contiguous range of tiles (A row-panel reuse in the XCD-private L2).
+#include <cstdlib>
 #include "common.h"
 #include "gemm_epilogue.hpp"
 
@@ -122,6 +123,7 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_nt_kernel(GemmArgs p) {
   if (vec_ok(p) && nw + 64 <= p.N) {
     constexpr int LS = 72;                                  // padded row stride (floats)
     float* wreg = reinterpret_cast<float*>(smem + wave * 16384);
+    float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
 #pragma unroll
@@ -137,9 +139,10 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_nt_kernel(GemmArgs p) {
         const int m = mw + half * 32 + row;
         float v[8];
         ld8(wreg + row * LS + c8, v);
-        if (m < p.M) epilogue8<EPI>(p, m, nw + c8, v);
+        if (m < p.M) epilogue8<EPI>(p, m, nw + c8, v, cs);
       }
     }
+    colsum_flush(p, nw + (lane & 7) * 8, cs, lane);
     return;
   }
   float bias_n[4], vec_n[4];
@@ -181,6 +184,11 @@ int launch(const GemmArgs& p, hipStream_t s) {
 
 }  // namespace
 
+namespace memhip {
+int gemm_ring_dispatch(const GemmArgs& p, hipStream_t s);
+int gemm256_dispatch(const GemmArgs& p, hipStream_t s);
+}
+
 extern "C" int memhip_gemm_bf16_nt(const memhip_gemm_args_t* a, memhip_stream_t stream) {
   MEMHIP_REQUIRE(a, "gemm: null args");
   GemmArgs p;
@@ -194,9 +202,30 @@ extern "C" int memhip_gemm_bf16_nt(const memhip_gemm_args_t* a, memhip_stream_t 
                  "gemm: operands must be 16-byte aligned with ld %% 8 == 0");
   hipStream_t s = as_stream(stream);
   switch (p.epilogue) {
+    case MEMHIP_EPI_BIAS_BF16: MEMHIP_REQUIRE(p.out0, "gemm: out0"); break;
+    case MEMHIP_EPI_BIAS_GELU: MEMHIP_REQUIRE(p.out0 && p.out1, "gemm: out0/out1"); break;
+    case MEMHIP_EPI_RESIDUAL: MEMHIP_REQUIRE(p.resid, "gemm: residual args"); break;
+    case MEMHIP_EPI_DGELU: MEMHIP_REQUIRE(p.out0 && p.aux, "gemm: dgelu args"); break;
+    case MEMHIP_EPI_F32: MEMHIP_REQUIRE(p.out0, "gemm: out0"); break;
+    case MEMHIP_EPI_PATCH_EMBED: MEMHIP_REQUIRE(p.resid && p.vec1 && p.aux, "gemm: patch args"); break;
+    default: return fail(MEMHIP_EINVAL, "gemm: unknown epilogue %d", p.epilogue);
+  }
+  // large token-dimension products: persistent 256x256-tile structure (gemm256.hip); the 256x128
+  // ring variant (gemm_ring.hip) is kept for A/B measurements only (MEMHIP_GEMM_RING=1)
+  static const bool k256_on = !(getenv("MEMHIP_GEMM256") && atoi(getenv("MEMHIP_GEMM256")) == 0);
+  static const bool ring_on = getenv("MEMHIP_GEMM_RING") && atoi(getenv("MEMHIP_GEMM_RING")) == 1;
+  if (k256_on) {
+    const int rc = gemm256_dispatch(p, s);
+    if (rc != MEMHIP_EUNSUPPORTED) return rc;
+  }
+  if (ring_on) {
+    const int rc = gemm_ring_dispatch(p, s);
+    if (rc != MEMHIP_EUNSUPPORTED) return rc;
+  }
+  switch (p.epilogue) {
     case MEMHIP_EPI_BIAS_BF16: MEMHIP_REQUIRE(p.out0, "gemm: out0"); return launch<MEMHIP_EPI_BIAS_BF16>(p, s);
     case MEMHIP_EPI_BIAS_GELU: MEMHIP_REQUIRE(p.out0 && p.out1, "gemm: out0/out1"); return launch<MEMHIP_EPI_BIAS_GELU>(p, s);
-    case MEMHIP_EPI_RESIDUAL: MEMHIP_REQUIRE(p.out0 && p.resid && p.vec1, "gemm: residual args"); return launch<MEMHIP_EPI_RESIDUAL>(p, s);
+    case MEMHIP_EPI_RESIDUAL: return launch<MEMHIP_EPI_RESIDUAL>(p, s);
     case MEMHIP_EPI_DGELU: MEMHIP_REQUIRE(p.out0 && p.aux, "gemm: dgelu args"); return launch<MEMHIP_EPI_DGELU>(p, s);
     case MEMHIP_EPI_F32: MEMHIP_REQUIRE(p.out0, "gemm: out0"); return launch<MEMHIP_EPI_F32>(p, s);
     case MEMHIP_EPI_PATCH_EMBED: MEMHIP_REQUIRE(p.resid && p.vec1 && p.aux, "gemm: patch args"); return launch<MEMHIP_EPI_PATCH_EMBED>(p, s);

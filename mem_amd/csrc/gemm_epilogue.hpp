@@ -21,6 +21,7 @@ struct GemmArgs {   // == memhip_gemm_args_t
   float colscale; int colscale_n;
   int rows_per_sample;
   int accumulate;
+  float* colsum;   // optional: += column sums of the (rounded) primary output
 };
 
 __device__ __forceinline__ float bf16_round(float v) { return (float)(__bf16)v; }
@@ -57,6 +58,7 @@ __device__ __forceinline__ void epilogue(const GemmArgs& p, int m, int n, float 
     __bf16 y = (__bf16)v;
     if (n < p.colscale_n) y = (__bf16)((float)y * p.colscale);
     reinterpret_cast<__bf16*>(p.out0)[(long long)m * p.ldo0 + n] = y;
+    if (p.colsum) atomicAdd(p.colsum + n, (float)y);
   } else if constexpr (EPI == MEMHIP_EPI_BIAS_GELU) {
     const __bf16 h = (__bf16)(acc + bias_n);
     reinterpret_cast<__bf16*>(p.out0)[(long long)m * p.ldo0 + n] = h;
@@ -73,7 +75,9 @@ __device__ __forceinline__ void epilogue(const GemmArgs& p, int m, int n, float 
   } else if constexpr (EPI == MEMHIP_EPI_DGELU) {
     const float da = bf16_round(acc);
     const float h = (float)reinterpret_cast<const __bf16*>(p.aux)[(long long)m * p.ldaux + n];
-    reinterpret_cast<__bf16*>(p.out0)[(long long)m * p.ldo0 + n] = (__bf16)(da * gelu_grad_f(h));
+    const __bf16 o = (__bf16)(da * gelu_grad_f(h));
+    reinterpret_cast<__bf16*>(p.out0)[(long long)m * p.ldo0 + n] = o;
+    if (p.colsum) atomicAdd(p.colsum + n, (float)o);
   } else if constexpr (EPI == MEMHIP_EPI_F32) {
     float* o = reinterpret_cast<float*>(p.out0) + (long long)m * p.ldo0 + n;
     *o = p.accumulate ? (*o + acc) : acc;
@@ -103,7 +107,7 @@ __device__ __forceinline__ void st8(float* p, const float* o) {
 // Row-vector form: 8 consecutive output columns n..n+7 of row m (n % 8 == 0, n + 8 <= N, every
 // leading dimension a multiple of 8 elements): 16-byte global accesses only.
 template <int EPI>
-__device__ __forceinline__ void epilogue8(const GemmArgs& p, int m, int n, const float* acc) {
+__device__ __forceinline__ void epilogue8(const GemmArgs& p, int m, int n, const float* acc, float* cs) {
   float bias[8];
   if (p.bias) ld8(p.bias + n, bias);
   else {
@@ -116,6 +120,7 @@ __device__ __forceinline__ void epilogue8(const GemmArgs& p, int m, int n, const
     for (int k = 0; k < 8; ++k) {
       y[k] = (__bf16)(acc[k] + bias[k]);
       if (n + k < p.colscale_n) y[k] = (__bf16)((float)y[k] * p.colscale);
+      cs[k] += (float)y[k];
     }
     *reinterpret_cast<ebf16x8*>(reinterpret_cast<__bf16*>(p.out0) + (long long)m * p.ldo0 + n) = y;
   } else if constexpr (EPI == MEMHIP_EPI_BIAS_GELU) {
@@ -144,7 +149,10 @@ __device__ __forceinline__ void epilogue8(const GemmArgs& p, int m, int n, const
     const ebf16x8 h = *reinterpret_cast<const ebf16x8*>(reinterpret_cast<const __bf16*>(p.aux) + (long long)m * p.ldaux + n);
     ebf16x8 o;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) o[k] = (__bf16)(bf16_round(acc[k]) * gelu_grad_f((float)h[k]));
+    for (int k = 0; k < 8; ++k) {
+      o[k] = (__bf16)(bf16_round(acc[k]) * gelu_grad_f((float)h[k]));
+      cs[k] += (float)o[k];
+    }
     *reinterpret_cast<ebf16x8*>(reinterpret_cast<__bf16*>(p.out0) + (long long)m * p.ldo0 + n) = o;
   } else if constexpr (EPI == MEMHIP_EPI_F32) {
     float* o = reinterpret_cast<float*>(p.out0) + (long long)m * p.ldo0 + n;
@@ -167,6 +175,22 @@ __device__ __forceinline__ void epilogue8(const GemmArgs& p, int m, int n, const
     for (int k = 0; k < 8; ++k)
       x[k] = __fadd_rn(__fmul_rn(bf16_round(acc[k] + bias[k]), 1.0f - w), __fmul_rn(mt[k], w));
     st8(p.resid + ((long long)b * (L + 1) + 1 + pi) * p.ldr + n, x);
+  }
+}
+
+// Column sums of the rounded output (bias gradient of the producing Linear): cs[8] holds this lane's
+// partial sums for columns n..n+7 over the rows it handled; lanes with equal (lane & 7) own the same
+// columns.  One atomic per column per wave.
+__device__ __forceinline__ void colsum_flush(const GemmArgs& p, int n, float* cs, int lane) {
+  if (!p.colsum) return;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    float v = cs[k];
+    v += __shfl_xor(v, 8);
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 32);
+    if ((lane >> 3) == 0) atomicAdd(p.colsum + n + k, v);
+    cs[k] = 0.f;
   }
 }
 

@@ -19,7 +19,8 @@ class GemmArgs(C.Structure):
                 ("out0", vp), ("ldo0", i64), ("out1", vp), ("ldo1", i64),
                 ("bias", vp), ("vec1", vp), ("resid", vp), ("ldr", i64),
                 ("aux", vp), ("ldaux", i64), ("rowmask", vp), ("keep_prob", f32),
-                ("colscale", f32), ("colscale_n", i32), ("rows_per_sample", i32), ("accumulate", i32)]
+                ("colscale", f32), ("colscale_n", i32), ("rows_per_sample", i32), ("accumulate", i32),
+                ("colsum", vp)]
 
 
 declare({"memhip_gemm_bf16_nt": (i32, [C.POINTER(GemmArgs), vp])})
@@ -35,7 +36,7 @@ GEMM_TIMER = None
 
 
 def gemm_nt(A, B, M, N, K, epi, out0=None, out1=None, bias=None, vec1=None, resid=None, aux=None,
-            rowmask=None, keep_prob=1.0, colscale=1.0, colscale_n=0, rows_per_sample=1, accumulate=False,
+            rowmask=None, keep_prob=1.0, colscale=1.0, colscale_n=0, rows_per_sample=1, accumulate=False, colsum=None,
             lda=None, ldb=None, ldo0=None, ldo1=None, ldr=None, ldaux=None):
     """C[M,N] = A[M,K] @ B[N,K]^T with a fused epilogue.  A/B bf16, row-major, K contiguous."""
     a = GemmArgs()
@@ -54,6 +55,7 @@ def gemm_nt(A, B, M, N, K, epi, out0=None, out1=None, bias=None, vec1=None, resi
     a.rowmask = _p(rowmask)
     a.keep_prob, a.colscale, a.colscale_n = keep_prob, colscale, colscale_n
     a.rows_per_sample, a.accumulate = rows_per_sample, int(accumulate)
+    a.colsum = _p(colsum)
     if GEMM_TIMER is None:
         check(lib.memhip_gemm_bf16_nt(C.byref(a), stream_ptr()), "gemm_bf16_nt")
     else:

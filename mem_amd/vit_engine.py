@@ -306,10 +306,10 @@ class ViTEngine:
             ops.branch_bwd(dx, a["y2"], self.P(pre + "gamma_2") if has_g else None, self.dY,
                            self.G(pre + "gamma_2") if has_g else None, self.G(pre + "mlp.fc2.bias"), M, D,
                            rowmask=dp_masks[2 * i + 1] if use_dp else None, keep_prob=keep, rows_per_sample=T)
-            ops.gemm_nt(self.dY, self.wT[i]["fc2"], M, Hd, D, ops.EPI_DGELU, out0=self.dbig, aux=a["hpre"])
+            ops.gemm_nt(self.dY, self.wT[i]["fc2"], M, Hd, D, ops.EPI_DGELU, out0=self.dbig, aux=a["hpre"],
+                        colsum=self.G(pre + "mlp.fc1.bias"))        # fc1 bias grad = column sums of dh
             self._wgrad(self.dY, a["a"], M, D, Hd, pre + "mlp.fc2.weight")
-            self._wgrad(self.dbig, a["h2"], M, Hd, D, pre + "mlp.fc1.weight",
-                        bias_grads=((self.G(pre + "mlp.fc1.bias"), 0, Hd),))
+            self._wgrad(self.dbig, a["h2"], M, Hd, D, pre + "mlp.fc1.weight")
             ops.gemm_nt(self.dbig, self.wT[i]["fc1"], M, D, Hd, ops.EPI_BIAS_BF16, out0=self.dh_small)
             ops.layernorm_bwd(self.dh_small, xmid, self.P(pre + "norm2.weight"), a["mean2"], a["rstd2"], dx,
                               self.G(pre + "norm2.weight"), self.G(pre + "norm2.bias"), M, D, accumulate=True)

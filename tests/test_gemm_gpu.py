@@ -84,7 +84,9 @@ def test_dgelu_and_f32_accumulate():
     A, B = _rand((M, K), 12).bfloat16(), _rand((N, K), 13, 0.08).bfloat16()
     h = _rand((M, N), 14).bfloat16()
     out = torch.zeros((M, N), dtype=torch.bfloat16, device="cuda")
-    ops.gemm_nt(A, B, M, N, K, ops.EPI_DGELU, out0=out, aux=h)
+    cs = torch.zeros(N, device="cuda")
+    ops.gemm_nt(A, B, M, N, K, ops.EPI_DGELU, out0=out, aux=h, colsum=cs)
+    torch.testing.assert_close(cs, out.float().sum(0), rtol=1e-3, atol=5e-2)
     da = (A.float() @ B.float().t()).bfloat16().float()
     hh = h.float().requires_grad_(True)
     torch.nn.functional.gelu(hh).backward(torch.ones_like(hh))
@@ -149,3 +151,50 @@ def test_gemm_tn_weight_gradient(R, N, K):
     cs = torch.zeros(N, device="cuda")
     ops.colsum_bf16(A, R, N, cs)
     torch.testing.assert_close(cs, A.float().sum(0), rtol=1e-4, atol=1e-2)
+
+
+@pytest.mark.parametrize("M,N,K", [(2048, 128, 64), (4000, 768, 768), (2304 + 17, 2304, 768), (5000, 384, 3072),
+                                   (4096, 256, 64), (4096 + 100, 768, 768), (9000, 2304, 128), (4500, 512, 3072)])
+def test_ring_gemm_large_m_all_epilogues(M, N, K):
+    """M >= 2048 and N % 128 == 0 dispatch to the persistent ring-pipelined kernel (gemm_ring.hip):
+    exact-integer layout check + every fused epilogue against torch."""
+    from mem_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(M + N)
+    Ai = torch.randint(-3, 4, (M, K), generator=g, device="cuda").float()
+    Bi = torch.randint(-3, 4, (N, K), generator=g, device="cuda").float() + (torch.arange(N, device="cuda").view(N, 1) % 5)
+    C = torch.zeros((M, N), dtype=torch.float32, device="cuda")
+    ops.gemm_nt(Ai.bfloat16(), Bi.bfloat16(), M, N, K, ops.EPI_F32, out0=C)
+    torch.testing.assert_close(C, Ai @ Bi.t(), rtol=0, atol=0)
+    ops.gemm_nt(Ai.bfloat16(), Bi.bfloat16(), M, N, K, ops.EPI_F32, out0=C, accumulate=True)
+    torch.testing.assert_close(C, 2 * (Ai @ Bi.t()), rtol=0, atol=0)
+    A, B, bias = _rand((M, K), 1).bfloat16(), _rand((N, K), 2, 0.05).bfloat16(), _rand((N,), 3)
+    ref = A.float() @ B.float().t() + bias
+    out = torch.full((M + 5, N), 7.0, dtype=torch.bfloat16, device="cuda")
+    ops.gemm_nt(A, B, M, N, K, ops.EPI_BIAS_BF16, out0=out, bias=bias, colscale=0.125, colscale_n=N // 2)
+    r = ref.bfloat16()
+    r[:, : N // 2] = (r[:, : N // 2].float() * 0.125).bfloat16()
+    torch.testing.assert_close(out[:M].float(), r.float(), rtol=2e-2, atol=2e-2)
+    assert (out[M:] == 7.0).all()
+    h, a = torch.zeros((M, N), dtype=torch.bfloat16, device="cuda"), torch.zeros((M, N), dtype=torch.bfloat16, device="cuda")
+    ops.gemm_nt(A, B, M, N, K, ops.EPI_BIAS_GELU, out0=h, out1=a, bias=bias)
+    torch.testing.assert_close(h.float(), ref.bfloat16().float(), rtol=2e-2, atol=2e-2)
+    torch.testing.assert_close(a.float(), torch.nn.functional.gelu(h.float()).bfloat16().float(), rtol=1e-2, atol=1e-3)
+    T = 17
+    Bn = (M + T - 1) // T
+    gamma, x0 = _rand((N,), 10, 0.1), _rand((M, N), 11)
+    keep = (torch.arange(Bn, device="cuda") % 3 != 0).float()
+    x, y = torch.empty_like(x0), torch.zeros((M, N), dtype=torch.bfloat16, device="cuda")
+    ops.gemm_nt(A, B, M, N, K, ops.EPI_RESIDUAL, out0=y, bias=bias, vec1=gamma, resid=x, aux=x0, ldaux=N, rowmask=keep,
+                keep_prob=0.9, rows_per_sample=T)
+    t = (gamma * y.float()).cpu().div(0.9) * keep.cpu().repeat_interleave(T)[:M].view(-1, 1)
+    torch.testing.assert_close(x, x0 + t.cuda(), rtol=0, atol=0)
+    torch.testing.assert_close(y.float(), ref.bfloat16().float(), rtol=2e-2, atol=2e-2)
+    hh = _rand((M, N), 14).bfloat16()
+    o = torch.zeros((M, N), dtype=torch.bfloat16, device="cuda")
+    cs = torch.zeros(N, device="cuda")
+    ops.gemm_nt(A, B, M, N, K, ops.EPI_DGELU, out0=o, aux=hh, colsum=cs)
+    da = (A.float() @ B.float().t()).bfloat16().float()
+    hg = hh.float().requires_grad_(True)
+    torch.nn.functional.gelu(hg).backward(torch.ones_like(hg))
+    torch.testing.assert_close(o.float(), (da * hg.grad).bfloat16().float(), rtol=3e-2, atol=3e-2)
+    torch.testing.assert_close(cs, o.float().sum(0), rtol=1e-3, atol=5e-2)      # fused bias-gradient column sums
