@@ -15,6 +15,7 @@
 // The output is small (<= 3072 x 768) and the reduction long (50 432 tokens), so the grid is
 // split-K: S slices of the token range per output tile, combined with fp32 atomics into the
 // (pre-zeroed) gradient buffer -- S is chosen so that tiles * S fills the 256 CUs.
+#include <cstdlib>
 #include "common.h"
 
 namespace {
@@ -164,6 +165,11 @@ __global__ __launch_bounds__(256) void colsum_kernel(const __bf16* __restrict__ 
 
 }  // namespace
 
+namespace memhip {
+int gemm_tn256_dispatch(const void* A, long long lda, const void* B, long long ldb, int R, int N, int K, float* out,
+                        long long ldo, int accumulate, hipStream_t s);
+}
+
 extern "C" int memhip_gemm_bf16_tn(const void* A, int64_t lda, const void* B, int64_t ldb, int R, int N, int K,
                                    float* out, int64_t ldo, int accumulate, memhip_stream_t stream) {
   MEMHIP_REQUIRE(R >= 0 && N > 0 && K > 0, "gemm_tn: bad shape R=%d N=%d K=%d", R, N, K);
@@ -172,6 +178,11 @@ extern "C" int memhip_gemm_bf16_tn(const void* A, int64_t lda, const void* B, in
   MEMHIP_REQUIRE(N % 8 == 0 && K % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0 && ((uintptr_t)A & 15) == 0 &&
                      ((uintptr_t)B & 15) == 0, "gemm_tn: operands must be 16-byte aligned, N/K/ld %% 8 == 0");
   hipStream_t s = as_stream(stream);
+  static const bool k256_on = !(getenv("MEMHIP_TN256") && atoi(getenv("MEMHIP_TN256")) == 0);
+  if (k256_on) {
+    const int rc = gemm_tn256_dispatch(A, lda, B, ldb, R, N, K, out, ldo, accumulate, s);
+    if (rc != MEMHIP_EUNSUPPORTED) return rc;
+  }
   const int tiles = cdiv(N, BM) * cdiv(K, BN);
   const int stages = cdiv(R, BR);
   int splits = cdiv(768, tiles);                       // ~3 workgroups per CU

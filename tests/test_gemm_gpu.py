@@ -129,7 +129,8 @@ def test_vitb_shapes_throughput_sanity():
 
 
 @pytest.mark.parametrize("R,N,K", [(256, 128, 128), (394, 768, 768), (50432 // 8, 2304, 768), (1000, 512, 3072),
-                                   (333, 128, 512), (70, 768, 512), (5000, 8192, 768)])
+                                   (333, 128, 512), (70, 768, 512), (5000, 8192, 768), (2048, 256, 256),
+                                   (50432, 768, 768), (4099, 3072, 768), (3000, 768, 3072), (2500, 512, 256)])
 def test_gemm_tn_weight_gradient(R, N, K):
     """out[N,K] += A[R,N]^T @ B[R,K] with the transposing LDS read + split-K atomics."""
     from mem_amd import ops
