@@ -227,28 +227,31 @@ int memhip_cross_entropy(void* logits_bf16, int64_t ld, const int64_t* labels, i
 /* ------------------------------------------------------------------------
  * Fused attention with shared relative position bias, head_dim 64, <= 256 tokens
  * replaces Attention.forward q*scale .. (attn@v)   mem/modeling_finetune.py:137-154
- *          RelativePositionBias.forward              mem/modeling_finetune.py:242-247
+ *          RelativePositionBias (index + forward)    mem/modeling_finetune.py:213-247
  * ------------------------------------------------------------------------
- * qkv   bf16 [B*T, 3D] token-major, columns [q*scale | k | v], head h at h*64
- * bias  f32 [heads, TP, TP], TP = memhip_attn_tokens_padded(T) (zero padding)
- * out   bf16 [B*T, D];  lse f32 [B, heads, TP] (saved for backward)
- * bwd:  dqkv bf16 [B*T, 3D] (dq already multiplied by `scale`);
- *       dtable f32 [num_rel, heads] += bias gradient bucketed through
- *       relidx_pad i32 [TP, TP] (-1 in the padding); NULL skips it.
- *       dq_bias / dv_bias f32 [D] += column sums of dq / dv (the q_bias / v_bias gradients).
+ * qkv    bf16 [B*T, 3D] token-major, columns [q*scale | k | v], head h at h*64
+ * table  f32 [(2Wh-1)(2Ww-1)+3, heads] = relative_position_bias_table; T = Wh*Ww + 1 (cls first).
+ *        The additive bias is gathered from the table on chip (bucket index computed
+ *        arithmetically, identical to relative_position_index); no [heads,T,T] tensor is read.
+ * out    bf16 [B*T, D];  lse f32 [B, heads, TP], TP = memhip_attn_tokens_padded(T) (for backward)
+ * bwd:   delta f32 [B*T, heads] = rowsum(dout * out) per head (memhip_attn_delta);
+ *        dqkv bf16 [B*T, 3D] (dq already multiplied by `scale`);
+ *        dtable f32 [num_rel, heads] += table gradient (NULL skips it);
+ *        dq_bias / dv_bias f32 [D] += column sums of dq / dv (the q_bias / v_bias gradients).
+ * memhip_relpos_gather materialises the bias tensor (tests / inspection only).
  */
 int memhip_attn_tokens_padded(int T);
 int memhip_relpos_gather(const float* table, const int32_t* index /*[T*T]*/, int T, int TP, int heads,
                          float* bias_pad, float* biasT_pad /*[heads,TP(key),TP(query)] or NULL*/,
                          memhip_stream_t stream);
-int memhip_attn_fwd(const void* qkv, int64_t ldqkv, int B, int T, int D, int heads, const float* bias_pad,
-                    void* out, int64_t ldo, float* lse, memhip_stream_t stream);
-int memhip_attn_bwd(const void* qkv, int64_t ldqkv, const void* dout, const void* out, int64_t ldo,
-                    const float* lse, const float* bias_pad, const float* biasT_pad,
-                    const int32_t* relidx_pad, int num_rel, int B, int T, int D, int heads, float scale,
-                    void* dqkv, int64_t lddqkv, float* dtable, float* dq_bias /*[D] += or NULL*/,
-                    float* dv_bias /*[D] += or NULL*/, float* delta_ws /*f32 [B,heads,TP] scratch*/,
-                    memhip_stream_t stream);
+int memhip_attn_fwd(const void* qkv, int64_t ldqkv, int B, int T, int D, int heads, const float* table,
+                    int window_h, int window_w, void* out, int64_t ldo, float* lse, memhip_stream_t stream);
+int memhip_attn_delta(const void* dout, const void* out, int64_t ldo, int64_t rows, int heads, float* delta,
+                      memhip_stream_t stream);
+int memhip_attn_bwd(const void* qkv, int64_t ldqkv, const void* dout, int64_t ldo, const float* lse,
+                    const float* delta, const float* table, int window_h, int window_w, int B, int T, int D,
+                    int heads, float scale, void* dqkv, int64_t lddqkv, float* dtable, float* dq_bias,
+                    float* dv_bias, memhip_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * Layout / dtype movers

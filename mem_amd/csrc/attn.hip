@@ -1,19 +1,27 @@
 // Fused multi-head attention with the shared additive relative-position bias, forward and
 // backward (reference: Attention.forward, mem/modeling_finetune.py:137-154, with the bias of
-// RelativePositionBias :242-247 broadcast over the batch).  head_dim = 64 (ViT-B and ViT-L).
+// RelativePositionBias :213-247 broadcast over the batch).  head_dim = 64 (ViT-B and ViT-L),
+// up to 256 tokens.
 //
 // CDNA4 mapping.  The whole 197-token problem of one (sample, head) stays on chip; nothing of the
-// [B,H,N,N] score tensor ever reaches HBM.  8-wave workgroups, a wave owns a 32-token block.
-// Scores are computed TRANSPOSED (S^T = K Q^T, v_mfma_f32_32x32x16_bf16) so that a lane owns one
-// query column and a softmax row reduction is in-lane + one cross-half shuffle; the fp32
-// accumulator tile is then already the B operand of the next product (O^T = V^T P^T, and in
-// backward dV^T, dK^T, dQ^T) -- no LDS round trip for P / dS.  K/V (forward), Q/dO (backward, kv
-// kernel) and K/V (backward, q kernel) head slices are staged once per workgroup as row-major,
-// XOR-swizzled LDS images with LDS-DMA; "row" fragments are ds_read_b128, the fragments that must
-// be read down a column use the transposing LDS read ds_read_b64_tr_b16 -- no transposed copies.
-// The relative-position-bias gradient is reduced on chip into the 732-bucket table with
-// fixed-point INTEGER LDS atomics (float LDS atomics are ~30x slower on gfx950) and flushed once
-// per workgroup.
+// [B,H,N,N] score tensor ever reaches HBM.  Scores are computed TRANSPOSED (S^T = K Q^T,
+// v_mfma_f32_32x32x16_bf16) so that a lane owns one query column and a softmax row reduction is
+// in-lane + one cross-half shuffle; the fp32 accumulator tile is then already the B operand of the
+// next product (O^T = V^T P^T; in backward dV^T, dK^T, dQ^T) -- no LDS round trip for P / dS.
+// Head slices are staged as row-major XOR-swizzled LDS images by LDS-DMA; "row" fragments are
+// ds_read_b128, fragments that run down a column use the transposing read ds_read_b64_tr_b16.
+//
+// Latency structure (what the first version got wrong: 60 % of wave time was s_waitcnt):
+//   * every kernel is PERSISTENT over `spb` consecutive samples of one head with double-buffered
+//     LDS images: the LDS-DMA of sample b+1 and the few per-wave register fragments of sample b+1
+//     are issued before sample b is computed;
+//   * the compute phase contains NO global loads: the additive bias is not read from a [H,N,N]
+//     tensor but gathered from the head's 732-entry table held in LDS, with the bucket index
+//     computed arithmetically (index(q,k) = C(q) - Kc(k), three special cls buckets) -- so nothing
+//     forces the in-flight prefetch to drain (vmcnt completes in order on CDNA4);
+//   * delta = rowsum(dO * O) arrives precomputed (fused into the proj-dgrad GEMM epilogue).
+// The bias-table gradient is bucketed with fixed-point INTEGER LDS atomics (ds_add_f32 costs ~190
+// cycles per wave-instruction on gfx950, ds_add_u32 ~6: tools/micro/lds_atomic.hip).
 //
 // Rounding points follow the reference under autocast: q k^T and the P V / dO V^T / dS K products
 // are rounded to bf16, bias add + softmax (+ its backward) run in fp32, P and dS are rounded to
@@ -27,20 +35,25 @@ using namespace memhip;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
 
 constexpr int HD = 64;   // head dim
+constexpr int kMaxLds = 160 * 1024;   // bytes of LDS one workgroup may use on gfx950
 
 __device__ __forceinline__ float bfr(float v) { return (float)(__bf16)v; }
-
-__device__ __forceinline__ bf16x8 ld16(const __bf16* p) { return *reinterpret_cast<const bf16x8*>(p); }
-
-__device__ __forceinline__ bf16x8 cat4(const __bf16* lo, const __bf16* hi) {
-  const bf16x4 a = *reinterpret_cast<const bf16x4*>(lo), b = *reinterpret_cast<const bf16x4*>(hi);
-  bf16x8 r;
-  r[0] = a[0]; r[1] = a[1]; r[2] = a[2]; r[3] = a[3];
-  r[4] = b[0]; r[5] = b[1]; r[6] = b[2]; r[7] = b[3];
-  return r;
+// round two fp32 values to bf16 precision with one packed convert (v_cvt_pk_bf16_f32 + shift + and)
+template <typename V>
+__device__ __forceinline__ void bfr2(V& x, int i) {             // rounds x[i], x[i+1]
+  typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+  typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+  const bf16x2_t pk = __builtin_convertvector(f32x2_t{x[i], x[i + 1]}, bf16x2_t);
+  const unsigned u = __builtin_bit_cast(unsigned, pk);
+  x[i] = __uint_as_float(u << 16);
+  x[i + 1] = __uint_as_float(u & 0xffff0000u);
 }
+__device__ __forceinline__ float fexp2(float x) { return __builtin_amdgcn_exp2f(x); }   // bare v_exp_f32
+__device__ __forceinline__ float flog2(float x) { return __builtin_amdgcn_logf(x); }    // bare v_log_f32
+__device__ __forceinline__ bf16x8 ld16(const __bf16* p) { return *reinterpret_cast<const bf16x8*>(p); }
 
 // bf16 fragment (k-step s) of an fp32 accumulator tile, scaled: regs 8s..8s+7
 __device__ __forceinline__ bf16x8 acc_frag(const f32x16& x, int s, float mul) {
@@ -58,8 +71,7 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst) {
 }
 
 // LDS image of a [TP tokens][64] bf16 head slice: 128-B rows, 16-B chunk c of token t lives at
-// chunk position c ^ ((t >> 1) & 7)  (same XOR as the GEMM tiles: conflict-free ds_read_b128 row
-// fragments; the transposing reads below are 2-way at worst).
+// chunk position c ^ ((t >> 1) & 7) (conflict-free ds_read_b128 row fragments).
 __device__ __forceinline__ int tok_slot(int tok, int chunk) { return tok * 8 + (chunk ^ ((tok >> 1) & 7)); }
 
 // Stage src[tok*ld + 0..63] (tok < T, zero beyond) with LDS-DMA: one wave-instruction = 8 tokens.
@@ -74,36 +86,11 @@ __device__ __forceinline__ void stage_head(char* dst, const __bf16* src, long lo
   }
 }
 
-// row fragment: 8 consecutive head-dim elements (16-B chunk) of one token -> MFMA operand whose
-// lane-row is the token (lane r = tok, k = 16t + 8hh + j)
-__device__ __forceinline__ bf16x8 row_frag(const char* img, int tok, int chunk) {
-  return *reinterpret_cast<const bf16x8*>(img + tok_slot(tok, chunk) * 16);
-}
-
-// column fragment via ds_read_b64_tr_b16: lane (r = l&31 -> d = db*32 + r, hh = l>>5) receives the
-// 8 tokens tokbase+{0..3} and tokbase+8+{0..3} of head-dim column d  (tokbase already holds +4hh)
-typedef __attribute__((ext_vector_type(4))) short s16x4;
-__device__ __forceinline__ bf16x8 col_frag(const char* img, int tokbase, int db, int lane) {
-  const int rhalf = (lane >> 4) & 1, q = (lane >> 2) & 3, p = lane & 3;
-  const int ch = db * 4 + rhalf * 2 + (p >> 1), h8 = (p & 1) * 8;
-  const int t0 = tokbase + q, t1 = t0 + 8;
-  const char* a0 = img + tok_slot(t0, ch) * 16 + h8;
-  const char* a1 = img + tok_slot(t1, ch) * 16 + h8;
-  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)a0);
-  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)a1);
-  union { struct { s16x4 l, h; } s; bf16x8 v; } u;
-  u.s.l = lo;
-  u.s.h = hi;
-  return u.v;
-}
-
-// Per-lane byte offsets inside a head image for token block 0; token block kb adds the
-// compile-time constant kb*4096 (the XOR term only depends on the token's low 5 bits), so the
-// unrolled loops address LDS as base + immediate and carry 12 address registers instead of
-// recomputing (or hoisting) one swizzled address per fragment.
+// Per-lane byte offsets inside a head image for token block 0; token block kb adds the constant
+// kb*4096 (the XOR term only depends on the token's low 5 bits): base + immediate addressing.
 struct LaneOffs {
-  int row[4];        // row_frag(tok = kb*32 + r, chunk 2t + hh)
-  int col[2][2][2];  // col_frag(tokbase = kb*32 + 16ss + 4hh, db): [ss][db][lo/hi]
+  int row[4];        // row fragment: token kb*32 + r, chunk 2t + hh
+  int col[2][2][2];  // column fragment: tokens kb*32 + 16ss + 4hh + {0..3, 8..11}, d block db: [ss][db][lo/hi]
 };
 __device__ __forceinline__ LaneOffs lane_offs(int lane) {
   LaneOffs o;
@@ -138,29 +125,102 @@ __device__ __forceinline__ bf16x8 col_frag_o(const char* img, const LaneOffs& o,
 
 #define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
 
+// ---- relative-position bias from the head's table in LDS (mem/modeling_finetune.py:224-240):
+//   tokens 1.. are the Wh x Ww grid, token 0 is cls.  bucket(q,k) = (qy-ky+Wh-1)*(2Ww-1) + (qx-kx+Ww-1)
+//   = (Kc(q) + off) - Kc(k) with Kc(t) = ty*(2Ww-1) + tx, off = (Wh-1)*(2Ww-1) + (Ww-1); cls row ->
+//   nrd-3, cls column -> nrd-2, (cls,cls) -> nrd-1.
+// To keep the per-element work at ONE subtraction + ONE LDS gather (no selects), the three cls
+// buckets are reached arithmetically as well: codeQ(cls) = 4off+2 and codeK(cls) = -(off+1) push
+// the difference codeQ(q) - codeK(k) into disjoint regions of an EXTENDED table
+//   [0, 2off]           the (2Wh-1)(2Ww-1) grid buckets     (codeQ in [off, 2off], codeK in [0, off])
+//   [2off+1, 3off+1]    key = cls      (all = table[nrd-2])
+//   [3off+2, 4off+2]    query = cls    (all = table[nrd-3])
+//   5off+3              both cls       (= table[nrd-1])
+// Codes are stored pre-multiplied by 4 (byte offsets).  The table is stored times log2(e) so that
+// the softmax runs on exp2.
+struct RelGeom { int off, len; };
+__device__ __host__ __forceinline__ RelGeom rel_geom(int Wh, int Ww) {
+  const int off = (Wh - 1) * (2 * Ww - 1) + (Ww - 1);
+  return RelGeom{off, 5 * off + 4};
+}
+// target bucket of extended index i
+__device__ __forceinline__ int rel_target(int i, int off, int nrd) {
+  if (i <= 2 * off) return i;
+  if (i <= 3 * off + 1) return nrd - 2;
+  if (i <= 4 * off + 2) return nrd - 3;
+  return nrd - 1;                       // 4off+3 .. 5off+2 are never addressed; 5off+3 = (cls, cls)
+}
+constexpr float kLog2e = 1.4426950408889634f, kLn2 = 0.6931471805599453f;
+
+__device__ __forceinline__ void rel_setup(float* tabX, int* codeQ, int* codeK, const float* table, int nrd, int H,
+                                          int h, int T, int TP, int Wh, int Ww, float mul) {
+  const RelGeom g = rel_geom(Wh, Ww);
+  for (int i = threadIdx.x; i < g.len; i += blockDim.x) {
+    const int t = rel_target(i, g.off, nrd);
+    tabX[i] = table[(long long)t * H + h] * mul;
+  }
+  for (int t = threadIdx.x; t < TP; t += blockDim.x) {
+    int cq = g.off, ck = 0;                                   // padding tokens: any in-range value
+    if (t == 0) { cq = 4 * g.off + 2; ck = -(g.off + 1); }
+    else if (t < T) { const int u = t - 1; ck = (u / Ww) * (2 * Ww - 1) + (u % Ww); cq = ck + g.off; }
+    codeQ[t] = 4 * cq;
+    codeK[t] = 4 * ck;
+  }
+}
+__device__ __forceinline__ float lds_f32_at(const float* base, int byte_off) {
+  return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+
 // ------------------------------------------------------------------------------- forward
 template <int NKB>
-__global__ __launch_bounds__(512) void attn_fwd_kernel(const __bf16* __restrict__ qkv, long long ldq, int T,
-                                                       int D, int H, const float* __restrict__ bias,
-                                                       __bf16* __restrict__ out, long long ldo,
-                                                       float* __restrict__ lse) {
+__global__ __launch_bounds__(512) void attn_fwd_kernel(const __bf16* __restrict__ qkv, long long ldq, int B, int T,
+                                                       int D, int H, const float* __restrict__ table, int nrd,
+                                                       int Wh, int Ww, __bf16* __restrict__ out, long long ldo,
+                                                       float* __restrict__ lse, int spb) {
   constexpr int TP = NKB * 32;
-  __shared__ __attribute__((aligned(16))) char Ks[TP * 128];
-  __shared__ __attribute__((aligned(16))) char Vs[TP * 128];
-  const int b = blockIdx.x / H, h = blockIdx.x % H;
-  const __bf16* base = qkv + (long long)b * T * ldq + h * HD;      // q slice of this head
-  stage_head(Ks, base + D, ldq, T, TP);
-  stage_head(Vs, base + 2 * D, ldq, T, TP);
-  __syncthreads();
+  constexpr int IMG = TP * 128;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const RelGeom geo = rel_geom(Wh, Ww);
+  float* tabX = reinterpret_cast<float*>(smem);                // extended bias table * log2(e), at LDS offset 0
+  int* codeQ = reinterpret_cast<int*>(tabX + geo.len);
+  int* codeK = codeQ + TP;
+  char* imgs = smem + (((geo.len + 2 * TP) * 4 + 15) & ~15);
+  const int h = blockIdx.x % H, b0 = (blockIdx.x / H) * spb;
+  const int b1 = b0 + spb < B ? b0 + spb : B;
+  if (b0 >= b1) return;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 31, hh = lane >> 5;
   const LaneOffs lo = lane_offs(lane);
-  for (int qb = wave; qb < NKB; qb += 8) {
-    const int q = qb * 32 + r;
-    const int qc = q < T ? q : T - 1;
+  rel_setup(tabX, codeQ, codeK, table, nrd, H, h, T, TP, Wh, Ww, kLog2e);
+  const int qb = wave;                         // NKB <= 8: one 32-query block per wave
+  const bool active = qb < NKB;
+  const int q = qb * 32 + r;
+  const int qc = q < T ? q : T - 1;
+  {
+    const __bf16* s0 = qkv + (long long)b0 * T * ldq + h * HD;
+    stage_head(imgs, s0 + D, ldq, T, TP);
+    stage_head(imgs + IMG, s0 + 2 * D, ldq, T, TP);
+  }
+  bf16x8 Qn[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) Qn[t] = ld16(qkv + ((long long)b0 * T + qc) * ldq + h * HD + 16 * t + 8 * hh);
+  for (int b = b0; b < b1; ++b) {
+    const int cur = (b - b0) & 1;
+    const char* Ks = imgs + cur * 2 * IMG;
+    const char* Vs = Ks + IMG;
     bf16x8 Qf[4];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) Qf[t] = ld16(base + (long long)qc * ldq + 16 * t + 8 * hh);
+    for (int t = 0; t < 4; ++t) Qf[t] = Qn[t];
+    __syncthreads();                         // sample b's images landed; sample b-1 fully consumed
+    if (b + 1 < b1) {                        // prefetch sample b+1: register fragments first, then LDS-DMA
+      const __bf16* s1 = qkv + (long long)(b + 1) * T * ldq + h * HD;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) Qn[t] = ld16(s1 + (long long)qc * ldq + 16 * t + 8 * hh);
+      stage_head(imgs + (cur ^ 1) * 2 * IMG, s1 + D, ldq, T, TP);
+      stage_head(imgs + (cur ^ 1) * 2 * IMG + IMG, s1 + 2 * D, ldq, T, TP);
+    }
+    if (!active) continue;
+    const int cq4 = codeQ[qc];
     f32x16 s[NKB];
 #pragma unroll
     for (int kb = 0; kb < NKB; ++kb) {
@@ -169,20 +229,21 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(const __bf16* __restrict_
 #pragma unroll
       for (int t = 0; t < 4; ++t) s[kb] = MFMA32(row_frag_o(Ks, lo, kb, t), Qf[t], s[kb]);
     }
-    // + bias, key mask, row max  (lane: query q; regs: keys)
-    const float* brow = bias + ((long long)h * TP + q) * TP;
     float mx = -INFINITY;
 #pragma unroll
     for (int kb = 0; kb < NKB; ++kb) {
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int key0 = kb * 32 + 8 * g + 4 * hh;
-        const float4 bv = *reinterpret_cast<const float4*>(brow + key0);
-        const float bb[4] = {bv.x, bv.y, bv.z, bv.w};
+        const int4 kc = *reinterpret_cast<const int4*>(codeK + key0);
+        const int kcs[4] = {kc.x, kc.y, kc.z, kc.w};
+        bfr2(s[kb], 4 * g);
+        bfr2(s[kb], 4 * g + 2);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          float v = bfr(s[kb][4 * g + e]) + bb[e];
-          if (key0 + e >= T) v = -INFINITY;
+          // log2-domain score: (q.k) * log2e + bias * log2e   (one gather, one fma)
+          float v = fmaf(s[kb][4 * g + e], kLog2e, lds_f32_at(tabX, cq4 - kcs[e]));
+          if (kb == NKB - 1 && key0 + e >= T) v = -INFINITY;
           s[kb][4 * g + e] = v;
           mx = fmaxf(mx, v);
         }
@@ -194,14 +255,13 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(const __bf16* __restrict_
     for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
-        const float p = __expf(s[kb][i] - mx);
+        const float p = fexp2(s[kb][i] - mx);
         s[kb][i] = p;
         sum += p;
       }
     sum += __shfl_xor(sum, 32);
     const float inv = 1.0f / sum;
-    if (hh == 0 && q < T) lse[((long long)b * H + h) * TP + q] = mx + __logf(sum);
-    // O^T[d][q] = sum_key V^T[d][key] P^T[key][q]
+    if (hh == 0 && q < T) lse[((long long)b * H + h) * TP + q] = (mx + flog2(sum)) * kLn2;
     f32x16 o[2];
 #pragma unroll
     for (int db = 0; db < 2; ++db)
@@ -231,74 +291,84 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(const __bf16* __restrict_
   }
 }
 
-// ------------------------------------------------------------------------------- backward
-// Two kernels (P and dS are recomputed in each, in the orientation that makes their fp32
-// accumulator tile directly the next MFMA's B operand):
-//   attn_bwd_kv : workgroup = (sample, head); a wave owns 32 keys and sweeps the queries with tiles
-//                 [q rows][key cols] -> dV^T, dK^T.  Also produces delta = rowsum(dO*O) for (B).
-//   attn_bwd_q  : workgroup = (head, SPB consecutive samples); a wave owns 32 queries and sweeps the
-//                 keys with tiles [key rows][q cols] -> dQ^T per sample, while the bias gradient
-//                 dS^T is summed over the workgroup's samples IN REGISTERS and only then bucketed
-//                 (LDS float atomics are ~125 cycles per wave-instruction: once per SPB samples).
+// ------------------------------------------------------------------------------- backward (dK, dV)
+// a wave owns 32 keys and sweeps the queries with tiles [q rows][key cols]
 template <int NKB>
 __global__ __launch_bounds__(512) void attn_bwd_kv_kernel(const __bf16* __restrict__ qkv, long long ldq,
-                                                          const __bf16* __restrict__ dout,
-                                                          const __bf16* __restrict__ out, long long ldo,
+                                                          const __bf16* __restrict__ dout, long long ldo,
                                                           const float* __restrict__ lse,
-                                                          const float* __restrict__ biasT,
+                                                          const float* __restrict__ delta,
+                                                          const float* __restrict__ table, int nrd, int Wh, int Ww,
                                                           __bf16* __restrict__ dqkv, long long lddq,
-                                                          float* __restrict__ delta, float* __restrict__ dvbias,
-                                                          int T, int D, int H) {
+                                                          float* __restrict__ dvbias, int B, int T, int D, int H,
+                                                          int spb) {
   constexpr int TP = NKB * 32;
-  __shared__ __attribute__((aligned(16))) char Qs[TP * 128];
-  __shared__ __attribute__((aligned(16))) char dOs[TP * 128];
-  __shared__ __attribute__((aligned(16))) float lseS[TP];
-  __shared__ __attribute__((aligned(16))) float delS[TP];
-  __shared__ float vsum[HD];
-  const int b = blockIdx.x / H, h = blockIdx.x % H;
-  const long long row0 = (long long)b * T;
-  const __bf16* qb_ = qkv + row0 * ldq + h * HD;          // Q' slice (already scaled)
-  const __bf16* kb_ = qb_ + D;
-  const __bf16* vb_ = qb_ + 2 * D;
-  const __bf16* dob = dout + row0 * ldo + h * HD;
-  const __bf16* ob = out + row0 * ldo + h * HD;
-  stage_head(Qs, qb_, ldq, T, TP);
-  stage_head(dOs, dob, ldo, T, TP);
-  for (int q = threadIdx.x; q < TP; q += blockDim.x) {
-    float dl = 0.f, l = 0.f;
-    if (q < T) {
-#pragma unroll
-      for (int c = 0; c < 8; ++c) {
-        const bf16x8 a = ld16(dob + (long long)q * ldo + 8 * c), o = ld16(ob + (long long)q * ldo + 8 * c);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) dl += (float)a[i] * (float)o[i];
-      }
-      l = lse[((long long)b * H + h) * TP + q];
-    }
-    delS[q] = dl;
-    lseS[q] = l;
-    delta[((long long)b * H + h) * TP + q] = dl;
-  }
-  if (threadIdx.x < HD) vsum[threadIdx.x] = 0.f;
-  __syncthreads();
+  constexpr int IMG = TP * 128;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const RelGeom geo = rel_geom(Wh, Ww);
+  float* tabX = reinterpret_cast<float*>(smem);
+  int* codeQ = reinterpret_cast<int*>(tabX + geo.len);
+  int* codeK = codeQ + TP;
+  float* lseS = reinterpret_cast<float*>(codeK + TP);       // [2][TP]  (log2 domain)
+  float* delS = lseS + 2 * TP;                              // [2][TP]
+  float* vsum = delS + 2 * TP;                              // [64]
+  char* imgs = smem + (((geo.len + 6 * TP + HD) * 4 + 15) & ~15);
+  const int h = blockIdx.x % H, b0 = (blockIdx.x / H) * spb;
+  const int b1 = b0 + spb < B ? b0 + spb : B;
+  if (b0 >= b1) return;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 31, hh = lane >> 5;
   const LaneOffs lo = lane_offs(lane);
-  for (int kb = wave; kb < NKB; kb += 8) {
-    const int key = kb * 32 + r;
-    const int kc = key < T ? key : T - 1;
-    bf16x8 Kf[4], Vf[4];
+  rel_setup(tabX, codeQ, codeK, table, nrd, H, h, T, TP, Wh, Ww, kLog2e);
+  if (threadIdx.x < HD) vsum[threadIdx.x] = 0.f;
+  const int kb = wave;
+  const bool active = kb < NKB;
+  const int key = kb * 32 + r;
+  const int kc_tok = key < T ? key : T - 1;
+  auto stage_sample = [&](int b, int buf) {
+    const __bf16* s = qkv + (long long)b * T * ldq + h * HD;
+    stage_head(imgs + buf * 2 * IMG, s, ldq, T, TP);                                        // Q'
+    stage_head(imgs + buf * 2 * IMG + IMG, dout + (long long)b * T * ldo + h * HD, ldo, T, TP);   // dO
+  };
+  bf16x8 Kn[4], Vn[4];
+  float bsum[32];
+#pragma unroll
+  for (int i = 0; i < 32; ++i) bsum[i] = 0.f;
+  float lsen = 0.f, deln = 0.f;                             // this thread's element of the next lse/delta rows
+  auto load_next = [&](int b) {
+    const __bf16* s = qkv + ((long long)b * T + kc_tok) * ldq + h * HD;
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-      Kf[t] = ld16(kb_ + (long long)kc * ldq + 16 * t + 8 * hh);
-      Vf[t] = ld16(vb_ + (long long)kc * ldq + 16 * t + 8 * hh);
+      Kn[t] = ld16(s + D + 16 * t + 8 * hh);
+      Vn[t] = ld16(s + 2 * D + 16 * t + 8 * hh);
     }
+    const int qq = threadIdx.x;
+    lsen = (qq < T) ? lse[((long long)b * H + h) * TP + qq] * kLog2e : 0.f;
+    deln = (qq < T) ? delta[((long long)b * T + qq) * H + h] : 0.f;
+  };
+  load_next(b0);
+  stage_sample(b0, 0);
+  for (int b = b0; b < b1; ++b) {
+    const int cur = (b - b0) & 1;
+    const char* Qs = imgs + cur * 2 * IMG;
+    const char* dOs = Qs + IMG;
+    bf16x8 Kf[4], Vf[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { Kf[t] = Kn[t]; Vf[t] = Vn[t]; }
+    if ((int)threadIdx.x < TP) { lseS[cur * TP + threadIdx.x] = lsen; delS[cur * TP + threadIdx.x] = deln; }
+    __syncthreads();
+    if (b + 1 < b1) { load_next(b + 1); stage_sample(b + 1, cur ^ 1); }
+    if (!active) continue;
+    const int ck4 = codeK[kc_tok];
+    const float kmask = key < T ? 1.f : 0.f;
+    const float* lseC = lseS + cur * TP;
+    const float* delC = delS + cur * TP;
     f32x16 dVt[2], dKt[2];
 #pragma unroll
     for (int db = 0; db < 2; ++db)
 #pragma unroll
       for (int i = 0; i < 16; ++i) { dVt[db][i] = 0.f; dKt[db][i] = 0.f; }
-    const float* bcol = biasT + ((long long)h * TP + key) * TP;     // biasT[h][key][q]
+#pragma unroll
     for (int qb = 0; qb < NKB; ++qb) {
       f32x16 S, dP;
 #pragma unroll
@@ -311,18 +381,23 @@ __global__ __launch_bounds__(512) void attn_bwd_kv_kernel(const __bf16* __restri
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int q0 = qb * 32 + 8 * g + 4 * hh;
-        const float4 bv = *reinterpret_cast<const float4*>(bcol + q0);
-        const float4 lv = *reinterpret_cast<const float4*>(lseS + q0);
-        const float4 dv = *reinterpret_cast<const float4*>(delS + q0);
-        const float bb[4] = {bv.x, bv.y, bv.z, bv.w}, ll[4] = {lv.x, lv.y, lv.z, lv.w},
-                    dd[4] = {dv.x, dv.y, dv.z, dv.w};
+        const int4 qcv = *reinterpret_cast<const int4*>(codeQ + q0);
+        const float4 lv = *reinterpret_cast<const float4*>(lseC + q0);
+        const float4 dv = *reinterpret_cast<const float4*>(delC + q0);
+        const int qcs[4] = {qcv.x, qcv.y, qcv.z, qcv.w};
+        const float ll[4] = {lv.x, lv.y, lv.z, lv.w}, dd[4] = {dv.x, dv.y, dv.z, dv.w};
+        bfr2(S, 4 * g);
+        bfr2(S, 4 * g + 2);
+        bfr2(dP, 4 * g);
+        bfr2(dP, 4 * g + 2);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int i = 4 * g + e;
-          const float sv = bfr(S[i]) + bb[e];
-          const float p = (q0 + e < T && key < T) ? __expf(sv - ll[e]) : 0.f;
+          const float sv = fmaf(S[i], kLog2e, lds_f32_at(tabX, qcs[e] - ck4));
+          float p = fexp2(sv - ll[e]) * kmask;                 // kmask = 0 for padding keys
+          if (qb == NKB - 1 && q0 + e >= T) p = 0.f;
           S[i] = p;
-          dP[i] = p * (bfr(dP[i]) - dd[e]);
+          dP[i] = p * (dP[i] - dd[e]);
         }
       }
 #pragma unroll
@@ -344,118 +419,132 @@ __global__ __launch_bounds__(512) void attn_bwd_kv_kernel(const __bf16* __restri
 #pragma unroll
         for (int e = 0; e < 4; ++e) { wv[e] = (__bf16)dVt[db][4 * g + e]; wk[e] = (__bf16)dKt[db][4 * g + e]; }
         if (key < T) {
-          __bf16* drow = dqkv + (row0 + key) * lddq + h * HD;
+          __bf16* drow = dqkv + ((long long)b * T + key) * lddq + h * HD;
           *reinterpret_cast<bf16x4*>(drow + 2 * D + db * 32 + 8 * g + 4 * hh) = wv;
           *reinterpret_cast<bf16x4*>(drow + D + db * 32 + 8 * g + 4 * hh) = wk;
         }
-        if (dvbias) {                       // v_bias gradient: column sums of the stored (bf16) dV
+        // v_bias gradient: column sums of the stored (bf16) dV, kept per lane until the end
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            float v = key < T ? (float)wv[e] : 0.f;
-            for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o);
-            if (r == 0) atomicAdd(vsum + db * 32 + 8 * g + 4 * hh + e, v);
-          }
-        }
+        for (int e = 0; e < 4; ++e) bsum[db * 16 + 4 * g + e] += (float)wv[e] * kmask;
       }
   }
   if (dvbias) {
+    __syncthreads();
+    if (active) {
+#pragma unroll
+      for (int i = 0; i < 32; ++i) {
+        float v = bsum[i];
+        for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        if (r == 0) atomicAdd(vsum + (i >> 4) * 32 + 8 * ((i >> 2) & 3) + 4 * hh + (i & 3), v);
+      }
+    }
     __syncthreads();
     if (threadIdx.x < HD) atomicAdd(dvbias + h * HD + threadIdx.x, vsum[threadIdx.x]);
   }
 }
 
-// attn_bwd_q: the relative-position-bias gradient is bucketed with INTEGER LDS atomics (fixed
-// point): ds_add_f32 costs ~190 cycles per wave-instruction on gfx950, ds_add_u32 ~6 (measured,
-// tools/micro/lds_atomic.hip).  Per sample the scale is 2^24 / bound with
+// ------------------------------------------------------------------------------- backward (dQ, dBias)
+// a wave owns 32 queries and sweeps the keys with tiles [key rows][q cols].  The bias-table
+// gradient is bucketed with fixed-point integer LDS atomics: per sample the scale is 2^24 / bound,
 //   |dS| = p |dP - delta| <= max_q |dO_q| * max_key |V_key| + max_q |delta_q| =: bound,
-// so a bucket (<= 196 terms) cannot overflow int32 and the quantisation step is 2^-24 of the bound;
-// the integer buckets are folded into fp32 buckets once per sample.
-template <int NKB>
+// so a bucket (<= 196 terms) cannot overflow int32; the integer buckets are folded into fp32
+// buckets once per sample and flushed to the table gradient once per workgroup.
+template <int NKB, bool DT>
 __global__ __launch_bounds__(512) void attn_bwd_q_kernel(const __bf16* __restrict__ qkv, long long ldq,
                                                          const __bf16* __restrict__ dout, long long ldo,
                                                          const float* __restrict__ lse,
                                                          const float* __restrict__ delta,
-                                                         const float* __restrict__ bias,
-                                                         const int* __restrict__ relidx, int nrd,
+                                                         const float* __restrict__ table, int nrd, int Wh, int Ww,
                                                          __bf16* __restrict__ dqkv, long long lddq,
                                                          float* __restrict__ dtable, float* __restrict__ dqbias,
                                                          int B, int T, int D, int H, float scale, int spb) {
   constexpr int TP = NKB * 32;
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  constexpr int KVB = 2 * TP * 128;                           // one [K | V] image pair; two of them (double buffer)
-  float* qsum = reinterpret_cast<float*>(smem_raw + 4 * TP * 128);   // [64]
-  float* binsf = qsum + HD;                                   // [nrd] fp32 buckets (this workgroup)
-  int* binsi = reinterpret_cast<int*>(binsf + nrd);           // [nrd] fixed-point buckets (this sample)
-  int* red = binsi + nrd;                                     // [4] block maxima (float bits)
+  constexpr int IMG = TP * 128;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const RelGeom geo = rel_geom(Wh, Ww);
+  float* tabX = reinterpret_cast<float*>(smem);
+  int* binsi = reinterpret_cast<int*>(tabX + geo.len);      // [len] fixed-point buckets (this sample), extended index
+  float* binsf = reinterpret_cast<float*>(binsi + geo.len); // [len] fp32 buckets (this workgroup)
+  float* qsum = binsf + geo.len;                            // [64]
+  int* red = reinterpret_cast<int*>(qsum + HD);             // [4] block maxima (float bits)
+  int* codeQ = red + 4;
+  int* codeK = codeQ + TP;
+  char* imgs = smem + (((3 * geo.len + HD + 4 + 2 * TP) * 4 + 15) & ~15);
   const int h = blockIdx.x % H, b0 = (blockIdx.x / H) * spb;
   const int b1 = b0 + spb < B ? b0 + spb : B;
+  if (b0 >= b1) return;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 31, hh = lane >> 5;
-  for (int i = threadIdx.x; i < HD + 2 * nrd + 4; i += blockDim.x) qsum[i] = 0.f;   // contiguous region
-  const int qb = wave;                       // NKB <= 8: one query block per wave
-  const bool active = qb < NKB;
   const LaneOffs lo = lane_offs(lane);
+  rel_setup(tabX, codeQ, codeK, table, nrd, H, h, T, TP, Wh, Ww, kLog2e);
+  for (int i = threadIdx.x; i < 2 * geo.len + HD + 4; i += blockDim.x) binsi[i] = 0;   // binsi, binsf, qsum, red
+  const int qb = wave;
+  const bool active = qb < NKB;
   const int q = qb * 32 + r;
   const int qc = q < T ? q : T - 1;
-  const float* brow = bias + ((long long)h * TP + (active ? q : 0)) * TP;
-  const int* irow = relidx + (long long)(active ? q : 0) * TP;
-  if (b0 < b1) {
-    const __bf16* s0 = qkv + (long long)b0 * T * ldq + h * HD;
-    stage_head(smem_raw, s0 + D, ldq, T, TP);
-    stage_head(smem_raw + TP * 128, s0 + 2 * D, ldq, T, TP);
-  }
+  bf16x8 Qn[4], dOn[4];
+  float bsum[32];
+#pragma unroll
+  for (int i = 0; i < 32; ++i) bsum[i] = 0.f;
+  const float qmask = q < T ? 1.f : 0.f;
+  float lqn = 0.f, dqn = 0.f;
+  auto load_q = [&](int b) {
+    const long long row = (long long)b * T + qc;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      Qn[t] = ld16(qkv + row * ldq + h * HD + 16 * t + 8 * hh);
+      dOn[t] = ld16(dout + row * ldo + h * HD + 16 * t + 8 * hh);
+    }
+    lqn = lse[((long long)b * H + h) * TP + qc] * kLog2e;
+    dqn = delta[row * H + h];
+  };
+  auto stage_sample = [&](int b, int buf) {
+    const __bf16* s = qkv + (long long)b * T * ldq + h * HD;
+    stage_head(imgs + buf * 2 * IMG, s + D, ldq, T, TP);               // K
+    stage_head(imgs + buf * 2 * IMG + IMG, s + 2 * D, ldq, T, TP);     // V
+  };
+  load_q(b0);
+  stage_sample(b0, 0);
   for (int b = b0; b < b1; ++b) {
     const int cur = (b - b0) & 1;
-    const char* Ks = smem_raw + cur * KVB;
-    const char* Vs = Ks + TP * 128;
-    const long long row0 = (long long)b * T;
-    const __bf16* qb_ = qkv + row0 * ldq + h * HD;
-    const __bf16* dob = dout + row0 * ldo + h * HD;
-    __syncthreads();                      // K/V of sample b have landed; sample b-1 is fully consumed
-    if (b + 1 < b1) {                     // prefetch the next sample behind this one's compute
-      const __bf16* s1 = qkv + (row0 + T) * ldq + h * HD;
-      stage_head(smem_raw + (cur ^ 1) * KVB, s1 + D, ldq, T, TP);
-      stage_head(smem_raw + (cur ^ 1) * KVB + TP * 128, s1 + 2 * D, ldq, T, TP);
-    }
-    // ---- bound for the fixed-point scale
-    float lq = 0.f, dq_ = 0.f;
-    if (dtable) {
-      if (threadIdx.x < T) {
+    const char* Ks = imgs + cur * 2 * IMG;
+    const char* Vs = Ks + IMG;
+    bf16x8 Qf[4], dOf[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { Qf[t] = Qn[t]; dOf[t] = dOn[t]; }
+    const float lq = lqn, dq_ = dqn;
+    __syncthreads();                      // K/V of sample b landed; sample b-1 fully consumed
+    if (b + 1 < b1) { load_q(b + 1); stage_sample(b + 1, cur ^ 1); }
+    // ---- bound for the fixed-point scale (LDS only)
+    float fx = 0.f;
+    if (DT) {
+      if ((int)threadIdx.x < T) {
         float vn = 0.f;
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
-          const bf16x8 v = row_frag(Vs, threadIdx.x, c);
+          const bf16x8 v = *reinterpret_cast<const bf16x8*>(Vs + tok_slot(threadIdx.x, c) * 16);
 #pragma unroll
           for (int i = 0; i < 8; ++i) vn += (float)v[i] * (float)v[i];
         }
         atomicMax(red + 0, __float_as_int(vn));                       // max |V_key|^2
       }
-    }
-    bf16x8 Qf[4], dOf[4];
-    if (active) {
-      float dn = 0.f;
+      if (active && q < T) {
+        float dn = 0.f;
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        Qf[t] = ld16(qb_ + (long long)qc * ldq + 16 * t + 8 * hh);
-        dOf[t] = ld16(dob + (long long)qc * ldo + 16 * t + 8 * hh);
+        for (int t = 0; t < 4; ++t)
 #pragma unroll
-        for (int i = 0; i < 8; ++i) dn += (float)dOf[t][i] * (float)dOf[t][i];
-      }
-      lq = lse[((long long)b * H + h) * TP + q];
-      dq_ = delta[((long long)b * H + h) * TP + q];
-      if (dtable && q < T) {
+          for (int i = 0; i < 8; ++i) dn += (float)dOf[t][i] * (float)dOf[t][i];
         dn += __shfl_xor(dn, 32);                                     // the two lane halves hold half a row each
         atomicMax(red + 1, __float_as_int(dn));                       // max |dO_q|^2
         atomicMax(red + 2, __float_as_int(fabsf(dq_)));               // max |delta_q|
       }
-    }
-    float fx = 0.f;
-    if (dtable) {
-      __syncthreads();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();                                   // LDS-only sync: the prefetch stays in flight
       const float bound = sqrtf(__int_as_float(red[0])) * sqrtf(__int_as_float(red[1])) + __int_as_float(red[2]);
       fx = bound > 0.f ? 16777216.0f / bound : 0.f;
     }
     if (active) {
+      const int cq4 = codeQ[qc];
       f32x16 dQt[2];
 #pragma unroll
       for (int db = 0; db < 2; ++db)
@@ -474,19 +563,23 @@ __global__ __launch_bounds__(512) void attn_bwd_q_kernel(const __bf16* __restric
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const int key0 = kb * 32 + 8 * g + 4 * hh;
-          const float4 bv = *reinterpret_cast<const float4*>(brow + key0);
-          const int4 iv = *reinterpret_cast<const int4*>(irow + key0);
-          const float bb[4] = {bv.x, bv.y, bv.z, bv.w};
-          const int ii[4] = {iv.x, iv.y, iv.z, iv.w};
+          const int4 kc = *reinterpret_cast<const int4*>(codeK + key0);
+          const int kcs[4] = {kc.x, kc.y, kc.z, kc.w};
+          bfr2(St, 4 * g);
+          bfr2(St, 4 * g + 2);
+          bfr2(dPt, 4 * g);
+          bfr2(dPt, 4 * g + 2);
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             const int i = 4 * g + e;
-            const bool ok = (q < T) && (key0 + e < T);
-            const float sv = bfr(St[i]) + bb[e];
-            const float p = ok ? __expf(sv - lq) : 0.f;
-            const float ds = p * (bfr(dPt[i]) - dq_);
+            const int idx4 = cq4 - kcs[e];
+            const float sv = fmaf(St[i], kLog2e, lds_f32_at(tabX, idx4));
+            float p = fexp2(sv - lq) * qmask;                   // qmask = 0 for padding queries
+            if (kb == NKB - 1 && key0 + e >= T) p = 0.f;
+            const float ds = p * (dPt[i] - dq_);
             dPt[i] = ds;
-            if (ok && dtable) atomicAdd(binsi + ii[e], __float2int_rn(ds * fx));
+            // masked elements add 0 (their codes are valid): no divergent branch around the atomic
+            if (DT) atomicAdd(reinterpret_cast<int*>(reinterpret_cast<char*>(binsi) + idx4), (int)(ds * fx));
           }
         }
 #pragma unroll
@@ -504,21 +597,17 @@ __global__ __launch_bounds__(512) void attn_bwd_q_kernel(const __bf16* __restric
           bf16x4 w;
 #pragma unroll
           for (int e = 0; e < 4; ++e) w[e] = (__bf16)(bfr(dQt[db][4 * g + e]) * scale);
-          if (q < T) *reinterpret_cast<bf16x4*>(dqkv + (row0 + q) * lddq + h * HD + db * 32 + 8 * g + 4 * hh) = w;
-          if (dqbias) {
+          if (q < T)
+            *reinterpret_cast<bf16x4*>(dqkv + ((long long)b * T + q) * lddq + h * HD + db * 32 + 8 * g + 4 * hh) = w;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              float v = q < T ? (float)w[e] : 0.f;
-              for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o);
-              if (r == 0) atomicAdd(qsum + db * 32 + 8 * g + 4 * hh + e, v);
-            }
-          }
+          for (int e = 0; e < 4; ++e) bsum[db * 16 + 4 * g + e] += (float)w[e] * qmask;   // q_bias gradient
         }
     }
-    if (dtable) {                          // fold this sample's fixed-point buckets into fp32
-      __syncthreads();
+    if (DT) {                              // fold this sample's fixed-point buckets into fp32
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
       const float inv = fx > 0.f ? 1.0f / fx : 0.f;
-      for (int i = threadIdx.x; i < nrd; i += blockDim.x) {
+      for (int i = threadIdx.x; i < geo.len; i += blockDim.x) {
         binsf[i] += (float)binsi[i] * inv;
         binsi[i] = 0;
       }
@@ -526,12 +615,61 @@ __global__ __launch_bounds__(512) void attn_bwd_q_kernel(const __bf16* __restric
     }
   }
   __syncthreads();
-  if (dtable)
-    for (int i = threadIdx.x; i < nrd; i += blockDim.x) {
+  if (DT) {
+    // grid buckets one to one; the two cls regions are summed on chip first (hundreds of atomics on
+    // ONE address per workgroup would serialise in L2)
+    for (int i = threadIdx.x; i <= 2 * geo.off; i += blockDim.x) {
       const float v = binsf[i];
       if (v != 0.f) atomicAdd(dtable + (long long)i * H + h, v);
     }
+    if (wave < 2) {
+      const int base = wave == 0 ? 2 * geo.off + 1 : 3 * geo.off + 2;
+      float v = 0.f;
+      for (int i = lane; i <= geo.off; i += 64) v += binsf[base + i];
+      for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+      if (lane == 0) atomicAdd(dtable + (long long)(wave == 0 ? nrd - 2 : nrd - 3) * H + h, v);
+    } else if (threadIdx.x == 128) {
+      atomicAdd(dtable + (long long)(nrd - 1) * H + h, binsf[5 * geo.off + 3]);
+    }
+  }
+  if (dqbias) {
+    if (active) {
+#pragma unroll
+      for (int i = 0; i < 32; ++i) {
+        float v = bsum[i];
+        for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        if (r == 0) atomicAdd(qsum + (i >> 4) * 32 + 8 * ((i >> 2) & 3) + 4 * hh + (i & 3), v);
+      }
+    }
+    __syncthreads();
+  }
   if (dqbias && threadIdx.x < HD) atomicAdd(dqbias + h * HD + threadIdx.x, qsum[threadIdx.x]);
+}
+
+// rowsum(dO * O) per (token, head): standalone form of what the proj-dgrad GEMM epilogue fuses
+__global__ __launch_bounds__(256) void attn_delta_kernel(const __bf16* __restrict__ dout, const __bf16* __restrict__ out,
+                                                         long long ldo, long long rows, int H,
+                                                         float* __restrict__ delta) {
+  const long long i = (long long)blockIdx.x * 32 + (threadIdx.x >> 3);     // (row, head) pair index
+  if (i >= rows * H) return;
+  const long long row = i / H;
+  const int h = (int)(i - row * H);
+  const int c = (threadIdx.x & 7) * 8;
+  const bf16x8 a = ld16(dout + row * ldo + h * HD + c), o = ld16(out + row * ldo + h * HD + c);
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) s += (float)a[k] * (float)o[k];
+  s += __shfl_xor(s, 1);
+  s += __shfl_xor(s, 2);
+  s += __shfl_xor(s, 4);
+  if ((threadIdx.x & 7) == 0) delta[i] = s;
+}
+
+int pick_spb(int B, int heads) {
+  int spb = (B * heads + 255) / 256;           // one workgroup per CU when the batch allows
+  if (spb < 1) spb = 1;
+  if (spb > 16) spb = 16;
+  return spb;
 }
 
 }  // namespace
@@ -546,54 +684,94 @@ __global__ __launch_bounds__(512) void attn_bwd_q_kernel(const __bf16* __restric
 
 extern "C" int memhip_attn_tokens_padded(int T) { return ((T + 31) / 32) * 32; }
 
-extern "C" int memhip_attn_fwd(const void* qkv, int64_t ldqkv, int B, int T, int D, int heads,
-                               const float* bias_pad, void* out, int64_t ldo, float* lse,
+extern "C" int memhip_attn_fwd(const void* qkv, int64_t ldqkv, int B, int T, int D, int heads, const float* table,
+                               int window_h, int window_w, void* out, int64_t ldo, float* lse,
                                memhip_stream_t stream) {
   MEMHIP_REQUIRE(B >= 0 && T > 0 && heads > 0 && D == heads * HD, "attn_fwd: head_dim must be 64 (D=%d heads=%d)", D, heads);
+  MEMHIP_REQUIRE(window_h > 0 && window_w > 0 && window_h * window_w + 1 == T, "attn_fwd: T must be window_h*window_w + 1");
   if (B == 0) return MEMHIP_OK;
-  MEMHIP_REQUIRE(qkv && bias_pad && out && lse, "attn_fwd: null pointer");
+  MEMHIP_REQUIRE(qkv && table && out && lse, "attn_fwd: null pointer");
   MEMHIP_REQUIRE(ldqkv % 8 == 0 && ldo % 8 == 0, "attn_fwd: ld must be a multiple of 8");
   hipStream_t s = as_stream(stream);
   const int nkb = (T + 31) / 32;
-#define FWD(N) hipLaunchKernelGGL(attn_fwd_kernel<N>, dim3(B * heads), dim3(512), 0, s, (const __bf16*)qkv, \
-                                  (long long)ldqkv, T, D, heads, bias_pad, (__bf16*)out, (long long)ldo, lse)
+  const int nrd = (2 * window_h - 1) * (2 * window_w - 1) + 3;
+  const int spb = pick_spb(B, heads);
+#define FWD(N)                                                                                          \
+  {                                                                                                     \
+    const size_t sm = (size_t)4 * N * 32 * 128 + (size_t)(rel_geom(window_h, window_w).len + 2 * N * 32) * 4 + 32; \
+    if (sm > (size_t)kMaxLds) return fail(MEMHIP_EUNSUPPORTED, "attn_fwd: LDS budget exceeded");         \
+    static bool attr_done = false;                                                                      \
+    if (!attr_done) {                                                                                   \
+      MEMHIP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel<N>),                 \
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds));             \
+      attr_done = true;                                                                                 \
+    }                                                                                                   \
+    hipLaunchKernelGGL(attn_fwd_kernel<N>, dim3(((B + spb - 1) / spb) * heads), dim3(512), sm, s,       \
+                       (const __bf16*)qkv, (long long)ldqkv, B, T, D, heads, table, nrd, window_h,      \
+                       window_w, (__bf16*)out, (long long)ldo, lse, spb);                               \
+  }
   ATTN_DISPATCH(nkb, FWD)
 #undef FWD
   return check_launch("attn_fwd");
 }
 
-extern "C" int memhip_attn_bwd(const void* qkv, int64_t ldqkv, const void* dout, const void* out, int64_t ldo,
-                               const float* lse, const float* bias_pad, const float* biasT_pad,
-                               const int32_t* relidx_pad, int num_rel, int B, int T, int D, int heads,
-                               float scale, void* dqkv, int64_t lddqkv, float* dtable, float* dq_bias,
-                               float* dv_bias, float* delta_ws, memhip_stream_t stream) {
+extern "C" int memhip_attn_delta(const void* dout, const void* out, int64_t ldo, int64_t rows, int heads,
+                                 float* delta, memhip_stream_t stream) {
+  MEMHIP_REQUIRE(rows >= 0 && heads > 0 && ldo % 8 == 0, "attn_delta: bad arguments");
+  if (rows == 0) return MEMHIP_OK;
+  MEMHIP_REQUIRE(dout && out && delta, "attn_delta: null pointer");
+  const long long pairs = rows * heads;
+  hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((pairs + 31) / 32)), dim3(256), 0, as_stream(stream),
+                     (const __bf16*)dout, (const __bf16*)out, (long long)ldo, (long long)rows, heads, delta);
+  return check_launch("attn_delta");
+}
+
+extern "C" int memhip_attn_bwd(const void* qkv, int64_t ldqkv, const void* dout, int64_t ldo, const float* lse,
+                               const float* delta, const float* table, int window_h, int window_w, int B,
+                               int T, int D, int heads, float scale, void* dqkv, int64_t lddqkv, float* dtable,
+                               float* dq_bias, float* dv_bias, memhip_stream_t stream) {
   MEMHIP_REQUIRE(B >= 0 && T > 0 && heads > 0 && D == heads * HD, "attn_bwd: head_dim must be 64");
+  MEMHIP_REQUIRE(window_h > 0 && window_w > 0 && window_h * window_w + 1 == T, "attn_bwd: T must be window_h*window_w + 1");
   if (B == 0) return MEMHIP_OK;
-  MEMHIP_REQUIRE(qkv && dout && out && lse && bias_pad && biasT_pad && dqkv && delta_ws, "attn_bwd: null pointer");
-  MEMHIP_REQUIRE(!dtable || (relidx_pad && num_rel > 0), "attn_bwd: dtable needs relidx_pad");
+  MEMHIP_REQUIRE(qkv && dout && lse && delta && table && dqkv, "attn_bwd: null pointer");
   MEMHIP_REQUIRE(ldqkv % 8 == 0 && ldo % 8 == 0 && lddqkv % 8 == 0, "attn_bwd: ld must be a multiple of 8");
   hipStream_t s = as_stream(stream);
   const int nkb = (T + 31) / 32;
-  const int nrd = dtable ? num_rel : 0;
+  const int nrd = (2 * window_h - 1) * (2 * window_w - 1) + 3;
+  const int spb = pick_spb(B, heads);
+  const int grid = ((B + spb - 1) / spb) * heads;
+  const int glen = rel_geom(window_h, window_w).len;
 #define BWD(N)                                                                                          \
   {                                                                                                     \
-    hipLaunchKernelGGL(attn_bwd_kv_kernel<N>, dim3(B * heads), dim3(512), 0, s, (const __bf16*)qkv,     \
-                       (long long)ldqkv, (const __bf16*)dout, (const __bf16*)out, (long long)ldo, lse,  \
-                       biasT_pad, (__bf16*)dqkv, (long long)lddqkv, delta_ws, dv_bias, T, D, heads);    \
-    const size_t sm = (size_t)4 * N * 32 * 128 + (size_t)(HD + 2 * nrd + 4) * 4 + 16;                   \
-    int spb = (B * heads + 255) / 256;           /* one workgroup per CU when the batch allows */       \
-    if (spb < 1) spb = 1;                                                                               \
-    if (spb > 16) spb = 16;                                                                             \
     static bool attr_done = false;                                                                      \
     if (!attr_done) {                                                                                   \
-      MEMHIP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_q_kernel<N>),               \
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));   \
+      MEMHIP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_kv_kernel<N>),              \
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds));             \
+      MEMHIP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_q_kernel<N, true>),         \
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds));             \
+      MEMHIP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_q_kernel<N, false>),        \
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds));             \
       attr_done = true;                                                                                 \
     }                                                                                                   \
-    hipLaunchKernelGGL(attn_bwd_q_kernel<N>, dim3(((B + spb - 1) / spb) * heads), dim3(512), sm, s,     \
-                       (const __bf16*)qkv, (long long)ldqkv, (const __bf16*)dout, (long long)ldo, lse,  \
-                       delta_ws, bias_pad, relidx_pad, nrd, (__bf16*)dqkv, (long long)lddqkv, dtable,   \
-                       dq_bias, B, T, D, heads, scale, spb);                                            \
+    const size_t sm_kv = (size_t)4 * N * 32 * 128 + (size_t)(glen + 6 * N * 32 + HD) * 4 + 32;          \
+    const size_t sm_q = (size_t)4 * N * 32 * 128 + (size_t)(3 * glen + HD + 4 + 2 * N * 32) * 4 + 32;   \
+    if (sm_kv > (size_t)kMaxLds || sm_q > (size_t)kMaxLds)                                              \
+      return fail(MEMHIP_EUNSUPPORTED, "attn_bwd: %d tokens with a %dx%d window exceed the LDS budget", T, window_h, \
+                  window_w);                                                                            \
+    hipLaunchKernelGGL(attn_bwd_kv_kernel<N>, dim3(grid), dim3(512), sm_kv, s, (const __bf16*)qkv,      \
+                       (long long)ldqkv, (const __bf16*)dout, (long long)ldo, lse, delta, table, nrd,   \
+                       window_h, window_w, (__bf16*)dqkv, (long long)lddqkv, dv_bias, B, T, D, heads,   \
+                       spb);                                                                            \
+    if (dtable)                                                                                         \
+      hipLaunchKernelGGL((attn_bwd_q_kernel<N, true>), dim3(grid), dim3(512), sm_q, s, (const __bf16*)qkv, \
+                         (long long)ldqkv, (const __bf16*)dout, (long long)ldo, lse, delta, table, nrd, \
+                         window_h, window_w, (__bf16*)dqkv, (long long)lddqkv, dtable, dq_bias, B, T, D, \
+                         heads, scale, spb);                                                            \
+    else                                                                                                \
+      hipLaunchKernelGGL((attn_bwd_q_kernel<N, false>), dim3(grid), dim3(512), sm_q, s, (const __bf16*)qkv, \
+                         (long long)ldqkv, (const __bf16*)dout, (long long)ldo, lse, delta, table, nrd, \
+                         window_h, window_w, (__bf16*)dqkv, (long long)lddqkv, dtable, dq_bias, B, T, D, \
+                         heads, scale, spb);                                                            \
   }
   ATTN_DISPATCH(nkb, BWD)
 #undef BWD

@@ -75,8 +75,9 @@ declare({
     "memhip_cross_entropy": (i32, [vp, i64, vp, i32, i32, f32, vp, vp, i32, vp, vp]),
     "memhip_attn_tokens_padded": (i32, [i32]),
     "memhip_relpos_gather": (i32, [vp, vp, i32, i32, i32, vp, vp, vp]),
-    "memhip_attn_fwd": (i32, [vp, i64, i32, i32, i32, i32, vp, vp, i64, vp, vp]),
-    "memhip_attn_bwd": (i32, [vp, i64, vp, vp, i64, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, vp, i64, vp, vp, vp, vp, vp]),
+    "memhip_attn_fwd": (i32, [vp, i64, i32, i32, i32, i32, vp, i32, i32, vp, i64, vp, vp]),
+    "memhip_attn_delta": (i32, [vp, vp, i64, i64, i32, vp, vp]),
+    "memhip_attn_bwd": (i32, [vp, i64, vp, i64, vp, vp, vp, i32, i32, i32, i32, i32, i32, f32, vp, i64, vp, vp, vp, vp]),
     "memhip_cast_f32_bf16": (i32, [vp, vp, i64, vp]),
     "memhip_transpose_cast_f32_bf16": (i32, [vp, i64, i32, i32, vp, i64, vp]),
     "memhip_transpose_bf16": (i32, [vp, i64, i32, i32, vp, i64, i32, vp, i32, i32, vp, i32, i32, vp]),
@@ -124,17 +125,20 @@ def relpos_gather(table, index_i32, T, TP, heads, bias_pad, biasT_pad=None):
                                    stream_ptr()), "relpos_gather")
 
 
-def attn_fwd(qkv, B, T, D, heads, bias_pad, out, lse):
-    check(lib.memhip_attn_fwd(ptr(qkv), qkv.stride(0), B, T, D, heads, ptr(bias_pad), ptr(out), out.stride(0),
-                              ptr(lse), stream_ptr()), "attn_fwd")
+def attn_fwd(qkv, B, T, D, heads, table, window, out, lse):
+    check(lib.memhip_attn_fwd(ptr(qkv), qkv.stride(0), B, T, D, heads, ptr(table), window[0], window[1], ptr(out),
+                              out.stride(0), ptr(lse), stream_ptr()), "attn_fwd")
 
 
-def attn_bwd(qkv, dout, out, lse, bias_pad, biasT_pad, relidx_pad, num_rel, B, T, D, heads, scale, dqkv, dtable,
-             delta_ws, dq_bias=None, dv_bias=None):
-    check(lib.memhip_attn_bwd(ptr(qkv), qkv.stride(0), ptr(dout), ptr(out), out.stride(0), ptr(lse),
-                              ptr(bias_pad), ptr(biasT_pad), ptr(relidx_pad), num_rel, B, T, D, heads, scale,
-                              ptr(dqkv), dqkv.stride(0), ptr(dtable), ptr(dq_bias), ptr(dv_bias), ptr(delta_ws),
-                              stream_ptr()), "attn_bwd")
+def attn_delta(dout, out, rows, heads, delta):
+    check(lib.memhip_attn_delta(ptr(dout), ptr(out), out.stride(0), rows, heads, ptr(delta), stream_ptr()),
+          "attn_delta")
+
+
+def attn_bwd(qkv, dout, lse, delta, table, window, B, T, D, heads, scale, dqkv, dtable, dq_bias=None, dv_bias=None):
+    check(lib.memhip_attn_bwd(ptr(qkv), qkv.stride(0), ptr(dout), dout.stride(0), ptr(lse), ptr(delta), ptr(table),
+                              window[0], window[1], B, T, D, heads, scale, ptr(dqkv), dqkv.stride(0), ptr(dtable),
+                              ptr(dq_bias), ptr(dv_bias), stream_ptr()), "attn_bwd")
 
 
 def cast_f32_bf16(src, dst, n):

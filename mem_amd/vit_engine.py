@@ -146,12 +146,7 @@ class ViTEngine:
                               fc1=torch.empty((D, Hd), dtype=bf, device=dev),
                               fc2=torch.empty((Hd, D), dtype=bf, device=dev))
         self.wT_lm = torch.empty((D, V), dtype=bf, device=dev)
-        idx = self.model.rel_pos_bias.relative_position_index.to(dev)
-        self.relidx = idx.to(torch.int32).contiguous()
-        self.relidx_pad = torch.full((self.TP, self.TP), -1, dtype=torch.int32, device=dev)
-        self.relidx_pad[: self.T, : self.T] = self.relidx
-        self.bias_pad = torch.zeros((self.heads, self.TP, self.TP), dtype=torch.float32, device=dev)
-        self.biasT_pad = torch.zeros((self.heads, self.TP, self.TP), dtype=torch.float32, device=dev)
+        self.window = tuple(self.model.rel_pos_bias.window_size)
         self.gn_ws = torch.zeros(1024, dtype=torch.float64, device=dev)
         self.gnorm = torch.zeros(1, dtype=torch.float32, device=dev)
         self.loss_acc = torch.zeros(2, dtype=torch.float32, device=dev)
@@ -186,7 +181,7 @@ class ViTEngine:
         self.dbig = e(M, Hd)
         self.dqkv = e(M, 3 * D)
         self.dao = e(M, D)
-        self.delta_ws = e(B, self.heads, self.TP, dt=f32)
+        self.delta_ws = e(M, self.heads, dt=f32)
         self.dYpe = e(B * self.L, D)
         self.B, self.Mm_cap = B, Mm_cap
 
@@ -228,8 +223,7 @@ class ViTEngine:
         ops.gemm_nt(self.patches, self.W16("patch_embed.proj.weight", D, self.Kpe), B * L, D, self.Kpe,
                     ops.EPI_PATCH_EMBED, bias=self.P("patch_embed.proj.bias"), vec1=self.P("mask_token"),
                     resid=x0, aux=mask_u8, rows_per_sample=L, ldaux=0)
-        ops.relpos_gather(self.P("rel_pos_bias.relative_position_bias_table"), self.relidx, T, self.TP, self.heads,
-                          self.bias_pad, self.biasT_pad)
+        table = self.P("rel_pos_bias.relative_position_bias_table")
         for i in range(self.depth):
             pre = f"blocks.{i}."
             a = self.act[i]
@@ -243,7 +237,7 @@ class ViTEngine:
                               a["rstd1"], M, D)
             ops.gemm_nt(a["h1"], self.W16(pre + "attn.qkv.weight", 3 * D, D), M, 3 * D, D, ops.EPI_BIAS_BF16,
                         out0=a["qkv"], bias=self.P(pre + "attn.qkvbias3"), colscale=self.scale, colscale_n=D)
-            ops.attn_fwd(a["qkv"], B, T, D, self.heads, self.bias_pad, a["ao"], a["lse"])
+            ops.attn_fwd(a["qkv"], B, T, D, self.heads, table, self.window, a["ao"], a["lse"])
             ops.gemm_nt(a["ao"], self.W16(pre + "attn.proj.weight", D, D), M, D, D, ops.EPI_RESIDUAL, out0=a["y1"],
                         bias=self.P(pre + "attn.proj.bias"), vec1=g1, resid=xmid, aux=xin, ldaux=D,
                         rowmask=dp_masks[2 * i] if use_dp else None, keep_prob=keep, rows_per_sample=T)
@@ -294,6 +288,7 @@ class ViTEngine:
         if self.grad_hook:
             self.grad_hook(0)
         dtable = self.G("rel_pos_bias.relative_position_bias_table")
+        table = self.P("rel_pos_bias.relative_position_bias_table")
         for i in reversed(range(self.depth)):
             pre = f"blocks.{i}."
             a = self.act[i]
@@ -319,9 +314,10 @@ class ViTEngine:
                            rowmask=dp_masks[2 * i] if use_dp else None, keep_prob=keep, rows_per_sample=T)
             ops.gemm_nt(self.dY, self.wT[i]["proj"], M, D, D, ops.EPI_BIAS_BF16, out0=self.dao)
             self._wgrad(self.dY, a["ao"], M, D, D, pre + "attn.proj.weight")
-            ops.attn_bwd(a["qkv"], self.dao, a["ao"], a["lse"], self.bias_pad, self.biasT_pad, self.relidx_pad,
-                         self.nrd, B, T, D, self.heads, self.scale, self.dqkv, dtable, self.delta_ws,
-                         dq_bias=self.G(pre + "attn.q_bias"), dv_bias=self.G(pre + "attn.v_bias"))
+            ops.attn_delta(self.dao, a["ao"], M, self.heads, self.delta_ws)
+            ops.attn_bwd(a["qkv"], self.dao, a["lse"], self.delta_ws, table, self.window, B, T, D, self.heads,
+                         self.scale, self.dqkv, dtable, dq_bias=self.G(pre + "attn.q_bias"),
+                         dv_bias=self.G(pre + "attn.v_bias"))
             self._wgrad(self.dqkv, a["h1"], M, 3 * D, D, pre + "attn.qkv.weight")
             ops.gemm_nt(self.dqkv, self.wT[i]["qkv"], M, D, 3 * D, ops.EPI_BIAS_BF16, out0=self.dh_small)
             ops.layernorm_bwd(self.dh_small, xin, self.P(pre + "norm1.weight"), a["mean1"], a["rstd1"], dx,

@@ -1,11 +1,12 @@
 """One tiny masked-pretraining step of the fused HIP ViT on cuda:0, checked against the oracle
-(CPU restatement, bf16 autocast).  Used by __graft_entry__.smoke()."""
+(CPU restatement, bf16 autocast).  Checker code: lives under tests/ because it imports the oracle;
+used by __graft_entry__.smoke()."""
 import torch
 
 
 def run():
-    from .modeling_pretrain import pt_vit
-    from .optim_factory import FlatAdamW, get_parameter_groups
+    from mem_amd.modeling_pretrain import pt_vit
+    from mem_amd.optim_factory import FlatAdamW, get_parameter_groups
     from oracle.gen_golden import TINY, vit_inputs
     from oracle.vit_ref import RefViT, fill_by_name, make_optimizer, train_step
     import contextlib, io

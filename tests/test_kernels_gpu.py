@@ -128,8 +128,9 @@ def _attn_ref(qkv, bias, B, T, D, H, scale):
     return o.transpose(1, 2).reshape(B * T, D), p
 
 
-@pytest.mark.parametrize("B,T,H", [(3, 197, 12), (2, 17, 2), (2, 65, 4), (1, 256, 2)])
-def test_attention_fwd_bwd(B, T, H):
+@pytest.mark.parametrize("B,T,H,win", [(3, 197, 12, (14, 14)), (2, 17, 2, (4, 4)), (5, 65, 4, (8, 8)),
+                                       (1, 256, 2, (15, 17)), (40, 37, 3, (4, 9))])
+def test_attention_fwd_bwd(B, T, H, win):
     from mem_amd import ops
     from oracle.vit_ref import rel_pos_index
     D = 64 * H
@@ -138,22 +139,18 @@ def test_attention_fwd_bwd(B, T, H):
     qkv = _rand((B * T, 3 * D), 20, 1.0)
     qkv[:, :D] *= scale
     qkv = qkv.bfloat16()
-    side = int(math.isqrt(T - 1))
-    if side * side == T - 1:
-        idx, nrd = rel_pos_index((side, side))
-        idx = idx.cuda()
-    else:
-        nrd = 50
-        idx = torch.randint(0, nrd, (T, T), device="cuda")
+    idx, nrd = rel_pos_index(win)
+    idx = idx.cuda()
     table = _rand((nrd, H), 21, 0.5)
     bias_pad = torch.zeros((H, TP, TP), device="cuda")
     biasT_pad = torch.zeros_like(bias_pad)
     ops.relpos_gather(table, idx.int().contiguous(), T, TP, H, bias_pad, biasT_pad)
     bias = table[idx.view(-1)].view(T, T, H).permute(2, 0, 1).contiguous()
     assert torch.equal(bias_pad[:, :T, :T], bias) and bias_pad[:, T:].abs().sum() == 0
+    assert torch.equal(biasT_pad, bias_pad.transpose(1, 2).contiguous())
     out = torch.zeros((B * T, D), dtype=torch.bfloat16, device="cuda")
     lse = torch.zeros((B, H, TP), device="cuda")
-    ops.attn_fwd(qkv, B, T, D, H, bias_pad, out, lse)
+    ops.attn_fwd(qkv, B, T, D, H, table, win, out, lse)          # bias gathered on chip from the table
     ref, p = _attn_ref(qkv, bias, B, T, D, H, scale)
     torch.testing.assert_close(out.float(), ref.float(), rtol=2e-2, atol=2e-2)
     q, k, _ = qkv.float().view(B, T, 3, H, 64).permute(2, 0, 3, 1, 4)
@@ -169,13 +166,11 @@ def test_attention_fwd_bwd(B, T, H):
     o.transpose(1, 2).reshape(B * T, D).backward(dout.float())
     dqkv = torch.zeros((B * T, 3 * D), dtype=torch.bfloat16, device="cuda")
     dtable = torch.zeros((nrd, H), device="cuda")
-    relidx_pad = torch.full((TP, TP), -1, dtype=torch.int32, device="cuda")
-    relidx_pad[:T, :T] = idx.int()
-    delta_ws = torch.zeros((B, H, TP), device="cuda")
+    delta = torch.zeros((B * T, H), device="cuda")
+    ops.attn_delta(dout, out, B * T, H, delta)
+    torch.testing.assert_close(delta, (dout.float() * out.float()).view(B * T, H, 64).sum(-1), rtol=1e-4, atol=1e-3)
     dqb, dvb = torch.zeros(D, device="cuda"), torch.zeros(D, device="cuda")
-    ops.attn_bwd(qkv, dout, out, lse, bias_pad, biasT_pad, relidx_pad, nrd, B, T, D, H, scale, dqkv, dtable, delta_ws,
-                 dq_bias=dqb, dv_bias=dvb)
-    assert torch.equal(biasT_pad, bias_pad.transpose(1, 2).contiguous())
+    ops.attn_bwd(qkv, dout, lse, delta, table, win, B, T, D, H, scale, dqkv, dtable, dq_bias=dqb, dv_bias=dvb)
     torch.testing.assert_close(dqb, dqkv[:, :D].float().sum(0), rtol=1e-3, atol=1e-2)
     torch.testing.assert_close(dvb, dqkv[:, 2 * D:].float().sum(0), rtol=1e-3, atol=1e-2)
     g = qf.grad.clone()

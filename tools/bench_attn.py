@@ -6,20 +6,17 @@ B, T, H = 256, 197, 12
 D = 64 * H
 TP = ops.attn_tokens_padded(T)
 qkv = (torch.randn(B * T, 3 * D, device="cuda") * 0.5).bfloat16()
-idx, nrd = rel_pos_index((14, 14)); idx = idx.cuda()
+idx, nrd = rel_pos_index((14, 14))
 table = torch.randn(nrd, H, device="cuda") * 0.3
-bias_pad = torch.zeros(H, TP, TP, device="cuda")
-biasT_pad = torch.zeros_like(bias_pad)
-ops.relpos_gather(table, idx.int().contiguous(), T, TP, H, bias_pad, biasT_pad)
 out = torch.zeros(B * T, D, dtype=torch.bfloat16, device="cuda"); lse = torch.zeros(B, H, TP, device="cuda")
 dout = torch.randn(B * T, D, device="cuda").bfloat16()
 dqkv = torch.zeros(B * T, 3 * D, dtype=torch.bfloat16, device="cuda"); dtable = torch.zeros(nrd, H, device="cuda")
-relidx_pad = torch.full((TP, TP), -1, dtype=torch.int32, device="cuda"); relidx_pad[:T, :T] = idx.int()
+delta = torch.zeros(B * T, H, device="cuda"); dqb = torch.zeros(D, device="cuda"); dvb = torch.zeros(D, device="cuda")
 def t(f, n=10):
     f(); torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(n): f()
     torch.cuda.synchronize(); return (time.perf_counter() - t0) / n * 1e6
-print("fwd us", t(lambda: ops.attn_fwd(qkv, B, T, D, H, bias_pad, out, lse)))
-dws = torch.zeros(B, H, TP, device="cuda"); dqb = torch.zeros(D, device="cuda"); dvb = torch.zeros(D, device="cuda")
-print("bwd us (dtable+bias)", t(lambda: ops.attn_bwd(qkv, dout, out, lse, bias_pad, biasT_pad, relidx_pad, nrd, B, T, D, H, 0.125, dqkv, dtable, dws, dqb, dvb)))
-print("bwd us (no dtable)", t(lambda: ops.attn_bwd(qkv, dout, out, lse, bias_pad, biasT_pad, relidx_pad, nrd, B, T, D, H, 0.125, dqkv, None, dws)))
+print("fwd us", t(lambda: ops.attn_fwd(qkv, B, T, D, H, table, (14, 14), out, lse)))
+print("delta us", t(lambda: ops.attn_delta(dout, out, B * T, H, delta)))
+print("bwd us (dtable+bias)", t(lambda: ops.attn_bwd(qkv, dout, lse, delta, table, (14, 14), B, T, D, H, 0.125, dqkv, dtable, dqb, dvb)))
+print("bwd us (no dtable)", t(lambda: ops.attn_bwd(qkv, dout, lse, delta, table, (14, 14), B, T, D, H, 0.125, dqkv, None)))
