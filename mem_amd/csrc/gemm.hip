@@ -187,6 +187,7 @@ int launch(const GemmArgs& p, hipStream_t s) {
 namespace memhip {
 int gemm_ring_dispatch(const GemmArgs& p, hipStream_t s);
 int gemm256_dispatch(const GemmArgs& p, hipStream_t s);
+int gemm_p8_dispatch(const GemmArgs& p, hipStream_t s);
 }
 
 extern "C" int memhip_gemm_bf16_nt(const memhip_gemm_args_t* a, memhip_stream_t stream) {
@@ -214,6 +215,11 @@ extern "C" int memhip_gemm_bf16_nt(const memhip_gemm_args_t* a, memhip_stream_t 
   // ring variant (gemm_ring.hip) is kept for A/B measurements only (MEMHIP_GEMM_RING=1)
   static const bool k256_on = !(getenv("MEMHIP_GEMM256") && atoi(getenv("MEMHIP_GEMM256")) == 0);
   static const bool ring_on = getenv("MEMHIP_GEMM_RING") && atoi(getenv("MEMHIP_GEMM_RING")) == 1;
+  static const bool p8_on = !(getenv("MEMHIP_GEMM_P8") && atoi(getenv("MEMHIP_GEMM_P8")) == 0);
+  if (p8_on) {
+    const int rc = gemm_p8_dispatch(p, s);
+    if (rc != MEMHIP_EUNSUPPORTED) return rc;
+  }
   if (k256_on) {
     const int rc = gemm256_dispatch(p, s);
     if (rc != MEMHIP_EUNSUPPORTED) return rc;

@@ -1,0 +1,303 @@
+// 256x256-tile, 64-deep, phase-interleaved persistent bf16 NT GEMM (same contract and epilogues
+// as gemm.hip / gemm256.hip).
+//
+// What gemm256.hip leaves on the table: its eight waves run in lockstep -- all of them issue the
+// LDS-DMA of the next stage, all of them read their fragments, all of them run their 32 MFMAs, so
+// on every SIMD the matrix pipe idles while both of its waves load.  Here the two waves of a SIMD
+// (waves w and w+4) run half a phase apart:
+//
+//   * a K-tile (64 deep) of the 256x256 output tile is four 128x128 quadrants; a PHASE is one
+//     quadrant: a LOAD segment (this phase's fragment reads, 2 LDS-DMA instructions of prefetch),
+//     s_barrier, a COMPUTE segment of 16 MFMAs (16x16x32), s_barrier;
+//   * waves 4-7 execute one extra s_barrier up front, so their LOAD segments coincide with the
+//     COMPUTE segments of waves 0-3 and vice versa: matrix work beside memory work on every SIMD;
+//   * quadrant order (A0,B0) (A0,B1) (A1,B1) (A1,B0): the A sub-tile (64 rows x 64 k per wave) and
+//     both B sub-tiles (32 columns x 64 k) live in registers, a phase reads 12 / 4 / 8 / 0
+//     fragments;
+//   * operands move HBM -> LDS by LDS-DMA as 16 KiB half-tiles (128 rows x 64 k, 128-byte rows,
+//     16-byte chunks XOR-swizzled with (row >> 1) & 7 on the SOURCE address), two buffers of
+//     {A0, A1, B0, B1}; one half-tile is issued per phase, in the order the slots fall free:
+//         phase 1 of K-tile c: A1(c+1)   phase 2: B0(c+2)   phase 3: A0(c+2)   phase 4: B1(c+2)
+//     so every half-tile is in flight for at least five phases; s_waitcnt vmcnt(10) (five
+//     half-tiles may stay in flight) before the first barrier of phases 4, 1, 2 retires exactly
+//     what the NEXT phase reads.  The stream never stops at output-tile boundaries (persistent
+//     workgroups, XCD-contiguous tile order) and idles on the last K-tile at the very end.
+//
+// Hazards (barrier intervals are global: waves 0-3 load in even intervals, waves 4-7 in odd):
+//   RAW  LDS-DMA -> ds_read: the counted vmcnt sits before a phase's first barrier, the read in
+//        the next phase -- every wave has waited and passed one more barrier by then.
+//   WAR  ds_read -> LDS-DMA: a slot is restaged two phases after the phase that read it; B0 one
+//        phase after, which is safe because phase 1 retires its B reads (issued first) with
+//        lgkmcnt(8) BEFORE its first barrier.
+// The epilogue transposes through a wave-private 4 KiB staging area behind the ring (160 KiB of
+// LDS in all), so it needs no barrier and the prefetch stream keeps running under it.
+#include <cstdlib>
+#include "common.h"
+#include "gemm_epilogue.hpp"
+
+namespace {
+
+using namespace memhip;
+
+constexpr int BM = 256, BN = 256, BK = 64;
+constexpr int kThreads = 512;
+constexpr int kHalf = 128 * BK * 2;     // 16 KiB: 128 rows x 64 k
+constexpr int kBuf = 4 * kHalf;         // A0 A1 B0 B1
+constexpr int kRing = 2 * kBuf;         // 128 KiB
+constexpr int kLds = kRing + 8 * 4096;  // + epilogue staging = 160 KiB
+enum { HA0 = 0, HA1 = 1, HB0 = 2, HB1 = 3 };
+constexpr int kGroupM = 8;            // tile rows per group of the tile order
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                   (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
+}
+
+#define P8_WAIT_VM() asm volatile("s_waitcnt vmcnt(10)" ::: "memory")
+#define P8_BARRIER()                      \
+  do {                                    \
+    __builtin_amdgcn_sched_barrier(0);    \
+    __builtin_amdgcn_s_barrier();         \
+    __builtin_amdgcn_sched_barrier(0);    \
+  } while (0)
+
+template <int EPI>
+__global__ __launch_bounds__(kThreads) void gemm_p8_kernel(GemmArgs p, int ntm, int ntn) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  const int nk = p.K / BK;
+  const int ntiles = ntm * ntn;
+  // every XCD (workgroups b, b+8, ...) takes a contiguous run of tile ids per round
+  const int per_xcd = (gridDim.x + 7) / 8;
+  const int first = (gridDim.x % 8 == 0) ? ((int)blockIdx.x % 8) * per_xcd + (int)blockIdx.x / 8 : (int)blockIdx.x;
+  const int my_tiles = (ntiles - first + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int total = my_tiles * nk;
+  if (total <= 0) return;
+
+  // ---- LDS-DMA issue constants: a half-tile is 16 pieces of 8 rows x 128 B; this wave moves pieces
+  // 2*wave and 2*wave+1
+  int prow[2];
+  unsigned offA[2], offB[2], pch[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    prow[j] = (wave * 2 + j) * 8 + (lane >> 3);
+    pch[j] = (unsigned)(((lane & 7) ^ ((prow[j] >> 1) & 7)) * 16);
+    offA[j] = (unsigned)((long long)prow[j] * p.lda * 2) + pch[j];
+    offB[j] = (unsigned)((long long)prow[j] * p.ldb * 2) + pch[j];
+  }
+  // tile id -> (tm, tn): ids sweep groups of kGroupM tile rows column by column, so the 32
+  // consecutive ids one XCD takes per round form an 8 x 4 block of tiles: its L2 is filled with
+  // 8 A panels + 4 B panels instead of 1 + 32
+  auto decode = [&](int id, int& tm, int& tn) {
+    const int gsz = kGroupM * ntn;
+    const int grp = id / gsz, rem = id - grp * gsz;
+    const int rows = ntm - grp * kGroupM < kGroupM ? ntm - grp * kGroupM : kGroupM;
+    tn = rem / rows;
+    tm = grp * kGroupM + (rem - tn * rows);
+  };
+  auto stage = [&](int H, int buf, int tm, int tn, int kt) {
+    char* slot = smem + buf * kBuf + H * kHalf + wave * 2048;
+    if (H == HA0 || H == HA1) {
+      const int r0 = tm * BM + (H == HA1 ? 128 : 0);
+      const char* base = reinterpret_cast<const char*>(p.A) + ((long long)r0 * p.lda + kt * BK) * 2;
+      if (tm == ntm - 1 && r0 + 128 > p.M) {          // last M tile: clamp rows to M-1
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          int gr = r0 + prow[j];
+          gr = gr < p.M ? gr : p.M - 1;
+          glds16(base + (long long)(gr - r0) * p.lda * 2 + pch[j], slot + j * 1024);
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) glds16(base + offA[j], slot + j * 1024);
+      }
+    } else {
+      const int c0 = tn * BN + (H == HB1 ? 128 : 0);
+      const char* base = reinterpret_cast<const char*>(p.B) + ((long long)c0 * p.ldb + kt * BK) * 2;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) glds16(base + offB[j], slot + j * 1024);
+    }
+  };
+  // K-tile cursors of the prefetch stream (clamped to the last K-tile at the end of the stream)
+  int g2 = 0, id2 = first, k2 = 0, tm2, tn2;            // becomes K-tile c+2
+  decode(id2, tm2, tn2);
+  auto advance2 = [&]() {
+    if (g2 + 1 < total) {
+      ++g2;
+      if (++k2 == nk) { k2 = 0; id2 += gridDim.x; decode(id2, tm2, tn2); }
+    }
+  };
+  // prologue: K-tile 0 entirely, B0 A0 B1 of K-tile 1
+  stage(HB0, 0, tm2, tn2, k2); stage(HA0, 0, tm2, tn2, k2); stage(HB1, 0, tm2, tn2, k2); stage(HA1, 0, tm2, tn2, k2);
+  advance2();
+  int tm1 = tm2, tn1 = tn2, k1 = k2;                    // K-tile c+1
+  stage(HB0, 1, tm1, tn1, k1); stage(HA0, 1, tm1, tn1, k1); stage(HB1, 1, tm1, tn1, k1);
+  advance2();
+  P8_WAIT_VM();
+  P8_BARRIER();
+  if (wr == 1) P8_BARRIER();                            // waves 4-7 run half a phase behind
+
+  // ---- fragment read addresses: row = 16*x + (lane & 15), chunk = 4*kh + (lane >> 4)
+  const int sw = (lane >> 1) & 7;
+  const int roff0 = (lane & 15) * 128 + ((((lane >> 4)) ^ sw) << 4);
+  const char* rdA[2] = {smem + wr * 8192 + roff0, smem + wr * 8192 + (roff0 ^ 64)};
+  const char* rdB[2] = {smem + 2 * kHalf + wc * 4096 + roff0, smem + 2 * kHalf + wc * 4096 + (roff0 ^ 64)};
+
+  f32x4 acc[4][4][2];
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[q][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  int c_tile = first, c_k = 0;
+  float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  bf16x8 a[4][2], b0[2][2], b1[2][2];
+
+#define P8_READ_A(half)                                                                                   \
+  _Pragma("unroll") for (int mf = 0; mf < 4; ++mf) _Pragma("unroll") for (int kh = 0; kh < 2; ++kh)       \
+      a[mf][kh] = *reinterpret_cast<const bf16x8*>(rdA[kh] + bo + (half) * kHalf + mf * 2048)
+#define P8_READ_B(dst, half)                                                                              \
+  _Pragma("unroll") for (int nf = 0; nf < 2; ++nf) _Pragma("unroll") for (int kh = 0; kh < 2; ++kh)       \
+      dst[nf][kh] = *reinterpret_cast<const bf16x8*>(rdB[kh] + bo + (half) * kHalf + nf * 2048)
+#define P8_MFMA(q, bsrc)                                                                                  \
+  do {                                                                                                    \
+    __builtin_amdgcn_s_setprio(1);                                                                        \
+    _Pragma("unroll") for (int kh = 0; kh < 2; ++kh) _Pragma("unroll") for (int mf = 0; mf < 4; ++mf)     \
+        _Pragma("unroll") for (int nf = 0; nf < 2; ++nf) acc[q][mf][nf] =                                 \
+            __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mf][kh], bsrc[nf][kh], acc[q][mf][nf], 0, 0, 0);    \
+    __builtin_amdgcn_s_setprio(0);                                                                        \
+  } while (0)
+
+  for (int c = 0; c < total; ++c) {
+    const int bo = (c & 1) * kBuf;             // byte offset of this K-tile's buffer
+    const int bc = c & 1;
+    // ---- phase 1: quadrant (A0, B0)
+    P8_READ_B(b0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    P8_READ_A(0);
+    __builtin_amdgcn_sched_barrier(0);
+    stage(HA1, bc ^ 1, tm1, tn1, k1);
+    P8_WAIT_VM();
+    asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");   // the B0 reads are done: B0 may be restaged next phase
+    P8_BARRIER();
+    P8_MFMA(0, b0);
+    P8_BARRIER();
+    // ---- phase 2: quadrant (A0, B1)
+    P8_READ_B(b1, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    stage(HB0, bc, tm2, tn2, k2);
+    P8_WAIT_VM();
+    P8_BARRIER();
+    P8_MFMA(1, b1);
+    P8_BARRIER();
+    // ---- phase 3: quadrant (A1, B1)
+    P8_READ_A(1);
+    __builtin_amdgcn_sched_barrier(0);
+    stage(HA0, bc, tm2, tn2, k2);
+    P8_BARRIER();
+    P8_MFMA(3, b1);
+    P8_BARRIER();
+    // ---- phase 4: quadrant (A1, B0)
+    stage(HB1, bc, tm2, tn2, k2);
+    P8_WAIT_VM();
+    P8_BARRIER();
+    P8_MFMA(2, b0);
+    P8_BARRIER();
+    tm1 = tm2; tn1 = tn2; k1 = k2;
+    advance2();
+
+    if (c_k == nk - 1) {
+      // waves 0-3 wait for the last compute segment of waves 4-7, so that all eight waves run the
+      // (VALU-bound, barrier-free) epilogue together; waves 4-7 fall half a phase behind again after it
+      if (wr == 0) P8_BARRIER();
+      // ---- epilogue of tile c_tile: 8 passes of 16 rows x 64 columns (two 32-column runs, one per
+      // B half) through this wave's 4 KiB; column block XOR-ed with bit 2 of the row (2-way writes)
+      int tm, tn;
+      decode(c_tile, tm, tn);
+      float* wreg = reinterpret_cast<float*>(smem + kRing + wave * 4096);
+      const int c8 = (lane & 7) * 8;
+      const int ncol = tn * BN + (c8 >> 5) * 128 + wc * 32 + (c8 & 31);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int mf = 0; mf < 4; ++mf) {
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int nf = 0; nf < 2; ++nf)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const int row = (lane >> 4) * 4 + r;
+                wreg[row * 64 + ((j * 32 + nf * 16 + (lane & 15)) ^ (((row >> 2) & 1) << 4))] = acc[i * 2 + j][mf][nf][r];
+                acc[i * 2 + j][mf][nf][r] = 0.f;
+              }
+#pragma unroll
+          for (int it = 0; it < 2; ++it) {
+            const int row = it * 8 + (lane >> 3);
+            const int m = tm * BM + i * 128 + wr * 64 + mf * 16 + row;
+            float v[8];
+            ld8(wreg + row * 64 + (c8 ^ (((row >> 2) & 1) << 4)), v);
+            if (m < p.M) epilogue8<EPI>(p, m, ncol, v, cs);
+          }
+        }
+      colsum_flush(p, ncol, cs, lane);
+      c_k = 0;
+      c_tile += gridDim.x;
+      if (wr == 1) P8_BARRIER();
+    } else {
+      ++c_k;
+    }
+  }
+  if (wr == 0) P8_BARRIER();                               // balances the last stagger barrier of waves 4-7
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // no LDS-DMA may outlive the workgroup
+}
+
+template <int EPI>
+int launch_p8(const GemmArgs& p, hipStream_t s, int num_cu) {
+  const int ntm = (p.M + BM - 1) / BM, ntn = p.N / BN;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_p8_kernel<EPI>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
+    if (e != hipSuccess) return fail(MEMHIP_ELAUNCH, "gemm_p8: set smem attr: %s", hipGetErrorString(e));
+    attr_done = true;
+  }
+  const int grid = ntm * ntn < num_cu ? ntm * ntn : num_cu;
+  hipLaunchKernelGGL(gemm_p8_kernel<EPI>, dim3(grid), dim3(kThreads), kLds, s, p, ntm, ntn);
+  return check_launch("gemm_bf16_nt(p8)");
+}
+
+}  // namespace
+
+namespace memhip {
+
+// Returns MEMHIP_EUNSUPPORTED when the shape does not fit this structure (caller falls back).
+int gemm_p8_dispatch(const GemmArgs& p, hipStream_t s) {
+  const bool vec = ((p.ldo0 | p.ldo1 | p.ldr | p.ldaux) & 7) == 0;      // host twin of vec_ok()
+  static const int min_n = getenv("MEMHIP_GEMM_P8_MIN_N") ? atoi(getenv("MEMHIP_GEMM_P8_MIN_N")) : 1024;
+  if (p.M < 4096 || p.N < min_n || p.N % BN != 0 || p.K % BK != 0 || p.K < 2 * BK || !vec) return MEMHIP_EUNSUPPORTED;
+  static int num_cu = 0;
+  if (!num_cu) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return MEMHIP_EUNSUPPORTED;
+    num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  }
+  switch (p.epilogue) {
+    case MEMHIP_EPI_BIAS_BF16: return launch_p8<MEMHIP_EPI_BIAS_BF16>(p, s, num_cu);
+    case MEMHIP_EPI_BIAS_GELU: return launch_p8<MEMHIP_EPI_BIAS_GELU>(p, s, num_cu);
+    case MEMHIP_EPI_RESIDUAL: return launch_p8<MEMHIP_EPI_RESIDUAL>(p, s, num_cu);
+    case MEMHIP_EPI_DGELU: return launch_p8<MEMHIP_EPI_DGELU>(p, s, num_cu);
+    case MEMHIP_EPI_F32: return launch_p8<MEMHIP_EPI_F32>(p, s, num_cu);
+    default: return MEMHIP_EUNSUPPORTED;
+  }
+}
+
+}  // namespace memhip
