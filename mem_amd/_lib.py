@@ -11,7 +11,8 @@ import os
 import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmemhip.so")
+# MEMHIP_LIB points at an alternative build of the same library (kernel experiments)
+LIB_PATH = os.environ.get("MEMHIP_LIB") or os.path.join(_HERE, "libmemhip.so")
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(

@@ -124,6 +124,8 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_nt_kernel(GemmArgs p) {
     constexpr int LS = 72;                                  // padded row stride (floats)
     float* wreg = reinterpret_cast<float*>(smem + wave * 16384);
     float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    EpiCols cols;
+    epi_cols_load<EPI>(p, nw + (lane & 7) * 8, cols);
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
 #pragma unroll
@@ -139,7 +141,7 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_nt_kernel(GemmArgs p) {
         const int m = mw + half * 32 + row;
         float v[8];
         ld8(wreg + row * LS + c8, v);
-        if (m < p.M) epilogue8<EPI>(p, m, nw + c8, v, cs);
+        if (m < p.M) epilogue8<EPI>(p, m, nw + c8, v, cs, cols);
       }
     }
     colsum_flush(p, nw + (lane & 7) * 8, cs, lane);

@@ -134,6 +134,8 @@ __global__ __launch_bounds__(kThreads) void gemm256_kernel(GemmArgs p, int ntm, 
       const int tm = c_tile / ntn, tn = c_tile - tm * ntn;
       const int mw = tm * BM + wr * 128, nw = tn * BN + wc * 64;
       float* wreg = reinterpret_cast<float*>(smem + ((s + 3) % kSlots) * kStage + wave * 4096);
+      EpiCols cols;
+      epi_cols_load<EPI>(p, nw + (lane & 7) * 8, cols);
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
 #pragma unroll
@@ -150,7 +152,7 @@ __global__ __launch_bounds__(kThreads) void gemm256_kernel(GemmArgs p, int ntm, 
           const int m = mw + i * 16 + row;
           float v[8];
           ld8(wreg + row * 64 + (c8 ^ (((row >> 2) & 1) << 4)), v);
-          if (m < p.M) epilogue8<EPI>(p, m, nw + c8, v, cs);
+          if (m < p.M) epilogue8<EPI>(p, m, nw + c8, v, cs, cols);
         }
       }
       colsum_flush(p, nw + (lane & 7) * 8, cs, lane);
@@ -187,7 +189,7 @@ namespace memhip {
 
 // Returns MEMHIP_EUNSUPPORTED when the shape does not fit this structure (caller falls back).
 int gemm256_dispatch(const GemmArgs& p, hipStream_t s) {
-  const bool vec = ((p.ldo0 | p.ldo1 | p.ldr | p.ldaux) & 7) == 0;      // host twin of vec_ok()
+  const bool vec = ((p.ldo0 | p.ldo1 | p.ldr | p.ldaux | p.colscale_n) & 7) == 0;      // host twin of vec_ok()
   // N = 768 (3 tiles wide) leaves the third round of 591 tiles 31 % full on 256 CUs and measures
   // 5-10 % below the 128x128 kernel (tools/bench_gemm.py); wide N gains 12-25 %.  MEMHIP_GEMM256_MIN_N
   // overrides the threshold for experiments.

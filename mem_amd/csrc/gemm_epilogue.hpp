@@ -94,6 +94,8 @@ __device__ __forceinline__ void epilogue(const GemmArgs& p, int m, int n, float 
 
 
 typedef __attribute__((ext_vector_type(8))) __bf16 ebf16x8;
+typedef __attribute__((ext_vector_type(2))) __bf16 ebf16x2;
+typedef __attribute__((ext_vector_type(2))) float ef32x2;
 
 __device__ __forceinline__ void ld8(const float* p, float* o) {
   const float4 a = reinterpret_cast<const float4*>(p)[0], b = reinterpret_cast<const float4*>(p)[1];
@@ -104,56 +106,158 @@ __device__ __forceinline__ void st8(float* p, const float* o) {
   reinterpret_cast<float4*>(p)[1] = float4{o[4], o[5], o[6], o[7]};
 }
 
+// The vector epilogues are VALU work that no MFMA overlaps (all waves of a workgroup reach them
+// together), so they are written for instruction count: two values per v_cvt_pk_bf16_f32, the
+// rounded value recovered with one shift / and, packed fp32 math (v_pk_fma_f32 ...) for the erf
+// polynomial, ONE exponential shared by erf and the normal pdf in the GELU derivative, and every
+// optional feature (bias, column scale, column sums, drop-path) behind a wave-uniform branch.
+__device__ __forceinline__ unsigned pack_bf16x2(ef32x2 v) {
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, ebf16x2));
+}
+__device__ __forceinline__ ef32x2 unpack_bf16x2(unsigned u) {
+  return ef32x2{__uint_as_float(u << 16), __uint_as_float(u & 0xffff0000u)};
+}
+__device__ __forceinline__ ef32x2 fma2(ef32x2 a, ef32x2 b, ef32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ ef32x2 splat2(float v) { return ef32x2{v, v}; }
+
+// erf(x / sqrt 2) and exp(-x^2 / 2) for two values (A&S 7.1.26, see erf_fast)
+__device__ __forceinline__ void erf_exp2(ef32x2 x, ef32x2& erf, ef32x2& e) {
+  const ef32x2 z = x * splat2(0.70710678118654752440f);
+  const ef32x2 az = __builtin_elementwise_abs(z);
+  const ef32x2 d = fma2(splat2(0.3275911f), az, splat2(1.0f));
+  const ef32x2 t = ef32x2{__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+  ef32x2 poly = fma2(splat2(1.061405429f), t, splat2(-1.453152027f));
+  poly = fma2(poly, t, splat2(1.421413741f));
+  poly = fma2(poly, t, splat2(-0.284496736f));
+  poly = fma2(poly, t, splat2(0.254829592f));
+  const ef32x2 w = az * az * splat2(-1.4426950408889634f);
+  e = ef32x2{__builtin_amdgcn_exp2f(w.x), __builtin_amdgcn_exp2f(w.y)};
+  const ef32x2 y = fma2(-(poly * t), e, splat2(1.0f));
+  erf = ef32x2{copysignf(y.x, z.x), copysignf(y.y, z.y)};
+}
+__device__ __forceinline__ ef32x2 gelu2(ef32x2 x) {
+  ef32x2 erf, e;
+  erf_exp2(x, erf, e);
+  const ef32x2 hx = x * splat2(0.5f);
+  return fma2(hx, erf, hx);
+}
+__device__ __forceinline__ ef32x2 gelu_grad2(ef32x2 x) {
+  ef32x2 erf, e;
+  erf_exp2(x, erf, e);
+  const ef32x2 cdf = fma2(splat2(0.5f), erf, splat2(0.5f));
+  return fma2(x * splat2(0.39894228040143267794f), e, cdf);
+}
+
 // Row-vector form: 8 consecutive output columns n..n+7 of row m (n % 8 == 0, n + 8 <= N, every
-// leading dimension a multiple of 8 elements): 16-byte global accesses only.
+// leading dimension a multiple of 8 elements, colscale_n % 8 == 0): 16-byte global accesses only.
+// Per-column operands of a lane's 8 columns, loaded once per tile (not once per row)
+struct EpiCols {
+  ef32x2 bias[4];
+  float g[8];
+};
 template <int EPI>
-__device__ __forceinline__ void epilogue8(const GemmArgs& p, int m, int n, const float* acc, float* cs) {
-  float bias[8];
-  if (p.bias) ld8(p.bias + n, bias);
-  else {
+__device__ __forceinline__ void epi_cols_load(const GemmArgs& p, int n, EpiCols& c) {
+  if constexpr (EPI != MEMHIP_EPI_DGELU && EPI != MEMHIP_EPI_F32) {
+    if (p.bias) {
+      const float4 b0 = reinterpret_cast<const float4*>(p.bias + n)[0], b1 = reinterpret_cast<const float4*>(p.bias + n)[1];
+      c.bias[0] = ef32x2{b0.x, b0.y}; c.bias[1] = ef32x2{b0.z, b0.w}; c.bias[2] = ef32x2{b1.x, b1.y}; c.bias[3] = ef32x2{b1.z, b1.w};
+    } else {
 #pragma unroll
-    for (int k = 0; k < 8; ++k) bias[k] = 0.f;
+      for (int k = 0; k < 4; ++k) c.bias[k] = ef32x2{0.f, 0.f};
+    }
+  }
+  if constexpr (EPI == MEMHIP_EPI_RESIDUAL) {
+    if (p.vec1) ld8(p.vec1 + n, c.g);
+  }
+}
+
+template <int EPI>
+__device__ __forceinline__ void epilogue8(const GemmArgs& p, int m, int n, const float* acc, float* cs, const EpiCols& c) {
+  ef32x2 t[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) t[k] = ef32x2{acc[2 * k], acc[2 * k + 1]};
+  if constexpr (EPI != MEMHIP_EPI_DGELU && EPI != MEMHIP_EPI_F32) {
+    if (p.bias) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) t[k] += c.bias[k];
+    }
   }
   if constexpr (EPI == MEMHIP_EPI_BIAS_BF16) {
-    ebf16x8 y;
+    unsigned y[4];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      y[k] = (__bf16)(acc[k] + bias[k]);
-      if (n + k < p.colscale_n) y[k] = (__bf16)((float)y[k] * p.colscale);
-      cs[k] += (float)y[k];
+    for (int k = 0; k < 4; ++k) y[k] = pack_bf16x2(t[k]);
+    if (p.colscale_n > 0 && n < p.colscale_n) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) y[k] = pack_bf16x2(unpack_bf16x2(y[k]) * splat2(p.colscale));
     }
-    *reinterpret_cast<ebf16x8*>(reinterpret_cast<__bf16*>(p.out0) + (long long)m * p.ldo0 + n) = y;
-  } else if constexpr (EPI == MEMHIP_EPI_BIAS_GELU) {
-    ebf16x8 h, a;
+    if (p.colsum) {
 #pragma unroll
-    for (int k = 0; k < 8; ++k) { h[k] = (__bf16)(acc[k] + bias[k]); a[k] = (__bf16)gelu_f((float)h[k]); }
-    *reinterpret_cast<ebf16x8*>(reinterpret_cast<__bf16*>(p.out0) + (long long)m * p.ldo0 + n) = h;
-    *reinterpret_cast<ebf16x8*>(reinterpret_cast<__bf16*>(p.out1) + (long long)m * p.ldo1 + n) = a;
+      for (int k = 0; k < 4; ++k) {
+        const ef32x2 f = unpack_bf16x2(y[k]);
+        cs[2 * k] += f.x;
+        cs[2 * k + 1] += f.y;
+      }
+    }
+    *reinterpret_cast<uint4*>(reinterpret_cast<__bf16*>(p.out0) + (long long)m * p.ldo0 + n) = uint4{y[0], y[1], y[2], y[3]};
+  } else if constexpr (EPI == MEMHIP_EPI_BIAS_GELU) {
+    unsigned h[4], a[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      h[k] = pack_bf16x2(t[k]);
+      a[k] = pack_bf16x2(gelu2(unpack_bf16x2(h[k])));
+    }
+    *reinterpret_cast<uint4*>(reinterpret_cast<__bf16*>(p.out0) + (long long)m * p.ldo0 + n) = uint4{h[0], h[1], h[2], h[3]};
+    *reinterpret_cast<uint4*>(reinterpret_cast<__bf16*>(p.out1) + (long long)m * p.ldo1 + n) = uint4{a[0], a[1], a[2], a[3]};
   } else if constexpr (EPI == MEMHIP_EPI_RESIDUAL) {
-    ebf16x8 y;
-    float g[8], x[8];
-    if (p.vec1) ld8(p.vec1 + n, g);
+    unsigned y[4];
+    float x[8];
     if (p.aux) ld8(reinterpret_cast<const float*>(p.aux) + (long long)m * p.ldaux + n, x);
     else ld8(p.resid + (long long)m * p.ldr + n, x);
-    const float rm = p.rowmask ? p.rowmask[m / p.rows_per_sample] : 1.f;
+    float br[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      y[k] = (__bf16)(acc[k] + bias[k]);
-      float t = p.vec1 ? __fmul_rn(g[k], (float)y[k]) : (float)y[k];
-      if (p.rowmask) t = __fmul_rn(__fdiv_rn(t, p.keep_prob), rm);
-      x[k] = __fadd_rn(x[k], t);
+    for (int k = 0; k < 4; ++k) {
+      y[k] = pack_bf16x2(t[k]);
+      const ef32x2 f = unpack_bf16x2(y[k]);
+      br[2 * k] = f.x;
+      br[2 * k + 1] = f.y;
     }
-    if (p.out0) *reinterpret_cast<ebf16x8*>(reinterpret_cast<__bf16*>(p.out0) + (long long)m * p.ldo0 + n) = y;
+    if (p.vec1) {                              // layer scale: gamma * branch (own rounding, as the reference)
+#pragma unroll
+      for (int k = 0; k < 8; ++k) br[k] = __fmul_rn(c.g[k], br[k]);
+    }
+    if (p.rowmask) {                           // drop path: branch / keep_prob * mask[sample]
+      const float rm = p.rowmask[m / p.rows_per_sample];
+      const float rk = __frcp_rn(p.keep_prob);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        // correctly rounded quotient from one Newton step on the reciprocal (no denormal inputs here)
+        const float q0 = br[k] * rk;
+        const float q = fmaf(fmaf(-q0, p.keep_prob, br[k]), rk, q0);
+        br[k] = __fmul_rn(q, rm);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) x[k] = __fadd_rn(x[k], br[k]);
+    if (p.out0) *reinterpret_cast<uint4*>(reinterpret_cast<__bf16*>(p.out0) + (long long)m * p.ldo0 + n) = uint4{y[0], y[1], y[2], y[3]};
     st8(p.resid + (long long)m * p.ldr + n, x);
   } else if constexpr (EPI == MEMHIP_EPI_DGELU) {
-    const ebf16x8 h = *reinterpret_cast<const ebf16x8*>(reinterpret_cast<const __bf16*>(p.aux) + (long long)m * p.ldaux + n);
-    ebf16x8 o;
+    const uint4 hv = *reinterpret_cast<const uint4*>(reinterpret_cast<const __bf16*>(p.aux) + (long long)m * p.ldaux + n);
+    const unsigned h[4] = {hv.x, hv.y, hv.z, hv.w};
+    unsigned o[4];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      o[k] = (__bf16)(bf16_round(acc[k]) * gelu_grad_f((float)h[k]));
-      cs[k] += (float)o[k];
+    for (int k = 0; k < 4; ++k) {
+      const ef32x2 da = unpack_bf16x2(pack_bf16x2(t[k]));            // the matmul output is bf16
+      o[k] = pack_bf16x2(da * gelu_grad2(unpack_bf16x2(h[k])));
     }
-    *reinterpret_cast<ebf16x8*>(reinterpret_cast<__bf16*>(p.out0) + (long long)m * p.ldo0 + n) = o;
+    if (p.colsum) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const ef32x2 f = unpack_bf16x2(o[k]);
+        cs[2 * k] += f.x;
+        cs[2 * k + 1] += f.y;
+      }
+    }
+    *reinterpret_cast<uint4*>(reinterpret_cast<__bf16*>(p.out0) + (long long)m * p.ldo0 + n) = uint4{o[0], o[1], o[2], o[3]};
   } else if constexpr (EPI == MEMHIP_EPI_F32) {
     float* o = reinterpret_cast<float*>(p.out0) + (long long)m * p.ldo0 + n;
     float x[8];
@@ -172,9 +276,35 @@ __device__ __forceinline__ void epilogue8(const GemmArgs& p, int m, int n, const
     float mt[8], x[8];
     ld8(p.vec1 + n, mt);
 #pragma unroll
-    for (int k = 0; k < 8; ++k)
-      x[k] = __fadd_rn(__fmul_rn(bf16_round(acc[k] + bias[k]), 1.0f - w), __fmul_rn(mt[k], w));
+    for (int k = 0; k < 4; ++k) {
+      const ef32x2 f = unpack_bf16x2(pack_bf16x2(t[k]));
+      x[2 * k] = __fadd_rn(__fmul_rn(f.x, 1.0f - w), __fmul_rn(mt[2 * k], w));
+      x[2 * k + 1] = __fadd_rn(__fmul_rn(f.y, 1.0f - w), __fmul_rn(mt[2 * k + 1], w));
+    }
     st8(p.resid + ((long long)b * (L + 1) + 1 + pi) * p.ldr + n, x);
+  }
+}
+
+template <int EPI>
+__device__ __forceinline__ void epilogue8(const GemmArgs& p, int m, int n, const float* acc, float* cs) {
+  EpiCols c;
+  epi_cols_load<EPI>(p, n, c);
+  epilogue8<EPI>(p, m, n, acc, cs, c);
+}
+
+// Column sums when the 16 lanes with equal (lane >> 4) hold the same 8 columns n..n+7 for 16
+// different rows (accumulator-layout epilogue of gemm_p8.hip).
+__device__ __forceinline__ void colsum_flush16(const GemmArgs& p, int n, float* cs, int lane) {
+  if (!p.colsum) return;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    float v = cs[k];
+    v += __shfl_xor(v, 1);
+    v += __shfl_xor(v, 2);
+    v += __shfl_xor(v, 4);
+    v += __shfl_xor(v, 8);
+    if ((lane & 15) == 0) atomicAdd(p.colsum + n + k, v);
+    cs[k] = 0.f;
   }
 }
 
@@ -196,7 +326,7 @@ __device__ __forceinline__ void colsum_flush(const GemmArgs& p, int n, float* cs
 
 // all leading dimensions / pointers the vector epilogue touches are 16-byte friendly
 __device__ __forceinline__ bool vec_ok(const GemmArgs& p) {
-  return ((p.ldo0 | p.ldo1 | p.ldr | p.ldaux) & 7) == 0 && (p.N & 7) == 0;
+  return ((p.ldo0 | p.ldo1 | p.ldr | p.ldaux | p.colscale_n) & 7) == 0 && (p.N & 7) == 0;
 }
 
 }  // namespace memhip

@@ -12,25 +12,26 @@
 //   * waves 4-7 execute one extra s_barrier up front, so their LOAD segments coincide with the
 //     COMPUTE segments of waves 0-3 and vice versa: matrix work beside memory work on every SIMD;
 //   * quadrant order (A0,B0) (A0,B1) (A1,B1) (A1,B0): the A sub-tile (64 rows x 64 k per wave) and
-//     both B sub-tiles (32 columns x 64 k) live in registers, a phase reads 12 / 4 / 8 / 0
-//     fragments;
+//     both B sub-tiles (32 columns x 64 k) live in registers; phase 4 already reads B0 of the NEXT
+//     K-tile into the register set B1 has left, so the phases read 8 / 4 / 8 / 4 fragments;
 //   * operands move HBM -> LDS by LDS-DMA as 16 KiB half-tiles (128 rows x 64 k, 128-byte rows,
 //     16-byte chunks XOR-swizzled with (row >> 1) & 7 on the SOURCE address), two buffers of
 //     {A0, A1, B0, B1}; one half-tile is issued per phase, in the order the slots fall free:
 //         phase 1 of K-tile c: A1(c+1)   phase 2: B0(c+2)   phase 3: A0(c+2)   phase 4: B1(c+2)
 //     so every half-tile is in flight for at least five phases; s_waitcnt vmcnt(10) (five
-//     half-tiles may stay in flight) before the first barrier of phases 4, 1, 2 retires exactly
+//     half-tiles may stay in flight) before the first barrier of every phase retires exactly
 //     what the NEXT phase reads.  The stream never stops at output-tile boundaries (persistent
 //     workgroups, XCD-contiguous tile order) and idles on the last K-tile at the very end.
 //
 // Hazards (barrier intervals are global: waves 0-3 load in even intervals, waves 4-7 in odd):
 //   RAW  LDS-DMA -> ds_read: the counted vmcnt sits before a phase's first barrier, the read in
 //        the next phase -- every wave has waited and passed one more barrier by then.
-//   WAR  ds_read -> LDS-DMA: a slot is restaged two phases after the phase that read it; B0 one
-//        phase after, which is safe because phase 1 retires its B reads (issued first) with
-//        lgkmcnt(8) BEFORE its first barrier.
-// The epilogue transposes through a wave-private 4 KiB staging area behind the ring (160 KiB of
-// LDS in all), so it needs no barrier and the prefetch stream keeps running under it.
+//   WAR  ds_read -> LDS-DMA: a slot is restaged two phases after the phase that read it (the reads
+//        are retired by lgkmcnt(0) right after that phase's first barrier, one full phase earlier).
+// The MFMAs take (B fragment, A fragment), so an accumulator tile is C^T: a lane holds four
+// consecutive output columns of one row, and the B rows are interleaved so that its two n-fragments
+// are 8 consecutive columns: the epilogue runs straight out of the registers with 16-byte accesses
+// (no LDS transposition, no barrier) while the prefetch stream keeps running under it.
 #include <cstdlib>
 #include "common.h"
 #include "gemm_epilogue.hpp"
@@ -44,7 +45,7 @@ constexpr int kThreads = 512;
 constexpr int kHalf = 128 * BK * 2;     // 16 KiB: 128 rows x 64 k
 constexpr int kBuf = 4 * kHalf;         // A0 A1 B0 B1
 constexpr int kRing = 2 * kBuf;         // 128 KiB
-constexpr int kLds = kRing + 8 * 4096;  // + epilogue staging = 160 KiB
+constexpr int kLds = kRing;
 enum { HA0 = 0, HA1 = 1, HB0 = 2, HB1 = 3 };
 constexpr int kGroupM = 8;            // tile rows per group of the tile order
 
@@ -56,7 +57,15 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst) {
                                    (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
 }
 
-#define P8_WAIT_VM() asm volatile("s_waitcnt vmcnt(10)" ::: "memory")
+// LDS image of a half-tile: 128-byte rows, 16-byte chunk c of row r at position c ^ key(r).  The 16
+// lanes of a ds_read_b128 group read one chunk of 16 rows and must see 16 distinct (r & 1, key(r)):
+//   A rows are 16x + i           -> key_a(r) = (r >> 1) & 7
+//   B rows are 32x + 8(i >> 2) + 4 nf + (i & 3)  (i = lane & 15; this interleave makes the two
+//   n-fragments of a lane 8 CONSECUTIVE output columns) -> key_b(r) = ((r >> 1) & 1) | 2 ((r >> 3) & 3)
+__device__ __forceinline__ int key_a(int r) { return (r >> 1) & 7; }
+__device__ __forceinline__ int key_b(int r) { return ((r >> 1) & 1) | (((r >> 3) & 3) << 1); }
+
+#define P8_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
 #define P8_BARRIER()                      \
   do {                                    \
     __builtin_amdgcn_sched_barrier(0);    \
@@ -86,9 +95,9 @@ __global__ __launch_bounds__(kThreads) void gemm_p8_kernel(GemmArgs p, int ntm, 
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     prow[j] = (wave * 2 + j) * 8 + (lane >> 3);
-    pch[j] = (unsigned)(((lane & 7) ^ ((prow[j] >> 1) & 7)) * 16);
+    pch[j] = (unsigned)(((lane & 7) ^ key_a(prow[j])) * 16);
     offA[j] = (unsigned)((long long)prow[j] * p.lda * 2) + pch[j];
-    offB[j] = (unsigned)((long long)prow[j] * p.ldb * 2) + pch[j];
+    offB[j] = (unsigned)((long long)prow[j] * p.ldb * 2) + (unsigned)(((lane & 7) ^ key_b(prow[j])) * 16);
   }
   // tile id -> (tm, tn): ids sweep groups of kGroupM tile rows column by column, so the 32
   // consecutive ids one XCD takes per round form an 8 x 4 block of tiles: its L2 is filled with
@@ -138,7 +147,7 @@ __global__ __launch_bounds__(kThreads) void gemm_p8_kernel(GemmArgs p, int ntm, 
   int tm1 = tm2, tn1 = tn2, k1 = k2;                    // K-tile c+1
   stage(HB0, 1, tm1, tn1, k1); stage(HA0, 1, tm1, tn1, k1); stage(HB1, 1, tm1, tn1, k1);
   advance2();
-  P8_WAIT_VM();
+  P8_WAIT_VM(10);
   P8_BARRIER();
   if (wr == 1) P8_BARRIER();                            // waves 4-7 run half a phase behind
 
@@ -146,7 +155,9 @@ __global__ __launch_bounds__(kThreads) void gemm_p8_kernel(GemmArgs p, int ntm, 
   const int sw = (lane >> 1) & 7;
   const int roff0 = (lane & 15) * 128 + ((((lane >> 4)) ^ sw) << 4);
   const char* rdA[2] = {smem + wr * 8192 + roff0, smem + wr * 8192 + (roff0 ^ 64)};
-  const char* rdB[2] = {smem + 2 * kHalf + wc * 4096 + roff0, smem + 2 * kHalf + wc * 4096 + (roff0 ^ 64)};
+  const int bi = lane & 15;
+  const int roffb = (((bi >> 2) * 8 + (bi & 3)) * 128) + (((lane >> 4) ^ key_b((bi >> 2) * 8 + (bi & 3))) << 4);
+  const char* rdB[2] = {smem + 2 * kHalf + wc * 4096 + roffb, smem + 2 * kHalf + wc * 4096 + (roffb ^ 64)};
 
   f32x4 acc[4][4][2];
 #pragma unroll
@@ -157,102 +168,117 @@ __global__ __launch_bounds__(kThreads) void gemm_p8_kernel(GemmArgs p, int ntm, 
       for (int j = 0; j < 2; ++j) acc[q][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   int c_tile = first, c_k = 0;
-  float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  bf16x8 a[4][2], b0[2][2], b1[2][2];
+  bf16x8 a[4][2], bx[2][2], by[2][2];
 
 #define P8_READ_A(half)                                                                                   \
   _Pragma("unroll") for (int mf = 0; mf < 4; ++mf) _Pragma("unroll") for (int kh = 0; kh < 2; ++kh)       \
       a[mf][kh] = *reinterpret_cast<const bf16x8*>(rdA[kh] + bo + (half) * kHalf + mf * 2048)
-#define P8_READ_B(dst, half)                                                                              \
+#define P8_READ_B(dst, boff, half)                                                                        \
   _Pragma("unroll") for (int nf = 0; nf < 2; ++nf) _Pragma("unroll") for (int kh = 0; kh < 2; ++kh)       \
-      dst[nf][kh] = *reinterpret_cast<const bf16x8*>(rdB[kh] + bo + (half) * kHalf + nf * 2048)
+      dst[nf][kh] = *reinterpret_cast<const bf16x8*>(rdB[kh] + (boff) + (half) * kHalf + nf * 512)
 #define P8_MFMA(q, bsrc)                                                                                  \
   do {                                                                                                    \
     __builtin_amdgcn_s_setprio(1);                                                                        \
     _Pragma("unroll") for (int kh = 0; kh < 2; ++kh) _Pragma("unroll") for (int mf = 0; mf < 4; ++mf)     \
         _Pragma("unroll") for (int nf = 0; nf < 2; ++nf) acc[q][mf][nf] =                                 \
-            __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mf][kh], bsrc[nf][kh], acc[q][mf][nf], 0, 0, 0);    \
+            __builtin_amdgcn_mfma_f32_16x16x32_bf16(bsrc[nf][kh], a[mf][kh], acc[q][mf][nf], 0, 0, 0);    \
     __builtin_amdgcn_s_setprio(0);                                                                        \
   } while (0)
+// One K-tile = four phases.  B0 of this K-tile is already in `bq0` (read during phase 4 of the
+// previous K-tile); phase 4 reads B0 of the next K-tile into `bq1`, so the two register sets swap
+// roles from one K-tile to the next and the phases read 8 / 4 / 8 / 4 fragments.
+#define P8_KTILE(bq0, bq1)                                                                                  \
+  do {                                                                                                    \
+    const int bo = bc * kBuf;                                                                             \
+    /* phase 1: quadrant (A0, B0) */                                                                      \
+    P8_READ_A(0);                                                                                         \
+    __builtin_amdgcn_sched_barrier(0);                                                                    \
+    stage(HA1, bc ^ 1, tm1, tn1, k1);                                                                     \
+    P8_WAIT_VM(10);                                                                                       \
+    P8_BARRIER();                                                                                         \
+    P8_MFMA(0, bq0);                                                                                      \
+    P8_BARRIER();                                                                                         \
+    /* phase 2: quadrant (A0, B1) */                                                                      \
+    P8_READ_B(bq1, bo, 1);                                                                                \
+    __builtin_amdgcn_sched_barrier(0);                                                                    \
+    stage(HB0, bc, tm2, tn2, k2);                                                                         \
+    P8_WAIT_VM(10);                                                                                       \
+    P8_BARRIER();                                                                                         \
+    P8_MFMA(1, bq1);                                                                                      \
+    P8_BARRIER();                                                                                         \
+    /* phase 3: quadrant (A1, B1) */                                                                      \
+    P8_READ_A(1);                                                                                         \
+    __builtin_amdgcn_sched_barrier(0);                                                                    \
+    stage(HA0, bc, tm2, tn2, k2);                                                                         \
+    P8_WAIT_VM(10);                                                                                       \
+    P8_BARRIER();                                                                                         \
+    P8_MFMA(3, bq1);                                                                                      \
+    P8_BARRIER();                                                                                         \
+    /* phase 4: quadrant (A1, B0); B0 of the next K-tile comes from the other buffer */                   \
+    P8_READ_B(bq1, (bc ^ 1) * kBuf, 0);                                                                   \
+    __builtin_amdgcn_sched_barrier(0);                                                                    \
+    stage(HB1, bc, tm2, tn2, k2);                                                                         \
+    P8_WAIT_VM(10);                                                                                       \
+    P8_BARRIER();                                                                                         \
+    P8_MFMA(2, bq0);                                                                                      \
+    P8_BARRIER();                                                                                         \
+  } while (0)
+#define P8_READ_B0_FIRST() P8_READ_B(bx, 0, 0)
 
-  for (int c = 0; c < total; ++c) {
-    const int bo = (c & 1) * kBuf;             // byte offset of this K-tile's buffer
-    const int bc = c & 1;
-    // ---- phase 1: quadrant (A0, B0)
-    P8_READ_B(b0, 0);
-    __builtin_amdgcn_sched_barrier(0);
-    P8_READ_A(0);
-    __builtin_amdgcn_sched_barrier(0);
-    stage(HA1, bc ^ 1, tm1, tn1, k1);
-    P8_WAIT_VM();
-    asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");   // the B0 reads are done: B0 may be restaged next phase
-    P8_BARRIER();
-    P8_MFMA(0, b0);
-    P8_BARRIER();
-    // ---- phase 2: quadrant (A0, B1)
-    P8_READ_B(b1, 1);
-    __builtin_amdgcn_sched_barrier(0);
-    stage(HB0, bc, tm2, tn2, k2);
-    P8_WAIT_VM();
-    P8_BARRIER();
-    P8_MFMA(1, b1);
-    P8_BARRIER();
-    // ---- phase 3: quadrant (A1, B1)
-    P8_READ_A(1);
-    __builtin_amdgcn_sched_barrier(0);
-    stage(HA0, bc, tm2, tn2, k2);
-    P8_BARRIER();
-    P8_MFMA(3, b1);
-    P8_BARRIER();
-    // ---- phase 4: quadrant (A1, B0)
-    stage(HB1, bc, tm2, tn2, k2);
-    P8_WAIT_VM();
-    P8_BARRIER();
-    P8_MFMA(2, b0);
-    P8_BARRIER();
-    tm1 = tm2; tn1 = tn2; k1 = k2;
-    advance2();
+  P8_READ_B0_FIRST();
+  // K-tiles go in pairs (K % 128 == 0), so that buffer parity and the B register roles are static
+  for (int c = 0; c < total; c += 2) {
+    {
+      constexpr int bc = 0;
+      P8_KTILE(bx, by);
+      tm1 = tm2; tn1 = tn2; k1 = k2;
+      advance2();
+    }
+    {
+      constexpr int bc = 1;
+      P8_KTILE(by, bx);
+      tm1 = tm2; tn1 = tn2; k1 = k2;
+      advance2();
+    }
 
-    if (c_k == nk - 1) {
+    if (c_k == nk - 2) {
       // waves 0-3 wait for the last compute segment of waves 4-7, so that all eight waves run the
       // (VALU-bound, barrier-free) epilogue together; waves 4-7 fall half a phase behind again after it
       if (wr == 0) P8_BARRIER();
-      // ---- epilogue of tile c_tile: 8 passes of 16 rows x 64 columns (two 32-column runs, one per
-      // B half) through this wave's 4 KiB; column block XOR-ed with bit 2 of the row (2-way writes)
+      // ---- epilogue of tile c_tile straight out of the accumulators: the MFMAs ran with swapped
+      // operands, so a lane holds 4 consecutive columns (registers) of one row (lane & 15)
       int tm, tn;
       decode(c_tile, tm, tn);
-      float* wreg = reinterpret_cast<float*>(smem + kRing + wave * 4096);
-      const int c8 = (lane & 7) * 8;
-      const int ncol = tn * BN + (c8 >> 5) * 128 + wc * 32 + (c8 & 31);
+      const int mrow = tm * BM + wr * 64 + (lane & 15);
+      const int ncol = tn * BN + wc * 32 + (lane >> 4) * 8;
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int j = 0; j < 2; ++j) {
+        const int n = ncol + j * 128;
+        float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        EpiCols cols;
+        epi_cols_load<EPI>(p, n, cols);
 #pragma unroll
-        for (int mf = 0; mf < 4; ++mf) {
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-          for (int j = 0; j < 2; ++j)
+          for (int mf = 0; mf < 4; ++mf) {
+            const int m = mrow + i * 128 + mf * 16;
+            float v[8];
 #pragma unroll
             for (int nf = 0; nf < 2; ++nf)
 #pragma unroll
               for (int r = 0; r < 4; ++r) {
-                const int row = (lane >> 4) * 4 + r;
-                wreg[row * 64 + ((j * 32 + nf * 16 + (lane & 15)) ^ (((row >> 2) & 1) << 4))] = acc[i * 2 + j][mf][nf][r];
+                v[nf * 4 + r] = acc[i * 2 + j][mf][nf][r];
                 acc[i * 2 + j][mf][nf][r] = 0.f;
               }
-#pragma unroll
-          for (int it = 0; it < 2; ++it) {
-            const int row = it * 8 + (lane >> 3);
-            const int m = tm * BM + i * 128 + wr * 64 + mf * 16 + row;
-            float v[8];
-            ld8(wreg + row * 64 + (c8 ^ (((row >> 2) & 1) << 4)), v);
-            if (m < p.M) epilogue8<EPI>(p, m, ncol, v, cs);
+            if (m < p.M) epilogue8<EPI>(p, m, n, v, cs, cols);
           }
-        }
-      colsum_flush(p, ncol, cs, lane);
+        colsum_flush16(p, n, cs, lane);
+      }
       c_k = 0;
       c_tile += gridDim.x;
       if (wr == 1) P8_BARRIER();
     } else {
-      ++c_k;
+      c_k += 2;
     }
   }
   if (wr == 0) P8_BARRIER();                               // balances the last stagger barrier of waves 4-7
@@ -280,9 +306,9 @@ namespace memhip {
 
 // Returns MEMHIP_EUNSUPPORTED when the shape does not fit this structure (caller falls back).
 int gemm_p8_dispatch(const GemmArgs& p, hipStream_t s) {
-  const bool vec = ((p.ldo0 | p.ldo1 | p.ldr | p.ldaux) & 7) == 0;      // host twin of vec_ok()
+  const bool vec = ((p.ldo0 | p.ldo1 | p.ldr | p.ldaux | p.colscale_n) & 7) == 0;      // host twin of vec_ok()
   static const int min_n = getenv("MEMHIP_GEMM_P8_MIN_N") ? atoi(getenv("MEMHIP_GEMM_P8_MIN_N")) : 1024;
-  if (p.M < 4096 || p.N < min_n || p.N % BN != 0 || p.K % BK != 0 || p.K < 2 * BK || !vec) return MEMHIP_EUNSUPPORTED;
+  if (p.M < 4096 || p.N < min_n || p.N % BN != 0 || p.K % (2 * BK) != 0 || !vec) return MEMHIP_EUNSUPPORTED;
   static int num_cu = 0;
   if (!num_cu) {
     int dev = 0;

@@ -200,7 +200,7 @@ namespace memhip {
 
 // Returns MEMHIP_EUNSUPPORTED when the shape does not fit this structure (caller falls back).
 int gemm_ring_dispatch(const GemmArgs& p, hipStream_t s) {
-  const bool vec = ((p.ldo0 | p.ldo1 | p.ldr | p.ldaux) & 7) == 0;      // host twin of vec_ok()
+  const bool vec = ((p.ldo0 | p.ldo1 | p.ldr | p.ldaux | p.colscale_n) & 7) == 0;      // host twin of vec_ok()
   // measured (tools/bench_gemm.py): wins for N >= 1024 (+8..12 %), loses 4..10 % at N = 768 where
   // 1182 tiles over 256 CUs leave a 40 % empty last round -> those stay on the 128x128 kernel
   if (p.M < 2048 || p.N < 1024 || p.N % BN != 0 || p.K % BK != 0 || !vec) return MEMHIP_EUNSUPPORTED;
