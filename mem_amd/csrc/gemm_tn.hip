@@ -168,6 +168,8 @@ __global__ __launch_bounds__(256) void colsum_kernel(const __bf16* __restrict__ 
 namespace memhip {
 int gemm_tn256_dispatch(const void* A, long long lda, const void* B, long long ldb, int R, int N, int K, float* out,
                         long long ldo, int accumulate, hipStream_t s);
+int gemm_tn_p8_dispatch(const void* A, long long lda, const void* B, long long ldb, int R, int N, int K, float* out,
+                        long long ldo, int accumulate, hipStream_t s);
 }
 
 extern "C" int memhip_gemm_bf16_tn(const void* A, int64_t lda, const void* B, int64_t ldb, int R, int N, int K,
@@ -178,6 +180,11 @@ extern "C" int memhip_gemm_bf16_tn(const void* A, int64_t lda, const void* B, in
   MEMHIP_REQUIRE(N % 8 == 0 && K % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0 && ((uintptr_t)A & 15) == 0 &&
                      ((uintptr_t)B & 15) == 0, "gemm_tn: operands must be 16-byte aligned, N/K/ld %% 8 == 0");
   hipStream_t s = as_stream(stream);
+  static const bool p8_on = !(getenv("MEMHIP_TN_P8") && atoi(getenv("MEMHIP_TN_P8")) == 0);
+  if (p8_on) {
+    const int rc = gemm_tn_p8_dispatch(A, lda, B, ldb, R, N, K, out, ldo, accumulate, s);
+    if (rc != MEMHIP_EUNSUPPORTED) return rc;
+  }
   static const bool k256_on = !(getenv("MEMHIP_TN256") && atoi(getenv("MEMHIP_TN256")) == 0);
   if (k256_on) {
     const int rc = gemm_tn256_dispatch(A, lda, B, ldb, R, N, K, out, ldo, accumulate, s);

@@ -1,0 +1,261 @@
+// Phase-interleaved 256x256 weight-gradient GEMM  out[N,K] += sum_r A[r,N] * B[r,K]  (contract of
+// gemm_tn.hip).  The structure of gemm_p8.hip applied to the token-major operands:
+//
+//   * one workgroup = one (256x256 output tile, slice of the token rows); a K-TILE here is 64 token
+//     rows, staged as four 16 KiB half-tiles {A0, A1, B0, B1} of [64 tokens][128 columns] (256-byte
+//     rows, the 32-byte segment index XOR-ed with (row & 7) on the LDS-DMA source address);
+//   * fragments are read down the columns with ds_read_b64_tr_b16 (two reads = one 8-element MFMA
+//     operand, k slots permuted identically for A and B, see gemm_tn.hip);
+//   * four phases per K-tile = four 128x128 quadrants, quadrant order (A0,B0) (A0,B1) (A1,B1)
+//     (A1,B0), phase 4 pre-reads B0 of the next K-tile; waves 4-7 run half a phase behind waves
+//     0-3, so that on every SIMD one wave's 16 MFMAs cover the other's LDS reads and LDS-DMA issue;
+//   * one half-tile of prefetch per phase (A1(c+1), B0(c+2), A0(c+2), B1(c+2)), five in flight,
+//     s_waitcnt vmcnt(10) before the first barrier of every phase; hazards as in gemm_p8.hip.
+// The fp32 result is added to the (pre-zeroed / accumulating) gradient with atomics shaped as two
+// 128-byte runs per wave-instruction (staged through the idle ring).
+#include <cstdlib>
+#include "common.h"
+
+namespace {
+
+using namespace memhip;
+
+constexpr int BM = 256, BN = 256, BR = 64;
+constexpr int kThreads = 512;
+constexpr int kHalf = BR * 128 * 2;     // 16 KiB: 64 tokens x 128 columns
+constexpr int kBuf = 4 * kHalf;         // A0 A1 B0 B1
+constexpr int kRing = 2 * kBuf;         // 128 KiB
+enum { HA0 = 0, HA1 = 1, HB0 = 2, HB1 = 3 };
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+__device__ __attribute__((aligned(256))) unsigned char g_tnp8_zero[256];   // zero-initialised
+
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                   (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
+}
+// rows r and r+16 of one 16-column block
+__device__ __forceinline__ bf16x8 tr_pair(const char* a0) {
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)a0);
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0 + 16 * 256));
+  union { struct { s16x4 l, h; } s; bf16x8 v; } u;
+  u.s.l = lo;
+  u.s.h = hi;
+  return u.v;
+}
+
+#define TP_WAIT_VM() asm volatile("s_waitcnt vmcnt(10)" ::: "memory")
+#define TP_BARRIER()                      \
+  do {                                    \
+    __builtin_amdgcn_sched_barrier(0);    \
+    __builtin_amdgcn_s_barrier();         \
+    __builtin_amdgcn_sched_barrier(0);    \
+  } while (0)
+
+__global__ __launch_bounds__(kThreads) void gemm_tn_p8_kernel(const __bf16* __restrict__ A, long long lda,
+                                                              const __bf16* __restrict__ B, long long ldb,
+                                                              int R, int N, int K, float* __restrict__ out,
+                                                              long long ldo, int rows_per_split) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  const int ntk = K / BN;
+  const int tiles = (N / BM) * ntk;
+  const int tile = blockIdx.x % tiles, sp = blockIdx.x / tiles;
+  const int n0 = (tile / ntk) * BM, k0 = (tile % ntk) * BN;
+  const int rbeg = sp * rows_per_split;
+  int rend = rbeg + rows_per_split;
+  rend = rend < R ? rend : R;
+  if (rbeg >= rend) return;
+  const int total = ((rend - rbeg + 2 * BR - 1) / (2 * BR)) * 2;     // K-tiles, rounded up to a pair (zero rows)
+
+  // ---- LDS-DMA issue constants: a half-tile is 16 pieces of 4 token rows x 256 B; this wave moves
+  // pieces 2*wave and 2*wave+1
+  int prow[2];
+  unsigned offA[2], offB[2];
+  const int cpos = lane & 15;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    prow[j] = (wave * 2 + j) * 4 + (lane >> 4);
+    const unsigned chunk = (unsigned)((((cpos >> 1) ^ (prow[j] & 7)) << 1) | (cpos & 1));
+    offA[j] = (unsigned)((long long)prow[j] * lda * 2) + chunk * 16;
+    offB[j] = (unsigned)((long long)prow[j] * ldb * 2) + chunk * 16;
+  }
+  const char* zsrc = reinterpret_cast<const char*>(g_tnp8_zero) + cpos * 16;
+  auto stage = [&](int H, int buf, int g) {                 // K-tile g of this workgroup's slice
+    char* slot = smem + buf * kBuf + H * kHalf + wave * 2048;
+    const int r0 = rbeg + g * BR;
+    const bool isA = H == HA0 || H == HA1;
+    const int c0 = (isA ? n0 : k0) + ((H == HA1 || H == HB1) ? 128 : 0);
+    const char* base = reinterpret_cast<const char*>(isA ? A : B) + ((long long)r0 * (isA ? lda : ldb) + c0) * 2;
+    if (r0 + BR <= rend) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) glds16(base + (isA ? offA[j] : offB[j]), slot + j * 1024);
+    } else {                                                // tail of the slice: rows >= rend add zeros
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const char* src = (r0 + prow[j] < rend) ? base + (isA ? offA[j] : offB[j]) : zsrc;
+        glds16(src, slot + j * 1024);
+      }
+    }
+  };
+  // prologue: K-tile 0 entirely, B0 A0 B1 of K-tile 1 (K-tiles >= total are all-zero rows)
+  stage(HB0, 0, 0); stage(HA0, 0, 0); stage(HB1, 0, 0); stage(HA1, 0, 0);
+  stage(HB0, 1, 1); stage(HA0, 1, 1); stage(HB1, 1, 1);
+  TP_WAIT_VM();
+  TP_BARRIER();
+  if (wr == 1) TP_BARRIER();                                // waves 4-7 run half a phase behind
+
+  // ---- transposing fragment reads: this lane addresses 4 columns (p) of token row 4g+q (+16)
+  const int g4 = lane >> 4, q4 = (lane >> 2) & 3, pp = lane & 3;
+  const int row0 = 4 * g4 + q4, r7 = row0 & 7;
+  int aoff[4], boff[2];
+#pragma unroll
+  for (int f = 0; f < 4; ++f) aoff[f] = row0 * 256 + (((wr * 4 + f) ^ r7) << 5) + pp * 8;
+#pragma unroll
+  for (int f = 0; f < 2; ++f) boff[f] = 2 * kHalf + row0 * 256 + (((wc * 2 + f) ^ r7) << 5) + pp * 8;
+
+  f32x4 acc[4][4][2];
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[q][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  bf16x8 a[4][2], bx[2][2], by[2][2];
+
+#define TP_READ_A(half)                                                                                   \
+  _Pragma("unroll") for (int nf = 0; nf < 4; ++nf) _Pragma("unroll") for (int rh = 0; rh < 2; ++rh)       \
+      a[nf][rh] = tr_pair(smem + bo + (half) * kHalf + aoff[nf] + rh * 8192)
+#define TP_READ_B(dst, boff_, half)                                                                       \
+  _Pragma("unroll") for (int kf = 0; kf < 2; ++kf) _Pragma("unroll") for (int rh = 0; rh < 2; ++rh)       \
+      dst[kf][rh] = tr_pair(smem + (boff_) + (half) * kHalf + boff[kf] + rh * 8192)
+#define TP_MFMA(q, bsrc)                                                                                  \
+  do {                                                                                                    \
+    __builtin_amdgcn_s_setprio(1);                                                                        \
+    _Pragma("unroll") for (int rh = 0; rh < 2; ++rh) _Pragma("unroll") for (int nf = 0; nf < 4; ++nf)     \
+        _Pragma("unroll") for (int kf = 0; kf < 2; ++kf) acc[q][nf][kf] =                                 \
+            __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[nf][rh], bsrc[kf][rh], acc[q][nf][kf], 0, 0, 0);    \
+    __builtin_amdgcn_s_setprio(0);                                                                        \
+  } while (0)
+#define TP_KTILE(bq0, bq1)                                                                                \
+  do {                                                                                                    \
+    const int bo = bc * kBuf;                                                                             \
+    /* phase 1: quadrant (A0, B0) */                                                                      \
+    TP_READ_A(0);                                                                                         \
+    __builtin_amdgcn_sched_barrier(0);                                                                    \
+    stage(HA1, bc ^ 1, c + bc + 1);                                                                       \
+    TP_WAIT_VM();                                                                                         \
+    TP_BARRIER();                                                                                         \
+    TP_MFMA(0, bq0);                                                                                      \
+    TP_BARRIER();                                                                                         \
+    /* phase 2: quadrant (A0, B1) */                                                                      \
+    TP_READ_B(bq1, bo, 1);                                                                                \
+    __builtin_amdgcn_sched_barrier(0);                                                                    \
+    stage(HB0, bc, c + bc + 2);                                                                           \
+    TP_WAIT_VM();                                                                                         \
+    TP_BARRIER();                                                                                         \
+    TP_MFMA(1, bq1);                                                                                      \
+    TP_BARRIER();                                                                                         \
+    /* phase 3: quadrant (A1, B1) */                                                                      \
+    TP_READ_A(1);                                                                                         \
+    __builtin_amdgcn_sched_barrier(0);                                                                    \
+    stage(HA0, bc, c + bc + 2);                                                                           \
+    TP_WAIT_VM();                                                                                         \
+    TP_BARRIER();                                                                                         \
+    TP_MFMA(3, bq1);                                                                                      \
+    TP_BARRIER();                                                                                         \
+    /* phase 4: quadrant (A1, B0); B0 of the next K-tile comes from the other buffer */                   \
+    TP_READ_B(bq1, (bc ^ 1) * kBuf, 0);                                                                   \
+    __builtin_amdgcn_sched_barrier(0);                                                                    \
+    stage(HB1, bc, c + bc + 2);                                                                           \
+    TP_WAIT_VM();                                                                                         \
+    TP_BARRIER();                                                                                         \
+    TP_MFMA(2, bq0);                                                                                      \
+    TP_BARRIER();                                                                                         \
+  } while (0)
+
+  TP_READ_B(bx, 0, 0);
+  for (int c = 0; c < total; c += 2) {
+    {
+      constexpr int bc = 0;
+      TP_KTILE(bx, by);
+    }
+    {
+      constexpr int bc = 1;
+      TP_KTILE(by, bx);
+    }
+  }
+  if (wr == 0) TP_BARRIER();                               // balances the stagger barrier of waves 4-7
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the idle tail of the prefetch stream has landed
+  TP_BARRIER();                                            // every wave is done with the ring
+
+  // ---- epilogue: fp32 atomics.  C layout of a 16x16 tile: col (k) = lane & 15, row (n) =
+  // 4 * (lane >> 4) + reg.  A pass moves 16 n-rows x 64 k (the wave's 32 columns in each B half)
+  // through this wave's 4 KiB, then adds row by row: one wave-instruction = two 128-byte runs.
+  float* wreg = reinterpret_cast<float*>(smem + wave * 4096);
+  const int kcol = k0 + (lane >> 5) * 128 + wc * 32 + (lane & 31);
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int nf = 0; nf < 4; ++nf) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int kf = 0; kf < 2; ++kf)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int row = (lane >> 4) * 4 + r;
+            wreg[row * 64 + ((j * 32 + kf * 16 + (lane & 15)) ^ (((row >> 2) & 1) << 4))] = acc[i * 2 + j][nf][kf][r];
+          }
+#pragma unroll
+      for (int row = 0; row < 16; ++row) {
+        const float v = wreg[row * 64 + (lane ^ (((row >> 2) & 1) << 4))];
+        atomicAdd(out + (long long)(n0 + i * 128 + wr * 64 + nf * 16 + row) * ldo + kcol, v);
+      }
+    }
+}
+
+}  // namespace
+
+namespace memhip {
+
+// MEMHIP_EUNSUPPORTED when the shape does not fit (caller falls back to the other TN kernels).
+int gemm_tn_p8_dispatch(const void* A, long long lda, const void* B, long long ldb, int R, int N, int K, float* out,
+                        long long ldo, int accumulate, hipStream_t s) {
+  if (N % BM != 0 || K % BN != 0 || R < 2048) return MEMHIP_EUNSUPPORTED;
+  static int num_cu = 0;
+  if (!num_cu) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return MEMHIP_EUNSUPPORTED;
+    num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  }
+  const int tiles = (N / BM) * (K / BN);
+  const int pairs = cdiv(R, 2 * BR);                       // the token rows advance in pairs of K-tiles
+  int splits = num_cu / tiles;
+  if (splits < 1) splits = 1;
+  if (splits > pairs / 2) splits = pairs / 2 > 0 ? pairs / 2 : 1;        // >= 256 rows per split
+  const int rows_per_split = cdiv(pairs, splits) * 2 * BR;
+  splits = cdiv(R, rows_per_split);
+  if (!accumulate) {
+    hipError_t e = hipMemset2DAsync(out, (size_t)ldo * sizeof(float), 0, (size_t)K * sizeof(float), (size_t)N, s);
+    if (e != hipSuccess) return fail(MEMHIP_ELAUNCH, "gemm_tn_p8: memset: %s", hipGetErrorString(e));
+  }
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_p8_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, kRing);
+    if (e != hipSuccess) return fail(MEMHIP_ELAUNCH, "gemm_tn_p8: set smem attr: %s", hipGetErrorString(e));
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(gemm_tn_p8_kernel, dim3(tiles * splits), dim3(kThreads), kRing, s, (const __bf16*)A, lda,
+                     (const __bf16*)B, ldb, R, N, K, out, ldo, rows_per_split);
+  return check_launch("gemm_bf16_tn(p8)");
+}
+
+}  // namespace memhip
