@@ -234,7 +234,10 @@ int memhip_cross_entropy(void* logits_bf16, int64_t ld, const int64_t* labels, i
  *        The additive bias is gathered from the table on chip (bucket index computed
  *        arithmetically, identical to relative_position_index); no [heads,T,T] tensor is read.
  * out    bf16 [B*T, D];  lse f32 [B, heads, TP], TP = memhip_attn_tokens_padded(T) (for backward)
- * bwd:   delta f32 [B*T, heads] = rowsum(dout * out) per head (memhip_attn_delta);
+ * bwd:   delta f32 [(2*B*T + 4) * heads]: memhip_attn_delta fills [B*T, heads] = rowsum(dout * out)
+ *        per head and, behind it, [B*T, heads] = |dout_row,head|^2; the last 4 * heads floats are
+ *        scratch of memhip_attn_bwd (per-head bounds max |dout_row|^2, max |delta|, max |v_key|^2
+ *        that scale the fixed-point buckets of the table gradient);
  *        dqkv bf16 [B*T, 3D] (dq already multiplied by `scale`);
  *        dtable f32 [num_rel, heads] += table gradient (NULL skips it);
  *        dq_bias / dv_bias f32 [D] += column sums of dq / dv (the q_bias / v_bias gradients).
@@ -249,7 +252,7 @@ int memhip_attn_fwd(const void* qkv, int64_t ldqkv, int B, int T, int D, int hea
 int memhip_attn_delta(const void* dout, const void* out, int64_t ldo, int64_t rows, int heads, float* delta,
                       memhip_stream_t stream);
 int memhip_attn_bwd(const void* qkv, int64_t ldqkv, const void* dout, int64_t ldo, const float* lse,
-                    const float* delta, const float* table, int window_h, int window_w, int B, int T, int D,
+                    float* delta, const float* table, int window_h, int window_w, int B, int T, int D,
                     int heads, float scale, void* dqkv, int64_t lddqkv, float* dtable, float* dq_bias,
                     float* dv_bias, memhip_stream_t stream);
 
@@ -271,6 +274,12 @@ int memhip_im2col_bf16(const float* x, int B, int C, int H, int W, int ph, int p
                        memhip_stream_t stream);
 /* x[b*T, :] = cls_token (mem/modeling_pretrain.py:101,108) */
 int memhip_fill_cls(float* x, int64_t ldx, int B, int T, int D, const float* cls, memhip_stream_t stream);
+/* y[n] += sum_k W[n,k] x[k]  (W bf16 [N, ldw], x f32 [K], y f32 [N]); optionally x_acc[k] += x[k] and
+ * zero[k] = 0 (K floats each, may be NULL; `zero` must not alias x).  Used for the v_bias gradient:
+ * sum over keys of dV = sum over queries of d(attn_out) (softmax rows sum to one) = (column sums of the
+ * proj-output gradient) @ W_proj, so v_bias.grad is one 768x768 GEMV per block (modeling_finetune.py:128-139). */
+int memhip_gemv_bf16_acc(const void* W, int64_t ldw, int N, int K, const float* x, float* y, float* x_acc,
+                         float* zero, memhip_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * Optimizer step on flat fp32 buffers (tensors padded to 1024 elements)

@@ -293,11 +293,12 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(const __bf16* __restrict_
 
 // ------------------------------------------------------------------------------- backward (dK, dV)
 // a wave owns 32 keys and sweeps the queries with tiles [q rows][key cols]
-template <int NKB>
+template <int NKB, bool VB>
 __global__ __launch_bounds__(512) void attn_bwd_kv_kernel(const __bf16* __restrict__ qkv, long long ldq,
                                                           const __bf16* __restrict__ dout, long long ldo,
                                                           const float* __restrict__ lse,
                                                           const float* __restrict__ delta,
+                                                          float* __restrict__ stats,
                                                           const float* __restrict__ table, int nrd, int Wh, int Ww,
                                                           __bf16* __restrict__ dqkv, long long lddq,
                                                           float* __restrict__ dvbias, int B, int T, int D, int H,
@@ -331,9 +332,10 @@ __global__ __launch_bounds__(512) void attn_bwd_kv_kernel(const __bf16* __restri
     stage_head(imgs + buf * 2 * IMG + IMG, dout + (long long)b * T * ldo + h * HD, ldo, T, TP);   // dO
   };
   bf16x8 Kn[4], Vn[4];
-  float bsum[32];
+  float bsum[VB ? 32 : 1];
 #pragma unroll
-  for (int i = 0; i < 32; ++i) bsum[i] = 0.f;
+  for (int i = 0; i < (VB ? 32 : 1); ++i) bsum[i] = 0.f;
+  float vmax = 0.f, dmax = 0.f, nmax = 0.f;
   float lsen = 0.f, deln = 0.f;                             // this thread's element of the next lse/delta rows
   auto load_next = [&](int b) {
     const __bf16* s = qkv + ((long long)b * T + kc_tok) * ldq + h * HD;
@@ -345,6 +347,7 @@ __global__ __launch_bounds__(512) void attn_bwd_kv_kernel(const __bf16* __restri
     const int qq = threadIdx.x;
     lsen = (qq < T) ? lse[((long long)b * H + h) * TP + qq] * kLog2e : 0.f;
     deln = (qq < T) ? delta[((long long)b * T + qq) * H + h] : 0.f;
+    if (stats && qq < T) nmax = fmaxf(nmax, delta[((long long)B * T + (long long)b * T + qq) * H + h]);   // |dO_q|^2
   };
   load_next(b0);
   stage_sample(b0, 0);
@@ -355,6 +358,18 @@ __global__ __launch_bounds__(512) void attn_bwd_kv_kernel(const __bf16* __restri
     bf16x8 Kf[4], Vf[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) { Kf[t] = Kn[t]; Vf[t] = Vn[t]; }
+    if (stats) {
+      // bounds for the fixed-point table-gradient buckets of attn_bwd_q_kernel (runs after this kernel):
+      // max_k |V_k|^2 (half a row per lane; padding keys repeat key T-1) and max_q |delta_q|
+      float vn = 0.f;
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) vn = fmaf((float)Vf[t][i], (float)Vf[t][i], vn);
+      vn += __shfl_xor(vn, 32);
+      vmax = fmaxf(vmax, vn);
+      dmax = fmaxf(dmax, fabsf(deln));
+    }
     if ((int)threadIdx.x < TP) { lseS[cur * TP + threadIdx.x] = lsen; delS[cur * TP + threadIdx.x] = deln; }
     __syncthreads();
     if (b + 1 < b1) { load_next(b + 1); stage_sample(b + 1, cur ^ 1); }
@@ -424,11 +439,25 @@ __global__ __launch_bounds__(512) void attn_bwd_kv_kernel(const __bf16* __restri
           *reinterpret_cast<bf16x4*>(drow + D + db * 32 + 8 * g + 4 * hh) = wk;
         }
         // v_bias gradient: column sums of the stored (bf16) dV, kept per lane until the end
+        if constexpr (VB) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) bsum[db * 16 + 4 * g + e] += (float)wv[e] * kmask;
+          for (int e = 0; e < 4; ++e) bsum[db * 16 + 4 * g + e] += (float)wv[e] * kmask;
+        }
       }
   }
-  if (dvbias) {
+  if (stats) {
+    for (int o = 32; o > 0; o >>= 1) {
+      vmax = fmaxf(vmax, __shfl_xor(vmax, o));
+      dmax = fmaxf(dmax, __shfl_xor(dmax, o));
+      nmax = fmaxf(nmax, __shfl_xor(nmax, o));
+    }
+    if (lane == 0) {
+      atomicMax(reinterpret_cast<int*>(stats) + h * 4 + 0, __float_as_int(nmax));
+      atomicMax(reinterpret_cast<int*>(stats) + h * 4 + 1, __float_as_int(dmax));
+      atomicMax(reinterpret_cast<int*>(stats) + h * 4 + 2, __float_as_int(vmax));
+    }
+  }
+  if (VB) {
     __syncthreads();
     if (active) {
 #pragma unroll
@@ -454,6 +483,7 @@ __global__ __launch_bounds__(512) void attn_bwd_q_kernel(const __bf16* __restric
                                                          const __bf16* __restrict__ dout, long long ldo,
                                                          const float* __restrict__ lse,
                                                          const float* __restrict__ delta,
+                                                         const float* __restrict__ stats,
                                                          const float* __restrict__ table, int nrd, int Wh, int Ww,
                                                          __bf16* __restrict__ dqkv, long long lddq,
                                                          float* __restrict__ dtable, float* __restrict__ dqbias,
@@ -463,13 +493,11 @@ __global__ __launch_bounds__(512) void attn_bwd_q_kernel(const __bf16* __restric
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const RelGeom geo = rel_geom(Wh, Ww);
   float* tabX = reinterpret_cast<float*>(smem);
-  int* binsi = reinterpret_cast<int*>(tabX + geo.len);      // [len] fixed-point buckets (this sample), extended index
-  float* binsf = reinterpret_cast<float*>(binsi + geo.len); // [len] fp32 buckets (this workgroup)
-  float* qsum = binsf + geo.len;                            // [64]
-  int* red = reinterpret_cast<int*>(qsum + HD);             // [4] block maxima (float bits)
-  int* codeQ = red + 4;
+  int* binsi = reinterpret_cast<int*>(tabX + geo.len);      // [len] fixed-point buckets (this workgroup), extended index
+  float* qsum = reinterpret_cast<float*>(binsi + geo.len);  // [64]
+  int* codeQ = reinterpret_cast<int*>(qsum + HD);
   int* codeK = codeQ + TP;
-  char* imgs = smem + (((3 * geo.len + HD + 4 + 2 * TP) * 4 + 15) & ~15);
+  char* imgs = smem + (((2 * geo.len + HD + 2 * TP) * 4 + 15) & ~15);
   const int h = blockIdx.x % H, b0 = (blockIdx.x / H) * spb;
   const int b1 = b0 + spb < B ? b0 + spb : B;
   if (b0 >= b1) return;
@@ -477,11 +505,19 @@ __global__ __launch_bounds__(512) void attn_bwd_q_kernel(const __bf16* __restric
   const int r = lane & 31, hh = lane >> 5;
   const LaneOffs lo = lane_offs(lane);
   rel_setup(tabX, codeQ, codeK, table, nrd, H, h, T, TP, Wh, Ww, kLog2e);
-  for (int i = threadIdx.x; i < 2 * geo.len + HD + 4; i += blockDim.x) binsi[i] = 0;   // binsi, binsf, qsum, red
+  for (int i = threadIdx.x; i < geo.len + HD; i += blockDim.x) binsi[i] = 0;   // binsi, qsum
   const int qb = wave;
   const bool active = qb < NKB;
   const int q = qb * 32 + r;
   const int qc = q < T ? q : T - 1;
+  // fixed-point scale of the table-gradient buckets, from the head's bounds (see memhip_attn_delta):
+  //   |dS| = p |dP - delta| <= max|dO_q| max|V_k| + max|delta_q| =: bound;  scale = 2^19 / bound, so that
+  //   the <= 16 samples x 196 terms a bucket can collect stay below 2^31.
+  float fx = 0.f;
+  if (DT) {
+    const float bound = sqrtf(stats[h * 4 + 0]) * sqrtf(stats[h * 4 + 2]) + stats[h * 4 + 1];
+    fx = bound > 0.f ? 524288.0f / bound : 0.f;
+  }
   bf16x8 Qn[4], dOn[4];
   float bsum[32];
 #pragma unroll
@@ -515,34 +551,6 @@ __global__ __launch_bounds__(512) void attn_bwd_q_kernel(const __bf16* __restric
     const float lq = lqn, dq_ = dqn;
     __syncthreads();                      // K/V of sample b landed; sample b-1 fully consumed
     if (b + 1 < b1) { load_q(b + 1); stage_sample(b + 1, cur ^ 1); }
-    // ---- bound for the fixed-point scale (LDS only)
-    float fx = 0.f;
-    if (DT) {
-      if ((int)threadIdx.x < T) {
-        float vn = 0.f;
-#pragma unroll
-        for (int c = 0; c < 8; ++c) {
-          const bf16x8 v = *reinterpret_cast<const bf16x8*>(Vs + tok_slot(threadIdx.x, c) * 16);
-#pragma unroll
-          for (int i = 0; i < 8; ++i) vn += (float)v[i] * (float)v[i];
-        }
-        atomicMax(red + 0, __float_as_int(vn));                       // max |V_key|^2
-      }
-      if (active && q < T) {
-        float dn = 0.f;
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-          for (int i = 0; i < 8; ++i) dn += (float)dOf[t][i] * (float)dOf[t][i];
-        dn += __shfl_xor(dn, 32);                                     // the two lane halves hold half a row each
-        atomicMax(red + 1, __float_as_int(dn));                       // max |dO_q|^2
-        atomicMax(red + 2, __float_as_int(fabsf(dq_)));               // max |delta_q|
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();                                   // LDS-only sync: the prefetch stays in flight
-      const float bound = sqrtf(__int_as_float(red[0])) * sqrtf(__int_as_float(red[1])) + __int_as_float(red[2]);
-      fx = bound > 0.f ? 16777216.0f / bound : 0.f;
-    }
     if (active) {
       const int cq4 = codeQ[qc];
       f32x16 dQt[2];
@@ -579,7 +587,7 @@ __global__ __launch_bounds__(512) void attn_bwd_q_kernel(const __bf16* __restric
             const float ds = p * (dPt[i] - dq_);
             dPt[i] = ds;
             // masked elements add 0 (their codes are valid): no divergent branch around the atomic
-            if (DT) atomicAdd(reinterpret_cast<int*>(reinterpret_cast<char*>(binsi) + idx4), (int)(ds * fx));
+            if (DT) atomicAdd(reinterpret_cast<int*>(reinterpret_cast<char*>(binsi) + idx4), __float2int_rn(ds * fx));
           }
         }
 #pragma unroll
@@ -603,33 +611,24 @@ __global__ __launch_bounds__(512) void attn_bwd_q_kernel(const __bf16* __restric
           for (int e = 0; e < 4; ++e) bsum[db * 16 + 4 * g + e] += (float)w[e] * qmask;   // q_bias gradient
         }
     }
-    if (DT) {                              // fold this sample's fixed-point buckets into fp32
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      const float inv = fx > 0.f ? 1.0f / fx : 0.f;
-      for (int i = threadIdx.x; i < geo.len; i += blockDim.x) {
-        binsf[i] += (float)binsi[i] * inv;
-        binsi[i] = 0;
-      }
-      if (threadIdx.x < 4) red[threadIdx.x] = 0;
-    }
   }
   __syncthreads();
   if (DT) {
     // grid buckets one to one; the two cls regions are summed on chip first (hundreds of atomics on
     // ONE address per workgroup would serialise in L2)
+    const float inv = fx > 0.f ? 1.0f / fx : 0.f;
     for (int i = threadIdx.x; i <= 2 * geo.off; i += blockDim.x) {
-      const float v = binsf[i];
-      if (v != 0.f) atomicAdd(dtable + (long long)i * H + h, v);
+      const int v = binsi[i];
+      if (v != 0) atomicAdd(dtable + (long long)i * H + h, (float)v * inv);
     }
     if (wave < 2) {
       const int base = wave == 0 ? 2 * geo.off + 1 : 3 * geo.off + 2;
       float v = 0.f;
-      for (int i = lane; i <= geo.off; i += 64) v += binsf[base + i];
+      for (int i = lane; i <= geo.off; i += 64) v += (float)binsi[base + i] * inv;
       for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
       if (lane == 0) atomicAdd(dtable + (long long)(wave == 0 ? nrd - 2 : nrd - 3) * H + h, v);
     } else if (threadIdx.x == 128) {
-      atomicAdd(dtable + (long long)(nrd - 1) * H + h, binsf[5 * geo.off + 3]);
+      atomicAdd(dtable + (long long)(nrd - 1) * H + h, (float)binsi[5 * geo.off + 3] * inv);
     }
   }
   if (dqbias) {
@@ -646,7 +645,7 @@ __global__ __launch_bounds__(512) void attn_bwd_q_kernel(const __bf16* __restric
   if (dqbias && threadIdx.x < HD) atomicAdd(dqbias + h * HD + threadIdx.x, qsum[threadIdx.x]);
 }
 
-// rowsum(dO * O) per (token, head): standalone form of what the proj-dgrad GEMM epilogue fuses
+// rowsum(dO * O) and |dO|^2 per (token, head)
 __global__ __launch_bounds__(256) void attn_delta_kernel(const __bf16* __restrict__ dout, const __bf16* __restrict__ out,
                                                          long long ldo, long long rows, int H,
                                                          float* __restrict__ delta) {
@@ -656,13 +655,23 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const __bf16* __restric
   const int h = (int)(i - row * H);
   const int c = (threadIdx.x & 7) * 8;
   const bf16x8 a = ld16(dout + row * ldo + h * HD + c), o = ld16(out + row * ldo + h * HD + c);
-  float s = 0.f;
+  float s = 0.f, n2 = 0.f;
 #pragma unroll
-  for (int k = 0; k < 8; ++k) s += (float)a[k] * (float)o[k];
-  s += __shfl_xor(s, 1);
-  s += __shfl_xor(s, 2);
-  s += __shfl_xor(s, 4);
-  if ((threadIdx.x & 7) == 0) delta[i] = s;
+  for (int k = 0; k < 8; ++k) {
+    s = fmaf((float)a[k], (float)o[k], s);
+    n2 = fmaf((float)a[k], (float)a[k], n2);
+  }
+  s += __shfl_xor(s, 1);   n2 += __shfl_xor(n2, 1);
+  s += __shfl_xor(s, 2);   n2 += __shfl_xor(n2, 2);
+  s += __shfl_xor(s, 4);   n2 += __shfl_xor(n2, 4);
+  if ((threadIdx.x & 7) == 0) {
+    delta[i] = s;
+    delta[rows * H + i] = n2;              // |dO_row,h|^2: bound of the table-gradient buckets (attn_bwd)
+  }
+}
+
+__global__ void attn_stats_zero_kernel(float* stats, int n) {
+  for (int i = threadIdx.x; i < n; i += blockDim.x) stats[i] = 0.f;
 }
 
 int pick_spb(int B, int heads) {
@@ -727,7 +736,7 @@ extern "C" int memhip_attn_delta(const void* dout, const void* out, int64_t ldo,
 }
 
 extern "C" int memhip_attn_bwd(const void* qkv, int64_t ldqkv, const void* dout, int64_t ldo, const float* lse,
-                               const float* delta, const float* table, int window_h, int window_w, int B,
+                               float* delta, const float* table, int window_h, int window_w, int B,
                                int T, int D, int heads, float scale, void* dqkv, int64_t lddqkv, float* dtable,
                                float* dq_bias, float* dv_bias, memhip_stream_t stream) {
   MEMHIP_REQUIRE(B >= 0 && T > 0 && heads > 0 && D == heads * HD, "attn_bwd: head_dim must be 64");
@@ -741,11 +750,15 @@ extern "C" int memhip_attn_bwd(const void* qkv, int64_t ldqkv, const void* dout,
   const int spb = pick_spb(B, heads);
   const int grid = ((B + spb - 1) / spb) * heads;
   const int glen = rel_geom(window_h, window_w).len;
+  float* stats = delta + 2LL * B * T * heads;             // per-head bounds, written by the kv kernel for the q kernel
+  if (dtable) hipLaunchKernelGGL(attn_stats_zero_kernel, dim3(1), dim3(64), 0, s, stats, 4 * heads);
 #define BWD(N)                                                                                          \
   {                                                                                                     \
     static bool attr_done = false;                                                                      \
     if (!attr_done) {                                                                                   \
-      MEMHIP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_kv_kernel<N>),              \
+      MEMHIP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_kv_kernel<N, true>),        \
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds));             \
+      MEMHIP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_kv_kernel<N, false>),       \
                                      hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds));             \
       MEMHIP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_q_kernel<N, true>),         \
                                      hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds));             \
@@ -754,24 +767,30 @@ extern "C" int memhip_attn_bwd(const void* qkv, int64_t ldqkv, const void* dout,
       attr_done = true;                                                                                 \
     }                                                                                                   \
     const size_t sm_kv = (size_t)4 * N * 32 * 128 + (size_t)(glen + 6 * N * 32 + HD) * 4 + 32;          \
-    const size_t sm_q = (size_t)4 * N * 32 * 128 + (size_t)(3 * glen + HD + 4 + 2 * N * 32) * 4 + 32;   \
+    const size_t sm_q = (size_t)4 * N * 32 * 128 + (size_t)(2 * glen + HD + 2 * N * 32) * 4 + 32;       \
     if (sm_kv > (size_t)kMaxLds || sm_q > (size_t)kMaxLds)                                              \
       return fail(MEMHIP_EUNSUPPORTED, "attn_bwd: %d tokens with a %dx%d window exceed the LDS budget", T, window_h, \
                   window_w);                                                                            \
-    hipLaunchKernelGGL(attn_bwd_kv_kernel<N>, dim3(grid), dim3(512), sm_kv, s, (const __bf16*)qkv,      \
-                       (long long)ldqkv, (const __bf16*)dout, (long long)ldo, lse, delta, table, nrd,   \
-                       window_h, window_w, (__bf16*)dqkv, (long long)lddqkv, dv_bias, B, T, D, heads,   \
-                       spb);                                                                            \
+    if (dv_bias)                                                                                        \
+      hipLaunchKernelGGL((attn_bwd_kv_kernel<N, true>), dim3(grid), dim3(512), sm_kv, s, (const __bf16*)qkv, \
+                         (long long)ldqkv, (const __bf16*)dout, (long long)ldo, lse, delta,             \
+                         dtable ? stats : (float*)nullptr, table, nrd, window_h, window_w, (__bf16*)dqkv, \
+                         (long long)lddqkv, dv_bias, B, T, D, heads, spb);                              \
+    else                                                                                                \
+      hipLaunchKernelGGL((attn_bwd_kv_kernel<N, false>), dim3(grid), dim3(512), sm_kv, s, (const __bf16*)qkv, \
+                         (long long)ldqkv, (const __bf16*)dout, (long long)ldo, lse, delta,             \
+                         dtable ? stats : (float*)nullptr, table, nrd, window_h, window_w, (__bf16*)dqkv, \
+                         (long long)lddqkv, dv_bias, B, T, D, heads, spb);                              \
     if (dtable)                                                                                         \
       hipLaunchKernelGGL((attn_bwd_q_kernel<N, true>), dim3(grid), dim3(512), sm_q, s, (const __bf16*)qkv, \
-                         (long long)ldqkv, (const __bf16*)dout, (long long)ldo, lse, delta, table, nrd, \
-                         window_h, window_w, (__bf16*)dqkv, (long long)lddqkv, dtable, dq_bias, B, T, D, \
-                         heads, scale, spb);                                                            \
+                         (long long)ldqkv, (const __bf16*)dout, (long long)ldo, lse, delta, stats,      \
+                         table, nrd, window_h, window_w, (__bf16*)dqkv, (long long)lddqkv, dtable,      \
+                         dq_bias, B, T, D, heads, scale, spb);                                          \
     else                                                                                                \
       hipLaunchKernelGGL((attn_bwd_q_kernel<N, false>), dim3(grid), dim3(512), sm_q, s, (const __bf16*)qkv, \
-                         (long long)ldqkv, (const __bf16*)dout, (long long)ldo, lse, delta, table, nrd, \
-                         window_h, window_w, (__bf16*)dqkv, (long long)lddqkv, dtable, dq_bias, B, T, D, \
-                         heads, scale, spb);                                                            \
+                         (long long)ldqkv, (const __bf16*)dout, (long long)ldo, lse, delta, stats,      \
+                         table, nrd, window_h, window_w, (__bf16*)dqkv, (long long)lddqkv, dtable,      \
+                         dq_bias, B, T, D, heads, scale, spb);                                          \
   }
   ATTN_DISPATCH(nkb, BWD)
 #undef BWD

@@ -112,6 +112,33 @@ __global__ __launch_bounds__(256) void relpos_gather_kernel(const float* __restr
   }
 }
 
+
+// y[n] += sum_k W[n,k] * x[k]  (bf16 weights, fp32 vectors), one wave per output; optionally
+// x_acc[k] += x[k] and zero[k] = 0 (see memhip_gemv_bf16_acc in memhip.h).
+__global__ __launch_bounds__(256) void gemv_acc_kernel(const __bf16* __restrict__ W, long long ldw, int N, int K,
+                                                       const float* __restrict__ x, float* __restrict__ y,
+                                                       float* __restrict__ x_acc, float* __restrict__ zero) {
+  const int lane = threadIdx.x & 63;
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (n < N) {
+    float s = 0.f;
+    for (int k = lane * 8; k < K; k += 512) {
+      const bf16x8 w = *reinterpret_cast<const bf16x8*>(W + (long long)n * ldw + k);
+      const float4 a = *reinterpret_cast<const float4*>(x + k), b = *reinterpret_cast<const float4*>(x + k + 4);
+      s += (float)w[0] * a.x + (float)w[1] * a.y + (float)w[2] * a.z + (float)w[3] * a.w + (float)w[4] * b.x +
+           (float)w[5] * b.y + (float)w[6] * b.z + (float)w[7] * b.w;
+    }
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (lane == 0) y[n] += s;
+  }
+  if (blockIdx.x == 0) {
+    for (int k = threadIdx.x; k < K; k += blockDim.x) {
+      if (x_acc) x_acc[k] += x[k];
+      if (zero) zero[k] = 0.f;
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int memhip_cast_f32_bf16(const float* in, void* out, int64_t n, memhip_stream_t stream) {
@@ -181,4 +208,14 @@ extern "C" int memhip_relpos_gather(const float* table, const int32_t* index, in
   hipLaunchKernelGGL(relpos_gather_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), table, index, T, TP,
                      heads, bias, biasT);
   return check_launch("relpos_gather");
+}
+
+extern "C" int memhip_gemv_bf16_acc(const void* W, int64_t ldw, int N, int K, const float* x, float* y, float* x_acc,
+                                    float* zero, memhip_stream_t stream) {
+  MEMHIP_REQUIRE(N >= 0 && K >= 0 && K % 8 == 0 && ldw % 8 == 0, "gemv: K and ldw must be multiples of 8");
+  if (N == 0 || K == 0) return MEMHIP_OK;
+  MEMHIP_REQUIRE(W && x && y, "gemv: null pointer");
+  hipLaunchKernelGGL(gemv_acc_kernel, dim3((N + 3) / 4), dim3(256), 0, as_stream(stream), (const __bf16*)W,
+                     (long long)ldw, N, K, x, y, x_acc, zero);
+  return check_launch("gemv_bf16_acc");
 }

@@ -83,6 +83,7 @@ declare({
     "memhip_transpose_bf16": (i32, [vp, i64, i32, i32, vp, i64, i32, vp, i32, i32, vp, i32, i32, vp]),
     "memhip_im2col_bf16": (i32, [vp, i32, i32, i32, i32, i32, i32, vp, vp]),
     "memhip_fill_cls": (i32, [vp, i64, i32, i32, i32, vp, vp]),
+    "memhip_gemv_bf16_acc": (i32, [vp, i64, i32, i32, vp, vp, vp, vp, vp]),
     "memhip_grad_norm_workspace": (sz, []),
     "memhip_grad_norm": (i32, [vp, i64, vp, vp, sz, vp]),
     "memhip_adamw": (i32, [vp, vp, vp, vp, i64, vp, f64, f64, f64, f64, f64, i32, vp, f64, vp]),
@@ -104,6 +105,12 @@ def branch_bwd(dx, y, gamma, dy, dgamma, dbias, M, D, rowmask=None, keep_prob=1.
     check(lib.memhip_branch_bwd(ptr(dx), dx.stride(0), ptr(y), y.stride(0), ptr(gamma), ptr(rowmask), keep_prob,
                                 rows_per_sample, M, D, ptr(dy), dy.stride(0), ptr(dgamma), ptr(dbias),
                                 stream_ptr()), "branch_bwd")
+
+
+def gemv_acc(W, N, K, x, y, x_acc=None, zero=None):
+    """y[N] += W[N,K] (bf16) @ x[K]; optionally x_acc += x and zero[:] = 0."""
+    check(lib.memhip_gemv_bf16_acc(ptr(W), W.stride(0), N, K, ptr(x), ptr(y), ptr(x_acc), ptr(zero), stream_ptr()),
+          "gemv_bf16_acc")
 
 
 def embed_bwd(dx, mask_u8, B, L, D, dy, dcls, dmask_token):

@@ -181,7 +181,8 @@ class ViTEngine:
         self.dbig = e(M, Hd)
         self.dqkv = e(M, 3 * D)
         self.dao = e(M, D)
-        self.delta_ws = e(M, self.heads, dt=f32)
+        self.delta_ws = e(2 * M + 4, self.heads, dt=f32)   # rowsum(dO*O), |dO|^2, 4 rows of per-head bounds
+        self.bias_scr = torch.zeros(2, D, dtype=f32, device=dev)   # ping-pong colsum(dY) of the proj branch
         self.dYpe = e(B * self.L, D)
         self.B, self.Mm_cap = B, Mm_cap
 
@@ -309,15 +310,21 @@ class ViTEngine:
             ops.layernorm_bwd(self.dh_small, xmid, self.P(pre + "norm2.weight"), a["mean2"], a["rstd2"], dx,
                               self.G(pre + "norm2.weight"), self.G(pre + "norm2.bias"), M, D, accumulate=True)
             # -- attention branch
+            # proj.bias gradient (column sums of dY) goes to a scratch vector first: the v_bias gradient is
+            # derived from it.  sum_k dV[k] = sum_q dO[q] * sum_k P[q,k] and the softmax rows sum to one, so
+            # v_bias.grad = colsum(d attn_out) = colsum(dY) @ W_proj: one 768x768 GEMV instead of column
+            # sums inside the attention kernel (which cost it 32 VGPRs and its occupancy).
+            scr = self.bias_scr[i & 1]
             ops.branch_bwd(dx, a["y1"], self.P(pre + "gamma_1") if has_g else None, self.dY,
-                           self.G(pre + "gamma_1") if has_g else None, self.G(pre + "attn.proj.bias"), M, D,
+                           self.G(pre + "gamma_1") if has_g else None, scr, M, D,
                            rowmask=dp_masks[2 * i] if use_dp else None, keep_prob=keep, rows_per_sample=T)
             ops.gemm_nt(self.dY, self.wT[i]["proj"], M, D, D, ops.EPI_BIAS_BF16, out0=self.dao)
+            ops.gemv_acc(self.wT[i]["proj"], D, D, scr, self.G(pre + "attn.v_bias"),
+                         x_acc=self.G(pre + "attn.proj.bias"), zero=self.bias_scr[(i & 1) ^ 1])
             self._wgrad(self.dY, a["ao"], M, D, D, pre + "attn.proj.weight")
             ops.attn_delta(self.dao, a["ao"], M, self.heads, self.delta_ws)
             ops.attn_bwd(a["qkv"], self.dao, a["lse"], self.delta_ws, table, self.window, B, T, D, self.heads,
-                         self.scale, self.dqkv, dtable, dq_bias=self.G(pre + "attn.q_bias"),
-                         dv_bias=self.G(pre + "attn.v_bias"))
+                         self.scale, self.dqkv, dtable, dq_bias=self.G(pre + "attn.q_bias"))
             self._wgrad(self.dqkv, a["h1"], M, 3 * D, D, pre + "attn.qkv.weight")
             ops.gemm_nt(self.dqkv, self.wT[i]["qkv"], M, D, 3 * D, ops.EPI_BIAS_BF16, out0=self.dh_small)
             ops.layernorm_bwd(self.dh_small, xin, self.P(pre + "norm1.weight"), a["mean1"], a["rstd1"], dx,
