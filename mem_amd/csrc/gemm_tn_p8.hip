@@ -65,7 +65,12 @@ __global__ __launch_bounds__(kThreads) void gemm_tn_p8_kernel(const __bf16* __re
   const int wr = wave >> 2, wc = wave & 3;
   const int ntk = K / BN;
   const int tiles = (N / BM) * ntk;
-  const int tile = blockIdx.x % tiles, sp = blockIdx.x / tiles;
+  // Workgroups b, b+8, ... share an XCD (and its L2).  All tiles of one token slice read the same
+  // rows of A and B, so consecutive ids of the (slice, tile) space go to ONE XCD: bijective remap of
+  // blockIdx (measured before: 1.13 GB fetched per launch for 0.39 GB of operands, HBM-bound).
+  const int gq = (int)gridDim.x / 8, gr = (int)gridDim.x % 8, xcd = (int)blockIdx.x % 8;
+  const int wid = (xcd < gr ? xcd * (gq + 1) : gr * (gq + 1) + (xcd - gr) * gq) + (int)blockIdx.x / 8;
+  const int tile = wid % tiles, sp = wid / tiles;
   const int n0 = (tile / ntk) * BM, k0 = (tile % ntk) * BN;
   const int rbeg = sp * rows_per_split;
   int rend = rbeg + rows_per_split;
