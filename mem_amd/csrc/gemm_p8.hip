@@ -307,8 +307,12 @@ namespace memhip {
 // Returns MEMHIP_EUNSUPPORTED when the shape does not fit this structure (caller falls back).
 int gemm_p8_dispatch(const GemmArgs& p, hipStream_t s) {
   const bool vec = ((p.ldo0 | p.ldo1 | p.ldr | p.ldaux | p.colscale_n) & 7) == 0;      // host twin of vec_ok()
+  // N = 768 is three tiles wide: 591 tiles fill the third round of 256 CUs to 31 %.  Measured
+  // (tools/bench_gemm.py): this structure still wins by 4-20 % when K >= 1536 (long tiles), and is
+  // level with / behind the 128x128 kernel at K = 768.  MEMHIP_GEMM_P8_MIN_N overrides the width rule.
   static const int min_n = getenv("MEMHIP_GEMM_P8_MIN_N") ? atoi(getenv("MEMHIP_GEMM_P8_MIN_N")) : 1024;
-  if (p.M < 4096 || p.N < min_n || p.N % BN != 0 || p.K % (2 * BK) != 0 || !vec) return MEMHIP_EUNSUPPORTED;
+  const bool wide = p.N >= min_n || (p.N >= 768 && p.K >= 1536);
+  if (p.M < 4096 || !wide || p.N % BN != 0 || p.K % (2 * BK) != 0 || !vec) return MEMHIP_EUNSUPPORTED;
   static int num_cu = 0;
   if (!num_cu) {
     int dev = 0;
