@@ -11,6 +11,7 @@
 // read is bank-conflict free.  Workgroup ids are remapped so that the 8 XCDs each walk a
 // contiguous range of tiles (A row-panel reuse in the XCD-private L2).
 #include <cstdlib>
+#include <cstddef>
 #include "common.h"
 #include "gemm_epilogue.hpp"
 
@@ -190,13 +191,16 @@ namespace memhip {
 int gemm_ring_dispatch(const GemmArgs& p, hipStream_t s);
 int gemm256_dispatch(const GemmArgs& p, hipStream_t s);
 int gemm_p8_dispatch(const GemmArgs& p, hipStream_t s);
+int gemm_p8_split_rows(const GemmArgs& p);
 }
 
 extern "C" int memhip_gemm_bf16_nt(const memhip_gemm_args_t* a, memhip_stream_t stream) {
   MEMHIP_REQUIRE(a, "gemm: null args");
   GemmArgs p;
-  static_assert(sizeof(GemmArgs) == sizeof(memhip_gemm_args_t), "GemmArgs ABI mirror");
-  __builtin_memcpy(&p, a, sizeof(p));
+  static_assert(sizeof(GemmArgs) >= sizeof(memhip_gemm_args_t) && offsetof(GemmArgs, m_base) >= sizeof(memhip_gemm_args_t) - 8,
+                "GemmArgs = ABI struct + internal tail");
+  __builtin_memset(&p, 0, sizeof(p));
+  __builtin_memcpy(&p, a, sizeof(memhip_gemm_args_t));
   MEMHIP_REQUIRE(p.M >= 0 && p.N > 0 && p.K > 0, "gemm: bad shape M=%d N=%d K=%d", p.M, p.N, p.K);
   if (p.M == 0) return MEMHIP_OK;
   MEMHIP_REQUIRE(p.K % BK == 0, "gemm: K=%d must be a multiple of %d", p.K, BK);
@@ -219,8 +223,38 @@ extern "C" int memhip_gemm_bf16_nt(const memhip_gemm_args_t* a, memhip_stream_t 
   static const bool ring_on = getenv("MEMHIP_GEMM_RING") && atoi(getenv("MEMHIP_GEMM_RING")) == 1;
   static const bool p8_on = !(getenv("MEMHIP_GEMM_P8") && atoi(getenv("MEMHIP_GEMM_P8")) == 0);
   if (p8_on) {
-    const int rc = gemm_p8_dispatch(p, s);
-    if (rc != MEMHIP_EUNSUPPORTED) return rc;
+    // A persistent 256x256-tile launch whose last round would be poorly filled (N = 768: 591 tiles on
+    // 256 CUs) only takes the rows of the full rounds; the remaining rows go to the 128x128 kernel
+    // below (finer tiles, 2-3 workgroups per CU).  Rows are independent, so this is two launches of
+    // the same contract on two row ranges.
+    static const bool split_on = !(getenv("MEMHIP_GEMM_SPLIT") && atoi(getenv("MEMHIP_GEMM_SPLIT")) == 0);
+    const int split = split_on ? gemm_p8_split_rows(p) : 0;
+    if (split > 0 && split < p.M && p.epilogue != MEMHIP_EPI_PATCH_EMBED) {
+      GemmArgs head = p;
+      head.M = split;
+      const int rc = gemm_p8_dispatch(head, s);
+      if (rc == MEMHIP_OK) {
+        const long long r = split;
+        p.A += r * p.lda;
+        if (p.out0) p.out0 = (char*)p.out0 + r * p.ldo0 * (p.epilogue == MEMHIP_EPI_F32 ? 4 : 2);
+        if (p.out1) p.out1 = (char*)p.out1 + r * p.ldo1 * 2;
+        if (p.resid) p.resid += r * p.ldr;
+        if (p.aux) p.aux = (const char*)p.aux + r * p.ldaux * (p.epilogue == MEMHIP_EPI_RESIDUAL ? 4 : 2);
+        p.M -= split;
+        p.m_base = split;
+        switch (p.epilogue) {
+          case MEMHIP_EPI_BIAS_BF16: return launch<MEMHIP_EPI_BIAS_BF16>(p, s);
+          case MEMHIP_EPI_BIAS_GELU: return launch<MEMHIP_EPI_BIAS_GELU>(p, s);
+          case MEMHIP_EPI_RESIDUAL: return launch<MEMHIP_EPI_RESIDUAL>(p, s);
+          case MEMHIP_EPI_DGELU: return launch<MEMHIP_EPI_DGELU>(p, s);
+          default: return launch<MEMHIP_EPI_F32>(p, s);
+        }
+      }
+      if (rc != MEMHIP_EUNSUPPORTED) return rc;
+    } else {
+      const int rc = gemm_p8_dispatch(p, s);
+      if (rc != MEMHIP_EUNSUPPORTED) return rc;
+    }
   }
   if (k256_on) {
     const int rc = gemm256_dispatch(p, s);

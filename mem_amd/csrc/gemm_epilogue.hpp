@@ -6,7 +6,7 @@
 
 namespace memhip {
 
-struct GemmArgs {   // == memhip_gemm_args_t
+struct GemmArgs {   // memhip_gemm_args_t, followed by launcher-internal fields
   const __bf16* A; const __bf16* B;
   long long lda, ldb;
   int M, N, K, epilogue;
@@ -22,6 +22,9 @@ struct GemmArgs {   // == memhip_gemm_args_t
   int rows_per_sample;
   int accumulate;
   float* colsum;   // optional: += column sums of the (rounded) primary output
+  // ---- internal (not part of the C ABI; zero when the struct is copied from memhip_gemm_args_t)
+  int m_base;      // row offset of this launch inside the caller's problem (a GEMM may be launched in two
+                   // row ranges): only the per-sample row mask index needs the absolute row
 };
 
 __device__ __forceinline__ float bf16_round(float v) { return (float)(__bf16)v; }
@@ -67,7 +70,7 @@ __device__ __forceinline__ void epilogue(const GemmArgs& p, int m, int n, float 
     const __bf16 y = (__bf16)(acc + bias_n);
     if (p.out0) reinterpret_cast<__bf16*>(p.out0)[(long long)m * p.ldo0 + n] = y;
     float t = p.vec1 ? __fmul_rn(vec_n, (float)y) : (float)y;            // gamma * branch
-    if (p.rowmask) t = __fmul_rn(__fdiv_rn(t, p.keep_prob), p.rowmask[m / p.rows_per_sample]);
+    if (p.rowmask) t = __fmul_rn(__fdiv_rn(t, p.keep_prob), p.rowmask[(m + p.m_base) / p.rows_per_sample]);
     // residual input: aux (fp32, ldaux) when given, else in place
     const float xin = p.aux ? reinterpret_cast<const float*>(p.aux)[(long long)m * p.ldaux + n]
                             : p.resid[(long long)m * p.ldr + n];
@@ -226,7 +229,7 @@ __device__ __forceinline__ void epilogue8(const GemmArgs& p, int m, int n, const
       for (int k = 0; k < 8; ++k) br[k] = __fmul_rn(c.g[k], br[k]);
     }
     if (p.rowmask) {                           // drop path: branch / keep_prob * mask[sample]
-      const float rm = p.rowmask[m / p.rows_per_sample];
+      const float rm = p.rowmask[(m + p.m_base) / p.rows_per_sample];
       const float rk = __frcp_rn(p.keep_prob);
 #pragma unroll
       for (int k = 0; k < 8; ++k) {

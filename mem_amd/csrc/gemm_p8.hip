@@ -304,22 +304,44 @@ int launch_p8(const GemmArgs& p, hipStream_t s, int num_cu) {
 
 namespace memhip {
 
-// Returns MEMHIP_EUNSUPPORTED when the shape does not fit this structure (caller falls back).
-int gemm_p8_dispatch(const GemmArgs& p, hipStream_t s) {
+static int p8_num_cu() {
+  static int num_cu = 0;
+  if (!num_cu) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
+    num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  }
+  return num_cu;
+}
+
+static bool p8_fits(const GemmArgs& p) {
   const bool vec = ((p.ldo0 | p.ldo1 | p.ldr | p.ldaux | p.colscale_n) & 7) == 0;      // host twin of vec_ok()
   // N = 768 is three tiles wide: 591 tiles fill the third round of 256 CUs to 31 %.  Measured
   // (tools/bench_gemm.py): this structure still wins by 4-20 % when K >= 1536 (long tiles), and is
   // level with / behind the 128x128 kernel at K = 768.  MEMHIP_GEMM_P8_MIN_N overrides the width rule.
   static const int min_n = getenv("MEMHIP_GEMM_P8_MIN_N") ? atoi(getenv("MEMHIP_GEMM_P8_MIN_N")) : 1024;
   const bool wide = p.N >= min_n || (p.N >= 768 && p.K >= 1536);
-  if (p.M < 4096 || !wide || p.N % BN != 0 || p.K % (2 * BK) != 0 || !vec) return MEMHIP_EUNSUPPORTED;
-  static int num_cu = 0;
-  if (!num_cu) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return MEMHIP_EUNSUPPORTED;
-    num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-  }
+  return p.M >= 4096 && wide && p.N % BN == 0 && p.K % (2 * BK) == 0 && vec;
+}
+
+// Rows the persistent launch should take when its last round of tiles would be less than half full
+// (0 = take everything): full rounds only, the caller runs the remaining rows on finer tiles.
+int gemm_p8_split_rows(const GemmArgs& p) {
+  if (!p8_fits(p)) return 0;
+  const int num_cu = p8_num_cu();
+  if (!num_cu) return 0;
+  const int ntm = (p.M + BM - 1) / BM, ntn = p.N / BN;
+  const int tiles = ntm * ntn, rounds = tiles / num_cu, rem = tiles % num_cu;
+  if (rounds < 1 || rem == 0 || rem * 2 > num_cu) return 0;
+  return (rounds * num_cu / ntn) * BM;
+}
+
+// Returns MEMHIP_EUNSUPPORTED when the shape does not fit this structure (caller falls back).
+int gemm_p8_dispatch(const GemmArgs& p, hipStream_t s) {
+  if (!p8_fits(p)) return MEMHIP_EUNSUPPORTED;
+  const int num_cu = p8_num_cu();
+  if (!num_cu) return MEMHIP_EUNSUPPORTED;
   switch (p.epilogue) {
     case MEMHIP_EPI_BIAS_BF16: return launch_p8<MEMHIP_EPI_BIAS_BF16>(p, s, num_cu);
     case MEMHIP_EPI_BIAS_GELU: return launch_p8<MEMHIP_EPI_BIAS_GELU>(p, s, num_cu);

@@ -155,7 +155,8 @@ def test_gemm_tn_weight_gradient(R, N, K):
 
 
 @pytest.mark.parametrize("M,N,K", [(2048, 128, 64), (4000, 768, 768), (2304 + 17, 2304, 768), (5000, 384, 3072),
-                                   (4096, 256, 64), (4096 + 100, 768, 768), (9000, 2304, 128), (4500, 512, 3072)])
+                                   (4096, 256, 64), (4096 + 100, 768, 768), (9000, 2304, 128), (4500, 512, 3072),
+                                   (25600 + 13, 768, 1536)])       # last: 303 tiles -> row-split launch (p8 + 128x128)
 def test_ring_gemm_large_m_all_epilogues(M, N, K):
     """M >= 2048 and N % 128 == 0 dispatch to the persistent ring-pipelined kernel (gemm_ring.hip):
     exact-integer layout check + every fused epilogue against torch."""
