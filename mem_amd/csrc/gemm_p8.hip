@@ -317,11 +317,10 @@ static int p8_num_cu() {
 
 static bool p8_fits(const GemmArgs& p) {
   const bool vec = ((p.ldo0 | p.ldo1 | p.ldr | p.ldaux | p.colscale_n) & 7) == 0;      // host twin of vec_ok()
-  // N = 768 is three tiles wide: 591 tiles fill the third round of 256 CUs to 31 %.  Measured
-  // (tools/bench_gemm.py): this structure still wins by 4-20 % when K >= 1536 (long tiles), and is
-  // level with / behind the 128x128 kernel at K = 768.  MEMHIP_GEMM_P8_MIN_N overrides the width rule.
-  static const int min_n = getenv("MEMHIP_GEMM_P8_MIN_N") ? atoi(getenv("MEMHIP_GEMM_P8_MIN_N")) : 1024;
-  const bool wide = p.N >= min_n || (p.N >= 768 && p.K >= 1536);
+  // Narrow outputs (N = 768: 591 tiles on 256 CUs) are taken too: the launcher hands the rows of a
+  // poorly filled last round to the 128x128 kernel (gemm_p8_split_rows).  MEMHIP_GEMM_P8_MIN_N overrides.
+  static const int min_n = getenv("MEMHIP_GEMM_P8_MIN_N") ? atoi(getenv("MEMHIP_GEMM_P8_MIN_N")) : 768;
+  const bool wide = p.N >= min_n;
   return p.M >= 4096 && wide && p.N % BN == 0 && p.K % (2 * BK) == 0 && vec;
 }
 
