@@ -123,6 +123,13 @@ __device__ __forceinline__ ef32x2 unpack_bf16x2(unsigned u) {
 __device__ __forceinline__ ef32x2 fma2(ef32x2 a, ef32x2 b, ef32x2 c) { return __builtin_elementwise_fma(a, b, c); }
 __device__ __forceinline__ ef32x2 splat2(float v) { return ef32x2{v, v}; }
 
+// 16-byte streaming store of a finished bf16 output row piece: nontemporal (measured +6 % on the
+// bias+GELU product, which writes 620 MB per launch: the lines do not linger in L2 as dirty data)
+typedef __attribute__((ext_vector_type(4))) unsigned eu32x4;
+__device__ __forceinline__ void st_stream16(void* base, long long elem_off, unsigned a, unsigned b, unsigned c, unsigned d) {
+  __builtin_nontemporal_store(eu32x4{a, b, c, d}, reinterpret_cast<eu32x4*>(reinterpret_cast<__bf16*>(base) + elem_off));
+}
+
 // erf(x / sqrt 2) and exp(-x^2 / 2) for two values (A&S 7.1.26, see erf_fast)
 __device__ __forceinline__ void erf_exp2(ef32x2 x, ef32x2& erf, ef32x2& e) {
   const ef32x2 z = x * splat2(0.70710678118654752440f);
@@ -201,7 +208,7 @@ __device__ __forceinline__ void epilogue8(const GemmArgs& p, int m, int n, const
         cs[2 * k + 1] += f.y;
       }
     }
-    *reinterpret_cast<uint4*>(reinterpret_cast<__bf16*>(p.out0) + (long long)m * p.ldo0 + n) = uint4{y[0], y[1], y[2], y[3]};
+    st_stream16(p.out0, (long long)m * p.ldo0 + n, y[0], y[1], y[2], y[3]);
   } else if constexpr (EPI == MEMHIP_EPI_BIAS_GELU) {
     unsigned h[4], a[4];
 #pragma unroll
@@ -209,8 +216,8 @@ __device__ __forceinline__ void epilogue8(const GemmArgs& p, int m, int n, const
       h[k] = pack_bf16x2(t[k]);
       a[k] = pack_bf16x2(gelu2(unpack_bf16x2(h[k])));
     }
-    *reinterpret_cast<uint4*>(reinterpret_cast<__bf16*>(p.out0) + (long long)m * p.ldo0 + n) = uint4{h[0], h[1], h[2], h[3]};
-    *reinterpret_cast<uint4*>(reinterpret_cast<__bf16*>(p.out1) + (long long)m * p.ldo1 + n) = uint4{a[0], a[1], a[2], a[3]};
+    st_stream16(p.out0, (long long)m * p.ldo0 + n, h[0], h[1], h[2], h[3]);
+    st_stream16(p.out1, (long long)m * p.ldo1 + n, a[0], a[1], a[2], a[3]);
   } else if constexpr (EPI == MEMHIP_EPI_RESIDUAL) {
     unsigned y[4];
     float x[8];
@@ -241,7 +248,7 @@ __device__ __forceinline__ void epilogue8(const GemmArgs& p, int m, int n, const
     }
 #pragma unroll
     for (int k = 0; k < 8; ++k) x[k] = __fadd_rn(x[k], br[k]);
-    if (p.out0) *reinterpret_cast<uint4*>(reinterpret_cast<__bf16*>(p.out0) + (long long)m * p.ldo0 + n) = uint4{y[0], y[1], y[2], y[3]};
+    if (p.out0) st_stream16(p.out0, (long long)m * p.ldo0 + n, y[0], y[1], y[2], y[3]);
     st8(p.resid + (long long)m * p.ldr + n, x);
   } else if constexpr (EPI == MEMHIP_EPI_DGELU) {
     const uint4 hv = *reinterpret_cast<const uint4*>(reinterpret_cast<const __bf16*>(p.aux) + (long long)m * p.ldaux + n);
@@ -260,7 +267,7 @@ __device__ __forceinline__ void epilogue8(const GemmArgs& p, int m, int n, const
         cs[2 * k + 1] += f.y;
       }
     }
-    *reinterpret_cast<uint4*>(reinterpret_cast<__bf16*>(p.out0) + (long long)m * p.ldo0 + n) = uint4{o[0], o[1], o[2], o[3]};
+    st_stream16(p.out0, (long long)m * p.ldo0 + n, o[0], o[1], o[2], o[3]);
   } else if constexpr (EPI == MEMHIP_EPI_F32) {
     float* o = reinterpret_cast<float*>(p.out0) + (long long)m * p.ldo0 + n;
     float x[8];
