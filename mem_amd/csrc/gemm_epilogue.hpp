@@ -181,8 +181,28 @@ __device__ __forceinline__ void epi_cols_load(const GemmArgs& p, int n, EpiCols&
   }
 }
 
+// Per-row operands (the GELU input for GELU', the fp32 residual for the residual epilogue): loaded
+// separately so that a caller can issue the loads of several rows before it consumes the first
+// (a load issued per row right before its use exposes one HBM latency per row).
 template <int EPI>
-__device__ __forceinline__ void epilogue8(const GemmArgs& p, int m, int n, const float* acc, float* cs, const EpiCols& c) {
+struct EpiRow {};
+template <>
+struct EpiRow<MEMHIP_EPI_DGELU> { uint4 h; };
+template <>
+struct EpiRow<MEMHIP_EPI_RESIDUAL> { float x[8]; };
+template <int EPI>
+__device__ __forceinline__ void epi_row_load(const GemmArgs& p, int m, int n, EpiRow<EPI>& r) {
+  if constexpr (EPI == MEMHIP_EPI_DGELU) {
+    r.h = *reinterpret_cast<const uint4*>(reinterpret_cast<const __bf16*>(p.aux) + (long long)m * p.ldaux + n);
+  } else if constexpr (EPI == MEMHIP_EPI_RESIDUAL) {
+    if (p.aux) ld8(reinterpret_cast<const float*>(p.aux) + (long long)m * p.ldaux + n, r.x);
+    else ld8(p.resid + (long long)m * p.ldr + n, r.x);
+  }
+}
+
+template <int EPI>
+__device__ __forceinline__ void epilogue8(const GemmArgs& p, int m, int n, const float* acc, float* cs, const EpiCols& c,
+                                          const EpiRow<EPI>& row) {
   ef32x2 t[4];
 #pragma unroll
   for (int k = 0; k < 4; ++k) t[k] = ef32x2{acc[2 * k], acc[2 * k + 1]};
@@ -221,8 +241,8 @@ __device__ __forceinline__ void epilogue8(const GemmArgs& p, int m, int n, const
   } else if constexpr (EPI == MEMHIP_EPI_RESIDUAL) {
     unsigned y[4];
     float x[8];
-    if (p.aux) ld8(reinterpret_cast<const float*>(p.aux) + (long long)m * p.ldaux + n, x);
-    else ld8(p.resid + (long long)m * p.ldr + n, x);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) x[k] = row.x[k];
     float br[8];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -251,8 +271,7 @@ __device__ __forceinline__ void epilogue8(const GemmArgs& p, int m, int n, const
     if (p.out0) st_stream16(p.out0, (long long)m * p.ldo0 + n, y[0], y[1], y[2], y[3]);
     st8(p.resid + (long long)m * p.ldr + n, x);
   } else if constexpr (EPI == MEMHIP_EPI_DGELU) {
-    const uint4 hv = *reinterpret_cast<const uint4*>(reinterpret_cast<const __bf16*>(p.aux) + (long long)m * p.ldaux + n);
-    const unsigned h[4] = {hv.x, hv.y, hv.z, hv.w};
+    const unsigned h[4] = {row.h.x, row.h.y, row.h.z, row.h.w};
     unsigned o[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -295,6 +314,12 @@ __device__ __forceinline__ void epilogue8(const GemmArgs& p, int m, int n, const
   }
 }
 
+template <int EPI>
+__device__ __forceinline__ void epilogue8(const GemmArgs& p, int m, int n, const float* acc, float* cs, const EpiCols& c) {
+  EpiRow<EPI> row;
+  epi_row_load<EPI>(p, m, n, row);
+  epilogue8<EPI>(p, m, n, acc, cs, c, row);
+}
 template <int EPI>
 __device__ __forceinline__ void epilogue8(const GemmArgs& p, int m, int n, const float* acc, float* cs) {
   EpiCols c;

@@ -257,8 +257,16 @@ __global__ __launch_bounds__(kThreads) void gemm_p8_kernel(GemmArgs p, int ntm, 
         float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         EpiCols cols;
         epi_cols_load<EPI>(p, n, cols);
+        // rows in batches of four: the per-row operand loads (GELU input / residual) of a batch are in
+        // flight together (row index clamped instead of branched, so that nothing orders them)
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < 2; ++i) {
+          EpiRow<EPI> rows[4];
+#pragma unroll
+          for (int mf = 0; mf < 4; ++mf) {
+            const int m = mrow + i * 128 + mf * 16;
+            epi_row_load<EPI>(p, m < p.M ? m : p.M - 1, n, rows[mf]);
+          }
 #pragma unroll
           for (int mf = 0; mf < 4; ++mf) {
             const int m = mrow + i * 128 + mf * 16;
@@ -270,8 +278,9 @@ __global__ __launch_bounds__(kThreads) void gemm_p8_kernel(GemmArgs p, int ntm, 
                 v[nf * 4 + r] = acc[i * 2 + j][mf][nf][r];
                 acc[i * 2 + j][mf][nf][r] = 0.f;
               }
-            if (m < p.M) epilogue8<EPI>(p, m, n, v, cs, cols);
+            if (m < p.M) epilogue8<EPI>(p, m, n, v, cs, cols, rows[mf]);
           }
+        }
         colsum_flush16(p, n, cs, lane);
       }
       c_k = 0;
