@@ -184,6 +184,15 @@ int memhip_gemm_bf16_nt(const memhip_gemm_args_t* args, memhip_stream_t stream);
  * the caller); accumulate=0: overwrite. */
 int memhip_gemm_bf16_tn(const void* A, int64_t lda, const void* B, int64_t ldb, int R, int N, int K,
                         float* out, int64_t ldo, int accumulate, memhip_stream_t stream);
+/* Same product with a caller-owned scratch buffer of memhip_gemm_bf16_tn_workspace(R,N,K) bytes (0 = the
+ * shape has no use for one): the per-slice partial tiles are then written with plain stores and summed
+ * by a reduction pass instead of fp32 atomics (64 MB of atomics per ViT-B weight gradient otherwise).
+ * workspace NULL / too small: identical to memhip_gemm_bf16_tn.  The sum order is fixed, so the result
+ * is run-to-run deterministic. */
+size_t memhip_gemm_bf16_tn_workspace(int R, int N, int K);
+int memhip_gemm_bf16_tn_ws(const void* A, int64_t lda, const void* B, int64_t ldb, int R, int N, int K,
+                           float* out, int64_t ldo, int accumulate, void* workspace, size_t workspace_bytes,
+                           memhip_stream_t stream);
 /* out f32 [C] += column sums of in bf16 [R, C]  (Linear bias gradients = grad_output.sum(0)) */
 int memhip_colsum_bf16(const void* in, int64_t ld, int R, int C, float* out, memhip_stream_t stream);
 

@@ -169,11 +169,24 @@ namespace memhip {
 int gemm_tn256_dispatch(const void* A, long long lda, const void* B, long long ldb, int R, int N, int K, float* out,
                         long long ldo, int accumulate, hipStream_t s);
 int gemm_tn_p8_dispatch(const void* A, long long lda, const void* B, long long ldb, int R, int N, int K, float* out,
-                        long long ldo, int accumulate, hipStream_t s);
+                        long long ldo, int accumulate, float* ws, size_t ws_bytes, hipStream_t s);
+size_t gemm_tn_p8_workspace(int R, int N, int K);
 }
+
+extern "C" size_t memhip_gemm_bf16_tn_workspace(int R, int N, int K) { return memhip::gemm_tn_p8_workspace(R, N, K); }
+
+extern "C" int memhip_gemm_bf16_tn_ws(const void* A, int64_t lda, const void* B, int64_t ldb, int R, int N, int K,
+                                      float* out, int64_t ldo, int accumulate, void* workspace,
+                                      size_t workspace_bytes, memhip_stream_t stream);
 
 extern "C" int memhip_gemm_bf16_tn(const void* A, int64_t lda, const void* B, int64_t ldb, int R, int N, int K,
                                    float* out, int64_t ldo, int accumulate, memhip_stream_t stream) {
+  return memhip_gemm_bf16_tn_ws(A, lda, B, ldb, R, N, K, out, ldo, accumulate, nullptr, 0, stream);
+}
+
+extern "C" int memhip_gemm_bf16_tn_ws(const void* A, int64_t lda, const void* B, int64_t ldb, int R, int N, int K,
+                                      float* out, int64_t ldo, int accumulate, void* workspace,
+                                      size_t workspace_bytes, memhip_stream_t stream) {
   MEMHIP_REQUIRE(R >= 0 && N > 0 && K > 0, "gemm_tn: bad shape R=%d N=%d K=%d", R, N, K);
   if (R == 0) return MEMHIP_OK;
   MEMHIP_REQUIRE(A && B && out, "gemm_tn: null pointer");
@@ -182,7 +195,8 @@ extern "C" int memhip_gemm_bf16_tn(const void* A, int64_t lda, const void* B, in
   hipStream_t s = as_stream(stream);
   static const bool p8_on = !(getenv("MEMHIP_TN_P8") && atoi(getenv("MEMHIP_TN_P8")) == 0);
   if (p8_on) {
-    const int rc = gemm_tn_p8_dispatch(A, lda, B, ldb, R, N, K, out, ldo, accumulate, s);
+    const int rc = gemm_tn_p8_dispatch(A, lda, B, ldb, R, N, K, out, ldo, accumulate, (float*)workspace,
+                                       workspace_bytes, s);
     if (rc != MEMHIP_EUNSUPPORTED) return rc;
   }
   static const bool k256_on = !(getenv("MEMHIP_TN256") && atoi(getenv("MEMHIP_TN256")) == 0);

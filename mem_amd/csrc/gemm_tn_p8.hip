@@ -11,8 +11,9 @@
 //     0-3, so that on every SIMD one wave's 16 MFMAs cover the other's LDS reads and LDS-DMA issue;
 //   * one half-tile of prefetch per phase (A1(c+1), B0(c+2), A0(c+2), B1(c+2)), five in flight,
 //     s_waitcnt vmcnt(10) before the first barrier of every phase; hazards as in gemm_p8.hip.
-// The fp32 result is added to the (pre-zeroed / accumulating) gradient with atomics shaped as two
-// 128-byte runs per wave-instruction (staged through the idle ring).
+// The fp32 partial tile is either added to the gradient with atomics shaped as two 128-byte runs
+// per wave-instruction, or (with a caller workspace) stored to a slab and summed by a reduction pass;
+// both are staged through the idle ring.
 #include <cstdlib>
 #include "common.h"
 
@@ -55,6 +56,10 @@ __device__ __forceinline__ bf16x8 tr_pair(const char* a0) {
     __builtin_amdgcn_sched_barrier(0);    \
   } while (0)
 
+// WS = false: the partial tile is added to `out` with fp32 atomics.  WS = true: it is written with
+// plain 16-byte stores to slab `sp` of a workspace [splits][N][K] (ldo = K), summed afterwards by
+// tn_reduce_kernel: 64 MB of atomics per GEMM run at ~1.3 TB/s, plain stores at 5-6 TB/s.
+template <bool WS>
 __global__ __launch_bounds__(kThreads) void gemm_tn_p8_kernel(const __bf16* __restrict__ A, long long lda,
                                                               const __bf16* __restrict__ B, long long ldb,
                                                               int R, int N, int K, float* __restrict__ out,
@@ -204,6 +209,7 @@ __global__ __launch_bounds__(kThreads) void gemm_tn_p8_kernel(const __bf16* __re
   // through this wave's 4 KiB, then adds row by row: one wave-instruction = two 128-byte runs.
   float* wreg = reinterpret_cast<float*>(smem + wave * 4096);
   const int kcol = k0 + (lane >> 5) * 128 + wc * 32 + (lane & 31);
+  float* dst = WS ? out + (long long)sp * N * ldo : out;
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -217,48 +223,111 @@ __global__ __launch_bounds__(kThreads) void gemm_tn_p8_kernel(const __bf16* __re
             const int row = (lane >> 4) * 4 + r;
             wreg[row * 64 + ((j * 32 + kf * 16 + (lane & 15)) ^ (((row >> 2) & 1) << 4))] = acc[i * 2 + j][nf][kf][r];
           }
+      const int nrow = n0 + i * 128 + wr * 64 + nf * 16;
+      if constexpr (WS) {
+        // 4 rows per instruction, 16 bytes per lane: lanes 0-7 the 32 columns of B half 0, 8-15 of half 1
 #pragma unroll
-      for (int row = 0; row < 16; ++row) {
-        const float v = wreg[row * 64 + (lane ^ (((row >> 2) & 1) << 4))];
-        atomicAdd(out + (long long)(n0 + i * 128 + wr * 64 + nf * 16 + row) * ldo + kcol, v);
+        for (int it = 0; it < 4; ++it) {
+          const int row = it * 4 + (lane >> 4), c4 = (lane & 15) * 4;
+          // plain (cached) store: the reduction pass reads the slab right away, from L2 / Infinity Cache
+          *reinterpret_cast<float4*>(dst + (long long)(nrow + row) * ldo + k0 + (c4 >> 5) * 128 + wc * 32 + (c4 & 31)) =
+              *reinterpret_cast<const float4*>(wreg + row * 64 + (c4 ^ (((row >> 2) & 1) << 4)));
+        }
+      } else {
+#pragma unroll
+        for (int row = 0; row < 16; ++row) {
+          const float v = wreg[row * 64 + (lane ^ (((row >> 2) & 1) << 4))];
+          atomicAdd(dst + (long long)(nrow + row) * ldo + kcol, v);
+        }
       }
     }
+}
+
+// out[n][k] (+)= sum over the S slabs of the workspace
+__global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict__ ws, int S, long long slab, int N, int K,
+                                                        float* __restrict__ out, long long ldo, int accumulate) {
+  const long long i4 = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i4 >= (long long)N * K) return;
+  float4 a = *reinterpret_cast<const float4*>(ws + i4);
+  for (int s = 1; s < S; ++s) {
+    const float4 b = *reinterpret_cast<const float4*>(ws + s * slab + i4);
+    a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+  }
+  const long long n = i4 / K, k = i4 - n * K;
+  float4* o = reinterpret_cast<float4*>(out + n * ldo + k);
+  if (accumulate) {
+    const float4 c = *o;
+    a.x += c.x; a.y += c.y; a.z += c.z; a.w += c.w;
+  }
+  *o = a;
 }
 
 }  // namespace
 
 namespace memhip {
 
-// MEMHIP_EUNSUPPORTED when the shape does not fit (caller falls back to the other TN kernels).
-int gemm_tn_p8_dispatch(const void* A, long long lda, const void* B, long long ldb, int R, int N, int K, float* out,
-                        long long ldo, int accumulate, hipStream_t s) {
-  if (N % BM != 0 || K % BN != 0 || R < 2048) return MEMHIP_EUNSUPPORTED;
+static void tn_p8_plan(int R, int N, int K, int num_cu, int& tiles, int& splits, int& rows_per_split) {
+  tiles = (N / BM) * (K / BN);
+  const int pairs = cdiv(R, 2 * BR);                       // the token rows advance in pairs of K-tiles
+  splits = num_cu / tiles;
+  if (splits < 1) splits = 1;
+  if (splits > pairs / 2) splits = pairs / 2 > 0 ? pairs / 2 : 1;        // >= 256 rows per split
+  rows_per_split = cdiv(pairs, splits) * 2 * BR;
+  splits = cdiv(R, rows_per_split);
+}
+static int tn_p8_num_cu() {
   static int num_cu = 0;
   if (!num_cu) {
     int dev = 0;
     hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return MEMHIP_EUNSUPPORTED;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
     num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   }
-  const int tiles = (N / BM) * (K / BN);
-  const int pairs = cdiv(R, 2 * BR);                       // the token rows advance in pairs of K-tiles
-  int splits = num_cu / tiles;
-  if (splits < 1) splits = 1;
-  if (splits > pairs / 2) splits = pairs / 2 > 0 ? pairs / 2 : 1;        // >= 256 rows per split
-  const int rows_per_split = cdiv(pairs, splits) * 2 * BR;
-  splits = cdiv(R, rows_per_split);
+  return num_cu;
+}
+
+// bytes of workspace with which the partial tiles go through plain stores + a reduction pass
+size_t gemm_tn_p8_workspace(int R, int N, int K) {
+  if (N % BM != 0 || K % BN != 0 || R < 2048) return 0;
+  const int num_cu = tn_p8_num_cu();
+  if (!num_cu) return 0;
+  int tiles, splits, rps;
+  tn_p8_plan(R, N, K, num_cu, tiles, splits, rps);
+  return splits > 1 ? (size_t)splits * N * K * sizeof(float) : 0;
+}
+
+// MEMHIP_EUNSUPPORTED when the shape does not fit (caller falls back to the other TN kernels).
+int gemm_tn_p8_dispatch(const void* A, long long lda, const void* B, long long ldb, int R, int N, int K, float* out,
+                        long long ldo, int accumulate, float* ws, size_t ws_bytes, hipStream_t s) {
+  if (N % BM != 0 || K % BN != 0 || R < 2048) return MEMHIP_EUNSUPPORTED;
+  const int num_cu = tn_p8_num_cu();
+  if (!num_cu) return MEMHIP_EUNSUPPORTED;
+  int tiles, splits, rows_per_split;
+  tn_p8_plan(R, N, K, num_cu, tiles, splits, rows_per_split);
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_p8_kernel<false>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, kRing);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_p8_kernel<true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, kRing);
+    if (e != hipSuccess) return fail(MEMHIP_ELAUNCH, "gemm_tn_p8: set smem attr: %s", hipGetErrorString(e));
+    attr_done = true;
+  }
+  const size_t need = (size_t)splits * N * K * sizeof(float);
+  if (ws && splits > 1 && ws_bytes >= need && ((uintptr_t)ws & 15) == 0 && ldo % 4 == 0) {
+    hipLaunchKernelGGL(gemm_tn_p8_kernel<true>, dim3(tiles * splits), dim3(kThreads), kRing, s, (const __bf16*)A, lda,
+                       (const __bf16*)B, ldb, R, N, K, ws, (long long)K, rows_per_split);
+    const long long quads = (long long)N * K / 4;
+    hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, s, ws, splits,
+                       (long long)N * K, N, K, out, ldo, accumulate);
+    return check_launch("gemm_bf16_tn(p8, workspace)");
+  }
   if (!accumulate) {
     hipError_t e = hipMemset2DAsync(out, (size_t)ldo * sizeof(float), 0, (size_t)K * sizeof(float), (size_t)N, s);
     if (e != hipSuccess) return fail(MEMHIP_ELAUNCH, "gemm_tn_p8: memset: %s", hipGetErrorString(e));
   }
-  static bool attr_done = false;
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_p8_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, kRing);
-    if (e != hipSuccess) return fail(MEMHIP_ELAUNCH, "gemm_tn_p8: set smem attr: %s", hipGetErrorString(e));
-    attr_done = true;
-  }
-  hipLaunchKernelGGL(gemm_tn_p8_kernel, dim3(tiles * splits), dim3(kThreads), kRing, s, (const __bf16*)A, lda,
+  hipLaunchKernelGGL(gemm_tn_p8_kernel<false>, dim3(tiles * splits), dim3(kThreads), kRing, s, (const __bf16*)A, lda,
                      (const __bf16*)B, ldb, R, N, K, out, ldo, rows_per_split);
   return check_launch("gemm_bf16_tn(p8)");
 }

@@ -183,20 +183,28 @@ def adamw(p, g, m, v, n, wd_flags, lr, beta1, beta2, eps, wd, step, gnorm=None, 
 
 declare({
     "memhip_gemm_bf16_tn": (i32, [vp, i64, vp, i64, i32, i32, i32, vp, i64, i32, vp]),
+    "memhip_gemm_bf16_tn_ws": (i32, [vp, i64, vp, i64, i32, i32, i32, vp, i64, i32, vp, sz, vp]),
+    "memhip_gemm_bf16_tn_workspace": (sz, [i32, i32, i32]),
     "memhip_colsum_bf16": (i32, [vp, i64, i32, i32, vp, vp]),
 })
 
 
-def gemm_tn(A, B, R, N, K, out, accumulate=True):
-    """out[N,K] (+)= A[R,N]^T @ B[R,K]  (weight gradient; A = dY, B = X, token-major bf16)."""
+def gemm_tn_workspace(R, N, K):
+    return int(lib.memhip_gemm_bf16_tn_workspace(R, N, K))
+
+
+def gemm_tn(A, B, R, N, K, out, accumulate=True, workspace=None):
+    """out[N,K] (+)= A[R,N]^T @ B[R,K]  (weight gradient; A = dY, B = X, token-major bf16).  `workspace`:
+    optional uint8 scratch tensor of >= gemm_tn_workspace(R,N,K) bytes (plain-store partial tiles)."""
+    ws, wsb = (ptr(workspace), workspace.numel() * workspace.element_size()) if workspace is not None else (None, 0)
     if GEMM_TIMER is None:
-        check(lib.memhip_gemm_bf16_tn(ptr(A), A.stride(0), ptr(B), B.stride(0), R, N, K, ptr(out), out.stride(0),
-                                      int(accumulate), stream_ptr()), "gemm_bf16_tn")
+        check(lib.memhip_gemm_bf16_tn_ws(ptr(A), A.stride(0), ptr(B), B.stride(0), R, N, K, ptr(out), out.stride(0),
+                                         int(accumulate), ws, wsb, stream_ptr()), "gemm_bf16_tn")
     else:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        check(lib.memhip_gemm_bf16_tn(ptr(A), A.stride(0), ptr(B), B.stride(0), R, N, K, ptr(out), out.stride(0),
-                                      int(accumulate), stream_ptr()), "gemm_bf16_tn")
+        check(lib.memhip_gemm_bf16_tn_ws(ptr(A), A.stride(0), ptr(B), B.stride(0), R, N, K, ptr(out), out.stride(0),
+                                         int(accumulate), ws, wsb, stream_ptr()), "gemm_bf16_tn")
         e1.record()
         GEMM_TIMER.append((e0, e1, 2.0 * R * N * K, 100))
 

@@ -182,6 +182,7 @@ class ViTEngine:
         self.dqkv = e(M, 3 * D)
         self.dao = e(M, D)
         self.delta_ws = e(2 * M + 4, self.heads, dt=f32)   # rowsum(dO*O), |dO|^2, 4 rows of per-head bounds
+        self._tn_ws = torch.empty(0, dtype=torch.uint8, device=dev)     # partial tiles of the weight-gradient GEMMs
         self.bias_scr = torch.zeros(2, D, dtype=f32, device=dev)   # ping-pong colsum(dY) of the proj branch
         self.dYpe = e(B * self.L, D)
         self.B, self.Mm_cap = B, Mm_cap
@@ -264,7 +265,10 @@ class ViTEngine:
     def _wgrad(self, dY, X, R, n_out, n_in, gname, bias_grads=()):
         """grad[gname] [n_out, n_in] += dY[R, n_out]^T @ X[R, n_in]; bias_grads = ((grad_view, c0, c1), ...)
         column sums of dY[:, c0:c1] (the Linear bias gradients)."""
-        ops.gemm_tn(dY, X, R, n_out, n_in, self.G(gname).view(n_out, n_in), accumulate=True)
+        need = ops.gemm_tn_workspace(R, n_out, n_in)
+        if need > self._tn_ws.numel():                      # grows to the largest product once
+            self._tn_ws = torch.empty(need, dtype=torch.uint8, device=self.dev)
+        ops.gemm_tn(dY, X, R, n_out, n_in, self.G(gname).view(n_out, n_in), accumulate=True, workspace=self._tn_ws)
         for gv, c0, c1 in bias_grads:
             ops.colsum_bf16(dY[:, c0:c1], R, c1 - c0, gv)
 

@@ -149,6 +149,18 @@ def test_gemm_tn_weight_gradient(R, N, K):
     out2 = torch.full((N, K), 5.0, dtype=torch.float32, device="cuda")
     ops.gemm_tn(A, B, R, N, K, out2, accumulate=False)
     torch.testing.assert_close(out2, ref - 2.0, rtol=2e-3, atol=2e-2)
+    # workspace form: partial tiles by plain stores + a reduction pass; fixed sum order => deterministic
+    need = ops.gemm_tn_workspace(R, N, K)
+    ws = torch.empty(max(need, 16), dtype=torch.uint8, device="cuda")
+    o1 = torch.full((N, K), -5.0, device="cuda")
+    ops.gemm_tn(A, B, R, N, K, o1, accumulate=False, workspace=ws)
+    torch.testing.assert_close(o1, ref - 2.0, rtol=2e-3, atol=2e-2)
+    o2 = torch.full((N, K), 9.0, device="cuda")
+    ops.gemm_tn(A, B, R, N, K, o2, accumulate=False, workspace=ws)
+    if need:
+        assert torch.equal(o1, o2)
+    ops.gemm_tn(A, B, R, N, K, o2, accumulate=True, workspace=ws)
+    torch.testing.assert_close(o2, 2 * (ref - 2.0), rtol=2e-3, atol=4e-2)
     cs = torch.zeros(N, device="cuda")
     ops.colsum_bf16(A, R, N, cs)
     torch.testing.assert_close(cs, A.float().sum(0), rtol=1e-4, atol=1e-2)

@@ -27,4 +27,6 @@ for name, r, n, k in [("w_qkv", M, 2304, 768), ("w_fc1", M, 3072, 768), ("w_fc2"
     A = torch.randn(r, n, device="cuda").bfloat16(); B = torch.randn(r, k, device="cuda").bfloat16()
     o = torch.zeros(n, k, device="cuda")
     dt = t(lambda: ops.gemm_tn(A, B, r, n, k, o, accumulate=True))
-    print(f"{name:12s} R={r:6d} N={n:5d} K={k:5d}  tn {2*r*n*k/dt/1e12:7.1f} TF ({dt*1e6:7.1f} us)", flush=True)
+    ws = torch.empty(max(ops.gemm_tn_workspace(r, n, k), 16), dtype=torch.uint8, device="cuda")
+    dt2 = t(lambda: ops.gemm_tn(A, B, r, n, k, o, accumulate=True, workspace=ws))
+    print(f"{name:12s} R={r:6d} N={n:5d} K={k:5d}  tn {2*r*n*k/dt/1e12:7.1f} TF ({dt*1e6:7.1f} us) | workspace {2*r*n*k/dt2/1e12:7.1f} TF ({dt2*1e6:7.1f} us)", flush=True)
