@@ -65,10 +65,17 @@ __device__ __forceinline__ bf16x8 acc_frag(const f32x16& x, int s, float mul) {
 
 __device__ __attribute__((aligned(256))) unsigned char g_attn_zero_page[128];   // zero-initialised
 
-__device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst) {
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
-                                   (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
+// LDS-DMA (global_load_lds_dwordx4) as INLINE ASM: through the builtin, hipcc (ROCm 7.2) knows an
+// LDS write is pending on the VM counter and puts s_waitcnt vmcnt(0) in front of the next LDS read
+// it cannot disambiguate -- i.e. the first fragment read of the sample drained the prefetch of the
+// next sample that had just been issued.  The asm form is invisible to the waitcnt pass; the kernels
+// wait explicitly (ATTN_DMA_WAIT) in front of the barrier that publishes the images.
+__device__ __forceinline__ void glds16(const void* gsrc, char* lds_dst) {
+  const unsigned lds = __builtin_amdgcn_readfirstlane(
+      (unsigned)(unsigned long long)((__attribute__((address_space(3))) char*)lds_dst));
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(lds) : "memory", "m0");
 }
+#define ATTN_DMA_WAIT() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 
 // LDS image of a [TP tokens][64] bf16 head slice: 128-B rows, 16-B chunk c of token t lives at
 // chunk position c ^ ((t >> 1) & 7) (conflict-free ds_read_b128 row fragments).
@@ -112,14 +119,28 @@ __device__ __forceinline__ LaneOffs lane_offs(int lane) {
 __device__ __forceinline__ bf16x8 row_frag_o(const char* img, const LaneOffs& o, int kb, int t) {
   return *reinterpret_cast<const bf16x8*>(img + o.row[t] + kb * 4096);
 }
+// Column fragments use the transposing LDS read as INLINE ASM: with the builtin, hipcc (ROCm 7.2)
+// cannot tell these reads from the in-flight LDS-DMA of the next sample and drains it (s_waitcnt
+// vmcnt(0)) in front of the first read -- the prefetch then overlaps nothing.  The asm form is
+// invisible to the compiler's waitcnt pass: whoever consumes a fragment waits with LDS_TR_WAIT().
+__device__ __forceinline__ s16x4 lds_tr16_b64(unsigned lds_addr) {
+  s16x4 r;
+  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(r) : "v"(lds_addr) : "memory");
+  return r;
+}
+__device__ __forceinline__ unsigned lds_addr_of(const char* p) {
+  return (unsigned)(unsigned long long)((__attribute__((address_space(3))) const char*)p);
+}
+#define LDS_TR_WAIT()                                    \
+  do {                                                   \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   \
+    __builtin_amdgcn_sched_barrier(0);                   \
+  } while (0)
 __device__ __forceinline__ bf16x8 col_frag_o(const char* img, const LaneOffs& o, int kb, int ss, int db) {
-  const char* a0 = img + o.col[ss][db][0] + kb * 4096;
-  const char* a1 = img + o.col[ss][db][1] + kb * 4096;
-  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)a0);
-  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)a1);
+  const unsigned base = lds_addr_of(img) + kb * 4096;
   union { struct { s16x4 l, h; } s; bf16x8 v; } u;
-  u.s.l = lo;
-  u.s.h = hi;
+  u.s.l = lds_tr16_b64(base + o.col[ss][db][0]);
+  u.s.h = lds_tr16_b64(base + o.col[ss][db][1]);
   return u.v;
 }
 
@@ -211,6 +232,7 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(const __bf16* __restrict_
     bf16x8 Qf[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) Qf[t] = Qn[t];
+    ATTN_DMA_WAIT();
     __syncthreads();                         // sample b's images landed; sample b-1 fully consumed
     if (b + 1 < b1) {                        // prefetch sample b+1: register fragments first, then LDS-DMA
       const __bf16* s1 = qkv + (long long)(b + 1) * T * ldq + h * HD;
@@ -269,12 +291,19 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(const __bf16* __restrict_
       for (int i = 0; i < 16; ++i) o[db][i] = 0.f;
 #pragma unroll
     for (int kb = 0; kb < NKB; ++kb) {
+      bf16x8 vf[2][2];
 #pragma unroll
-      for (int ss = 0; ss < 2; ++ss) {
-        const bf16x8 pf = acc_frag(s[kb], ss, inv);
+      for (int ss = 0; ss < 2; ++ss)
 #pragma unroll
-        for (int db = 0; db < 2; ++db) o[db] = MFMA32(col_frag_o(Vs, lo, kb, ss, db), pf, o[db]);
-      }
+        for (int db = 0; db < 2; ++db) vf[ss][db] = col_frag_o(Vs, lo, kb, ss, db);
+      bf16x8 pf[2];
+#pragma unroll
+      for (int ss = 0; ss < 2; ++ss) pf[ss] = acc_frag(s[kb], ss, inv);
+      LDS_TR_WAIT();
+#pragma unroll
+      for (int ss = 0; ss < 2; ++ss)
+#pragma unroll
+        for (int db = 0; db < 2; ++db) o[db] = MFMA32(vf[ss][db], pf[ss], o[db]);
     }
     if (q < T) {
       __bf16* orow = out + ((long long)b * T + q) * ldo + h * HD;
@@ -371,6 +400,7 @@ __global__ __launch_bounds__(512) void attn_bwd_kv_kernel(const __bf16* __restri
       dmax = fmaxf(dmax, fabsf(deln));
     }
     if ((int)threadIdx.x < TP) { lseS[cur * TP + threadIdx.x] = lsen; delS[cur * TP + threadIdx.x] = deln; }
+    ATTN_DMA_WAIT();
     __syncthreads();
     if (b + 1 < b1) { load_next(b + 1); stage_sample(b + 1, cur ^ 1); }
     if (!active) continue;
@@ -417,11 +447,18 @@ __global__ __launch_bounds__(512) void attn_bwd_kv_kernel(const __bf16* __restri
       }
 #pragma unroll
       for (int ss = 0; ss < 2; ++ss) {
-        const bf16x8 pf = acc_frag(S, ss, 1.0f), dsf = acc_frag(dP, ss, 1.0f);
+        bf16x8 cdo[2], cq[2];
 #pragma unroll
         for (int db = 0; db < 2; ++db) {
-          dVt[db] = MFMA32(col_frag_o(dOs, lo, qb, ss, db), pf, dVt[db]);
-          dKt[db] = MFMA32(col_frag_o(Qs, lo, qb, ss, db), dsf, dKt[db]);
+          cdo[db] = col_frag_o(dOs, lo, qb, ss, db);
+          cq[db] = col_frag_o(Qs, lo, qb, ss, db);
+        }
+        const bf16x8 pf = acc_frag(S, ss, 1.0f), dsf = acc_frag(dP, ss, 1.0f);
+        LDS_TR_WAIT();
+#pragma unroll
+        for (int db = 0; db < 2; ++db) {
+          dVt[db] = MFMA32(cdo[db], pf, dVt[db]);
+          dKt[db] = MFMA32(cq[db], dsf, dKt[db]);
         }
       }
     }
@@ -549,6 +586,7 @@ __global__ __launch_bounds__(512) void attn_bwd_q_kernel(const __bf16* __restric
 #pragma unroll
     for (int t = 0; t < 4; ++t) { Qf[t] = Qn[t]; dOf[t] = dOn[t]; }
     const float lq = lqn, dq_ = dqn;
+    ATTN_DMA_WAIT();
     __syncthreads();                      // K/V of sample b landed; sample b-1 fully consumed
     if (b + 1 < b1) { load_q(b + 1); stage_sample(b + 1, cur ^ 1); }
     if (active) {
@@ -590,12 +628,19 @@ __global__ __launch_bounds__(512) void attn_bwd_q_kernel(const __bf16* __restric
             if (DT) atomicAdd(reinterpret_cast<int*>(reinterpret_cast<char*>(binsi) + idx4), __float2int_rn(ds * fx));
           }
         }
+        bf16x8 ckf[2][2];
 #pragma unroll
-        for (int ss = 0; ss < 2; ++ss) {
-          const bf16x8 dsf = acc_frag(dPt, ss, 1.0f);
+        for (int ss = 0; ss < 2; ++ss)
 #pragma unroll
-          for (int db = 0; db < 2; ++db) dQt[db] = MFMA32(col_frag_o(Ks, lo, kb, ss, db), dsf, dQt[db]);
-        }
+          for (int db = 0; db < 2; ++db) ckf[ss][db] = col_frag_o(Ks, lo, kb, ss, db);
+        bf16x8 dsf[2];
+#pragma unroll
+        for (int ss = 0; ss < 2; ++ss) dsf[ss] = acc_frag(dPt, ss, 1.0f);
+        LDS_TR_WAIT();
+#pragma unroll
+        for (int ss = 0; ss < 2; ++ss)
+#pragma unroll
+          for (int db = 0; db < 2; ++db) dQt[db] = MFMA32(ckf[ss][db], dsf[ss], dQt[db]);
       }
       // lane col = q, regs -> d ;  d(q_lin) = d(q') * scale
 #pragma unroll
