@@ -23,6 +23,12 @@ __device__ __forceinline__ float wmax(float v) {
   return v;
 }
 
+// a / b from r = rcp(b): q0 = a*r, one residual correction (correctly rounded away from denormals)
+__device__ __forceinline__ float div_newton(float a, float b, float r) {
+  const float q0 = a * r;
+  return fmaf(fmaf(-q0, b, a), r, q0);
+}
+
 constexpr int kMaxChunks = 8;   // float4 chunks per lane: D <= 64*4*8 = 2048
 
 // ---------------------------------------------------------------- LayerNorm forward
@@ -81,6 +87,9 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 // workgroup = 4 waves x kRowsPerWave rows; dx per row (wave reductions), dgamma/dbeta per lane
 // column accumulated in registers over the workgroup's rows, then LDS -> one atomic per column.
 
+// NCH = float4 chunks per lane (D <= 256 * NCH): the per-lane arrays are sized for THIS D -- sized for the
+// maximum they cost 198 VGPRs (2 waves per SIMD) and the kernel could not hide HBM latency.
+template <int NCH>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const __bf16* __restrict__ dy, long long lddy,
                                                      const float* __restrict__ x, long long ldx,
                                                      const int* __restrict__ row_idx, int R, int D,
@@ -94,9 +103,13 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const __bf16* __restrict__ 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nch = D >> 2;
   const float4* g4 = reinterpret_cast<const float4*>(gamma);
-  float4 ag[kMaxChunks], ab[kMaxChunks];
+  float4 ag[NCH], ab[NCH], gm[NCH];
 #pragma unroll
-  for (int c = 0; c < kMaxChunks; ++c) { ag[c] = float4{0, 0, 0, 0}; ab[c] = float4{0, 0, 0, 0}; }
+  for (int c = 0; c < NCH; ++c) {
+    ag[c] = float4{0, 0, 0, 0};
+    ab[c] = float4{0, 0, 0, 0};
+    gm[c] = (lane + c * 64 < nch) ? g4[lane + c * 64] : float4{0, 0, 0, 0};
+  }
   // rows are dealt to (workgroup, wave) round-robin: the column accumulators persist over ALL of a
   // workgroup's rows, so the number of same-address atomics is gridDim.x per column, not R/32
   for (int r = blockIdx.x * 4 + wave; r < R; r += gridDim.x * 4) {
@@ -104,15 +117,21 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const __bf16* __restrict__ 
     const float4* xr = reinterpret_cast<const float4*>(x + src * ldx);
     const bf16x4* dyr = reinterpret_cast<const bf16x4*>(dy + (long long)r * lddy);
     const float mu = mean[r], rs = rstd[r];
-    float4 xh[kMaxChunks], gg[kMaxChunks];
+    float4 xh[NCH], gg[NCH], prev[NCH];
+    float4* o = reinterpret_cast<float4*>(dres + src * lddres);
+    if (accumulate) {                       // issued with the row, not after the reductions
+#pragma unroll
+      for (int c = 0; c < NCH; ++c)
+        if (lane + c * 64 < nch) prev[c] = o[lane + c * 64];
+    }
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int c = 0; c < kMaxChunks; ++c) {
+    for (int c = 0; c < NCH; ++c) {
       const int i = lane + c * 64;
       if (i < nch) {
         const float4 xv = xr[i];
         const bf16x4 d4 = dyr[i];
-        const float4 g = g4[i];
+        const float4 g = gm[c];
         const float d0 = (float)d4[0], d1 = (float)d4[1], d2 = (float)d4[2], d3 = (float)d4[3];
         xh[c] = float4{(xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs};
         gg[c] = float4{d0 * g.x, d1 * g.y, d2 * g.z, d3 * g.w};
@@ -123,14 +142,13 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const __bf16* __restrict__ 
       }
     }
     const float m1 = wsum(s1) / (float)D, m2 = wsum(s2) / (float)D;
-    float4* o = reinterpret_cast<float4*>(dres + src * lddres);
 #pragma unroll
-    for (int c = 0; c < kMaxChunks; ++c) {
+    for (int c = 0; c < NCH; ++c) {
       const int i = lane + c * 64;
       if (i < nch) {
         float4 d{rs * (gg[c].x - m1 - xh[c].x * m2), rs * (gg[c].y - m1 - xh[c].y * m2),
                  rs * (gg[c].z - m1 - xh[c].z * m2), rs * (gg[c].w - m1 - xh[c].w * m2)};
-        if (accumulate) { const float4 p = o[i]; d.x += p.x; d.y += p.y; d.z += p.z; d.w += p.w; }
+        if (accumulate) { const float4 p = prev[c]; d.x += p.x; d.y += p.y; d.z += p.z; d.w += p.w; }
         o[i] = d;
       }
     }
@@ -138,7 +156,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const __bf16* __restrict__ 
   float4* rg = reinterpret_cast<float4*>(red + (size_t)wave * 2 * D);
   float4* rb = reinterpret_cast<float4*>(red + (size_t)wave * 2 * D + D);
 #pragma unroll
-  for (int c = 0; c < kMaxChunks; ++c) {
+  for (int c = 0; c < NCH; ++c) {
     const int i = lane + c * 64;
     if (i < nch) { rg[i] = ag[c]; rb[i] = ab[c]; }
   }
@@ -160,6 +178,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const __bf16* __restrict__ 
 // column sums cost gridDim.x atomics per column (same-address atomics are the slow part)
 constexpr int kBrMaxChunks = 8;   // float4 chunks per lane: D <= 2048
 
+template <int NCH>
 __global__ __launch_bounds__(256) void branch_bwd_kernel(const float* __restrict__ dx, long long lddx,
                                                          const __bf16* __restrict__ y, long long ldy,
                                                          const float* __restrict__ gamma,
@@ -170,9 +189,10 @@ __global__ __launch_bounds__(256) void branch_bwd_kernel(const float* __restrict
   extern __shared__ float red[];   // [4][2][D]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nch = D >> 2;
-  float4 g[kBrMaxChunks], ag[kBrMaxChunks], ab[kBrMaxChunks];
+  float4 g[NCH], ag[NCH], ab[NCH];
+  const float rk = __frcp_rn(keep);
 #pragma unroll
-  for (int c = 0; c < kBrMaxChunks; ++c) {
+  for (int c = 0; c < NCH; ++c) {
     const int i = lane + c * 64;
     g[c] = (gamma && i < nch) ? reinterpret_cast<const float4*>(gamma)[i] : float4{1.f, 1.f, 1.f, 1.f};
     ag[c] = float4{0, 0, 0, 0};
@@ -184,13 +204,13 @@ __global__ __launch_bounds__(256) void branch_bwd_kernel(const float* __restrict
     bf16x4* orow = reinterpret_cast<bf16x4*>(dyo + (long long)m * lddy);
     const float k = rowmask ? rowmask[m / rps] : 1.f;
 #pragma unroll
-    for (int c = 0; c < kBrMaxChunks; ++c) {
+    for (int c = 0; c < NCH; ++c) {
       const int i = lane + c * 64;
       if (i < nch) {
         float4 d = dr[i];
-        if (rowmask) {
-          d.x = __fdiv_rn(d.x * k, keep); d.y = __fdiv_rn(d.y * k, keep);
-          d.z = __fdiv_rn(d.z * k, keep); d.w = __fdiv_rn(d.w * k, keep);
+        if (rowmask) {                       // (dx * mask) / keep: reciprocal + one Newton step = the IEEE quotient
+          d.x = div_newton(d.x * k, keep, rk); d.y = div_newton(d.y * k, keep, rk);
+          d.z = div_newton(d.z * k, keep, rk); d.w = div_newton(d.w * k, keep, rk);
         }
         const bf16x4 yv = yr[i];
         ag[c].x += d.x * (float)yv[0]; ag[c].y += d.y * (float)yv[1];
@@ -206,7 +226,7 @@ __global__ __launch_bounds__(256) void branch_bwd_kernel(const float* __restrict
   float4* rg = reinterpret_cast<float4*>(red + (size_t)wave * 2 * D);
   float4* rb = reinterpret_cast<float4*>(red + (size_t)wave * 2 * D + D);
 #pragma unroll
-  for (int c = 0; c < kBrMaxChunks; ++c) {
+  for (int c = 0; c < NCH; ++c) {
     const int i = lane + c * 64;
     if (i < nch) { rg[i] = ag[c]; rb[i] = ab[c]; }
   }
@@ -379,9 +399,17 @@ extern "C" int memhip_layernorm_bwd(const void* dy, int64_t lddy, const float* x
   MEMHIP_REQUIRE(ldx % 4 == 0 && lddy % 4 == 0 && lddres % 4 == 0, "layernorm_bwd: ld must be a multiple of 4");
   int grid = cdiv(R, 4);
   if (grid > 1024) grid = 1024;                      // 4 workgroups per CU, ~50 rows per wave at ViT-B scale
-  hipLaunchKernelGGL(ln_bwd_kernel, dim3(grid), dim3(256), (size_t)8 * D * sizeof(float),
-                     as_stream(stream), (const __bf16*)dy, (long long)lddy, x, (long long)ldx, row_idx, R, D,
-                     gamma, mean, rstd, dres, (long long)lddres, accumulate, dgamma, dbeta);
+#define LNB_LAUNCH(N)                                                                                    \
+  hipLaunchKernelGGL(ln_bwd_kernel<N>, dim3(grid), dim3(256), (size_t)8 * D * sizeof(float), as_stream(stream), \
+                     (const __bf16*)dy, (long long)lddy, x, (long long)ldx, row_idx, R, D, gamma, mean, rstd, dres, \
+                     (long long)lddres, accumulate, dgamma, dbeta)
+  const int nchl = cdiv(D / 4, 64);
+  if (nchl <= 1) LNB_LAUNCH(1);
+  else if (nchl <= 2) LNB_LAUNCH(2);
+  else if (nchl <= 3) LNB_LAUNCH(3);
+  else if (nchl <= 4) LNB_LAUNCH(4);
+  else LNB_LAUNCH(8);
+#undef LNB_LAUNCH
   return check_launch("layernorm_bwd");
 }
 
@@ -396,9 +424,17 @@ extern "C" int memhip_branch_bwd(const float* dx, int64_t lddx, const void* y, i
   MEMHIP_REQUIRE(D <= 64 * 4 * kBrMaxChunks, "branch_bwd: D=%d too large", D);
   int grid = cdiv(M, 4);
   if (grid > 1024) grid = 1024;
-  hipLaunchKernelGGL(branch_bwd_kernel, dim3(grid), dim3(256), (size_t)8 * D * sizeof(float), as_stream(stream), dx,
-                     (long long)lddx, (const __bf16*)y, (long long)ldy, gamma, rowmask, keep_prob,
-                     rows_per_sample > 0 ? rows_per_sample : 1, M, D, (__bf16*)dy, (long long)lddy, dgamma, dbias);
+#define BRB_LAUNCH(N)                                                                                    \
+  hipLaunchKernelGGL(branch_bwd_kernel<N>, dim3(grid), dim3(256), (size_t)8 * D * sizeof(float), as_stream(stream), \
+                     dx, (long long)lddx, (const __bf16*)y, (long long)ldy, gamma, rowmask, keep_prob,    \
+                     rows_per_sample > 0 ? rows_per_sample : 1, M, D, (__bf16*)dy, (long long)lddy, dgamma, dbias)
+  const int nchl = cdiv(D / 4, 64);
+  if (nchl <= 1) BRB_LAUNCH(1);
+  else if (nchl <= 2) BRB_LAUNCH(2);
+  else if (nchl <= 3) BRB_LAUNCH(3);
+  else if (nchl <= 4) BRB_LAUNCH(4);
+  else BRB_LAUNCH(8);
+#undef BRB_LAUNCH
   return check_launch("branch_bwd");
 }
 
