@@ -198,28 +198,49 @@ __global__ __launch_bounds__(256) void branch_bwd_kernel(const float* __restrict
     ag[c] = float4{0, 0, 0, 0};
     ab[c] = float4{0, 0, 0, 0};
   }
-  for (int m = blockIdx.x * 4 + wave; m < M; m += gridDim.x * 4) {
-    const float4* dr = reinterpret_cast<const float4*>(dx + (long long)m * lddx);
-    const bf16x4* yr = reinterpret_cast<const bf16x4*>(y + (long long)m * ldy);
-    bf16x4* orow = reinterpret_cast<bf16x4*>(dyo + (long long)m * lddy);
-    const float k = rowmask ? rowmask[m / rps] : 1.f;
+  // two rows per iteration: both rows' loads are in flight before either is consumed
+  const int stride = gridDim.x * 4;
+  for (int m0 = blockIdx.x * 4 + wave; m0 < M; m0 += 2 * stride) {
+    float4 dv[2][NCH];
+    bf16x4 yv[2][NCH];
+    float kk[2];
 #pragma unroll
-    for (int c = 0; c < NCH; ++c) {
-      const int i = lane + c * 64;
-      if (i < nch) {
-        float4 d = dr[i];
-        if (rowmask) {                       // (dx * mask) / keep: reciprocal + one Newton step = the IEEE quotient
-          d.x = div_newton(d.x * k, keep, rk); d.y = div_newton(d.y * k, keep, rk);
-          d.z = div_newton(d.z * k, keep, rk); d.w = div_newton(d.w * k, keep, rk);
+    for (int u = 0; u < 2; ++u) {
+      const int m = m0 + u * stride;
+      const int mc = m < M ? m : M - 1;
+      const float4* dr = reinterpret_cast<const float4*>(dx + (long long)mc * lddx);
+      const bf16x4* yr = reinterpret_cast<const bf16x4*>(y + (long long)mc * ldy);
+      kk[u] = rowmask ? rowmask[mc / rps] : 1.f;
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        const int i = lane + c * 64;
+        if (i < nch) { dv[u][c] = dr[i]; yv[u][c] = yr[i]; }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int m = m0 + u * stride;
+      if (m >= M) break;
+      bf16x4* orow = reinterpret_cast<bf16x4*>(dyo + (long long)m * lddy);
+      const float k = kk[u];
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        const int i = lane + c * 64;
+        if (i < nch) {
+          float4 d = dv[u][c];
+          if (rowmask) {                       // (dx * mask) / keep: reciprocal + one Newton step = the IEEE quotient
+            d.x = div_newton(d.x * k, keep, rk); d.y = div_newton(d.y * k, keep, rk);
+            d.z = div_newton(d.z * k, keep, rk); d.w = div_newton(d.w * k, keep, rk);
+          }
+          const bf16x4 yy = yv[u][c];
+          ag[c].x += d.x * (float)yy[0]; ag[c].y += d.y * (float)yy[1];
+          ag[c].z += d.z * (float)yy[2]; ag[c].w += d.w * (float)yy[3];
+          bf16x4 o;
+          o[0] = (__bf16)(d.x * g[c].x); o[1] = (__bf16)(d.y * g[c].y);
+          o[2] = (__bf16)(d.z * g[c].z); o[3] = (__bf16)(d.w * g[c].w);
+          orow[i] = o;
+          ab[c].x += (float)o[0]; ab[c].y += (float)o[1]; ab[c].z += (float)o[2]; ab[c].w += (float)o[3];
         }
-        const bf16x4 yv = yr[i];
-        ag[c].x += d.x * (float)yv[0]; ag[c].y += d.y * (float)yv[1];
-        ag[c].z += d.z * (float)yv[2]; ag[c].w += d.w * (float)yv[3];
-        bf16x4 o;
-        o[0] = (__bf16)(d.x * g[c].x); o[1] = (__bf16)(d.y * g[c].y);
-        o[2] = (__bf16)(d.z * g[c].z); o[3] = (__bf16)(d.w * g[c].w);
-        orow[i] = o;
-        ab[c].x += (float)o[0]; ab[c].y += (float)o[1]; ab[c].z += (float)o[2]; ab[c].w += (float)o[3];
       }
     }
   }
