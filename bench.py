@@ -113,6 +113,8 @@ def main():
     masker = MaskingGenerator((14, 14), 98, min_num_patches=16, seed=1234 + rank)
     label_pool = torch.randint(0, 8192, (B * 98,), generator=torch.Generator().manual_seed(1234 + rank)).cuda()
     T = eng.T
+    from mem_amd.utils import HostStager
+    st_rows, st_mask = HostStager(B * 98 * 4, "cuda"), HostStager(B * 196, "cuda")
 
     def step(it):
         for grp in opt.param_groups:
@@ -120,8 +122,8 @@ def main():
         x = pipe(ev_dev, offsets)                                     # rasterize + event_norm (HIP)
         m = masker.batch_u8(B).reshape(B, -1)                         # host MT19937 (bit-exact CPython stream)
         bi, pi = np.nonzero(m)
-        rows = torch.from_numpy((bi * T + 1 + pi).astype(np.int32)).cuda(non_blocking=True)
-        mask_u8 = torch.from_numpy(m.reshape(-1)).cuda(non_blocking=True)
+        rows = st_rows.put((bi * T + 1 + pi).astype(np.int32))        # pinned ring: the host never waits for the queue
+        mask_u8 = st_mask.put(m.reshape(-1))
         labels = label_pool[: rows.numel()]
         la = model.forward_loss(x, None, labels, rows=rows, mask_u8=mask_u8)
         model.backward()

@@ -322,3 +322,39 @@ def get_event_vae(weight_path, image_size, device):
     vae.load_state_dict(weights)
     print(f"loaded event vae from {weight_path}")
     return vae
+
+
+class HostStager:
+    """Small host -> device uploads without stalling the launch queue.
+
+    ``tensor.cuda()`` from pageable memory blocks the host until the copy has run, i.e. until every
+    kernel queued before it has finished: one per training step is enough to drain the queue and
+    expose launch latency on the kernels that follow.  The stager keeps a ring of pinned host
+    buffers + device twins; ``put`` copies into the next pinned slot and issues an asynchronous
+    stream-ordered upload (an event per slot guards reuse)."""
+
+    def __init__(self, nbytes, device, slots=4):
+        import torch
+        self.host = [torch.empty(nbytes, dtype=torch.uint8).pin_memory() for _ in range(slots)]
+        self.dev = [torch.empty(nbytes, dtype=torch.uint8, device=device) for _ in range(slots)]
+        self.ev = [None] * slots
+        self.k = 0
+
+    def put(self, array):
+        """array: contiguous numpy array; returns a device tensor view (same dtype, flat) valid until
+        `slots` further calls."""
+        import numpy as np
+        import torch
+        k = self.k
+        self.k = (k + 1) % len(self.host)
+        if self.ev[k] is not None:
+            self.ev[k].synchronize()
+        flat = np.ascontiguousarray(array).reshape(-1)
+        n = flat.nbytes
+        assert n <= self.host[k].numel(), "HostStager slot too small"
+        self.host[k][:n].numpy()[:] = flat.view(np.uint8)
+        self.dev[k][:n].copy_(self.host[k][:n], non_blocking=True)
+        e = torch.cuda.Event()
+        e.record()
+        self.ev[k] = e
+        return self.dev[k][:n].view(torch.from_numpy(flat[:0]).dtype)
