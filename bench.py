@@ -59,6 +59,8 @@ def main():
     ap.add_argument("--events", type=int, default=30000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gemm-timer", action="store_true")
+    ap.add_argument("--no-tokenizer-figure", action="store_true",
+                    help="skip the secondary figure that adds the frozen dVAE tokenizer forward (stock PyTorch-ROCm)")
     a = ap.parse_args()
 
     import numpy as np
@@ -156,6 +158,31 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    # ---- secondary figure: the frozen tokenizer forward that the reference runs every step to make the
+    # labels (engine_for_pretraining.py:144); not part of `value` (BASELINE: tokenizer outside the timed set)
+    tok_ms = tok_torch_ms = None
+    if not a.no_tokenizer_figure:
+        try:
+            from mem_amd.vae_model import DiscreteVAE, HipTokenizer
+            vae = DiscreteVAE(input_H=H, input_W=W, num_tokens=8192, codebook_dim=512, num_layers=4,
+                              num_resnet_blocks=3, hidden_dim=384, channels=3).cuda().eval()
+            img = torch.rand(B, 3, H, W, device="cuda")
+            tok = HipTokenizer(vae, max_batch=B)
+
+            def _time(fn, n):
+                for _ in range(2):
+                    fn()
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(n):
+                    fn()
+                torch.cuda.synchronize()
+                return (time.perf_counter() - t1) / n * 1e3
+            tok_ms = _time(lambda: tok.get_codebook_indices(img), 5)
+            tok_torch_ms = _time(lambda: vae.get_codebook_indices(img), 2)
+            del vae, img, tok
+        except Exception as e:                                        # the figure is optional
+            print(f"[bench] tokenizer figure skipped: {e}", file=sys.stderr)
     if rank == 0:
         ms = dt / a.steps * 1e3
         value = world * B * a.steps / dt
@@ -206,6 +233,14 @@ def main():
                           "model_flops_frac_of_peak": round(value / world * FLOP_PER_SAMPLE[C] / (PEAK_BF16_TFLOPS * 1e12), 4),
                           "last_loss": round(loss_last, 4)},
                "roofline": roof}
+        if tok_ms is not None:
+            out["with_tokenizer"] = {"value": round(world * B / ((ms + tok_ms) * 1e-3), 1), "unit": "samples/sec",
+                                     "tokenizer_ms_per_step": round(tok_ms, 3),
+                                     "tokenizer_ms_stock_torch_fp32": round(tok_torch_ms, 3),
+                                     "note": "secondary figure (SURVEY section 8d): the same step plus the frozen dVAE "
+                                             "tokenizer forward (4 conv + 3 ResBlocks + 1x1 -> 8192, 24.4 GFLOP/sample, "
+                                             "random weights) on the HIP implicit-GEMM path (csrc/conv.hip, bf16); the "
+                                             "fp32 torch module on stock PyTorch-ROCm is timed beside it"}
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

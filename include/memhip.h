@@ -266,6 +266,27 @@ int memhip_attn_bwd(const void* qkv, int64_t ldqkv, const void* dout, int64_t ld
                     float* dv_bias, memhip_stream_t stream);
 
 /* ------------------------------------------------------------------------
+ * Frozen dVAE tokenizer forward
+ * replaces DiscreteVAE.get_codebook_indices          eventvae/vae/vae_model.py:153-158
+ *          encoder stack / ResBlock                   eventvae/vae/vae_model.py:29-42,86-101
+ * called every pretraining step at                   mem/engine_for_pretraining.py:144
+ * ------------------------------------------------------------------------
+ * Activations are bf16 NHWC with a one-pixel zero border: [B, H+2, W+2, C] (the caller zeroes the
+ * buffers once; the kernels only write interiors).  conv2d: out = [relu](conv(in, weight) + bias) [+ add];
+ * weight bf16 [C_out, k*k*C_in] packed (ky, kx, c)-major; shapes 4x4/s2/p1, 3x3/s1/p1, 1x1/s1/p0;
+ * C_in = 4 (first layer: 3 channels + 1 zero, 4x4 only) or a multiple of 64; out_padded = 0 writes a
+ * dense [B*Ho*Wo, C_out] matrix (the token logits).  `add` has the layout of `out` (ResBlock residual).
+ * Precision: bf16 operands, fp32 accumulate (the reference runs this stage in fp32 / TF32). */
+int memhip_conv2d_nhwc_bf16(const void* in, const void* weight, const float* bias, const void* add, void* out,
+                            int B, int H, int W, int Cin, int Cout, int ksize, int stride, int pad, int relu,
+                            int out_padded, memhip_stream_t stream);
+/* x f32 NCHW [B, C<=4, H, W] -> bf16 [B, H+2, W+2, 4] interior; mean/std f32 [C] or both NULL (DiscreteVAE.norm) */
+int memhip_nchw_to_padded_nhwc4(const float* x, int B, int C, int H, int W, const float* mean, const float* stdv,
+                                void* out, memhip_stream_t stream);
+/* ids i64 [M] = argmax over the N columns of logits bf16 [M, ld] (first maximum) */
+int memhip_argmax_rows_bf16(const void* logits, int64_t ld, int M, int N, int64_t* ids, memhip_stream_t stream);
+
+/* ------------------------------------------------------------------------
  * Layout / dtype movers
  * ------------------------------------------------------------------------ */
 int memhip_cast_f32_bf16(const float* in, void* out_bf16, int64_t n, memhip_stream_t stream);

@@ -84,6 +84,9 @@ declare({
     "memhip_im2col_bf16": (i32, [vp, i32, i32, i32, i32, i32, i32, vp, vp]),
     "memhip_fill_cls": (i32, [vp, i64, i32, i32, i32, vp, vp]),
     "memhip_gemv_bf16_acc": (i32, [vp, i64, i32, i32, vp, vp, vp, vp, vp]),
+    "memhip_conv2d_nhwc_bf16": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
+    "memhip_nchw_to_padded_nhwc4": (i32, [vp, i32, i32, i32, i32, vp, vp, vp, vp]),
+    "memhip_argmax_rows_bf16": (i32, [vp, i64, i32, i32, vp, vp]),
     "memhip_grad_norm_workspace": (sz, []),
     "memhip_grad_norm": (i32, [vp, i64, vp, vp, sz, vp]),
     "memhip_adamw": (i32, [vp, vp, vp, vp, i64, vp, f64, f64, f64, f64, f64, i32, vp, f64, vp]),
@@ -111,6 +114,22 @@ def gemv_acc(W, N, K, x, y, x_acc=None, zero=None):
     """y[N] += W[N,K] (bf16) @ x[K]; optionally x_acc += x and zero[:] = 0."""
     check(lib.memhip_gemv_bf16_acc(ptr(W), W.stride(0), N, K, ptr(x), ptr(y), ptr(x_acc), ptr(zero), stream_ptr()),
           "gemv_bf16_acc")
+
+
+def conv2d_nhwc(x_pad, weight, bias, out, B, H, W, Cin, Cout, ksize, stride, pad, relu=False, add=None, out_padded=True):
+    """x_pad bf16 [B,H+2,W+2,Cin] -> out bf16 [B,Ho+2,Wo+2,Cout] interior (or dense [B*Ho*Wo,Cout])."""
+    check(lib.memhip_conv2d_nhwc_bf16(ptr(x_pad), ptr(weight), ptr(bias), ptr(add), ptr(out), B, H, W, Cin, Cout, ksize,
+                                      stride, pad, int(relu), int(out_padded), stream_ptr()), "conv2d_nhwc_bf16")
+
+
+def nchw_to_padded_nhwc4(x, out, mean=None, std=None):
+    B, Cc, H, W = x.shape
+    check(lib.memhip_nchw_to_padded_nhwc4(ptr(x), B, Cc, H, W, ptr(mean), ptr(std), ptr(out), stream_ptr()),
+          "nchw_to_padded_nhwc4")
+
+
+def argmax_rows(logits, M, N, ids):
+    check(lib.memhip_argmax_rows_bf16(ptr(logits), logits.stride(0), M, N, ptr(ids), stream_ptr()), "argmax_rows_bf16")
 
 
 def embed_bwd(dx, mask_u8, B, L, D, dy, dcls, dmask_token):

@@ -70,3 +70,115 @@ class DiscreteVAE(nn.Module):
         b, n, d = emb.shape
         h, w = self.input_H // 2 ** self.num_layers, self.input_W // 2 ** self.num_layers
         return self.decoder(emb.transpose(1, 2).reshape(b, d, h, w))
+
+
+class HipTokenizer:
+    """`DiscreteVAE.get_codebook_indices` on the hand-written HIP path (csrc/conv.hip): bf16 NHWC
+    activations with a one-pixel zero border, implicit-GEMM convolutions on the MFMA GEMM tile with
+    fused bias / ReLU / residual, argmax over the token logits.  Built from a (frozen) `DiscreteVAE`
+    whose weights it packs once; the torch module stays the fp32 reference-exact form.
+
+    Precision: bf16 operands with fp32 accumulation where the reference runs fp32 convolutions
+    (TF32 on the GPUs it was written for); labels are discrete, the parity bar is token agreement
+    (tests/test_tokenizer_gpu.py)."""
+
+    def __init__(self, vae: "DiscreteVAE", max_batch=256):
+        from . import ops
+        self.ops = ops
+        dev = next(vae.parameters()).device
+        assert dev.type == "cuda", "HipTokenizer needs the model on the GPU"
+        self.dev, self.H, self.W = dev, vae.input_H, vae.input_W
+        self.num_tokens = vae.num_tokens
+        self.norm = None
+        if vae.normalization is not None:
+            m, s = (torch.as_tensor(t, dtype=torch.float32, device=dev).contiguous() for t in vae.normalization)
+            self.norm = (m, s)
+        self.layers = []                                   # (kind, weight, bias, Cin, Cout, k, stride, pad, relu)
+        mods = list(vae.encoder)
+        self.cin0 = None
+        for m in mods:
+            if isinstance(m, nn.Sequential):               # Conv2d(4, s2, p1) + ReLU
+                conv = m[0]
+                self.layers.append(("conv",) + self._pack(conv) + (True,))
+                if self.cin0 is None:
+                    self.cin0 = conv.in_channels
+            elif isinstance(m, ResBlock):
+                c1, c2, c3 = m.net[0], m.net[2], m.net[4]
+                self.layers.append(("res", self._pack(c1), self._pack(c2), self._pack(c3)))
+            else:                                          # final Conv2d(hidden, num_tokens, 1)
+                self.layers.append(("head",) + self._pack(m) + (False,))
+        assert self.cin0 is not None and self.cin0 <= 4, "first layer must have <= 4 input channels"
+        self.max_batch = 0
+        self._alloc(max_batch)
+
+    @staticmethod
+    def _pack(conv):
+        w = conv.weight.detach()                           # [Cout, Cin, k, k]
+        co, ci, k, _ = w.shape
+        w = w.permute(0, 2, 3, 1)                          # (ky, kx, c)-major
+        if ci < 4:
+            w = torch.nn.functional.pad(w, (0, 4 - ci))
+            ci = 4
+        wp = w.reshape(co, k * k * ci).to(torch.bfloat16).contiguous()
+        b = conv.bias.detach().float().contiguous() if conv.bias is not None else None
+        return (wp, b, ci, co, k, conv.stride[0], conv.padding[0])
+
+    def _alloc(self, B):
+        """Zero-bordered activation buffers for batch B (allocated once; only interiors are written)."""
+        if B <= self.max_batch:
+            return
+        dev, bf = self.dev, torch.bfloat16
+        self.max_batch = B
+        H, W = self.H, self.W
+        self.x0 = torch.zeros((B, H + 2, W + 2, 4), dtype=bf, device=dev)
+        self.bufs = {}
+        h, w = H, W
+        for L in self.layers:
+            if L[0] == "conv":
+                _, wp, b, ci, co, k, s, p, _ = L
+                h, w = (h + 2 * p - k) // s + 1, (w + 2 * p - k) // s + 1
+                key = (h, w, co)
+                if key not in self.bufs:
+                    self.bufs[key] = [torch.zeros((B, h + 2, w + 2, co), dtype=bf, device=dev) for _ in range(3)]
+            elif L[0] == "res":
+                key = (h, w, L[1][3])
+                if key not in self.bufs:
+                    self.bufs[key] = [torch.zeros((B, h + 2, w + 2, L[1][3]), dtype=bf, device=dev) for _ in range(3)]
+                while len(self.bufs[key]) < 3:
+                    self.bufs[key].append(torch.zeros_like(self.bufs[key][0]))
+        self.hw_out = (h, w)
+        self.logits = torch.empty((B * h * w, self.num_tokens), dtype=bf, device=dev)
+        self.ids = torch.empty((B * h * w,), dtype=torch.int64, device=dev)
+
+    @torch.no_grad()
+    def get_codebook_indices(self, images):
+        """images f32 [B, C, H, W] on the GPU -> i64 [B, h*w] token ids."""
+        ops = self.ops
+        assert images.is_cuda and images.dtype == torch.float32 and images.shape[-2:] == (self.H, self.W)
+        images = images.contiguous()
+        B = images.shape[0]
+        self._alloc(B)
+        ops.nchw_to_padded_nhwc4(images, self.x0, *(self.norm or (None, None)))
+        cur, h, w = self.x0, self.H, self.W
+        for L in self.layers:
+            if L[0] == "conv":
+                _, wp, b, ci, co, k, s, p, relu = L
+                ho, wo = (h + 2 * p - k) // s + 1, (w + 2 * p - k) // s + 1
+                out = self.bufs[(ho, wo, co)][0]
+                ops.conv2d_nhwc(cur, wp, b, out, B, h, w, ci, co, k, s, p, relu=relu)
+                cur, h, w = out, ho, wo
+            elif L[0] == "res":
+                (w1, b1, ci, co, k1, s1, p1), (w2, b2, _, _, k2, s2, p2), (w3, b3, _, _, k3, s3, p3) = L[1], L[2], L[3]
+                pool = self.bufs[(h, w, co)]
+                t1 = next(t for t in pool if t is not cur)
+                t2 = next(t for t in pool if t is not cur and t is not t1)
+                ops.conv2d_nhwc(cur, w1, b1, t1, B, h, w, ci, co, k1, s1, p1, relu=True)
+                ops.conv2d_nhwc(t1, w2, b2, t2, B, h, w, co, co, k2, s2, p2, relu=True)
+                ops.conv2d_nhwc(t2, w3, b3, t1, B, h, w, co, co, k3, s3, p3, relu=False, add=cur)   # net(x) + x
+                cur = t1
+            else:
+                _, wp, b, ci, co, k, s, p, _ = L
+                ops.conv2d_nhwc(cur, wp, b, self.logits, B, h, w, ci, co, k, s, p, relu=False, out_padded=False)
+        M = B * h * w
+        ops.argmax_rows(self.logits, M, self.num_tokens, self.ids)
+        return self.ids[:M].view(B, h * w).clone()

@@ -127,3 +127,27 @@ def test_vit_tiny_train_golden():
         xb, mb, lb = vit_inputs(TINY, 4, 1000 + it % 8, 6)
         loss, gn, acc = V.train_step(m, opt, xb, mb, lb, it, g["lr"], g["wd"], clip_grad=30.0)
         assert loss == g["fp32__loss"][it] and gn == g["fp32__gnorm"][it], it
+
+
+def test_vae_tokenizer_oracle_and_module_vs_reference_golden():
+    """tests/golden/vae_tiny.npz was written by the REFERENCE DiscreteVAE (oracle/gen_golden_vae.py):
+    the oracle restatement and the product's torch module must reproduce its logits and ids exactly."""
+    import os
+    import numpy as np
+    import torch
+    from oracle.vae_ref import TINY_VAE, encoder_logits, fill_vae_by_name, get_codebook_indices, vae_inputs
+    from mem_amd.vae_model import DiscreteVAE
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "vae_tiny.npz"))
+    torch.set_num_threads(1)
+    m = DiscreteVAE(**TINY_VAE).eval()
+    sd = fill_vae_by_name(m.state_dict(), seed=0)
+    assert sorted(sd.keys()) == list(g["keys"])                   # same module tree / checkpoint keys
+    m.load_state_dict(sd)
+    img = vae_inputs(TINY_VAE, 6, 11)
+    with torch.no_grad():
+        lo = encoder_logits(sd, img, TINY_VAE["num_layers"], TINY_VAE["num_resnet_blocks"])
+        ids = get_codebook_indices(sd, img, TINY_VAE["num_layers"], TINY_VAE["num_resnet_blocks"])
+        assert np.array_equal(lo[0].numpy(), g["logits_b0"])
+        assert np.array_equal(ids.numpy().astype(np.int32), g["ids"])
+        assert np.array_equal(m.get_codebook_indices(img).numpy().astype(np.int32), g["ids"])
+        assert torch.equal(m(img, return_logits=True), lo)

@@ -1,0 +1,106 @@
+"""dVAE tokenizer forward on the HIP path (csrc/conv.hip) vs the torch module
+(reference: eventvae/vae/vae_model.py:29-113,153-158).  Labels are discrete: the bar is token
+agreement with the fp32 module, plus layer-level numeric checks of the implicit-GEMM convolution."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _vae(hidden, tokens, res, size, layers=4, seed=0):
+    from mem_amd.vae_model import DiscreteVAE
+    torch.manual_seed(seed)
+    return DiscreteVAE(input_H=size, input_W=size, num_tokens=tokens, codebook_dim=64, num_layers=layers,
+                       num_resnet_blocks=res, hidden_dim=hidden, channels=3).cuda().eval()
+
+
+@pytest.mark.parametrize("k,s,p,cin,cout,h", [(4, 2, 1, 64, 128, 16), (3, 1, 1, 128, 64, 14), (1, 1, 0, 64, 256, 14),
+                                              (4, 2, 1, 4, 64, 32)])
+def test_conv_layers_vs_torch(k, s, p, cin, cout, h):
+    from mem_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(k * 100 + cin)
+    B = 3
+    x = torch.randn(B, cin, h, h, generator=g, device="cuda")
+    if cin == 4:
+        x[:, 3] = 0
+    w = torch.randn(cout, cin, k, k, generator=g, device="cuda") * 0.05
+    b = torch.randn(cout, generator=g, device="cuda")
+    xb, wb = x.bfloat16(), w.bfloat16()
+    ref = torch.nn.functional.conv2d(xb.float(), wb.float(), b, stride=s, padding=p)
+    ho = ref.shape[-1]
+    xp = torch.zeros(B, h + 2, h + 2, cin, dtype=torch.bfloat16, device="cuda")
+    xp[:, 1:-1, 1:-1] = xb.permute(0, 2, 3, 1)
+    wp = wb.permute(0, 2, 3, 1).reshape(cout, -1).contiguous()
+    out = torch.zeros(B, ho + 2, ho + 2, cout, dtype=torch.bfloat16, device="cuda")
+    add = torch.zeros_like(out)
+    add[:, 1:-1, 1:-1] = torch.randn(B, ho, ho, cout, generator=g, device="cuda").bfloat16()
+    ops.conv2d_nhwc(xp, wp, b, out, B, h, h, cin, cout, k, s, p, relu=True)
+    got = out[:, 1:-1, 1:-1].permute(0, 3, 1, 2).float()
+    torch.testing.assert_close(got, torch.relu(ref).bfloat16().float(), rtol=2e-2, atol=2e-2)
+    assert out[:, 0].abs().max() == 0 and out[:, :, 0].abs().max() == 0          # the border stays zero
+    ops.conv2d_nhwc(xp, wp, b, out, B, h, h, cin, cout, k, s, p, relu=False, add=add)
+    want = (ref.bfloat16().float() + add[:, 1:-1, 1:-1].permute(0, 3, 1, 2).float()).bfloat16().float()
+    torch.testing.assert_close(out[:, 1:-1, 1:-1].permute(0, 3, 1, 2).float(), want, rtol=2e-2, atol=3e-2)
+    dense = torch.zeros(B * ho * ho, cout, dtype=torch.bfloat16, device="cuda")
+    ops.conv2d_nhwc(xp, wp, b, dense, B, h, h, cin, cout, k, s, p, relu=False, out_padded=False)
+    torch.testing.assert_close(dense.view(B, ho, ho, cout).permute(0, 3, 1, 2).float(), ref.bfloat16().float(),
+                               rtol=2e-2, atol=2e-2)
+
+
+def test_argmax_rows_first_maximum():
+    from mem_amd import ops
+    x = torch.randn(1000, 8192, device="cuda").bfloat16()
+    x[5, 100] = x[5, 7000] = 50.0                                  # tie: first index wins
+    ids = torch.empty(1000, dtype=torch.int64, device="cuda")
+    ops.argmax_rows(x, 1000, 8192, ids)
+    assert ids[5].item() == 100
+    assert torch.equal(x.float().gather(1, ids.view(-1, 1)).view(-1), x.float().max(1).values)
+
+
+@pytest.mark.parametrize("hidden,tokens,res,size", [(64, 512, 2, 64), (128, 1024, 1, 96)])
+def test_tokenizer_agreement_with_fp32_module(hidden, tokens, res, size):
+    from mem_amd.vae_model import HipTokenizer
+    vae = _vae(hidden, tokens, res, size)
+    tok = HipTokenizer(vae, max_batch=8)
+    img = torch.rand(8, 3, size, size, device="cuda")
+    ref = vae.get_codebook_indices(img)
+    ids = tok.get_codebook_indices(img)
+    assert ids.shape == ref.shape and ids.dtype == torch.int64
+    agree = (ids == ref).float().mean().item()
+    # where they differ, the fp32 logits of the two candidates must be a near tie
+    lg = vae(img, return_logits=True).flatten(2).transpose(1, 2)                  # [B, hw, tokens]
+    gap = (lg.gather(2, ref.unsqueeze(-1)) - lg.gather(2, ids.unsqueeze(-1))).squeeze(-1)
+    spread = lg.std().item()
+    assert agree >= 0.97, agree
+    assert gap.max().item() <= 0.05 * spread + 1e-3, (gap.max().item(), spread)
+
+
+def test_tokenizer_vit_b_config_shapes():
+    """The MEM tokenizer (4 layers, hidden 384, 3 ResBlocks, 8192 tokens, 224x224) at a small batch."""
+    from mem_amd.vae_model import HipTokenizer
+    vae = _vae(384, 8192, 3, 224, seed=3)
+    tok = HipTokenizer(vae, max_batch=4)
+    img = torch.rand(4, 3, 224, 224, device="cuda")
+    ids = tok.get_codebook_indices(img)
+    ref = vae.get_codebook_indices(img)
+    assert ids.shape == (4, 196)
+    assert (ids == ref).float().mean().item() >= 0.97
+
+
+def test_tokenizer_vs_reference_golden():
+    """ids written by the reference DiscreteVAE (tests/golden/vae_tiny.npz, fp32): the bf16 HIP path must
+    agree except where the reference's own top-2 logit gap is small."""
+    import os
+    import numpy as np
+    from oracle.vae_ref import TINY_VAE, fill_vae_by_name, vae_inputs
+    from mem_amd.vae_model import DiscreteVAE, HipTokenizer
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "vae_tiny.npz"))
+    m = DiscreteVAE(**TINY_VAE).eval()
+    m.load_state_dict(fill_vae_by_name(m.state_dict(), seed=0))
+    tok = HipTokenizer(m.cuda(), max_batch=6)
+    ids = tok.get_codebook_indices(vae_inputs(TINY_VAE, 6, 11).cuda()).cpu().numpy()
+    want, gap = g["ids"], g["top2_gap"]
+    diff = ids != want
+    assert diff.mean() <= 0.03, diff.mean()
+    spread = float(g["logits_b0"].std())
+    assert (gap[diff] <= 0.05 * spread + 1e-3).all(), (gap[diff].max(), spread)
