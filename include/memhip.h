@@ -214,6 +214,16 @@ int memhip_layernorm_bwd(const void* dy_bf16, int64_t lddy, const float* x, int6
                          const float* rstd, float* dres, int64_t lddres, int accumulate, float* dgamma,
                          float* dbeta, memhip_stream_t stream);
 
+/* memhip_layernorm_bwd (accumulating, no row gather) fused with the memhip_branch_bwd that follows it in a
+ * block's backward: the updated dres row is consumed in registers (one pass over the fp32 gradient stream
+ * less).  Arguments = those of the two calls; D <= 1024. */
+int memhip_layernorm_bwd_branch(const void* dy_bf16, int64_t lddy, const float* x, int64_t ldx, int R, int D,
+                                const float* gamma, const float* mean, const float* rstd, float* dres,
+                                int64_t lddres, float* dgamma, float* dbeta, const void* y_branch_bf16, int64_t ldyb,
+                                const float* gamma_branch, const float* rowmask, float keep_prob,
+                                int rows_per_sample, void* dy_branch_bf16, int64_t lddyb, float* dgamma_branch,
+                                float* dbias_branch, memhip_stream_t stream);
+
 /* Backward of `x = x + drop_path(gamma * y)` (mem/modeling_finetune.py:187-188):
  * dy bf16 = bf16(dt * gamma), dgamma += sum_m dt*y, dbias += sum_m dy with
  * dt = dx * rowmask[m / rows_per_sample] / keep_prob.  gamma/rowmask/dgamma/dbias may be NULL. */

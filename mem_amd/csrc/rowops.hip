@@ -261,6 +261,106 @@ __global__ __launch_bounds__(256) void branch_bwd_kernel(const float* __restrict
   }
 }
 
+// ---------------------------------------------------------------- fused LayerNorm backward + next branch backward
+// In the backward of a block the LayerNorm gradient is added to the residual-stream gradient dx and the
+// very next kernel (the backward of the previous residual branch) reads that dx back: fused, the row of
+// dx is produced, stored and consumed in registers -- one pass over the fp32 gradient stream less.
+//   dx[r] += LN'(dy[r]) ;  dt = dx[r] * mask[r / rps] / keep ;  dyb[r] = bf16(dt * gb) ;
+//   dgamma_ln += sum dy*xhat ; dbeta_ln += sum dy ; dgb += sum dt*y ; dbias_b += sum dyb
+template <int NCH>
+__global__ __launch_bounds__(256) void ln_bwd_branch_kernel(const __bf16* __restrict__ dy, long long lddy,
+                                                            const float* __restrict__ x, long long ldx, int R, int D,
+                                                            const float* __restrict__ gamma,
+                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                            float* __restrict__ dres, long long lddres,
+                                                            float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                            const __bf16* __restrict__ yb, long long ldyb,
+                                                            const float* __restrict__ gb, const float* __restrict__ rowmask,
+                                                            float keep, int rps, __bf16* __restrict__ dyo, long long lddyo,
+                                                            float* __restrict__ dgb, float* __restrict__ dbiasb) {
+  extern __shared__ float red[];   // [4][4][D]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nch = D >> 2;
+  float4 ag[NCH], ab[NCH], bg[NCH], bb[NCH], gm[NCH], gbr[NCH];
+  const float rk = __frcp_rn(keep);
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int i = lane + c * 64;
+    ag[c] = ab[c] = bg[c] = bb[c] = float4{0, 0, 0, 0};
+    gm[c] = i < nch ? reinterpret_cast<const float4*>(gamma)[i] : float4{0, 0, 0, 0};
+    gbr[c] = (gb && i < nch) ? reinterpret_cast<const float4*>(gb)[i] : float4{1.f, 1.f, 1.f, 1.f};
+  }
+  for (int r = blockIdx.x * 4 + wave; r < R; r += gridDim.x * 4) {
+    const float4* xr = reinterpret_cast<const float4*>(x + (long long)r * ldx);
+    const bf16x4* dyr = reinterpret_cast<const bf16x4*>(dy + (long long)r * lddy);
+    const bf16x4* ybr = reinterpret_cast<const bf16x4*>(yb + (long long)r * ldyb);
+    float4* o = reinterpret_cast<float4*>(dres + (long long)r * lddres);
+    const float mu = mean[r], rs = rstd[r];
+    const float km = rowmask ? rowmask[r / rps] : 1.f;
+    float4 xh[NCH], gg[NCH], prev[NCH];
+    bf16x4 yv[NCH];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int i = lane + c * 64;
+      if (i < nch) {
+        prev[c] = o[i];
+        yv[c] = ybr[i];
+        const float4 xv = xr[i];
+        const bf16x4 d4 = dyr[i];
+        const float d0 = (float)d4[0], d1 = (float)d4[1], d2 = (float)d4[2], d3 = (float)d4[3];
+        xh[c] = float4{(xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs};
+        gg[c] = float4{d0 * gm[c].x, d1 * gm[c].y, d2 * gm[c].z, d3 * gm[c].w};
+        s1 += (gg[c].x + gg[c].y) + (gg[c].z + gg[c].w);
+        s2 += (gg[c].x * xh[c].x + gg[c].y * xh[c].y) + (gg[c].z * xh[c].z + gg[c].w * xh[c].w);
+        ag[c].x += d0 * xh[c].x; ag[c].y += d1 * xh[c].y; ag[c].z += d2 * xh[c].z; ag[c].w += d3 * xh[c].w;
+        ab[c].x += d0; ab[c].y += d1; ab[c].z += d2; ab[c].w += d3;
+      }
+    }
+    const float m1 = wsum(s1) / (float)D, m2 = wsum(s2) / (float)D;
+    bf16x4* orow = reinterpret_cast<bf16x4*>(dyo + (long long)r * lddyo);
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int i = lane + c * 64;
+      if (i < nch) {
+        float4 d{prev[c].x + rs * (gg[c].x - m1 - xh[c].x * m2), prev[c].y + rs * (gg[c].y - m1 - xh[c].y * m2),
+                 prev[c].z + rs * (gg[c].z - m1 - xh[c].z * m2), prev[c].w + rs * (gg[c].w - m1 - xh[c].w * m2)};
+        o[i] = d;
+        if (rowmask) {
+          d.x = div_newton(d.x * km, keep, rk); d.y = div_newton(d.y * km, keep, rk);
+          d.z = div_newton(d.z * km, keep, rk); d.w = div_newton(d.w * km, keep, rk);
+        }
+        bg[c].x += d.x * (float)yv[c][0]; bg[c].y += d.y * (float)yv[c][1];
+        bg[c].z += d.z * (float)yv[c][2]; bg[c].w += d.w * (float)yv[c][3];
+        bf16x4 q;
+        q[0] = (__bf16)(d.x * gbr[c].x); q[1] = (__bf16)(d.y * gbr[c].y);
+        q[2] = (__bf16)(d.z * gbr[c].z); q[3] = (__bf16)(d.w * gbr[c].w);
+        orow[i] = q;
+        bb[c].x += (float)q[0]; bb[c].y += (float)q[1]; bb[c].z += (float)q[2]; bb[c].w += (float)q[3];
+      }
+    }
+  }
+  float4* r0 = reinterpret_cast<float4*>(red + (size_t)wave * 4 * D);
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int i = lane + c * 64;
+    if (i < nch) { r0[i] = ag[c]; r0[nch + i] = ab[c]; r0[2 * nch + i] = bg[c]; r0[3 * nch + i] = bb[c]; }
+  }
+  __syncthreads();
+  for (int n = threadIdx.x; n < D; n += 256) {
+    float a = 0.f, b = 0.f, c2 = 0.f, d2 = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const float* rw = red + (size_t)w * 4 * D;
+      a += rw[n]; b += rw[D + n]; c2 += rw[2 * D + n]; d2 += rw[3 * D + n];
+    }
+    atomicAdd(dgamma + n, a);
+    atomicAdd(dbeta + n, b);
+    if (dgb) atomicAdd(dgb + n, c2);
+    if (dbiasb) atomicAdd(dbiasb + n, d2);
+  }
+}
+
 // ---------------------------------------------------------------- patch-embed / token backward
 // forward (modeling_pretrain.py:101-108): row b*(L+1) = cls ; row b*(L+1)+1+p = y*(1-w) + mask_token*w
 // backward: dcls += dx[cls rows]; dmask_token += sum dx*w; dy = bf16(dx*(1-w))
@@ -490,4 +590,33 @@ extern "C" int memhip_cross_entropy(void* logits, int64_t ld, const int64_t* lab
 #undef CE_LAUNCH
   hipLaunchKernelGGL(ce_reduce_kernel, dim3(1), dim3(256), 0, s, row_loss, row_correct, M, out2);
   return check_launch("cross_entropy");
+}
+
+extern "C" int memhip_layernorm_bwd_branch(const void* dy, int64_t lddy, const float* x, int64_t ldx, int R, int D,
+                                           const float* gamma, const float* mean, const float* rstd, float* dres,
+                                           int64_t lddres, float* dgamma, float* dbeta, const void* y_branch,
+                                           int64_t ldyb, const float* gamma_branch, const float* rowmask,
+                                           float keep_prob, int rows_per_sample, void* dy_branch, int64_t lddyb,
+                                           float* dgamma_branch, float* dbias_branch, memhip_stream_t stream) {
+  MEMHIP_REQUIRE(R >= 0 && D > 0 && D % 4 == 0 && D <= 64 * 4 * 4, "layernorm_bwd_branch: D=%d unsupported (<= 1024)", D);
+  if (R == 0) return MEMHIP_OK;
+  MEMHIP_REQUIRE(dy && x && gamma && mean && rstd && dres && dgamma && dbeta && y_branch && dy_branch,
+                 "layernorm_bwd_branch: null pointer");
+  MEMHIP_REQUIRE(ldx % 4 == 0 && lddy % 4 == 0 && lddres % 4 == 0 && ldyb % 4 == 0 && lddyb % 4 == 0,
+                 "layernorm_bwd_branch: ld must be a multiple of 4");
+  int grid = cdiv(R, 4);
+  if (grid > 1024) grid = 1024;
+#define LBB_LAUNCH(N)                                                                                    \
+  hipLaunchKernelGGL(ln_bwd_branch_kernel<N>, dim3(grid), dim3(256), (size_t)16 * D * sizeof(float),      \
+                     as_stream(stream), (const __bf16*)dy, (long long)lddy, x, (long long)ldx, R, D, gamma, mean, \
+                     rstd, dres, (long long)lddres, dgamma, dbeta, (const __bf16*)y_branch, (long long)ldyb, \
+                     gamma_branch, rowmask, keep_prob, rows_per_sample > 0 ? rows_per_sample : 1,         \
+                     (__bf16*)dy_branch, (long long)lddyb, dgamma_branch, dbias_branch)
+  const int nchl = cdiv(D / 4, 64);
+  if (nchl <= 1) LBB_LAUNCH(1);
+  else if (nchl <= 2) LBB_LAUNCH(2);
+  else if (nchl <= 3) LBB_LAUNCH(3);
+  else LBB_LAUNCH(4);
+#undef LBB_LAUNCH
+  return check_launch("layernorm_bwd_branch");
 }

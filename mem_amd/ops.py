@@ -70,6 +70,8 @@ f64 = C.c_double
 declare({
     "memhip_layernorm_fwd": (i32, [vp, i64, vp, i32, i32, vp, vp, f32, vp, i64, vp, vp, vp]),
     "memhip_layernorm_bwd": (i32, [vp, i64, vp, i64, vp, i32, i32, vp, vp, vp, vp, i64, i32, vp, vp, vp]),
+    "memhip_layernorm_bwd_branch": (i32, [vp, i64, vp, i64, i32, i32, vp, vp, vp, vp, i64, vp, vp, vp, i64, vp, vp, f32,
+                                          i32, vp, i64, vp, vp, vp]),
     "memhip_branch_bwd": (i32, [vp, i64, vp, i64, vp, vp, f32, i32, i32, i32, vp, i64, vp, vp, vp]),
     "memhip_embed_bwd": (i32, [vp, i64, vp, i32, i32, i32, vp, i64, vp, vp, vp]),
     "memhip_cross_entropy": (i32, [vp, i64, vp, i32, i32, f32, vp, vp, i32, vp, vp]),
@@ -102,6 +104,16 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dres, dgamma, dbeta, R, D, accumulat
     check(lib.memhip_layernorm_bwd(ptr(dy), dy.stride(0), ptr(x), x.stride(0), ptr(row_idx), R, D, ptr(gamma),
                                    ptr(mean), ptr(rstd), ptr(dres), dres.stride(0), int(accumulate),
                                    ptr(dgamma), ptr(dbeta), stream_ptr()), "layernorm_bwd")
+
+
+def layernorm_bwd_branch(dy, x, gamma, mean, rstd, dres, dgamma, dbeta, R, D, y_b, gamma_b, dy_b, dgamma_b, dbias_b,
+                         rowmask=None, keep_prob=1.0, rows_per_sample=1):
+    """layernorm_bwd(accumulate=True) + the branch_bwd that reads the updated dres, in one pass."""
+    check(lib.memhip_layernorm_bwd_branch(ptr(dy), dy.stride(0), ptr(x), x.stride(0), R, D, ptr(gamma), ptr(mean),
+                                          ptr(rstd), ptr(dres), dres.stride(0), ptr(dgamma), ptr(dbeta), ptr(y_b),
+                                          y_b.stride(0), ptr(gamma_b), ptr(rowmask), keep_prob, rows_per_sample,
+                                          ptr(dy_b), dy_b.stride(0), ptr(dgamma_b), ptr(dbias_b), stream_ptr()),
+          "layernorm_bwd_branch")
 
 
 def branch_bwd(dx, y, gamma, dy, dgamma, dbias, M, D, rowmask=None, keep_prob=1.0, rows_per_sample=1):

@@ -17,6 +17,8 @@ MI355X-first structure (not an autograd graph):
 """
 import math
 
+import os
+
 import torch
 
 from . import ops
@@ -294,6 +296,7 @@ class ViTEngine:
             self.grad_hook(0)
         dtable = self.G("rel_pos_bias.relative_position_bias_table")
         table = self.P("rel_pos_bias.relative_position_bias_table")
+        fuse = D <= 1024 and os.environ.get("MEMHIP_FUSE_LN_BRANCH", "1") != "0"
         for i in reversed(range(self.depth)):
             pre = f"blocks.{i}."
             a = self.act[i]
@@ -302,26 +305,37 @@ class ViTEngine:
             use_dp = dp_masks is not None and blk.drop_prob > 0.0
             xin, xmid = self.x[2 * i], self.x[2 * i + 1]
             has_g = (pre + "gamma_1") in self.segs
-            # -- MLP branch
-            ops.branch_bwd(dx, a["y2"], self.P(pre + "gamma_2") if has_g else None, self.dY,
-                           self.G(pre + "gamma_2") if has_g else None, self.G(pre + "mlp.fc2.bias"), M, D,
-                           rowmask=dp_masks[2 * i + 1] if use_dp else None, keep_prob=keep, rows_per_sample=T)
+            # -- MLP branch (for every block but the last this already ran fused into the norm1 backward of
+            # block i+1, see below)
+            if i == self.depth - 1 or not fuse:
+                ops.branch_bwd(dx, a["y2"], self.P(pre + "gamma_2") if has_g else None, self.dY,
+                               self.G(pre + "gamma_2") if has_g else None, self.G(pre + "mlp.fc2.bias"), M, D,
+                               rowmask=dp_masks[2 * i + 1] if use_dp else None, keep_prob=keep, rows_per_sample=T)
             ops.gemm_nt(self.dY, self.wT[i]["fc2"], M, Hd, D, ops.EPI_DGELU, out0=self.dbig, aux=a["hpre"],
                         colsum=self.G(pre + "mlp.fc1.bias"))        # fc1 bias grad = column sums of dh
             self._wgrad(self.dY, a["a"], M, D, Hd, pre + "mlp.fc2.weight")
             self._wgrad(self.dbig, a["h2"], M, Hd, D, pre + "mlp.fc1.weight")
             ops.gemm_nt(self.dbig, self.wT[i]["fc1"], M, D, Hd, ops.EPI_BIAS_BF16, out0=self.dh_small)
-            ops.layernorm_bwd(self.dh_small, xmid, self.P(pre + "norm2.weight"), a["mean2"], a["rstd2"], dx,
-                              self.G(pre + "norm2.weight"), self.G(pre + "norm2.bias"), M, D, accumulate=True)
+            scr = self.bias_scr[i & 1]
+            if fuse:
+                # norm2 backward + attention-branch backward in one pass over dx (proj.bias column sums -> scr)
+                ops.layernorm_bwd_branch(self.dh_small, xmid, self.P(pre + "norm2.weight"), a["mean2"], a["rstd2"], dx,
+                                         self.G(pre + "norm2.weight"), self.G(pre + "norm2.bias"), M, D, a["y1"],
+                                         self.P(pre + "gamma_1") if has_g else None, self.dY,
+                                         self.G(pre + "gamma_1") if has_g else None, scr,
+                                         rowmask=dp_masks[2 * i] if use_dp else None, keep_prob=keep, rows_per_sample=T)
+            else:
+                ops.layernorm_bwd(self.dh_small, xmid, self.P(pre + "norm2.weight"), a["mean2"], a["rstd2"], dx,
+                                  self.G(pre + "norm2.weight"), self.G(pre + "norm2.bias"), M, D, accumulate=True)
             # -- attention branch
             # proj.bias gradient (column sums of dY) goes to a scratch vector first: the v_bias gradient is
             # derived from it.  sum_k dV[k] = sum_q dO[q] * sum_k P[q,k] and the softmax rows sum to one, so
             # v_bias.grad = colsum(d attn_out) = colsum(dY) @ W_proj: one 768x768 GEMV instead of column
             # sums inside the attention kernel (which cost it 32 VGPRs and its occupancy).
-            scr = self.bias_scr[i & 1]
-            ops.branch_bwd(dx, a["y1"], self.P(pre + "gamma_1") if has_g else None, self.dY,
-                           self.G(pre + "gamma_1") if has_g else None, scr, M, D,
-                           rowmask=dp_masks[2 * i] if use_dp else None, keep_prob=keep, rows_per_sample=T)
+            if not fuse:
+                ops.branch_bwd(dx, a["y1"], self.P(pre + "gamma_1") if has_g else None, self.dY,
+                               self.G(pre + "gamma_1") if has_g else None, scr, M, D,
+                               rowmask=dp_masks[2 * i] if use_dp else None, keep_prob=keep, rows_per_sample=T)
             ops.gemm_nt(self.dY, self.wT[i]["proj"], M, D, D, ops.EPI_BIAS_BF16, out0=self.dao)
             ops.gemv_acc(self.wT[i]["proj"], D, D, scr, self.G(pre + "attn.v_bias"),
                          x_acc=self.G(pre + "attn.proj.bias"), zero=self.bias_scr[(i & 1) ^ 1])
@@ -331,8 +345,20 @@ class ViTEngine:
                          self.scale, self.dqkv, dtable, dq_bias=self.G(pre + "attn.q_bias"))
             self._wgrad(self.dqkv, a["h1"], M, 3 * D, D, pre + "attn.qkv.weight")
             ops.gemm_nt(self.dqkv, self.wT[i]["qkv"], M, D, 3 * D, ops.EPI_BIAS_BF16, out0=self.dh_small)
-            ops.layernorm_bwd(self.dh_small, xin, self.P(pre + "norm1.weight"), a["mean1"], a["rstd1"], dx,
-                              self.G(pre + "norm1.weight"), self.G(pre + "norm1.bias"), M, D, accumulate=True)
+            if fuse and i > 0:
+                # norm1 backward of block i + MLP-branch backward of block i-1 in one pass over dx
+                pb, ab_, bb_ = f"blocks.{i - 1}.", self.act[i - 1], self.model.blocks[i - 1]
+                has_gb = (pb + "gamma_1") in self.segs
+                use_dpb = dp_masks is not None and bb_.drop_prob > 0.0
+                ops.layernorm_bwd_branch(self.dh_small, xin, self.P(pre + "norm1.weight"), a["mean1"], a["rstd1"], dx,
+                                         self.G(pre + "norm1.weight"), self.G(pre + "norm1.bias"), M, D, ab_["y2"],
+                                         self.P(pb + "gamma_2") if has_gb else None, self.dY,
+                                         self.G(pb + "gamma_2") if has_gb else None, self.G(pb + "mlp.fc2.bias"),
+                                         rowmask=dp_masks[2 * (i - 1) + 1] if use_dpb else None,
+                                         keep_prob=1.0 - bb_.drop_prob, rows_per_sample=T)
+            else:
+                ops.layernorm_bwd(self.dh_small, xin, self.P(pre + "norm1.weight"), a["mean1"], a["rstd1"], dx,
+                                  self.G(pre + "norm1.weight"), self.G(pre + "norm1.bias"), M, D, accumulate=True)
             if self.grad_hook:
                 self.grad_hook(self.depth - i)
         # ---- embedding
