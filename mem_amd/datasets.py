@@ -336,11 +336,11 @@ class SyntheticEventDataset(torch.utils.data.Dataset):
 def build_pretraining_dataset(args, is_train=True):
     """datasets.py:146-174.  Folder walking / .npy loading is I/O plumbing outside the hot path
     (SURVEY.md 2.1 row 8); ``--data_path synthetic`` builds the seeded synthetic stand-in."""
-    transform = DataAugmentationForPT(args, is_train)
-    print("Data Aug = %s" % str(transform))
     if args.data_path != "synthetic":
         raise NotImplementedError("only --data_path synthetic this round (dataset folder I/O is out of scope)")
-    args.fixed_canvas = True
+    args.fixed_canvas = True                  # synthetic streams are generated on the model's own canvas
+    transform = DataAugmentationForPT(args, is_train)
+    print("Data Aug = %s" % str(transform))
     n = getattr(args, "synthetic_samples", 64)
     return SyntheticEventDataset(n if is_train else max(2, n // 8), args.slice_max_evs, args.input_H, args.input_W,
                                  transform=transform, seed=1234 if is_train else 4321)

@@ -45,10 +45,6 @@ def _flush(pending, metric_logger, log_writer, optimizer, run):
             sys.exit(1)
         metric_logger.update(mlm_acc=mlm_acc)
         metric_logger.update(loss=loss_value)
-        metric_logger.update(loss_scale=meta["loss_scale"])
-        metric_logger.update(lr=meta["max_lr"])
-        metric_logger.update(min_lr=meta["min_lr"])
-        metric_logger.update(weight_decay=meta["wd"])
         metric_logger.update(grad_norm=grad_norm)
         if log_writer is not None:
             log_writer.update(mlm_acc=mlm_acc, head="loss")
@@ -95,6 +91,12 @@ def train_one_epoch(model: torch.nn.Module, d_vae: torch.nn.Module, data_loader:
         pending.append((loss_acc.clone(), grad_norm.clone(),
                         dict(loss_scale=loss_scaler.state_dict()["scale"], max_lr=max(lrs), min_lr=min(lrs),
                              wd=wds[-1] if wds else None)))
+        # host-side values go to the meters right away (the log line of this step shows them); the device
+        # values (loss, accuracy, gradient norm) follow at the next flush -- one host sync per print_freq steps
+        metric_logger.update(loss_scale=loss_scaler.state_dict()["scale"])
+        metric_logger.update(lr=max(lrs))
+        metric_logger.update(min_lr=min(lrs))
+        metric_logger.update(weight_decay=wds[-1] if wds else None)
         if (step + 1) % print_freq == 0:
             _flush(pending, metric_logger, log_writer, optimizer, run)
         if lr_scheduler is not None:

@@ -79,3 +79,23 @@ def test_vit_base_config1_10_steps():
     print("config#1 max |dloss| vs fp32 reference: %.3e" % d.max(), rec[:, 0], g["cfg1__loss"])
     assert d.max() <= 3e-2
     assert np.abs(rec[:, 1] / g["cfg1__gnorm"] - 1).max() <= 0.08
+
+
+def test_cli_entrypoint_two_epochs_synthetic(tmp_path):
+    """The reference's entrypoint surface end to end (run_mem_pretraining.py:226-440): synthetic event
+    streams -> augment/rasterize -> HIP tokenizer labels -> masked pretraining -> eval -> checkpoint + log."""
+    import json
+    from mem_amd.run_mem_pretraining import get_args, main
+    out = tmp_path / "run"
+    out.mkdir()
+    args = get_args(["--expweek", "t", "--data_path", "synthetic", "--input_H", "112", "--input_W", "112",
+                     "--batch_size", "8", "--epochs", "2", "--warmup_epochs", "0", "--synthetic_samples", "32",
+                     "--num_workers", "0", "--output_dir", str(out), "--num_tokens", "512", "--color_jitter", "0",
+                     "--rand_aug", "0", "--transformer_depth", "2", "--transformer_emb", "128",
+                     "--transformer_heads", "2", "--num_mask_patches", "20", "--min_mask_patches_per_block", "4",
+                     "--slice_max_evs", "5000"])
+    main(args)
+    log = [json.loads(l) for l in open(out / "log.txt")]
+    assert len(log) == 2 and all("train_loss" in e and "train_mlm_acc" in e and e["epoch"] in (0, 1) for e in log)
+    assert all(e["train_loss"] == e["train_loss"] for e in log)                 # finite
+    assert any(p.name.startswith("checkpoint-") for p in out.iterdir())
