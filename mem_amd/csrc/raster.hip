@@ -4,6 +4,7 @@
 // once with two 16-B loads per lane (a wave covers 2 KiB contiguous), binned with u32 atomics
 // that resolve in the XCD L2 / memory side, and a second streaming pass folds the u32 bins to
 // the reference's wrap-around uint8 counts.  Algorithmic bytes: 32*N + 3*H*W per sample.
+#include <cstdlib>
 #include "common.h"
 
 static_assert(sizeof(memhip_event_aug_t) == 56, "memhip_event_aug_t ABI layout");
@@ -142,6 +143,69 @@ __global__ __launch_bounds__(kThreads) void raster_finalize(
   }
 }
 
+
+// ---- small canvases without time surface: privatised counters.  Scattered u32 atomics resolve at the
+// memory side at ~25 G adds/s chip-wide (one 64-byte request per lane), an order of magnitude below
+// what the event stream could feed; LDS atomics do not have that limit.  One workgroup per (sample, band
+// of rows): its u32 counters for [pos, neg] x band live in LDS, it scans ALL events of the sample (the
+// re-reads of the other bands hit L2), and writes the wrapped uint8 counts straight to the output --
+// no workspace, no memset, no second pass.  Used when a sample needs <= kMaxBands bands.
+constexpr int kLdsThreads = 1024;
+constexpr int kBandPixels = 14336;            // 2 polarities x 14336 x 4 B = 112 KiB of LDS
+constexpr int kMaxBands = 6;
+
+__global__ __launch_bounds__(kLdsThreads) void raster_lds_kernel(
+    const double* __restrict__ ev, const int64_t* __restrict__ offsets,
+    const memhip_event_aug_t* __restrict__ augs, int H, int W, int rows_per_band,
+    uint8_t* __restrict__ out, int32_t* __restrict__ status) {
+  extern __shared__ unsigned int cnt[];       // [2][band_px]
+  const int b = blockIdx.y, band = blockIdx.x;
+  const long long HW = (long long)H * W;
+  const int row0 = band * rows_per_band;
+  const int rows = (row0 + rows_per_band <= H) ? rows_per_band : H - row0;
+  const int band_px = rows_per_band * W;
+  const long long lo = (long long)row0 * W, hi = lo + (long long)rows * W;
+  for (int i = threadIdx.x; i < 2 * band_px; i += kLdsThreads) cnt[i] = 0u;
+  __syncthreads();
+  const long long beg = offsets[b], n = offsets[b + 1] - beg;
+  const memhip_event_aug_t* a = augs ? augs + b : nullptr;
+  const double t_last = (a && a->time_flip && n > 0) ? ev[4 * (beg + n - 1) + 2] : 0.0;
+  int bad = 0;
+  for (long long i = threadIdx.x; i < n; i += kLdsThreads) {
+    const Ev e = load_event(ev, beg, n, i, a, t_last);
+    if (!e.keep) continue;
+    const long long xi = (long long)e.x;   // trunc toward zero == ndarray.astype(int)
+    const long long yi = (long long)e.y;
+    long long flat = xi + (long long)W * yi;
+    if (flat < -HW || flat >= HW) { ++bad; continue; }   // reference: IndexError
+    if (flat < 0) flat += HW;                             // NumPy negative index
+    if (flat < lo || flat >= hi) continue;
+    const int l = (int)(flat - lo);
+    if (e.p == 1.0) atomicAdd(cnt + l, 1u);
+    else if (e.p == -1.0) atomicAdd(cnt + band_px + l, 1u);
+  }
+  if (band == 0 && bad) atomicAdd(status + b, bad);
+  __syncthreads();
+  uint8_t* o = out + (size_t)b * 3 * HW + lo;
+  const int npx = rows * W;
+  for (int i = threadIdx.x * 4; i < npx; i += kLdsThreads * 4) {
+    if (i + 4 <= npx && ((lo + i) & 3) == 0) {
+      const unsigned int pv = (cnt[i] & 0xFFu) | ((cnt[i + 1] & 0xFFu) << 8) | ((cnt[i + 2] & 0xFFu) << 16) | (cnt[i + 3] << 24);
+      const unsigned int nv = (cnt[band_px + i] & 0xFFu) | ((cnt[band_px + i + 1] & 0xFFu) << 8) |
+                              ((cnt[band_px + i + 2] & 0xFFu) << 16) | (cnt[band_px + i + 3] << 24);
+      *reinterpret_cast<unsigned int*>(o + i) = pv;
+      *reinterpret_cast<unsigned int*>(o + HW + i) = 0u;            // time-surface channel: zeros
+      *reinterpret_cast<unsigned int*>(o + 2 * HW + i) = nv;
+    } else {
+      for (int k = i; k < i + 4 && k < npx; ++k) {
+        o[k] = (uint8_t)(cnt[k] & 0xFFu);
+        o[HW + k] = 0;
+        o[2 * HW + k] = (uint8_t)(cnt[band_px + k] & 0xFFu);
+      }
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" size_t memhip_rasterize_workspace(int B, int H, int W) {
@@ -163,6 +227,25 @@ extern "C" int memhip_rasterize_aug_f64(const double* ev, const int64_t* offsets
   if (workspace_bytes < need)
     return memhip::fail(MEMHIP_EWORKSPACE, "rasterize: workspace %zu < %zu", workspace_bytes, need);
   hipStream_t s = memhip::as_stream(stream);
+  {
+    // privatised-counter path (see raster_lds_kernel): small canvas, no time surface
+    int rpb = kBandPixels / W;
+    const int bands = rpb > 0 ? memhip::cdiv(H, rpb) : kMaxBands + 1;
+    static const bool lds_on = !(getenv("MEMHIP_RASTER_LDS") && atoi(getenv("MEMHIP_RASTER_LDS")) == 0);
+    if (lds_on && !time_surface && bands <= kMaxBands && ((uintptr_t)out & 3) == 0) {
+      rpb = memhip::cdiv(H, bands);                        // even bands
+      MEMHIP_HIP(hipMemsetAsync(status, 0, (size_t)B * sizeof(int32_t), s));
+      static bool attr_done = false;
+      if (!attr_done) {
+        MEMHIP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(raster_lds_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kBandPixels * 4));
+        attr_done = true;
+      }
+      hipLaunchKernelGGL(raster_lds_kernel, dim3(bands, B), dim3(kLdsThreads), (size_t)2 * rpb * W * 4, s, ev, offsets,
+                         aug, H, W, rpb, out, status);
+      return memhip::check_launch("rasterize(lds)");
+    }
+  }
   size_t bins_bytes = ((size_t)B * 3 * H * W * sizeof(unsigned int) + 15) & ~(size_t)15;
   unsigned int* bins = (unsigned int*)workspace;
   unsigned long long* tstat = (unsigned long long*)((char*)workspace + bins_bytes);
