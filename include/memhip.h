@@ -214,6 +214,16 @@ int memhip_layernorm_bwd(const void* dy_bf16, int64_t lddy, const float* x, int6
                          const float* rstd, float* dres, int64_t lddres, int accumulate, float* dgamma,
                          float* dbeta, memhip_stream_t stream);
 
+/* Layer-scale gradient from the weight gradient of the Linear that produced the branch:
+ *   dgamma[c] = (sum_k W[c,k] * dW[c,k] + bias[c] * dbias[c]) / gamma[c]      (0 where gamma[c] == 0)
+ * (x += gamma * y with y = A W^T + b: sum_m dt*y = sum_m dY*y / gamma and dW = dY^T A, dbias = colsum dY), so the
+ * forward does not store y and memhip_branch_bwd / memhip_layernorm_bwd_branch run with y = NULL, dgamma = NULL.
+ * W bf16 [N, ldw] (the operand the forward used), dW / dbias f32 = the gradients accumulated so far;
+ * dgamma is OVERWRITTEN (it is a function of the accumulated dW). */
+int memhip_layerscale_grad(const void* W_bf16, int64_t ldw, const float* dW, int64_t lddw, const float* bias,
+                           const float* dbias, const float* gamma, int N, int K, float* dgamma,
+                           memhip_stream_t stream);
+
 /* memhip_layernorm_bwd (accumulating, no row gather) fused with the memhip_branch_bwd that follows it in a
  * block's backward: the updated dres row is consumed in registers (one pass over the fp32 gradient stream
  * less).  Arguments = those of the two calls; D <= 1024. */
@@ -226,7 +236,8 @@ int memhip_layernorm_bwd_branch(const void* dy_bf16, int64_t lddy, const float* 
 
 /* Backward of `x = x + drop_path(gamma * y)` (mem/modeling_finetune.py:187-188):
  * dy bf16 = bf16(dt * gamma), dgamma += sum_m dt*y, dbias += sum_m dy with
- * dt = dx * rowmask[m / rows_per_sample] / keep_prob.  gamma/rowmask/dgamma/dbias may be NULL. */
+ * dt = dx * rowmask[m / rows_per_sample] / keep_prob.  gamma/rowmask/dgamma/dbias may be NULL; y may be NULL
+ * when dgamma is (see memhip_layerscale_grad). */
 int memhip_branch_bwd(const float* dx, int64_t lddx, const void* y_bf16, int64_t ldy, const float* gamma,
                       const float* rowmask, float keep_prob, int rows_per_sample, int M, int D,
                       void* dy_bf16, int64_t lddy, float* dgamma, float* dbias, memhip_stream_t stream);

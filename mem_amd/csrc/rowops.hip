@@ -209,12 +209,14 @@ __global__ __launch_bounds__(256) void branch_bwd_kernel(const float* __restrict
       const int m = m0 + u * stride;
       const int mc = m < M ? m : M - 1;
       const float4* dr = reinterpret_cast<const float4*>(dx + (long long)mc * lddx);
-      const bf16x4* yr = reinterpret_cast<const bf16x4*>(y + (long long)mc * ldy);
       kk[u] = rowmask ? rowmask[mc / rps] : 1.f;
 #pragma unroll
       for (int c = 0; c < NCH; ++c) {
         const int i = lane + c * 64;
-        if (i < nch) { dv[u][c] = dr[i]; yv[u][c] = yr[i]; }
+        if (i < nch) {
+          dv[u][c] = dr[i];
+          if (y) yv[u][c] = reinterpret_cast<const bf16x4*>(y + (long long)mc * ldy)[i];
+        }
       }
     }
 #pragma unroll
@@ -232,9 +234,11 @@ __global__ __launch_bounds__(256) void branch_bwd_kernel(const float* __restrict
             d.x = div_newton(d.x * k, keep, rk); d.y = div_newton(d.y * k, keep, rk);
             d.z = div_newton(d.z * k, keep, rk); d.w = div_newton(d.w * k, keep, rk);
           }
-          const bf16x4 yy = yv[u][c];
-          ag[c].x += d.x * (float)yy[0]; ag[c].y += d.y * (float)yy[1];
-          ag[c].z += d.z * (float)yy[2]; ag[c].w += d.w * (float)yy[3];
+          if (y) {
+            const bf16x4 yy = yv[u][c];
+            ag[c].x += d.x * (float)yy[0]; ag[c].y += d.y * (float)yy[1];
+            ag[c].z += d.z * (float)yy[2]; ag[c].w += d.w * (float)yy[3];
+          }
           bf16x4 o;
           o[0] = (__bf16)(d.x * g[c].x); o[1] = (__bf16)(d.y * g[c].y);
           o[2] = (__bf16)(d.z * g[c].z); o[3] = (__bf16)(d.w * g[c].w);
@@ -267,7 +271,7 @@ __global__ __launch_bounds__(256) void branch_bwd_kernel(const float* __restrict
 // dx is produced, stored and consumed in registers -- one pass over the fp32 gradient stream less.
 //   dx[r] += LN'(dy[r]) ;  dt = dx[r] * mask[r / rps] / keep ;  dyb[r] = bf16(dt * gb) ;
 //   dgamma_ln += sum dy*xhat ; dbeta_ln += sum dy ; dgb += sum dt*y ; dbias_b += sum dyb
-template <int NCH>
+template <int NCH, bool HAS_Y>
 __global__ __launch_bounds__(256) void ln_bwd_branch_kernel(const __bf16* __restrict__ dy, long long lddy,
                                                             const float* __restrict__ x, long long ldx, int R, int D,
                                                             const float* __restrict__ gamma,
@@ -281,42 +285,62 @@ __global__ __launch_bounds__(256) void ln_bwd_branch_kernel(const __bf16* __rest
   extern __shared__ float red[];   // [4][4][D]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nch = D >> 2;
-  float4 ag[NCH], ab[NCH], bg[NCH], bb[NCH], gm[NCH], gbr[NCH];
+  float4 ag[NCH], ab[NCH], bg[HAS_Y ? NCH : 1], bb[NCH];      // the gamma vectors are re-read per row (L1): 24 VGPRs
+  const float4* g4 = reinterpret_cast<const float4*>(gamma);
+  const float4* gb4 = reinterpret_cast<const float4*>(gb);
   const float rk = __frcp_rn(keep);
 #pragma unroll
   for (int c = 0; c < NCH; ++c) {
-    const int i = lane + c * 64;
-    ag[c] = ab[c] = bg[c] = bb[c] = float4{0, 0, 0, 0};
-    gm[c] = i < nch ? reinterpret_cast<const float4*>(gamma)[i] : float4{0, 0, 0, 0};
-    gbr[c] = (gb && i < nch) ? reinterpret_cast<const float4*>(gb)[i] : float4{1.f, 1.f, 1.f, 1.f};
+    ag[c] = ab[c] = bb[c] = float4{0, 0, 0, 0};
+    if (HAS_Y) bg[c] = float4{0, 0, 0, 0};
   }
-  for (int r = blockIdx.x * 4 + wave; r < R; r += gridDim.x * 4) {
+  // software prefetch: the raw loads of the wave's NEXT row are issued before the current row is reduced
+  const int rstride = gridDim.x * 4;
+  float4 xn[NCH], pn[NCH];
+  bf16x4 dn[NCH], yn[HAS_Y ? NCH : 1];
+  auto load_row = [&](int r) {
     const float4* xr = reinterpret_cast<const float4*>(x + (long long)r * ldx);
     const bf16x4* dyr = reinterpret_cast<const bf16x4*>(dy + (long long)r * lddy);
-    const bf16x4* ybr = reinterpret_cast<const bf16x4*>(yb + (long long)r * ldyb);
+    const float4* o = reinterpret_cast<const float4*>(dres + (long long)r * lddres);
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int i = lane + c * 64;
+      if (i < nch) {
+        pn[c] = o[i];
+        xn[c] = xr[i];
+        dn[c] = dyr[i];
+        if constexpr (HAS_Y) yn[c] = reinterpret_cast<const bf16x4*>(yb + (long long)r * ldyb)[i];
+      }
+    }
+  };
+  int r = blockIdx.x * 4 + wave;
+  if (r < R) load_row(r);
+  for (; r < R; r += rstride) {
     float4* o = reinterpret_cast<float4*>(dres + (long long)r * lddres);
     const float mu = mean[r], rs = rstd[r];
     const float km = rowmask ? rowmask[r / rps] : 1.f;
     float4 xh[NCH], gg[NCH], prev[NCH];
-    bf16x4 yv[NCH];
+    bf16x4 yv[HAS_Y ? NCH : 1];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
       const int i = lane + c * 64;
       if (i < nch) {
-        prev[c] = o[i];
-        yv[c] = ybr[i];
-        const float4 xv = xr[i];
-        const bf16x4 d4 = dyr[i];
+        prev[c] = pn[c];
+        if constexpr (HAS_Y) yv[c] = yn[c];
+        const float4 xv = xn[c];
+        const bf16x4 d4 = dn[c];
         const float d0 = (float)d4[0], d1 = (float)d4[1], d2 = (float)d4[2], d3 = (float)d4[3];
         xh[c] = float4{(xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs};
-        gg[c] = float4{d0 * gm[c].x, d1 * gm[c].y, d2 * gm[c].z, d3 * gm[c].w};
+        const float4 gmc = g4[i];
+        gg[c] = float4{d0 * gmc.x, d1 * gmc.y, d2 * gmc.z, d3 * gmc.w};
         s1 += (gg[c].x + gg[c].y) + (gg[c].z + gg[c].w);
         s2 += (gg[c].x * xh[c].x + gg[c].y * xh[c].y) + (gg[c].z * xh[c].z + gg[c].w * xh[c].w);
         ag[c].x += d0 * xh[c].x; ag[c].y += d1 * xh[c].y; ag[c].z += d2 * xh[c].z; ag[c].w += d3 * xh[c].w;
         ab[c].x += d0; ab[c].y += d1; ab[c].z += d2; ab[c].w += d3;
       }
     }
+    if (r + rstride < R) load_row(r + rstride);
     const float m1 = wsum(s1) / (float)D, m2 = wsum(s2) / (float)D;
     bf16x4* orow = reinterpret_cast<bf16x4*>(dyo + (long long)r * lddyo);
 #pragma unroll
@@ -330,11 +354,14 @@ __global__ __launch_bounds__(256) void ln_bwd_branch_kernel(const __bf16* __rest
           d.x = div_newton(d.x * km, keep, rk); d.y = div_newton(d.y * km, keep, rk);
           d.z = div_newton(d.z * km, keep, rk); d.w = div_newton(d.w * km, keep, rk);
         }
-        bg[c].x += d.x * (float)yv[c][0]; bg[c].y += d.y * (float)yv[c][1];
-        bg[c].z += d.z * (float)yv[c][2]; bg[c].w += d.w * (float)yv[c][3];
+        if constexpr (HAS_Y) {
+          bg[c].x += d.x * (float)yv[c][0]; bg[c].y += d.y * (float)yv[c][1];
+          bg[c].z += d.z * (float)yv[c][2]; bg[c].w += d.w * (float)yv[c][3];
+        }
+        const float4 gbc = gb ? gb4[i] : float4{1.f, 1.f, 1.f, 1.f};
         bf16x4 q;
-        q[0] = (__bf16)(d.x * gbr[c].x); q[1] = (__bf16)(d.y * gbr[c].y);
-        q[2] = (__bf16)(d.z * gbr[c].z); q[3] = (__bf16)(d.w * gbr[c].w);
+        q[0] = (__bf16)(d.x * gbc.x); q[1] = (__bf16)(d.y * gbc.y);
+        q[2] = (__bf16)(d.z * gbc.z); q[3] = (__bf16)(d.w * gbc.w);
         orow[i] = q;
         bb[c].x += (float)q[0]; bb[c].y += (float)q[1]; bb[c].z += (float)q[2]; bb[c].w += (float)q[3];
       }
@@ -344,7 +371,7 @@ __global__ __launch_bounds__(256) void ln_bwd_branch_kernel(const __bf16* __rest
 #pragma unroll
   for (int c = 0; c < NCH; ++c) {
     const int i = lane + c * 64;
-    if (i < nch) { r0[i] = ag[c]; r0[nch + i] = ab[c]; r0[2 * nch + i] = bg[c]; r0[3 * nch + i] = bb[c]; }
+    if (i < nch) { r0[i] = ag[c]; r0[nch + i] = ab[c]; r0[2 * nch + i] = HAS_Y ? bg[HAS_Y ? c : 0] : float4{0, 0, 0, 0}; r0[3 * nch + i] = bb[c]; }
   }
   __syncthreads();
   for (int n = threadIdx.x; n < D; n += 256) {
@@ -358,6 +385,33 @@ __global__ __launch_bounds__(256) void ln_bwd_branch_kernel(const __bf16* __rest
     atomicAdd(dbeta + n, b);
     if (dgb) atomicAdd(dgb + n, c2);
     if (dbiasb) atomicAdd(dbiasb + n, d2);
+  }
+}
+
+
+// Layer-scale gradient without the branch output:  x += gamma * y,  y = A W^T + b  gives
+//   dgamma_c = sum_m dt[m,c] y[m,c] = (sum_k W[c,k] dW[c,k] + b_c db_c) / gamma_c
+// because dW[c,k] = sum_m dY[m,c] A[m,k], db_c = sum_m dY[m,c] and dY = gamma * dt: the forward does not
+// have to store y (77 MB per branch at B=256) and the backward does not read it.  One wave per channel.
+__global__ __launch_bounds__(256) void layerscale_grad_kernel(const __bf16* __restrict__ W, long long ldw,
+                                                              const float* __restrict__ dW, long long lddw,
+                                                              const float* __restrict__ b, const float* __restrict__ db,
+                                                              const float* __restrict__ gamma, int N, int K,
+                                                              float* __restrict__ dgamma) {
+  const int lane = threadIdx.x & 63;
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (n >= N) return;
+  float s = 0.f;
+  for (int k = lane * 4; k < K; k += 256) {
+    const bf16x4 w = *reinterpret_cast<const bf16x4*>(W + (long long)n * ldw + k);
+    const float4 g = *reinterpret_cast<const float4*>(dW + (long long)n * lddw + k);
+    s += (float)w[0] * g.x + (float)w[1] * g.y + (float)w[2] * g.z + (float)w[3] * g.w;
+  }
+  s = wsum(s);
+  if (lane == 0) {
+    if (b && db) s += b[n] * db[n];
+    const float g = gamma[n];
+    dgamma[n] = g != 0.f ? s / g : 0.f;
   }
 }
 
@@ -540,7 +594,8 @@ extern "C" int memhip_branch_bwd(const float* dx, int64_t lddx, const void* y, i
                                  float* dgamma, float* dbias, memhip_stream_t stream) {
   MEMHIP_REQUIRE(M >= 0 && D > 0 && D % 4 == 0, "branch_bwd: bad M=%d D=%d", M, D);
   if (M == 0) return MEMHIP_OK;
-  MEMHIP_REQUIRE(dx && y && dy, "branch_bwd: null pointer");
+  MEMHIP_REQUIRE(dx && dy, "branch_bwd: null pointer");
+  MEMHIP_REQUIRE(y || !dgamma, "branch_bwd: dgamma needs y (or use memhip_layerscale_grad)");
   MEMHIP_REQUIRE(lddx % 4 == 0 && ldy % 4 == 0 && lddy % 4 == 0, "branch_bwd: ld must be a multiple of 4");
   MEMHIP_REQUIRE(D <= 64 * 4 * kBrMaxChunks, "branch_bwd: D=%d too large", D);
   int grid = cdiv(M, 4);
@@ -600,14 +655,17 @@ extern "C" int memhip_layernorm_bwd_branch(const void* dy, int64_t lddy, const f
                                            float* dgamma_branch, float* dbias_branch, memhip_stream_t stream) {
   MEMHIP_REQUIRE(R >= 0 && D > 0 && D % 4 == 0 && D <= 64 * 4 * 4, "layernorm_bwd_branch: D=%d unsupported (<= 1024)", D);
   if (R == 0) return MEMHIP_OK;
-  MEMHIP_REQUIRE(dy && x && gamma && mean && rstd && dres && dgamma && dbeta && y_branch && dy_branch,
+  MEMHIP_REQUIRE(dy && x && gamma && mean && rstd && dres && dgamma && dbeta && dy_branch,
                  "layernorm_bwd_branch: null pointer");
+  MEMHIP_REQUIRE(y_branch || !dgamma_branch, "layernorm_bwd_branch: dgamma_branch needs y_branch");
   MEMHIP_REQUIRE(ldx % 4 == 0 && lddy % 4 == 0 && lddres % 4 == 0 && ldyb % 4 == 0 && lddyb % 4 == 0,
                  "layernorm_bwd_branch: ld must be a multiple of 4");
   int grid = cdiv(R, 4);
-  if (grid > 1024) grid = 1024;
+  if (grid > 768) grid = 768;          // 3 resident workgroups per CU at this kernel's VGPR count: one full round
 #define LBB_LAUNCH(N)                                                                                    \
-  hipLaunchKernelGGL(ln_bwd_branch_kernel<N>, dim3(grid), dim3(256), (size_t)16 * D * sizeof(float),      \
+  if (y_branch) LBB_LAUNCH2(N, true); else LBB_LAUNCH2(N, false)
+#define LBB_LAUNCH2(N, Y)                                                                                \
+  hipLaunchKernelGGL((ln_bwd_branch_kernel<N, Y>), dim3(grid), dim3(256), (size_t)16 * D * sizeof(float), \
                      as_stream(stream), (const __bf16*)dy, (long long)lddy, x, (long long)ldx, R, D, gamma, mean, \
                      rstd, dres, (long long)lddres, dgamma, dbeta, (const __bf16*)y_branch, (long long)ldyb, \
                      gamma_branch, rowmask, keep_prob, rows_per_sample > 0 ? rows_per_sample : 1,         \
@@ -618,5 +676,17 @@ extern "C" int memhip_layernorm_bwd_branch(const void* dy, int64_t lddy, const f
   else if (nchl <= 3) LBB_LAUNCH(3);
   else LBB_LAUNCH(4);
 #undef LBB_LAUNCH
+#undef LBB_LAUNCH2
   return check_launch("layernorm_bwd_branch");
+}
+
+extern "C" int memhip_layerscale_grad(const void* W_bf16, int64_t ldw, const float* dW, int64_t lddw, const float* bias,
+                                      const float* dbias, const float* gamma, int N, int K, float* dgamma,
+                                      memhip_stream_t stream) {
+  MEMHIP_REQUIRE(N >= 0 && K > 0 && K % 4 == 0 && ldw % 4 == 0 && lddw % 4 == 0, "layerscale_grad: bad shape");
+  if (N == 0) return MEMHIP_OK;
+  MEMHIP_REQUIRE(W_bf16 && dW && gamma && dgamma && (!bias == !dbias), "layerscale_grad: null pointer");
+  hipLaunchKernelGGL(layerscale_grad_kernel, dim3((N + 3) / 4), dim3(256), 0, as_stream(stream), (const __bf16*)W_bf16,
+                     (long long)ldw, dW, (long long)lddw, bias, dbias, gamma, N, K, dgamma);
+  return check_launch("layerscale_grad");
 }

@@ -72,6 +72,7 @@ declare({
     "memhip_layernorm_bwd": (i32, [vp, i64, vp, i64, vp, i32, i32, vp, vp, vp, vp, i64, i32, vp, vp, vp]),
     "memhip_layernorm_bwd_branch": (i32, [vp, i64, vp, i64, i32, i32, vp, vp, vp, vp, i64, vp, vp, vp, i64, vp, vp, f32,
                                           i32, vp, i64, vp, vp, vp]),
+    "memhip_layerscale_grad": (i32, [vp, i64, vp, i64, vp, vp, vp, i32, i32, vp, vp]),
     "memhip_branch_bwd": (i32, [vp, i64, vp, i64, vp, vp, f32, i32, i32, i32, vp, i64, vp, vp, vp]),
     "memhip_embed_bwd": (i32, [vp, i64, vp, i32, i32, i32, vp, i64, vp, vp, vp]),
     "memhip_cross_entropy": (i32, [vp, i64, vp, i32, i32, f32, vp, vp, i32, vp, vp]),
@@ -111,13 +112,19 @@ def layernorm_bwd_branch(dy, x, gamma, mean, rstd, dres, dgamma, dbeta, R, D, y_
     """layernorm_bwd(accumulate=True) + the branch_bwd that reads the updated dres, in one pass."""
     check(lib.memhip_layernorm_bwd_branch(ptr(dy), dy.stride(0), ptr(x), x.stride(0), R, D, ptr(gamma), ptr(mean),
                                           ptr(rstd), ptr(dres), dres.stride(0), ptr(dgamma), ptr(dbeta), ptr(y_b),
-                                          y_b.stride(0), ptr(gamma_b), ptr(rowmask), keep_prob, rows_per_sample,
+                                          y_b.stride(0) if y_b is not None else 0, ptr(gamma_b), ptr(rowmask), keep_prob, rows_per_sample,
                                           ptr(dy_b), dy_b.stride(0), ptr(dgamma_b), ptr(dbias_b), stream_ptr()),
           "layernorm_bwd_branch")
 
 
+def layerscale_grad(W16, dW, bias, dbias, gamma, N, K, dgamma):
+    """dgamma[N] = (rowdot(W16, dW) + bias * dbias) / gamma  (overwrites dgamma)."""
+    check(lib.memhip_layerscale_grad(ptr(W16), W16.stride(0), ptr(dW), dW.stride(0), ptr(bias), ptr(dbias), ptr(gamma),
+                                     N, K, ptr(dgamma), stream_ptr()), "layerscale_grad")
+
+
 def branch_bwd(dx, y, gamma, dy, dgamma, dbias, M, D, rowmask=None, keep_prob=1.0, rows_per_sample=1):
-    check(lib.memhip_branch_bwd(ptr(dx), dx.stride(0), ptr(y), y.stride(0), ptr(gamma), ptr(rowmask), keep_prob,
+    check(lib.memhip_branch_bwd(ptr(dx), dx.stride(0), ptr(y), y.stride(0) if y is not None else 0, ptr(gamma), ptr(rowmask), keep_prob,
                                 rows_per_sample, M, D, ptr(dy), dy.stride(0), ptr(dgamma), ptr(dbias),
                                 stream_ptr()), "branch_bwd")
 

@@ -168,8 +168,8 @@ class ViTEngine:
         self.x = [torch.zeros((M, D), dtype=f32, device=dev) for _ in range(2 * self.depth + 1)]
         self.act = []
         for _ in range(self.depth):
-            self.act.append(dict(h1=e(M, D), qkv=e(M, 3 * D), ao=e(M, D), y1=e(M, D), h2=e(M, D), hpre=e(M, Hd),
-                                 a=e(M, Hd), y2=e(M, D), lse=e(B, self.heads, self.TP, dt=f32),
+            self.act.append(dict(h1=e(M, D), qkv=e(M, 3 * D), ao=e(M, D), h2=e(M, D), hpre=e(M, Hd),
+                                 a=e(M, Hd), lse=e(B, self.heads, self.TP, dt=f32),
                                  mean1=e(M, dt=f32), rstd1=e(M, dt=f32), mean2=e(M, dt=f32), rstd2=e(M, dt=f32)))
         # head
         self.hN = e(Mm_cap, D)
@@ -242,14 +242,14 @@ class ViTEngine:
             ops.gemm_nt(a["h1"], self.W16(pre + "attn.qkv.weight", 3 * D, D), M, 3 * D, D, ops.EPI_BIAS_BF16,
                         out0=a["qkv"], bias=self.P(pre + "attn.qkvbias3"), colscale=self.scale, colscale_n=D)
             ops.attn_fwd(a["qkv"], B, T, D, self.heads, table, self.window, a["ao"], a["lse"])
-            ops.gemm_nt(a["ao"], self.W16(pre + "attn.proj.weight", D, D), M, D, D, ops.EPI_RESIDUAL, out0=a["y1"],
+            ops.gemm_nt(a["ao"], self.W16(pre + "attn.proj.weight", D, D), M, D, D, ops.EPI_RESIDUAL, out0=None,
                         bias=self.P(pre + "attn.proj.bias"), vec1=g1, resid=xmid, aux=xin, ldaux=D,
                         rowmask=dp_masks[2 * i] if use_dp else None, keep_prob=keep, rows_per_sample=T)
             ops.layernorm_fwd(xmid, self.P(pre + "norm2.weight"), self.P(pre + "norm2.bias"), a["h2"], a["mean2"],
                               a["rstd2"], M, D)
             ops.gemm_nt(a["h2"], self.W16(pre + "mlp.fc1.weight", Hd, D), M, Hd, D, ops.EPI_BIAS_GELU, out0=a["hpre"],
                         out1=a["a"], bias=self.P(pre + "mlp.fc1.bias"))
-            ops.gemm_nt(a["a"], self.W16(pre + "mlp.fc2.weight", D, Hd), M, D, Hd, ops.EPI_RESIDUAL, out0=a["y2"],
+            ops.gemm_nt(a["a"], self.W16(pre + "mlp.fc2.weight", D, Hd), M, D, Hd, ops.EPI_RESIDUAL, out0=None,
                         bias=self.P(pre + "mlp.fc2.bias"), vec1=g2, resid=xout, aux=xmid, ldaux=D,
                         rowmask=dp_masks[2 * i + 1] if use_dp else None, keep_prob=keep, rows_per_sample=T)
         xl = self.x[2 * self.depth]
@@ -308,21 +308,25 @@ class ViTEngine:
             # -- MLP branch (for every block but the last this already ran fused into the norm1 backward of
             # block i+1, see below)
             if i == self.depth - 1 or not fuse:
-                ops.branch_bwd(dx, a["y2"], self.P(pre + "gamma_2") if has_g else None, self.dY,
-                               self.G(pre + "gamma_2") if has_g else None, self.G(pre + "mlp.fc2.bias"), M, D,
+                ops.branch_bwd(dx, None, self.P(pre + "gamma_2") if has_g else None, self.dY,
+                               None, self.G(pre + "mlp.fc2.bias"), M, D,
                                rowmask=dp_masks[2 * i + 1] if use_dp else None, keep_prob=keep, rows_per_sample=T)
             ops.gemm_nt(self.dY, self.wT[i]["fc2"], M, Hd, D, ops.EPI_DGELU, out0=self.dbig, aux=a["hpre"],
                         colsum=self.G(pre + "mlp.fc1.bias"))        # fc1 bias grad = column sums of dh
             self._wgrad(self.dY, a["a"], M, D, Hd, pre + "mlp.fc2.weight")
+            if has_g:
+                # layer-scale gradient from the weight gradient (no branch output y kept): memhip_layerscale_grad
+                ops.layerscale_grad(self.W16(pre + "mlp.fc2.weight", D, Hd), self.G(pre + "mlp.fc2.weight").view(D, Hd),
+                                    self.P(pre + "mlp.fc2.bias"), self.G(pre + "mlp.fc2.bias"),
+                                    self.P(pre + "gamma_2"), D, Hd, self.G(pre + "gamma_2"))
             self._wgrad(self.dbig, a["h2"], M, Hd, D, pre + "mlp.fc1.weight")
             ops.gemm_nt(self.dbig, self.wT[i]["fc1"], M, D, Hd, ops.EPI_BIAS_BF16, out0=self.dh_small)
             scr = self.bias_scr[i & 1]
             if fuse:
                 # norm2 backward + attention-branch backward in one pass over dx (proj.bias column sums -> scr)
                 ops.layernorm_bwd_branch(self.dh_small, xmid, self.P(pre + "norm2.weight"), a["mean2"], a["rstd2"], dx,
-                                         self.G(pre + "norm2.weight"), self.G(pre + "norm2.bias"), M, D, a["y1"],
-                                         self.P(pre + "gamma_1") if has_g else None, self.dY,
-                                         self.G(pre + "gamma_1") if has_g else None, scr,
+                                         self.G(pre + "norm2.weight"), self.G(pre + "norm2.bias"), M, D, None,
+                                         self.P(pre + "gamma_1") if has_g else None, self.dY, None, scr,
                                          rowmask=dp_masks[2 * i] if use_dp else None, keep_prob=keep, rows_per_sample=T)
             else:
                 ops.layernorm_bwd(self.dh_small, xmid, self.P(pre + "norm2.weight"), a["mean2"], a["rstd2"], dx,
@@ -333,13 +337,16 @@ class ViTEngine:
             # v_bias.grad = colsum(d attn_out) = colsum(dY) @ W_proj: one 768x768 GEMV instead of column
             # sums inside the attention kernel (which cost it 32 VGPRs and its occupancy).
             if not fuse:
-                ops.branch_bwd(dx, a["y1"], self.P(pre + "gamma_1") if has_g else None, self.dY,
-                               self.G(pre + "gamma_1") if has_g else None, scr, M, D,
+                ops.branch_bwd(dx, None, self.P(pre + "gamma_1") if has_g else None, self.dY, None, scr, M, D,
                                rowmask=dp_masks[2 * i] if use_dp else None, keep_prob=keep, rows_per_sample=T)
             ops.gemm_nt(self.dY, self.wT[i]["proj"], M, D, D, ops.EPI_BIAS_BF16, out0=self.dao)
             ops.gemv_acc(self.wT[i]["proj"], D, D, scr, self.G(pre + "attn.v_bias"),
                          x_acc=self.G(pre + "attn.proj.bias"), zero=self.bias_scr[(i & 1) ^ 1])
             self._wgrad(self.dY, a["ao"], M, D, D, pre + "attn.proj.weight")
+            if has_g:
+                ops.layerscale_grad(self.W16(pre + "attn.proj.weight", D, D), self.G(pre + "attn.proj.weight").view(D, D),
+                                    self.P(pre + "attn.proj.bias"), self.G(pre + "attn.proj.bias"),
+                                    self.P(pre + "gamma_1"), D, D, self.G(pre + "gamma_1"))
             ops.attn_delta(self.dao, a["ao"], M, self.heads, self.delta_ws)
             ops.attn_bwd(a["qkv"], self.dao, a["lse"], self.delta_ws, table, self.window, B, T, D, self.heads,
                          self.scale, self.dqkv, dtable, dq_bias=self.G(pre + "attn.q_bias"))
@@ -351,9 +358,9 @@ class ViTEngine:
                 has_gb = (pb + "gamma_1") in self.segs
                 use_dpb = dp_masks is not None and bb_.drop_prob > 0.0
                 ops.layernorm_bwd_branch(self.dh_small, xin, self.P(pre + "norm1.weight"), a["mean1"], a["rstd1"], dx,
-                                         self.G(pre + "norm1.weight"), self.G(pre + "norm1.bias"), M, D, ab_["y2"],
-                                         self.P(pb + "gamma_2") if has_gb else None, self.dY,
-                                         self.G(pb + "gamma_2") if has_gb else None, self.G(pb + "mlp.fc2.bias"),
+                                         self.G(pre + "norm1.weight"), self.G(pre + "norm1.bias"), M, D, None,
+                                         self.P(pb + "gamma_2") if has_gb else None, self.dY, None,
+                                         self.G(pb + "mlp.fc2.bias"),
                                          rowmask=dp_masks[2 * (i - 1) + 1] if use_dpb else None,
                                          keep_prob=1.0 - bb_.drop_prob, rows_per_sample=T)
             else:
