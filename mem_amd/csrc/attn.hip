@@ -719,11 +719,24 @@ __global__ void attn_stats_zero_kernel(float* stats, int n) {
   for (int i = threadIdx.x; i < n; i += blockDim.x) stats[i] = 0.f;
 }
 
+// Samples per workgroup.  One workgroup is resident per CU (LDS), so a grid of more than #CUs
+// workgroups runs a second, nearly empty round: ceil(256*12/256) = 12 samples per workgroup gives
+// 22 * 12 = 264 workgroups on 256 CUs, i.e. T(12) + T(4) -- 13 gives 240 workgroups and T(13)
+// (measured: forward 156 -> 130 us, backward 603 -> 503 us per layer).  Dealing (head, sample) pairs
+// perfectly evenly (12 per workgroup, runs crossing into the next head) was tried and is no faster:
+// the crossing workgroups pay the per-head setup twice.  Smallest count for which the grid fits one
+// round, capped at 16 (the table-gradient buckets are sized for that).
 int pick_spb(int B, int heads) {
-  int spb = (B * heads + 255) / 256;           // one workgroup per CU when the batch allows
-  if (spb < 1) spb = 1;
-  if (spb > 16) spb = 16;
-  return spb;
+  static int num_cu = 0;
+  if (!num_cu) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    num_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess &&
+              prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+  }
+  for (int spb = 1; spb <= 16; ++spb)
+    if ((long long)((B + spb - 1) / spb) * heads <= num_cu) return spb;
+  return 16;
 }
 
 }  // namespace
