@@ -213,6 +213,8 @@ extern "C" int memhip_gemm_bf16_nt(const memhip_gemm_args_t* a, memhip_stream_t 
     case MEMHIP_EPI_BIAS_GELU: MEMHIP_REQUIRE(p.out0 && p.out1, "gemm: out0/out1"); break;
     case MEMHIP_EPI_RESIDUAL: MEMHIP_REQUIRE(p.resid, "gemm: residual args"); break;
     case MEMHIP_EPI_DGELU: MEMHIP_REQUIRE(p.out0 && p.aux, "gemm: dgelu args"); break;
+    case MEMHIP_EPI_BIAS_GELU_DG: MEMHIP_REQUIRE(p.out0 && p.out1, "gemm: out0/out1"); break;
+    case MEMHIP_EPI_MUL_AUX: MEMHIP_REQUIRE(p.out0 && p.aux, "gemm: mul_aux args"); break;
     case MEMHIP_EPI_F32: MEMHIP_REQUIRE(p.out0, "gemm: out0"); break;
     case MEMHIP_EPI_PATCH_EMBED: MEMHIP_REQUIRE(p.resid && p.vec1 && p.aux, "gemm: patch args"); break;
     default: return fail(MEMHIP_EINVAL, "gemm: unknown epilogue %d", p.epilogue);
@@ -247,6 +249,8 @@ extern "C" int memhip_gemm_bf16_nt(const memhip_gemm_args_t* a, memhip_stream_t 
           case MEMHIP_EPI_BIAS_GELU: return launch<MEMHIP_EPI_BIAS_GELU>(p, s);
           case MEMHIP_EPI_RESIDUAL: return launch<MEMHIP_EPI_RESIDUAL>(p, s);
           case MEMHIP_EPI_DGELU: return launch<MEMHIP_EPI_DGELU>(p, s);
+          case MEMHIP_EPI_BIAS_GELU_DG: return launch<MEMHIP_EPI_BIAS_GELU_DG>(p, s);
+          case MEMHIP_EPI_MUL_AUX: return launch<MEMHIP_EPI_MUL_AUX>(p, s);
           default: return launch<MEMHIP_EPI_F32>(p, s);
         }
       }
@@ -269,6 +273,8 @@ extern "C" int memhip_gemm_bf16_nt(const memhip_gemm_args_t* a, memhip_stream_t 
     case MEMHIP_EPI_BIAS_GELU: MEMHIP_REQUIRE(p.out0 && p.out1, "gemm: out0/out1"); return launch<MEMHIP_EPI_BIAS_GELU>(p, s);
     case MEMHIP_EPI_RESIDUAL: return launch<MEMHIP_EPI_RESIDUAL>(p, s);
     case MEMHIP_EPI_DGELU: MEMHIP_REQUIRE(p.out0 && p.aux, "gemm: dgelu args"); return launch<MEMHIP_EPI_DGELU>(p, s);
+    case MEMHIP_EPI_BIAS_GELU_DG: return launch<MEMHIP_EPI_BIAS_GELU_DG>(p, s);
+    case MEMHIP_EPI_MUL_AUX: return launch<MEMHIP_EPI_MUL_AUX>(p, s);
     case MEMHIP_EPI_F32: MEMHIP_REQUIRE(p.out0, "gemm: out0"); return launch<MEMHIP_EPI_F32>(p, s);
     case MEMHIP_EPI_PATCH_EMBED: MEMHIP_REQUIRE(p.resid && p.vec1 && p.aux, "gemm: patch args"); return launch<MEMHIP_EPI_PATCH_EMBED>(p, s);
     default: return fail(MEMHIP_EINVAL, "gemm: unknown epilogue %d", p.epilogue);

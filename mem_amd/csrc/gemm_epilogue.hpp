@@ -66,6 +66,16 @@ __device__ __forceinline__ void epilogue(const GemmArgs& p, int m, int n, float 
     const __bf16 h = (__bf16)(acc + bias_n);
     reinterpret_cast<__bf16*>(p.out0)[(long long)m * p.ldo0 + n] = h;
     reinterpret_cast<__bf16*>(p.out1)[(long long)m * p.ldo1 + n] = (__bf16)gelu_f((float)h);
+  } else if constexpr (EPI == MEMHIP_EPI_BIAS_GELU_DG) {
+    const __bf16 h = (__bf16)(acc + bias_n);
+    reinterpret_cast<__bf16*>(p.out0)[(long long)m * p.ldo0 + n] = (__bf16)gelu_grad_f((float)h);
+    reinterpret_cast<__bf16*>(p.out1)[(long long)m * p.ldo1 + n] = (__bf16)gelu_f((float)h);
+  } else if constexpr (EPI == MEMHIP_EPI_MUL_AUX) {
+    const float da = bf16_round(acc);
+    const float g = (float)reinterpret_cast<const __bf16*>(p.aux)[(long long)m * p.ldaux + n];
+    const __bf16 o = (__bf16)(da * g);
+    reinterpret_cast<__bf16*>(p.out0)[(long long)m * p.ldo0 + n] = o;
+    if (p.colsum) atomicAdd(p.colsum + n, (float)o);
   } else if constexpr (EPI == MEMHIP_EPI_RESIDUAL) {
     const __bf16 y = (__bf16)(acc + bias_n);
     if (p.out0) reinterpret_cast<__bf16*>(p.out0)[(long long)m * p.ldo0 + n] = y;
@@ -151,6 +161,14 @@ __device__ __forceinline__ ef32x2 gelu2(ef32x2 x) {
   const ef32x2 hx = x * splat2(0.5f);
   return fma2(hx, erf, hx);
 }
+__device__ __forceinline__ void gelu_and_grad2(ef32x2 x, ef32x2& g, ef32x2& dg) {
+  ef32x2 erf, e;
+  erf_exp2(x, erf, e);
+  const ef32x2 hx = x * splat2(0.5f);
+  g = fma2(hx, erf, hx);
+  const ef32x2 cdf = fma2(splat2(0.5f), erf, splat2(0.5f));
+  dg = fma2(x * splat2(0.39894228040143267794f), e, cdf);
+}
 __device__ __forceinline__ ef32x2 gelu_grad2(ef32x2 x) {
   ef32x2 erf, e;
   erf_exp2(x, erf, e);
@@ -167,7 +185,7 @@ struct EpiCols {
 };
 template <int EPI>
 __device__ __forceinline__ void epi_cols_load(const GemmArgs& p, int n, EpiCols& c) {
-  if constexpr (EPI != MEMHIP_EPI_DGELU && EPI != MEMHIP_EPI_F32) {
+  if constexpr (EPI != MEMHIP_EPI_DGELU && EPI != MEMHIP_EPI_F32 && EPI != MEMHIP_EPI_MUL_AUX) {
     if (p.bias) {
       const float4 b0 = reinterpret_cast<const float4*>(p.bias + n)[0], b1 = reinterpret_cast<const float4*>(p.bias + n)[1];
       c.bias[0] = ef32x2{b0.x, b0.y}; c.bias[1] = ef32x2{b0.z, b0.w}; c.bias[2] = ef32x2{b1.x, b1.y}; c.bias[3] = ef32x2{b1.z, b1.w};
@@ -189,10 +207,12 @@ struct EpiRow {};
 template <>
 struct EpiRow<MEMHIP_EPI_DGELU> { uint4 h; };
 template <>
+struct EpiRow<MEMHIP_EPI_MUL_AUX> { uint4 h; };
+template <>
 struct EpiRow<MEMHIP_EPI_RESIDUAL> { float x[8]; };
 template <int EPI>
 __device__ __forceinline__ void epi_row_load(const GemmArgs& p, int m, int n, EpiRow<EPI>& r) {
-  if constexpr (EPI == MEMHIP_EPI_DGELU) {
+  if constexpr (EPI == MEMHIP_EPI_DGELU || EPI == MEMHIP_EPI_MUL_AUX) {
     r.h = *reinterpret_cast<const uint4*>(reinterpret_cast<const __bf16*>(p.aux) + (long long)m * p.ldaux + n);
   } else if constexpr (EPI == MEMHIP_EPI_RESIDUAL) {
     if (p.aux) ld8(reinterpret_cast<const float*>(p.aux) + (long long)m * p.ldaux + n, r.x);
@@ -206,7 +226,7 @@ __device__ __forceinline__ void epilogue8(const GemmArgs& p, int m, int n, const
   ef32x2 t[4];
 #pragma unroll
   for (int k = 0; k < 4; ++k) t[k] = ef32x2{acc[2 * k], acc[2 * k + 1]};
-  if constexpr (EPI != MEMHIP_EPI_DGELU && EPI != MEMHIP_EPI_F32) {
+  if constexpr (EPI != MEMHIP_EPI_DGELU && EPI != MEMHIP_EPI_F32 && EPI != MEMHIP_EPI_MUL_AUX) {
     if (p.bias) {
 #pragma unroll
       for (int k = 0; k < 4; ++k) t[k] += c.bias[k];
@@ -238,6 +258,31 @@ __device__ __forceinline__ void epilogue8(const GemmArgs& p, int m, int n, const
     }
     st_stream16(p.out0, (long long)m * p.ldo0 + n, h[0], h[1], h[2], h[3]);
     st_stream16(p.out1, (long long)m * p.ldo1 + n, a[0], a[1], a[2], a[3]);
+  } else if constexpr (EPI == MEMHIP_EPI_BIAS_GELU_DG) {
+    unsigned dgp[4], a[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      ef32x2 g, dg;
+      gelu_and_grad2(unpack_bf16x2(pack_bf16x2(t[k])), g, dg);
+      dgp[k] = pack_bf16x2(dg);
+      a[k] = pack_bf16x2(g);
+    }
+    st_stream16(p.out0, (long long)m * p.ldo0 + n, dgp[0], dgp[1], dgp[2], dgp[3]);
+    st_stream16(p.out1, (long long)m * p.ldo1 + n, a[0], a[1], a[2], a[3]);
+  } else if constexpr (EPI == MEMHIP_EPI_MUL_AUX) {
+    const unsigned h[4] = {row.h.x, row.h.y, row.h.z, row.h.w};
+    unsigned o[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) o[k] = pack_bf16x2(unpack_bf16x2(pack_bf16x2(t[k])) * unpack_bf16x2(h[k]));
+    if (p.colsum) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const ef32x2 f = unpack_bf16x2(o[k]);
+        cs[2 * k] += f.x;
+        cs[2 * k + 1] += f.y;
+      }
+    }
+    st_stream16(p.out0, (long long)m * p.ldo0 + n, o[0], o[1], o[2], o[3]);
   } else if constexpr (EPI == MEMHIP_EPI_RESIDUAL) {
     unsigned y[4];
     float x[8];

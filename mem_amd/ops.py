@@ -9,7 +9,7 @@ import torch
 
 from ._lib import check, declare, f32, i32, i64, lib, ptr, stream_ptr, sz, vp
 
-EPI_BIAS_BF16, EPI_BIAS_GELU, EPI_RESIDUAL, EPI_DGELU, EPI_F32, EPI_PATCH_EMBED = range(6)
+EPI_BIAS_BF16, EPI_BIAS_GELU, EPI_RESIDUAL, EPI_DGELU, EPI_F32, EPI_PATCH_EMBED, EPI_BIAS_GELU_DG, EPI_MUL_AUX = range(8)
 
 
 class GemmArgs(C.Structure):

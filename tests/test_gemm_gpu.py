@@ -212,3 +212,24 @@ def test_ring_gemm_large_m_all_epilogues(M, N, K):
     torch.nn.functional.gelu(hg).backward(torch.ones_like(hg))
     torch.testing.assert_close(o.float(), (da * hg.grad).bfloat16().float(), rtol=3e-2, atol=3e-2)
     torch.testing.assert_close(cs, o.float().sum(0), rtol=1e-3, atol=5e-2)      # fused bias-gradient column sums
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 256, 128), (4096 + 37, 1024, 256), (5000, 768, 768)])
+def test_gelu_with_stored_derivative(M, N, K):
+    """BIAS_GELU_DG stores gelu'(h) (bf16) next to gelu(h); MUL_AUX multiplies the incoming gradient with it:
+    together they must reproduce the DGELU path up to one bf16 rounding of gelu'."""
+    from mem_amd import ops
+    A, B, bias = _rand((M, K), 1).bfloat16(), _rand((N, K), 2, 0.05).bfloat16(), _rand((N,), 3)
+    h = (A.float() @ B.float().t() + bias).bfloat16().float()
+    dg, a = torch.zeros((M, N), dtype=torch.bfloat16, device="cuda"), torch.zeros((M, N), dtype=torch.bfloat16, device="cuda")
+    ops.gemm_nt(A, B, M, N, K, ops.EPI_BIAS_GELU_DG, out0=dg, out1=a, bias=bias)
+    hg = h.clone().requires_grad_(True)
+    torch.nn.functional.gelu(hg).backward(torch.ones_like(hg))
+    torch.testing.assert_close(a.float(), torch.nn.functional.gelu(h).bfloat16().float(), rtol=2e-2, atol=2e-3)
+    torch.testing.assert_close(dg.float(), hg.grad.bfloat16().float(), rtol=2e-2, atol=2e-2)
+    G, W2 = _rand((M, K), 7).bfloat16(), _rand((N, K), 8, 0.05).bfloat16()
+    o, cs = torch.zeros((M, N), dtype=torch.bfloat16, device="cuda"), torch.zeros(N, device="cuda")
+    ops.gemm_nt(G, W2, M, N, K, ops.EPI_MUL_AUX, out0=o, aux=dg, colsum=cs)
+    da = (G.float() @ W2.float().t()).bfloat16().float()
+    torch.testing.assert_close(o.float(), (da * dg.float()).bfloat16().float(), rtol=2e-2, atol=2e-2)
+    torch.testing.assert_close(cs, o.float().sum(0), rtol=1e-3, atol=5e-2)
