@@ -153,7 +153,17 @@ __global__ __launch_bounds__(256) void colsum_kernel(const __bf16* __restrict__ 
   const int r1 = min(R, r0 + rows_per_block);
   for (int c = (blockIdx.x * 256 + threadIdx.x) * 8; c < Cc; c += gridDim.x * 256 * 8) {
     float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (int r = r0; r < r1; ++r) {
+    int r = r0;
+    for (; r + 8 <= r1; r += 8) {                  // eight rows in flight per thread
+      bf16x8 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const bf16x8*>(in + (long long)(r + u) * ld + c);
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s[k] += (float)v[u][k];
+    }
+    for (; r < r1; ++r) {
       const bf16x8 v = *reinterpret_cast<const bf16x8*>(in + (long long)r * ld + c);
 #pragma unroll
       for (int k = 0; k < 8; ++k) s[k] += (float)v[k];
