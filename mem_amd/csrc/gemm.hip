@@ -192,6 +192,7 @@ int gemm_ring_dispatch(const GemmArgs& p, hipStream_t s);
 int gemm256_dispatch(const GemmArgs& p, hipStream_t s);
 int gemm_p8_dispatch(const GemmArgs& p, hipStream_t s);
 int gemm_p8_split_rows(const GemmArgs& p);
+int gemm_p8_half_dispatch(const GemmArgs& p, hipStream_t s);
 }
 
 extern "C" int memhip_gemm_bf16_nt(const memhip_gemm_args_t* a, memhip_stream_t stream) {
@@ -244,6 +245,12 @@ extern "C" int memhip_gemm_bf16_nt(const memhip_gemm_args_t* a, memhip_stream_t 
         if (p.aux) p.aux = (const char*)p.aux + r * p.ldaux * (p.epilogue == MEMHIP_EPI_RESIDUAL ? 4 : 2);
         p.M -= split;
         p.m_base = split;
+        // the left-over rows: the same phase structure on 128-row tiles (MEMHIP_GEMM_P8_HALF=0: 128x128 kernel)
+        static const bool half_on = !(getenv("MEMHIP_GEMM_P8_HALF") && atoi(getenv("MEMHIP_GEMM_P8_HALF")) == 0);
+        if (half_on) {
+          const int rch = gemm_p8_half_dispatch(p, s);
+          if (rch != MEMHIP_EUNSUPPORTED) return rch;
+        }
         switch (p.epilogue) {
           case MEMHIP_EPI_BIAS_BF16: return launch<MEMHIP_EPI_BIAS_BF16>(p, s);
           case MEMHIP_EPI_BIAS_GELU: return launch<MEMHIP_EPI_BIAS_GELU>(p, s);

@@ -42,10 +42,20 @@ using namespace memhip;
 
 constexpr int BM = 256, BN = 256, BK = 64;
 constexpr int kThreads = 512;
-constexpr int kHalf = 128 * BK * 2;     // 16 KiB: 128 rows x 64 k
-constexpr int kBuf = 4 * kHalf;         // A0 A1 B0 B1
-constexpr int kRing = 2 * kBuf;         // 128 KiB
-constexpr int kLds = kRing;
+constexpr int kHalf = 128 * BK * 2;     // 16 KiB: 128 rows x 64 k (a B half-tile; an A half-tile when BMT = 256)
+// The tile HEIGHT is a template parameter: BMT = 256 is the main kernel; BMT = 128 (A half-tiles of 64 rows,
+// 8 MFMAs per phase) handles the rows a launch of 256-row tiles would leave to a poorly filled last round.
+template <int BMT> struct P8Geo {
+  static constexpr int kAHalf = (BMT / 2) * BK * 2;        // bytes of an A half-tile
+  static constexpr int kBOff = 2 * kAHalf;                  // B0 behind A0, A1
+  static constexpr int kBuf = 2 * kAHalf + 2 * kHalf;       // A0 A1 B0 B1
+  static constexpr int kLds = 2 * kBuf;
+  static constexpr int MF = BMT / 64;                       // 16-row fragments per wave and A half
+  static constexpr int kAPieces = BMT / 128;                // LDS-DMA instructions per wave for an A half-tile
+  // glds in flight that a phase's wait must leave alone (= the five half-tiles issued after the one needed)
+  static constexpr int kWaitA = 3 * 2 + 2 * kAPieces;       // phases 2 and 4 (prologue): B A B A B ... newest
+  static constexpr int kWaitB = 2 * 2 + 3 * kAPieces;       // phases 1 and 3
+};
 enum { HA0 = 0, HA1 = 1, HB0 = 2, HB1 = 3 };
 constexpr int kGroupM = 8;            // tile rows per group of the tile order
 
@@ -73,8 +83,10 @@ __device__ __forceinline__ int key_b(int r) { return ((r >> 1) & 1) | (((r >> 3)
     __builtin_amdgcn_sched_barrier(0);    \
   } while (0)
 
-template <int EPI>
+template <int EPI, int BMT>
 __global__ __launch_bounds__(kThreads) void gemm_p8_kernel(GemmArgs p, int ntm, int ntn) {
+  using G = P8Geo<BMT>;
+  constexpr int kBuf = G::kBuf, MF = G::MF, AP = G::kAPieces, kAHalf = G::kAHalf;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -88,16 +100,21 @@ __global__ __launch_bounds__(kThreads) void gemm_p8_kernel(GemmArgs p, int ntm, 
   const int total = my_tiles * nk;
   if (total <= 0) return;
 
-  // ---- LDS-DMA issue constants: a half-tile is 16 pieces of 8 rows x 128 B; this wave moves pieces
-  // 2*wave and 2*wave+1
+  // ---- LDS-DMA issue constants: a 128-row half-tile is 16 pieces of 8 rows x 128 B, this wave moves pieces
+  // 2*wave and 2*wave+1; a 64-row A half-tile (BMT = 128) is 8 pieces, one per wave
   int prow[2];
   unsigned offA[2], offB[2], pch[2];
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     prow[j] = (wave * 2 + j) * 8 + (lane >> 3);
-    pch[j] = (unsigned)(((lane & 7) ^ key_a(prow[j])) * 16);
-    offA[j] = (unsigned)((long long)prow[j] * p.lda * 2) + pch[j];
     offB[j] = (unsigned)((long long)prow[j] * p.ldb * 2) + (unsigned)(((lane & 7) ^ key_b(prow[j])) * 16);
+  }
+  int arow[2];                                            // rows of this wave's A pieces inside an A half-tile
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    arow[j] = (wave * AP + j) * 8 + (lane >> 3);
+    pch[j] = (unsigned)(((lane & 7) ^ key_a(arow[j])) * 16);
+    offA[j] = (unsigned)((long long)arow[j] * p.lda * 2) + pch[j];
   }
   // tile id -> (tm, tn): ids sweep groups of kGroupM tile rows column by column, so the 32
   // consecutive ids one XCD takes per round form an 8 x 4 block of tiles: its L2 is filled with
@@ -110,22 +127,23 @@ __global__ __launch_bounds__(kThreads) void gemm_p8_kernel(GemmArgs p, int ntm, 
     tm = grp * kGroupM + (rem - tn * rows);
   };
   auto stage = [&](int H, int buf, int tm, int tn, int kt) {
-    char* slot = smem + buf * kBuf + H * kHalf + wave * 2048;
     if (H == HA0 || H == HA1) {
-      const int r0 = tm * BM + (H == HA1 ? 128 : 0);
+      char* slot = smem + buf * kBuf + (H == HA1 ? kAHalf : 0) + wave * AP * 1024;
+      const int r0 = tm * BMT + (H == HA1 ? BMT / 2 : 0);
       const char* base = reinterpret_cast<const char*>(p.A) + ((long long)r0 * p.lda + kt * BK) * 2;
-      if (tm == ntm - 1 && r0 + 128 > p.M) {          // last M tile: clamp rows to M-1
+      if (tm == ntm - 1 && r0 + BMT / 2 > p.M) {      // last M tile: clamp rows to M-1
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          int gr = r0 + prow[j];
+        for (int j = 0; j < AP; ++j) {
+          int gr = r0 + arow[j];
           gr = gr < p.M ? gr : p.M - 1;
           glds16(base + (long long)(gr - r0) * p.lda * 2 + pch[j], slot + j * 1024);
         }
       } else {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) glds16(base + offA[j], slot + j * 1024);
+        for (int j = 0; j < AP; ++j) glds16(base + offA[j], slot + j * 1024);
       }
     } else {
+      char* slot = smem + buf * kBuf + G::kBOff + (H == HB1 ? kHalf : 0) + wave * 2048;
       const int c0 = tn * BN + (H == HB1 ? 128 : 0);
       const char* base = reinterpret_cast<const char*>(p.B) + ((long long)c0 * p.ldb + kt * BK) * 2;
 #pragma unroll
@@ -147,39 +165,39 @@ __global__ __launch_bounds__(kThreads) void gemm_p8_kernel(GemmArgs p, int ntm, 
   int tm1 = tm2, tn1 = tn2, k1 = k2;                    // K-tile c+1
   stage(HB0, 1, tm1, tn1, k1); stage(HA0, 1, tm1, tn1, k1); stage(HB1, 1, tm1, tn1, k1);
   advance2();
-  P8_WAIT_VM(10);
+  P8_WAIT_VM(G::kWaitA);
   P8_BARRIER();
   if (wr == 1) P8_BARRIER();                            // waves 4-7 run half a phase behind
 
   // ---- fragment read addresses: row = 16*x + (lane & 15), chunk = 4*kh + (lane >> 4)
   const int sw = (lane >> 1) & 7;
   const int roff0 = (lane & 15) * 128 + ((((lane >> 4)) ^ sw) << 4);
-  const char* rdA[2] = {smem + wr * 8192 + roff0, smem + wr * 8192 + (roff0 ^ 64)};
+  const char* rdA[2] = {smem + wr * (MF * 2048) + roff0, smem + wr * (MF * 2048) + (roff0 ^ 64)};
   const int bi = lane & 15;
   const int roffb = (((bi >> 2) * 8 + (bi & 3)) * 128) + (((lane >> 4) ^ key_b((bi >> 2) * 8 + (bi & 3))) << 4);
-  const char* rdB[2] = {smem + 2 * kHalf + wc * 4096 + roffb, smem + 2 * kHalf + wc * 4096 + (roffb ^ 64)};
+  const char* rdB[2] = {smem + G::kBOff + wc * 4096 + roffb, smem + G::kBOff + wc * 4096 + (roffb ^ 64)};
 
-  f32x4 acc[4][4][2];
+  f32x4 acc[4][MF][2];
 #pragma unroll
   for (int q = 0; q < 4; ++q)
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MF; ++i)
 #pragma unroll
       for (int j = 0; j < 2; ++j) acc[q][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   int c_tile = first, c_k = 0;
-  bf16x8 a[4][2], bx[2][2], by[2][2];
+  bf16x8 a[MF][2], bx[2][2], by[2][2];
 
 #define P8_READ_A(half)                                                                                   \
-  _Pragma("unroll") for (int mf = 0; mf < 4; ++mf) _Pragma("unroll") for (int kh = 0; kh < 2; ++kh)       \
-      a[mf][kh] = *reinterpret_cast<const bf16x8*>(rdA[kh] + bo + (half) * kHalf + mf * 2048)
+  _Pragma("unroll") for (int mf = 0; mf < MF; ++mf) _Pragma("unroll") for (int kh = 0; kh < 2; ++kh)      \
+      a[mf][kh] = *reinterpret_cast<const bf16x8*>(rdA[kh] + bo + (half) * kAHalf + mf * 2048)
 #define P8_READ_B(dst, boff, half)                                                                        \
   _Pragma("unroll") for (int nf = 0; nf < 2; ++nf) _Pragma("unroll") for (int kh = 0; kh < 2; ++kh)       \
       dst[nf][kh] = *reinterpret_cast<const bf16x8*>(rdB[kh] + (boff) + (half) * kHalf + nf * 512)
 #define P8_MFMA(q, bsrc)                                                                                  \
   do {                                                                                                    \
     __builtin_amdgcn_s_setprio(1);                                                                        \
-    _Pragma("unroll") for (int kh = 0; kh < 2; ++kh) _Pragma("unroll") for (int mf = 0; mf < 4; ++mf)     \
+    _Pragma("unroll") for (int kh = 0; kh < 2; ++kh) _Pragma("unroll") for (int mf = 0; mf < MF; ++mf)    \
         _Pragma("unroll") for (int nf = 0; nf < 2; ++nf) acc[q][mf][nf] =                                 \
             __builtin_amdgcn_mfma_f32_16x16x32_bf16(bsrc[nf][kh], a[mf][kh], acc[q][mf][nf], 0, 0, 0);    \
     __builtin_amdgcn_s_setprio(0);                                                                        \
@@ -194,7 +212,7 @@ __global__ __launch_bounds__(kThreads) void gemm_p8_kernel(GemmArgs p, int ntm, 
     P8_READ_A(0);                                                                                         \
     __builtin_amdgcn_sched_barrier(0);                                                                    \
     stage(HA1, bc ^ 1, tm1, tn1, k1);                                                                     \
-    P8_WAIT_VM(10);                                                                                       \
+    P8_WAIT_VM(G::kWaitB);                                                                                \
     P8_BARRIER();                                                                                         \
     P8_MFMA(0, bq0);                                                                                      \
     P8_BARRIER();                                                                                         \
@@ -202,7 +220,7 @@ __global__ __launch_bounds__(kThreads) void gemm_p8_kernel(GemmArgs p, int ntm, 
     P8_READ_B(bq1, bo, 1);                                                                                \
     __builtin_amdgcn_sched_barrier(0);                                                                    \
     stage(HB0, bc, tm2, tn2, k2);                                                                         \
-    P8_WAIT_VM(10);                                                                                       \
+    P8_WAIT_VM(G::kWaitA);                                                                                \
     P8_BARRIER();                                                                                         \
     P8_MFMA(1, bq1);                                                                                      \
     P8_BARRIER();                                                                                         \
@@ -210,7 +228,7 @@ __global__ __launch_bounds__(kThreads) void gemm_p8_kernel(GemmArgs p, int ntm, 
     P8_READ_A(1);                                                                                         \
     __builtin_amdgcn_sched_barrier(0);                                                                    \
     stage(HA0, bc, tm2, tn2, k2);                                                                         \
-    P8_WAIT_VM(10);                                                                                       \
+    P8_WAIT_VM(G::kWaitB);                                                                                \
     P8_BARRIER();                                                                                         \
     P8_MFMA(3, bq1);                                                                                      \
     P8_BARRIER();                                                                                         \
@@ -218,7 +236,7 @@ __global__ __launch_bounds__(kThreads) void gemm_p8_kernel(GemmArgs p, int ntm, 
     P8_READ_B(bq1, (bc ^ 1) * kBuf, 0);                                                                   \
     __builtin_amdgcn_sched_barrier(0);                                                                    \
     stage(HB1, bc, tm2, tn2, k2);                                                                         \
-    P8_WAIT_VM(10);                                                                                       \
+    P8_WAIT_VM(G::kWaitA);                                                                                \
     P8_BARRIER();                                                                                         \
     P8_MFMA(2, bq0);                                                                                      \
     P8_BARRIER();                                                                                         \
@@ -249,7 +267,7 @@ __global__ __launch_bounds__(kThreads) void gemm_p8_kernel(GemmArgs p, int ntm, 
       // operands, so a lane holds 4 consecutive columns (registers) of one row (lane & 15)
       int tm, tn;
       decode(c_tile, tm, tn);
-      const int mrow = tm * BM + wr * 64 + (lane & 15);
+      const int mrow = tm * BMT + wr * (MF * 16) + (lane & 15);
       const int ncol = tn * BN + wc * 32 + (lane >> 4) * 8;
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
@@ -261,15 +279,15 @@ __global__ __launch_bounds__(kThreads) void gemm_p8_kernel(GemmArgs p, int ntm, 
         // flight together (row index clamped instead of branched, so that nothing orders them)
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-          EpiRow<EPI> rows[4];
+          EpiRow<EPI> rows[MF];
 #pragma unroll
-          for (int mf = 0; mf < 4; ++mf) {
-            const int m = mrow + i * 128 + mf * 16;
+          for (int mf = 0; mf < MF; ++mf) {
+            const int m = mrow + i * (BMT / 2) + mf * 16;
             epi_row_load<EPI>(p, m < p.M ? m : p.M - 1, n, rows[mf]);
           }
 #pragma unroll
-          for (int mf = 0; mf < 4; ++mf) {
-            const int m = mrow + i * 128 + mf * 16;
+          for (int mf = 0; mf < MF; ++mf) {
+            const int m = mrow + i * (BMT / 2) + mf * 16;
             float v[8];
 #pragma unroll
             for (int nf = 0; nf < 2; ++nf)
@@ -294,18 +312,18 @@ __global__ __launch_bounds__(kThreads) void gemm_p8_kernel(GemmArgs p, int ntm, 
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // no LDS-DMA may outlive the workgroup
 }
 
-template <int EPI>
+template <int EPI, int BMT>
 int launch_p8(const GemmArgs& p, hipStream_t s, int num_cu) {
-  const int ntm = (p.M + BM - 1) / BM, ntn = p.N / BN;
+  const int ntm = (p.M + BMT - 1) / BMT, ntn = p.N / BN;
   static bool attr_done = false;
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_p8_kernel<EPI>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_p8_kernel<EPI, BMT>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, P8Geo<BMT>::kLds);
     if (e != hipSuccess) return fail(MEMHIP_ELAUNCH, "gemm_p8: set smem attr: %s", hipGetErrorString(e));
     attr_done = true;
   }
   const int grid = ntm * ntn < num_cu ? ntm * ntn : num_cu;
-  hipLaunchKernelGGL(gemm_p8_kernel<EPI>, dim3(grid), dim3(kThreads), kLds, s, p, ntm, ntn);
+  hipLaunchKernelGGL((gemm_p8_kernel<EPI, BMT>), dim3(grid), dim3(kThreads), P8Geo<BMT>::kLds, s, p, ntm, ntn);
   return check_launch("gemm_bf16_nt(p8)");
 }
 
@@ -351,13 +369,29 @@ int gemm_p8_dispatch(const GemmArgs& p, hipStream_t s) {
   const int num_cu = p8_num_cu();
   if (!num_cu) return MEMHIP_EUNSUPPORTED;
   switch (p.epilogue) {
-    case MEMHIP_EPI_BIAS_BF16: return launch_p8<MEMHIP_EPI_BIAS_BF16>(p, s, num_cu);
-    case MEMHIP_EPI_BIAS_GELU: return launch_p8<MEMHIP_EPI_BIAS_GELU>(p, s, num_cu);
-    case MEMHIP_EPI_RESIDUAL: return launch_p8<MEMHIP_EPI_RESIDUAL>(p, s, num_cu);
-    case MEMHIP_EPI_DGELU: return launch_p8<MEMHIP_EPI_DGELU>(p, s, num_cu);
-    case MEMHIP_EPI_BIAS_GELU_DG: return launch_p8<MEMHIP_EPI_BIAS_GELU_DG>(p, s, num_cu);
-    case MEMHIP_EPI_MUL_AUX: return launch_p8<MEMHIP_EPI_MUL_AUX>(p, s, num_cu);
-    case MEMHIP_EPI_F32: return launch_p8<MEMHIP_EPI_F32>(p, s, num_cu);
+    case MEMHIP_EPI_BIAS_BF16: return launch_p8<MEMHIP_EPI_BIAS_BF16, 256>(p, s, num_cu);
+    case MEMHIP_EPI_BIAS_GELU: return launch_p8<MEMHIP_EPI_BIAS_GELU, 256>(p, s, num_cu);
+    case MEMHIP_EPI_RESIDUAL: return launch_p8<MEMHIP_EPI_RESIDUAL, 256>(p, s, num_cu);
+    case MEMHIP_EPI_DGELU: return launch_p8<MEMHIP_EPI_DGELU, 256>(p, s, num_cu);
+    case MEMHIP_EPI_BIAS_GELU_DG: return launch_p8<MEMHIP_EPI_BIAS_GELU_DG, 256>(p, s, num_cu);
+    case MEMHIP_EPI_MUL_AUX: return launch_p8<MEMHIP_EPI_MUL_AUX, 256>(p, s, num_cu);
+    case MEMHIP_EPI_F32: return launch_p8<MEMHIP_EPI_F32, 256>(p, s, num_cu);
+    default: return MEMHIP_EUNSUPPORTED;
+  }
+}
+
+// The 128-row-tile form for the rows that gemm_p8_split_rows leaves over (any M; same N / K rules).
+int gemm_p8_half_dispatch(const GemmArgs& p, hipStream_t s) {
+  const bool vec = ((p.ldo0 | p.ldo1 | p.ldr | p.ldaux | p.colscale_n) & 7) == 0;
+  if (p.M < 128 || p.N % BN != 0 || p.K % (2 * BK) != 0 || !vec) return MEMHIP_EUNSUPPORTED;
+  const int num_cu = p8_num_cu();
+  if (!num_cu) return MEMHIP_EUNSUPPORTED;
+  switch (p.epilogue) {
+    case MEMHIP_EPI_BIAS_BF16: return launch_p8<MEMHIP_EPI_BIAS_BF16, 128>(p, s, num_cu);
+    case MEMHIP_EPI_BIAS_GELU: return launch_p8<MEMHIP_EPI_BIAS_GELU, 128>(p, s, num_cu);
+    case MEMHIP_EPI_RESIDUAL: return launch_p8<MEMHIP_EPI_RESIDUAL, 128>(p, s, num_cu);
+    case MEMHIP_EPI_DGELU: return launch_p8<MEMHIP_EPI_DGELU, 128>(p, s, num_cu);
+    case MEMHIP_EPI_F32: return launch_p8<MEMHIP_EPI_F32, 128>(p, s, num_cu);
     default: return MEMHIP_EUNSUPPORTED;
   }
 }
