@@ -206,6 +206,163 @@ __global__ __launch_bounds__(kLdsThreads) void raster_lds_kernel(
   }
 }
 
+
+// ---- long streams (N-ImageNet scale, ~1 M events per sample) on canvases whose counters do not fit one
+// workgroup's LDS: two streaming passes instead of one global atomic per event.
+//   pass 1 (raster_bin_keys): every event is read ONCE (32 B), reduced to a 4-byte key (pixel inside its
+//     band of rows | polarity << 31) and the keys of each chunk of kBinChunk events are written back sorted
+//     by band (counting sort in LDS), with the band boundaries of the chunk in a small header.
+//   pass 2 (raster_bin_accum): one workgroup per (sample, band) walks the headers, reads only its own
+//     segments (contiguous, 4 B per event), counts in LDS and writes the wrapped uint8 planes.
+// HBM traffic per event: 32 B read + 4 B written + 4 B read, against 32 B algorithmic.
+// Counters: ONE u32 per pixel = [neg count : 16 | pos count : 16].  Only counts mod 256 are observable, so
+// 16 bits are enough provided the carry out of the low half is undone: the low half changes only by +1, so
+// exactly the add that sees 0xFFFF there carries, and that thread takes the carry back out of the high half.
+constexpr int kBinThreads = 512;
+constexpr int kBinEvPerThread = 8;
+constexpr int kBinChunk = kBinThreads * kBinEvPerThread;   // 4096 events
+constexpr int kBinMaxBands = 64;
+constexpr int kBinBandPixels = 40000;                      // 156.25 KiB of LDS
+constexpr int kAccThreads = 1024;
+constexpr int kBinOverflow = 1 << 30;                      // status flag: n_events smaller than the offsets say
+
+__global__ __launch_bounds__(kBinThreads) void raster_bin_keys(
+    const double* __restrict__ ev, const int64_t* __restrict__ offsets,
+    const memhip_event_aug_t* __restrict__ augs, int H, int W, int band_px, int nb, long long n_cap,
+    unsigned int* __restrict__ keys, unsigned int* __restrict__ hdr, int32_t* __restrict__ status) {
+  __shared__ unsigned int cnt[kBinMaxBands];
+  __shared__ unsigned int base[kBinMaxBands + 1];
+  __shared__ unsigned int sorted[kBinChunk];
+  const int b = blockIdx.y, tid = threadIdx.x;
+  const long long beg = offsets[b], n = offsets[b + 1] - beg, rel = beg - offsets[0];
+  const long long HW = (long long)H * W;
+  if (rel + n > n_cap) {
+    if (blockIdx.x == 0 && tid == 0) atomicAdd(status + b, kBinOverflow);
+    return;
+  }
+  const memhip_event_aug_t* a = augs ? augs + b : nullptr;
+  const double t_last = (a && a->time_flip && n > 0) ? ev[4 * (beg + n - 1) + 2] : 0.0;
+  const long long nchunks = (n + kBinChunk - 1) / kBinChunk;
+  const long long hbase = rel / kBinChunk + b;
+  int bad = 0;
+  for (long long c = blockIdx.x; c < nchunks; c += gridDim.x) {
+    if (tid < nb) cnt[tid] = 0u;
+    __syncthreads();
+    unsigned int key[kBinEvPerThread], where[kBinEvPerThread];
+#pragma unroll
+    for (int k = 0; k < kBinEvPerThread; ++k) {
+      const long long i = c * kBinChunk + (long long)k * kBinThreads + tid;
+      where[k] = 0xFFFFFFFFu;
+      if (i >= n) continue;
+      const Ev e = load_event(ev, beg, n, i, a, t_last);
+      if (!e.keep) continue;
+      const long long xi = (long long)e.x;   // trunc toward zero == ndarray.astype(int)
+      const long long yi = (long long)e.y;
+      long long flat = xi + (long long)W * yi;
+      if (flat < -HW || flat >= HW) { ++bad; continue; }   // reference: IndexError
+      if (flat < 0) flat += HW;                             // NumPy negative index
+      const bool isneg = e.p == -1.0;
+      if (!(e.p == 1.0) && !isneg) continue;
+      const int band = (int)(flat / band_px);
+      key[k] = (unsigned int)(flat - (long long)band * band_px) | (isneg ? 0x80000000u : 0u);
+      where[k] = ((unsigned int)band << 16) | atomicAdd(&cnt[band], 1u);   // slot inside the band's segment
+    }
+    __syncthreads();
+    if (tid < 64) {                          // exclusive scan of <= 64 band counts in one wave
+      const unsigned int v = tid < nb ? cnt[tid] : 0u;
+      unsigned int inc = v;
+      for (int o = 1; o < 64; o <<= 1) {
+        const unsigned int u = __shfl_up(inc, o);
+        if (tid >= o) inc += u;
+      }
+      if (tid < nb) base[tid] = inc - v;
+      if (tid == nb - 1) base[nb] = inc;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kBinEvPerThread; ++k)
+      if (where[k] != 0xFFFFFFFFu) sorted[base[where[k] >> 16] + (where[k] & 0xFFFFu)] = key[k];
+    __syncthreads();
+    const unsigned int total = base[nb];
+    unsigned int* kout = keys + rel + c * kBinChunk;
+    for (unsigned int j = tid; j < total; j += kBinThreads) kout[j] = sorted[j];
+    if (tid <= nb) hdr[(hbase + c) * (kBinMaxBands + 1) + tid] = base[tid];
+    __syncthreads();
+  }
+  if (bad) atomicAdd(status + b, bad);
+}
+
+__global__ __launch_bounds__(kAccThreads) void raster_bin_accum(
+    const int64_t* __restrict__ offsets, int H, int W, int band_px, long long n_cap,
+    const unsigned int* __restrict__ keys, const unsigned int* __restrict__ hdr, uint8_t* __restrict__ out) {
+  extern __shared__ unsigned int cnt[];       // [band_px]: neg << 16 | pos
+  const int band = blockIdx.x, b = blockIdx.y;
+  const long long HW = (long long)H * W;
+  const long long lo = (long long)band * band_px;
+  const int npx = (int)((lo + band_px <= HW ? band_px : HW - lo));
+  for (int i = threadIdx.x; i < band_px; i += kAccThreads) cnt[i] = 0u;
+  __syncthreads();
+  const long long beg = offsets[b], n = offsets[b + 1] - beg, rel = beg - offsets[0];
+  if (rel + n <= n_cap) {
+    const long long nchunks = (n + kBinChunk - 1) / kBinChunk;
+    const unsigned int* h = hdr + (rel / kBinChunk + b) * (kBinMaxBands + 1) + band;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    constexpr int kWaves = kAccThreads / 64;
+    long long c = wave;
+    unsigned int s = 0, e = 0;
+    if (c < nchunks) { s = h[c * (kBinMaxBands + 1)]; e = h[c * (kBinMaxBands + 1) + 1]; }
+    while (c < nchunks) {
+      const long long cn = c + kWaves;
+      unsigned int s2 = 0, e2 = 0;
+      if (cn < nchunks) { s2 = h[cn * (kBinMaxBands + 1)]; e2 = h[cn * (kBinMaxBands + 1) + 1]; }   // next header in flight
+      const unsigned int* kin = keys + rel + c * kBinChunk;
+      for (unsigned int j = s + lane; j < e; j += 64) {
+        const unsigned int key = kin[j];
+        const unsigned int l = key & 0x7FFFFFFFu;
+        if (key >> 31) {
+          atomicAdd(cnt + l, 0x10000u);
+        } else {
+          const unsigned int old = atomicAdd(cnt + l, 1u);
+          if ((old & 0xFFFFu) == 0xFFFFu) atomicSub(cnt + l, 0x10000u);   // undo the carry into the neg half
+        }
+      }
+      c = cn; s = s2; e = e2;
+    }
+  }
+  __syncthreads();
+  uint8_t* o = out + (size_t)b * 3 * HW + lo;
+  for (int i = threadIdx.x * 4; i < npx; i += kAccThreads * 4) {
+    if (i + 4 <= npx && ((lo + i) & 3) == 0) {
+      const unsigned int c0 = cnt[i], c1 = cnt[i + 1], c2 = cnt[i + 2], c3 = cnt[i + 3];
+      const unsigned int pv = (c0 & 0xFFu) | ((c1 & 0xFFu) << 8) | ((c2 & 0xFFu) << 16) | ((c3 & 0xFFu) << 24);
+      const unsigned int nv = ((c0 >> 16) & 0xFFu) | (((c1 >> 16) & 0xFFu) << 8) | (((c2 >> 16) & 0xFFu) << 16) |
+                              (((c3 >> 16) & 0xFFu) << 24);
+      *reinterpret_cast<unsigned int*>(o + i) = pv;
+      *reinterpret_cast<unsigned int*>(o + HW + i) = 0u;            // time-surface channel: zeros
+      *reinterpret_cast<unsigned int*>(o + 2 * HW + i) = nv;
+    } else {
+      for (int k = i; k < i + 4 && k < npx; ++k) {
+        o[k] = (uint8_t)(cnt[k] & 0xFFu);
+        o[HW + k] = 0;
+        o[2 * HW + k] = (uint8_t)((cnt[k] >> 16) & 0xFFu);
+      }
+    }
+  }
+}
+
+// bands of whole pixels (not rows): band_px pixels each, the last one shorter
+inline bool bin_geometry(int H, int W, int* band_px, int* nb) {
+  const long long HW = (long long)H * W;
+  long long n = (HW + kBinBandPixels - 1) / kBinBandPixels;
+  if (n > kBinMaxBands) return false;
+  long long px = (HW + n - 1) / n;
+  px = (px + 3) & ~3ll;                     // 4-pixel aligned bands keep the u32 output stores
+  if (px > kBinBandPixels) { px = kBinBandPixels; n = (HW + px - 1) / px; if (n > kBinMaxBands) return false; }
+  *band_px = (int)px;
+  *nb = (int)n;
+  return true;
+}
+
 }  // namespace
 
 extern "C" size_t memhip_rasterize_workspace(int B, int H, int W) {
@@ -330,4 +487,50 @@ extern "C" int memhip_events_extent(const double* ev, const int64_t* offsets,
                      reinterpret_cast<unsigned long long*>(extent));
   hipLaunchKernelGGL(extent_decode, dim3(nb), dim3(kThreads), 0, s, extent, B);
   return memhip::check_launch("events_extent");
+}
+
+extern "C" size_t memhip_rasterize_binned_workspace(int B, int H, int W, int64_t n_events) {
+  (void)H; (void)W;
+  if (B <= 0 || n_events < 0) return 0;
+  const size_t keys = (((size_t)n_events + kBinChunk) * sizeof(unsigned int) + 15) & ~(size_t)15;
+  const size_t hdr = ((size_t)n_events / kBinChunk + (size_t)B + 1) * (kBinMaxBands + 1) * sizeof(unsigned int);
+  return keys + hdr;
+}
+
+extern "C" int memhip_rasterize_binned_f64(const double* ev, const int64_t* offsets,
+                                           const memhip_event_aug_t* aug, int B, int H, int W,
+                                           int64_t n_events, uint8_t* out, int32_t* status,
+                                           void* workspace, size_t workspace_bytes, memhip_stream_t stream) {
+  MEMHIP_REQUIRE(B >= 0 && H > 0 && W > 0 && n_events >= 0, "rasterize_binned: bad shape B=%d H=%d W=%d", B, H, W);
+  if (B == 0) return MEMHIP_OK;
+  MEMHIP_REQUIRE(ev && offsets && out && status && workspace, "rasterize_binned: null pointer");
+  MEMHIP_REQUIRE(((uintptr_t)ev & 15) == 0 && ((uintptr_t)out & 3) == 0, "rasterize_binned: ev must be 16-byte, out 4-byte aligned");
+  int band_px = 0, nb = 0;
+  if (!bin_geometry(H, W, &band_px, &nb))
+    return memhip::fail(MEMHIP_EUNSUPPORTED, "rasterize_binned: %dx%d canvas needs more than %d bands", H, W, kBinMaxBands);
+  const size_t need = memhip_rasterize_binned_workspace(B, H, W, n_events);
+  if (workspace_bytes < need)
+    return memhip::fail(MEMHIP_EWORKSPACE, "rasterize_binned: workspace %zu < %zu", workspace_bytes, need);
+  hipStream_t s = memhip::as_stream(stream);
+  unsigned int* keys = (unsigned int*)workspace;
+  const size_t keys_bytes = (((size_t)n_events + kBinChunk) * sizeof(unsigned int) + 15) & ~(size_t)15;
+  unsigned int* hdr = (unsigned int*)((char*)workspace + keys_bytes);
+  MEMHIP_HIP(hipMemsetAsync(status, 0, (size_t)B * sizeof(int32_t), s));
+  static bool attr_done = false;
+  if (!attr_done) {
+    MEMHIP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(raster_bin_accum),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, kBinBandPixels * 4));
+    attr_done = true;
+  }
+  // chunks per sample are only known on the device: enough workgroups per sample to fill the chip at
+  // small B, grid-stride beyond
+  const long long avg_chunks = n_events / ((long long)B * kBinChunk) + 1;
+  long long bx = (2048 + B - 1) / B;
+  if (bx > 4 * avg_chunks) bx = 4 * avg_chunks;
+  if (bx < 1) bx = 1;
+  hipLaunchKernelGGL(raster_bin_keys, dim3((unsigned)bx, B), dim3(kBinThreads), 0, s, ev, offsets, aug, H, W, band_px, nb,
+                     (long long)n_events, keys, hdr, status);
+  hipLaunchKernelGGL(raster_bin_accum, dim3(nb, B), dim3(kAccThreads), (size_t)band_px * 4, s, offsets, H, W, band_px,
+                     (long long)n_events, keys, hdr, out);
+  return memhip::check_launch("rasterize_binned");
 }

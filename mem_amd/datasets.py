@@ -24,8 +24,21 @@ declare({
     "memhip_rasterize_workspace": (sz, [i32, i32, i32]),
     "memhip_rasterize_f64": (i32, [vp, vp, i32, i32, i32, i32, vp, vp, vp, sz, vp]),
     "memhip_rasterize_aug_f64": (i32, [vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, sz, vp]),
+    "memhip_rasterize_binned_workspace": (sz, [i32, i32, i32, C.c_int64]),
+    "memhip_rasterize_binned_f64": (i32, [vp, vp, vp, i32, i32, i32, C.c_int64, vp, vp, vp, sz, vp]),
     "memhip_events_extent": (i32, [vp, vp, vp, i32, vp, vp]),
 })
+
+# rasterize() switches to the two-pass binned kernels (csrc/raster.hip) when the canvas does not fit the
+# single-pass LDS kernel (more than 6 bands of 14336 pixels) or the streams are long; the time surface keeps
+# the global-atomic form
+_BINNED_MIN_EVENTS_PER_SAMPLE = 200_000
+_BINNED_MAX_PIXELS = 64 * 40000
+
+
+def _lds_fits(H, W):
+    rows = 14336 // W                      # kBandPixels / kMaxBands of raster_lds_kernel
+    return rows > 0 and -(-H // rows) <= 6
 
 
 class EventAug(C.Structure):
@@ -53,18 +66,30 @@ def _new_aug_array(n):
     return a
 
 
-def rasterize(ev, offsets, H, W, time_surface=False, aug=None, strict=True):
+def rasterize(ev, offsets, H, W, time_surface=False, aug=None, strict=True, binned=None):
     """ev f64 [n,4] (cuda), offsets i64 [B+1] (cuda), aug = uint8 cuda view of B aug records or
     None -> u8 [B,3,H,W] (cuda).  strict: raise IndexError like the reference when an event lands
-    outside the canvas (costs one host sync)."""
+    outside the canvas (costs one host sync).  binned: None = choose by size, True/False = force the
+    two-pass long-stream kernels / the single-pass kernels."""
     require_gpu()
     B = offsets.numel() - 1
     out = torch.empty((B, 3, H, W), dtype=torch.uint8, device=ev.device)
     status = torch.empty((B,), dtype=torch.int32, device=ev.device)
-    wsb = lib.memhip_rasterize_workspace(B, H, W)
-    ws = torch.empty((wsb,), dtype=torch.uint8, device=ev.device)
-    check(lib.memhip_rasterize_aug_f64(ptr(ev), ptr(offsets), ptr(aug), B, H, W, int(bool(time_surface)),
-                                       ptr(out), ptr(status), ptr(ws), wsb, stream_ptr()), "rasterize")
+    n_rows = int(ev.shape[0])
+    if binned is None:
+        binned = (not time_surface and B > 0 and H * W <= _BINNED_MAX_PIXELS and
+                  (n_rows >= _BINNED_MIN_EVENTS_PER_SAMPLE * B or not _lds_fits(H, W)))
+    if binned:
+        # n_rows bounds offsets[B] - offsets[0] without a host sync
+        wsb = lib.memhip_rasterize_binned_workspace(B, H, W, n_rows)
+        ws = torch.empty((wsb,), dtype=torch.uint8, device=ev.device)
+        check(lib.memhip_rasterize_binned_f64(ptr(ev), ptr(offsets), ptr(aug), B, H, W, n_rows, ptr(out), ptr(status),
+                                              ptr(ws), wsb, stream_ptr()), "rasterize_binned")
+    else:
+        wsb = lib.memhip_rasterize_workspace(B, H, W)
+        ws = torch.empty((wsb,), dtype=torch.uint8, device=ev.device)
+        check(lib.memhip_rasterize_aug_f64(ptr(ev), ptr(offsets), ptr(aug), B, H, W, int(bool(time_surface)),
+                                           ptr(out), ptr(status), ptr(ws), wsb, stream_ptr()), "rasterize")
     if strict and int(status.sum().item()) != 0:
         raise IndexError("event outside the H x W canvas (reference: np.add.at IndexError)")
     return out

@@ -173,3 +173,88 @@ def test_pipeline_full_size_properties():
     # (sum of the halves' images) mod 256
     h1 = D.rasterize(ev[: B * n // 2], off[: B // 2 + 1], H, W, False)
     assert torch.equal(h1, img[: B // 2])
+
+
+def test_binned_rasterizer_vs_oracle_ragged_and_edges():
+    """The two-pass long-stream kernels: ragged batch, chunk-boundary sizes, fractional / negative-wrapping
+    coordinates, p == 0, events outside the canvas (status), fused augmentations -- bit-equal to the oracle
+    and to the single-pass kernels."""
+    from mem_amd import datasets as D
+    from oracle import events_np as E
+    rng = np.random.default_rng(11)
+    for (H, W) in ((480, 640), (224, 224), (37, 1000)):
+        ns = [4096, 4097, 0, 1, 50000, 4095, 8192, 12289]
+        evs = []
+        for n in ns:
+            ev = np.stack([rng.uniform(0, W, n), rng.uniform(0, H, n), np.sort(rng.integers(0, 300000, n)),
+                           rng.integers(-1, 2, n)], 1).astype(np.float64).reshape(n, 4)      # p in {-1, 0, 1}
+            evs.append(ev)
+        evs[4][:900, :2] = (3.7, 4.2); evs[4][:900, 3] = 1          # > 255 hits on one pixel
+        evs[4][900:1300, :2] = (3.2, 4.9); evs[4][900:1300, 3] = -1
+        evs[7][:50, 1] = -1.0 - rng.integers(0, H - 1, 50)          # negative flat index: NumPy wrap
+        allv = np.concatenate(evs)
+        got = D.rasterize(_ev_dev(allv), _off(*ns), H, W, False, binned=True).cpu().numpy()
+        ref = D.rasterize(_ev_dev(allv), _off(*ns), H, W, False, binned=False).cpu().numpy()
+        assert np.array_equal(got, ref), (H, W)
+        for b, n in enumerate(ns):
+            want = E.event_arr_to_img(evs[b], H, W, False).transpose(2, 0, 1) if n else np.zeros((3, H, W), np.uint8)
+            assert np.array_equal(got[b], want), (H, W, b)
+    # out-of-canvas events raise like the reference, on both paths
+    bad = np.array([[5.0, 3.0, 0.0, 1.0], [10.0, 480.0, 1.0, 1.0]])
+    for binned in (True, False):
+        with pytest.raises(IndexError):
+            D.rasterize(_ev_dev(bad), _off(2), 480, 640, False, binned=binned)
+    # fused augmentations go through the same event decode
+    n, H, W = 20000, 480, 640
+    ev = np.stack([rng.integers(0, W, n), rng.integers(0, H, n), np.sort(rng.integers(0, 300000, n)),
+                   rng.integers(0, 2, n) * 2 - 1], 1).astype(np.float64)
+    s = D.EventStream(ev.copy())
+    s.aug["time_flip"], s.aug["flip_x"], s.aug["flip_w"] = 1, 1, W
+    s.aug["shift_x"], s.aug["shift_y"], s.aug["do_filter"], s.aug["filt_w"], s.aug["filt_h"] = -7, 5, 1, W, H
+    off, aug = s._dev()
+    a = D.rasterize(s.ev, off, H, W, False, aug, binned=True)
+    b = D.rasterize(s.ev, off, H, W, False, aug, binned=False)
+    assert torch.equal(a, b) and int(a.sum()) > 0
+
+
+def test_binned_rasterizer_16bit_carry():
+    """Counters are [neg:16 | pos:16] per pixel: 65536+ positive events on one pixel must not leak into the
+    negative count (the carry is taken back out)."""
+    from mem_amd import datasets as D
+    n_pos, n_neg = 3 * 65536 + 77, 65536 + 300
+    ev = np.zeros((n_pos + n_neg + 10, 4))
+    ev[:, 0], ev[:, 1] = 17, 9
+    ev[:n_pos, 3] = 1
+    ev[n_pos:n_pos + n_neg, 3] = -1
+    ev[n_pos + n_neg:, 0] = 18; ev[n_pos + n_neg:, 3] = -1          # the neighbour pixel stays clean
+    rng = np.random.default_rng(0)
+    ev = ev[rng.permutation(len(ev))]
+    img = D.rasterize(_ev_dev(ev), _off(len(ev)), 480, 640, False, binned=True)[0].cpu().numpy()
+    assert img[0, 9, 17] == n_pos % 256 and img[2, 9, 17] == n_neg % 256
+    assert img[2, 9, 18] == 10 and img[0, 9, 18] == 0
+    assert int(img.astype(np.int64).sum()) == n_pos % 256 + n_neg % 256 + 10
+
+
+def test_binned_rasterizer_config4_properties():
+    """BASELINE configs[3] size: ~1 M events per sample on a 480 x 640 canvas (uniform, and the hot-pixel
+    variant: 1 % of the events on 16 pixels) against torch.bincount, mod 256."""
+    from mem_amd import datasets as D
+    B, n, H, W = 8, 1_000_000, 480, 640
+    g = torch.Generator(device="cuda").manual_seed(4)
+    x = torch.randint(0, W, (B * n,), generator=g, device="cuda")
+    y = torch.randint(0, H, (B * n,), generator=g, device="cuda")
+    hot = torch.rand((B * n,), generator=g, device="cuda") < 0.01
+    hp = torch.randint(0, 16, (B * n,), generator=g, device="cuda")
+    x = torch.where(hot, 100 + 7 * hp, x); y = torch.where(hot, 50 + 3 * hp, y)
+    t = torch.rand((B * n,), generator=g, device="cuda", dtype=torch.float64) * 3e5
+    p = torch.randint(0, 2, (B * n,), generator=g, device="cuda") * 2 - 1
+    ev = torch.stack([x.double(), y.double(), t, p.double()], 1).contiguous()
+    off = torch.arange(0, B + 1, device="cuda", dtype=torch.int64) * n
+    img = D.rasterize(ev, off, H, W, False)                         # size-based choice -> binned path
+    flat = x + W * y + torch.arange(B, device="cuda").repeat_interleave(n) * H * W
+    pos = torch.bincount(flat[p == 1], minlength=B * H * W).view(B, H, W)
+    neg = torch.bincount(flat[p == -1], minlength=B * H * W).view(B, H, W)
+    assert int(pos.max()) > 255                                      # the hot pixels wrap
+    assert torch.equal(img[:, 0].long(), pos % 256) and torch.equal(img[:, 2].long(), neg % 256)
+    assert int(img[:, 1].sum()) == 0
+    assert torch.equal(img, D.rasterize(ev, off, H, W, False, binned=False))
