@@ -61,6 +61,8 @@ def main():
     ap.add_argument("--no-gemm-timer", action="store_true")
     ap.add_argument("--no-tokenizer-figure", action="store_true",
                     help="skip the secondary figure that adds the frozen dVAE tokenizer forward (stock PyTorch-ROCm)")
+    ap.add_argument("--no-raster-figure", action="store_true",
+                    help="skip the secondary figure for BASELINE configs[3] (rasterizer at 1 M events per sample)")
     a = ap.parse_args()
 
     import numpy as np
@@ -187,6 +189,39 @@ def main():
             del vae, img, tok
         except Exception as e:                                        # the figure is optional
             print(f"[bench] tokenizer figure skipped: {e}", file=sys.stderr)
+    # ---- secondary figure: BASELINE configs[3], the rasterizer alone at N-ImageNet scale (1 M events per
+    # sample, 480 x 640 canvas): HBM-bound, algorithmic bytes = 32 B per event + 3*H*W output bytes
+    raster_fig = None
+    if rank == 0 and not a.no_raster_figure:
+        try:
+            from mem_amd import datasets as D
+            rb, rn, rh, rw = 32, 1_000_000, 480, 640
+            g = torch.Generator(device="cuda").manual_seed(4)
+            ev = torch.stack([torch.randint(0, rw, (rb * rn,), generator=g, device="cuda").double(),
+                              torch.randint(0, rh, (rb * rn,), generator=g, device="cuda").double(),
+                              torch.rand((rb * rn,), generator=g, device="cuda", dtype=torch.float64) * 3e5,
+                              (torch.randint(0, 2, (rb * rn,), generator=g, device="cuda") * 2 - 1).double()], 1).contiguous()
+            off = torch.arange(0, rb + 1, device="cuda", dtype=torch.int64) * rn
+            for _ in range(2):
+                D.rasterize(ev, off, rh, rw, False, strict=False)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(10):
+                D.rasterize(ev, off, rh, rw, False, strict=False)
+            e1.record()
+            torch.cuda.synchronize()
+            rdt = e0.elapsed_time(e1) * 1e-3 / 10
+            byts = rb * (32 * rn + 3 * rh * rw)
+            raster_fig = {"workload": "BASELINE configs[3]: rasterizer, 1 M events per sample (f64 (N,4) rows), 480x640 canvas, "
+                                      "32 samples per launch", "events_per_sec": round(rb * rn / rdt),
+                          "us_per_sample": round(rdt / rb * 1e6, 2),
+                          "roofline": {"bound": "hbm", "kernel": "raster_bin_keys + raster_bin_accum",
+                                       "achieved": round(byts / rdt / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
+                                       "frac": round(byts / rdt / 8e12, 4), "algorithmic_bytes_per_sample": 32 * rn + 3 * rh * rw,
+                                       "traffic": None}}
+            del ev
+        except Exception as e:                                        # the figure is optional
+            print(f"[bench] rasterizer figure skipped: {e}", file=sys.stderr)
     if rank == 0:
         ms = dt / a.steps * 1e3
         value = world * B * a.steps / dt
@@ -247,6 +282,8 @@ def main():
                                              "tokenizer forward (4 conv + 3 ResBlocks + 1x1 -> 8192, 24.4 GFLOP/sample, "
                                              "random weights) on the HIP implicit-GEMM path (csrc/conv.hip, bf16); the "
                                              "fp32 torch module on stock PyTorch-ROCm is timed beside it"}
+        if raster_fig is not None:
+            out["rasterizer_1m_events"] = raster_fig
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

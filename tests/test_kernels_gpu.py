@@ -129,7 +129,10 @@ def _attn_ref(qkv, bias, B, T, D, H, scale):
 
 
 @pytest.mark.parametrize("B,T,H,win", [(3, 197, 12, (14, 14)), (2, 17, 2, (4, 4)), (5, 65, 4, (8, 8)),
-                                       (1, 256, 2, (15, 17)), (40, 37, 3, (4, 9))])
+                                       (1, 256, 2, (15, 17)), (40, 37, 3, (4, 9)),
+                                       # > 256 tokens: the streaming kernels (attn_stream.hip); 30x40 = ViT-L @ 480x640
+                                       (1, 257, 2, (16, 16)), (3, 324, 3, (17, 19)), (2, 1201, 2, (30, 40)),
+                                       (64, 290, 16, (17, 17))])
 def test_attention_fwd_bwd(B, T, H, win):
     from mem_amd import ops
     from oracle.vit_ref import rel_pos_index
