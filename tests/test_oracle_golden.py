@@ -115,6 +115,28 @@ def test_vit_tiny_fwdbwd_golden():
     assert "mask_token" in names["decay"] and "cls_token" in names["no_decay"]
 
 
+def test_vit_long_nonsquare_golden():
+    """256 x 320 canvas (16 x 20 + 1 = 321 tokens, non-square relative-position window): the oracle against
+    the reference outputs of oracle/gen_golden_long.py, bit for bit (bf16 autocast incl. every gradient)."""
+    from oracle.gen_golden import vit_inputs
+    from oracle.gen_golden_long import LONG, LONG_INPUTS
+    torch.set_num_threads(1)
+    g = np.load(os.path.join(GOLDEN, "vit_long.npz"))
+    m = V.RefViT(**LONG)
+    m.load_state_dict(V.fill_by_name(m.state_dict(), seed=3))
+    x, mask, labels = vit_inputs(LONG, *LONG_INPUTS)
+    with torch.autocast("cpu", dtype=torch.bfloat16):
+        lo = m(x, mask)
+        loss = torch.nn.CrossEntropyLoss()(lo, labels)
+    loss.backward()
+    assert np.array_equal(lo.detach().float().numpy(), g["bf16__logits"])
+    assert np.array_equal(loss.detach().numpy(), g["bf16__loss"])
+    for k, p in m.named_parameters():
+        assert np.array_equal(p.grad.numpy(), g[f"bf16__grad__{k}"]), k
+    with torch.no_grad():
+        assert np.array_equal(m(x, mask).numpy(), g["fp32__logits"])
+
+
 def test_vit_tiny_train_golden():
     """First 20 of the 100 golden steps (the full 100 are checked against the HIP path on the GPU)."""
     torch.set_num_threads(1)
