@@ -224,6 +224,7 @@ constexpr int kBinChunk = kBinThreads * kBinEvPerThread;   // 4096 events
 constexpr int kBinMaxBands = 64;
 constexpr int kBinBandPixels = 40000;                      // 156.25 KiB of LDS
 constexpr int kAccThreads = 1024;
+constexpr int kAccUnroll = 8;                              // keys per lane in flight in pass 2
 constexpr int kBinOverflow = 1 << 30;                      // status flag: n_events smaller than the offsets say
 
 __global__ __launch_bounds__(kBinThreads) void raster_bin_keys(
@@ -316,14 +317,24 @@ __global__ __launch_bounds__(kAccThreads) void raster_bin_accum(
       unsigned int s2 = 0, e2 = 0;
       if (cn < nchunks) { s2 = h[cn * (kBinMaxBands + 1)]; e2 = h[cn * (kBinMaxBands + 1) + 1]; }   // next header in flight
       const unsigned int* kin = keys + rel + c * kBinChunk;
-      for (unsigned int j = s + lane; j < e; j += 64) {
-        const unsigned int key = kin[j];
-        const unsigned int l = key & 0x7FFFFFFFu;
-        if (key >> 31) {
-          atomicAdd(cnt + l, 0x10000u);
-        } else {
-          const unsigned int old = atomicAdd(cnt + l, 1u);
-          if ((old & 0xFFFFu) == 0xFFFFu) atomicSub(cnt + l, 0x10000u);   // undo the carry into the neg half
+      for (unsigned int j0 = s + lane; j0 < e + lane; j0 += 64 * kAccUnroll) {   // wave-uniform trip count
+        unsigned int kv[kAccUnroll];
+#pragma unroll
+        for (int k = 0; k < kAccUnroll; ++k) {                // all loads of the batch in flight before the atomics
+          const unsigned int j = j0 + 64 * k;
+          kv[k] = j < e ? kin[j] : 0xFFFFFFFFu;
+        }
+#pragma unroll
+        for (int k = 0; k < kAccUnroll; ++k) {
+          const unsigned int key = kv[k];
+          if (key == 0xFFFFFFFFu) continue;                   // (a valid key never has all low bits set: l < band_px)
+          const unsigned int l = key & 0x7FFFFFFFu;
+          if (key >> 31) {
+            atomicAdd(cnt + l, 0x10000u);
+          } else {
+            const unsigned int old = atomicAdd(cnt + l, 1u);
+            if ((old & 0xFFFFu) == 0xFFFFu) atomicSub(cnt + l, 0x10000u);   // undo the carry into the neg half
+          }
         }
       }
       c = cn; s = s2; e = e2;
