@@ -36,6 +36,13 @@
 #include "common.h"
 #include "gemm_epilogue.hpp"
 
+#ifndef P8_EPI_AHEAD
+#define P8_EPI_AHEAD 2
+#endif
+#ifndef P8_EPI_RESID_LATE
+#define P8_EPI_RESID_LATE 2
+#endif
+
 namespace {
 
 using namespace memhip;
@@ -45,6 +52,8 @@ constexpr int kThreads = 512;
 constexpr int kHalf = 128 * BK * 2;     // 16 KiB: 128 rows x 64 k (a B half-tile; an A half-tile when BMT = 256)
 // The tile HEIGHT is a template parameter: BMT = 256 is the main kernel; BMT = 128 (A half-tiles of 64 rows,
 // 8 MFMAs per phase) handles the rows a launch of 256-row tiles would leave to a poorly filled last round.
+constexpr int kEpiAhead = P8_EPI_AHEAD;   // batches of epilogue row loads in flight ahead of the compute
+
 template <int BMT> struct P8Geo {
   static constexpr int kAHalf = (BMT / 2) * BK * 2;        // bytes of an A half-tile
   static constexpr int kBOff = 2 * kAHalf;                  // B0 behind A0, A1
@@ -269,38 +278,69 @@ __global__ __launch_bounds__(kThreads) void gemm_p8_kernel(GemmArgs p, int ntm, 
       decode(c_tile, tm, tn);
       const int mrow = tm * BMT + wr * (MF * 16) + (lane & 15);
       const int ncol = tn * BN + wc * 32 + (lane >> 4) * 8;
+      // four batches (j = column half, i = row half) of MF rows each.  The per-row operand loads (GELU input /
+      // residual) of batch b + kAhead are issued before batch b is computed: with one batch in flight
+      // a CU has 32 KB outstanding, i.e. ~20 GB/s per CU at ~1.5 us latency -- the epilogue was latency
+      // bound, not HBM bound.  Row indices are clamped instead of branched, so that nothing orders the loads.
+      // (the residual epilogue carries 8 registers per row: no room for a second batch beside 128 accumulators)
+      constexpr int kAhead = (EPI == MEMHIP_EPI_RESIDUAL || EPI == MEMHIP_EPI_PATCH_EMBED) ? 0 : kEpiAhead;
+      EpiRow<EPI> rows[4][MF];
+      auto load_batch = [&](int b) {
+        const int jj = b >> 1, ii = b & 1;
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int n = ncol + j * 128;
-        float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        EpiCols cols;
-        epi_cols_load<EPI>(p, n, cols);
-        // rows in batches of four: the per-row operand loads (GELU input / residual) of a batch are in
-        // flight together (row index clamped instead of branched, so that nothing orders them)
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          EpiRow<EPI> rows[MF];
-#pragma unroll
-          for (int mf = 0; mf < MF; ++mf) {
-            const int m = mrow + i * (BMT / 2) + mf * 16;
-            epi_row_load<EPI>(p, m < p.M ? m : p.M - 1, n, rows[mf]);
-          }
-#pragma unroll
-          for (int mf = 0; mf < MF; ++mf) {
-            const int m = mrow + i * (BMT / 2) + mf * 16;
-            float v[8];
-#pragma unroll
-            for (int nf = 0; nf < 2; ++nf)
-#pragma unroll
-              for (int r = 0; r < 4; ++r) {
-                v[nf * 4 + r] = acc[i * 2 + j][mf][nf][r];
-                acc[i * 2 + j][mf][nf][r] = 0.f;
-              }
-            if (m < p.M) epilogue8<EPI>(p, m, n, v, cs, cols, rows[mf]);
-          }
+        for (int mf = 0; mf < MF; ++mf) {
+          const int m = mrow + ii * (BMT / 2) + mf * 16;
+          epi_row_load<EPI>(p, m < p.M ? m : p.M - 1, ncol + jj * 128, rows[b][mf]);
         }
-        colsum_flush16(p, n, cs, lane);
+      };
+      // residual epilogue: batch 0 alone; batches 1 and 2 go out together once batch 0 has released its
+      // accumulators and row registers (the accumulators are re-zeroed after the loop, not inside it)
+      constexpr bool kLate = (EPI == MEMHIP_EPI_RESIDUAL || EPI == MEMHIP_EPI_PATCH_EMBED) && P8_EPI_RESID_LATE;
+#pragma unroll
+      for (int b = 0; b < kAhead && b < 4; ++b) load_batch(b);
+      float cs[8];
+      EpiCols cols;
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const int j = b >> 1, i = b & 1;
+        const int n = ncol + j * 128;
+        if (i == 0) {
+#pragma unroll
+          for (int r = 0; r < 8; ++r) cs[r] = 0.f;
+          epi_cols_load<EPI>(p, n, cols);
+        }
+        if constexpr (kLate) {
+          if (b == 0) load_batch(0);
+          if (P8_EPI_RESID_LATE == 1) {
+            if (b == 1) { load_batch(1); load_batch(2); }
+            if (b == 2) load_batch(3);
+          } else {
+            if (b == 1) load_batch(1);
+            if (b == 2) { load_batch(2); load_batch(3); }
+          }
+        } else {
+          if (b + kAhead < 4) load_batch(b + kAhead);
+        }
+#pragma unroll
+        for (int mf = 0; mf < MF; ++mf) {
+          const int m = mrow + i * (BMT / 2) + mf * 16;
+          float v[8];
+#pragma unroll
+          for (int nf = 0; nf < 2; ++nf)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[nf * 4 + r] = acc[i * 2 + j][mf][nf][r];
+          if (m < p.M) epilogue8<EPI>(p, m, n, v, cs, cols, rows[b][mf]);
+        }
+        if (i == 1) colsum_flush16(p, n, cs, lane);
       }
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+          for (int nf = 0; nf < 2; ++nf)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[q][mf][nf][r] = 0.f;
       c_k = 0;
       c_tile += gridDim.x;
       if (wr == 1) P8_BARRIER();
