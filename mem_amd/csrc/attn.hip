@@ -81,7 +81,7 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(const __bf16* __restrict_
       stage_head(imgs + (cur ^ 1) * 2 * IMG + IMG, s1 + 2 * D, ldq, T, TP);
     }
     if (!active) continue;
-    const int cq4 = codeQ[qc];
+    const int cq4 = codeQ[qc] + (int)lds_addr_of(reinterpret_cast<const char*>(tabX));   // absolute LDS address of the lane's table window
     f32x16 s[NKB];
 #pragma unroll
     for (int kb = 0; kb < NKB; ++kb) {
@@ -103,7 +103,7 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(const __bf16* __restrict_
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           // log2-domain score: (q.k) * log2e + bias * log2e   (one gather, one fma)
-          float v = fmaf(s[kb][4 * g + e], kLog2e, lds_f32_at(tabX, cq4 - kcs[e]));
+          float v = fmaf(s[kb][4 * g + e], kLog2e, lds_f32_abs(cq4 - kcs[e]));
           if (kb == NKB - 1 && key0 + e >= T) v = -INFINITY;
           s[kb][4 * g + e] = v;
           mx = fmaxf(mx, v);
@@ -243,7 +243,7 @@ __global__ __launch_bounds__(512) void attn_bwd_kv_kernel(const __bf16* __restri
     __syncthreads();
     if (b + 1 < b1) { load_next(b + 1); stage_sample(b + 1, cur ^ 1); }
     if (!active) continue;
-    const int ck4 = codeK[kc_tok];
+    const int ck4 = codeK[kc_tok] - (int)lds_addr_of(reinterpret_cast<const char*>(tabX));   // (folds the table's LDS base)
     const float kmask = key < T ? 1.f : 0.f;
     const float* lseC = lseS + cur * TP;
     const float* delC = delS + cur * TP;
@@ -277,7 +277,7 @@ __global__ __launch_bounds__(512) void attn_bwd_kv_kernel(const __bf16* __restri
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int i = 4 * g + e;
-          const float sv = fmaf(S[i], kLog2e, lds_f32_at(tabX, qcs[e] - ck4));
+          const float sv = fmaf(S[i], kLog2e, lds_f32_abs(qcs[e] - ck4));
           float p = fexp2(sv - ll[e]) * kmask;                 // kmask = 0 for padding keys
           if (qb == NKB - 1 && q0 + e >= T) p = 0.f;
           S[i] = p;
@@ -429,7 +429,8 @@ __global__ __launch_bounds__(512) void attn_bwd_q_kernel(const __bf16* __restric
     __syncthreads();                      // K/V of sample b landed; sample b-1 fully consumed
     if (b + 1 < b1) { load_q(b + 1); stage_sample(b + 1, cur ^ 1); }
     if (active) {
-      const int cq4 = codeQ[qc];
+      const int cq4 = codeQ[qc] + (int)lds_addr_of(reinterpret_cast<const char*>(tabX));   // absolute LDS address of the lane's table window
+      const int bins_delta = (int)(lds_addr_of(reinterpret_cast<const char*>(binsi)) - lds_addr_of(reinterpret_cast<const char*>(tabX)));
       f32x16 dQt[2];
 #pragma unroll
       for (int db = 0; db < 2; ++db)
@@ -458,13 +459,13 @@ __global__ __launch_bounds__(512) void attn_bwd_q_kernel(const __bf16* __restric
           for (int e = 0; e < 4; ++e) {
             const int i = 4 * g + e;
             const int idx4 = cq4 - kcs[e];
-            const float sv = fmaf(St[i], kLog2e, lds_f32_at(tabX, idx4));
+            const float sv = fmaf(St[i], kLog2e, lds_f32_abs(idx4));
             float p = fexp2(sv - lq) * qmask;                   // qmask = 0 for padding queries
             if (kb == NKB - 1 && key0 + e >= T) p = 0.f;
             const float ds = p * (dPt[i] - dq_);
             dPt[i] = ds;
             // masked elements add 0 (their codes are valid): no divergent branch around the atomic
-            if (DT) atomicAdd(reinterpret_cast<int*>(reinterpret_cast<char*>(binsi) + idx4), __float2int_rn(ds * fx));
+            if (DT) lds_add_i32_abs(idx4 + bins_delta, __float2int_rn(ds * fx));
           }
         }
         bf16x8 ckf[2][2];

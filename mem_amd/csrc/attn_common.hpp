@@ -164,6 +164,16 @@ __device__ __forceinline__ void rel_setup(float* tabX, int* codeQ, int* codeK, c
     codeK[t] = 4 * ck;
   }
 }
+// Gather from an ABSOLUTE LDS byte address.  The table's base is folded into the per-lane code once per sample;
+// through a generic `base + offset` hipcc emits a separate v_add_u32 of the (link-time) LDS base in front of
+// every ds_read_b32 -- one VALU instruction per score element in kernels that are VALU-issue bound.
+__device__ __forceinline__ float lds_f32_abs(int lds_byte_addr) {
+  return *reinterpret_cast<const __attribute__((address_space(3))) float*>((unsigned)lds_byte_addr);
+}
+__device__ __forceinline__ void lds_add_i32_abs(int lds_byte_addr, int v) {       // ds_add_u32, no return
+  __hip_atomic_fetch_add(reinterpret_cast<__attribute__((address_space(3))) int*>((unsigned)lds_byte_addr), v,
+                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
 __device__ __forceinline__ float lds_f32_at(const float* base, int byte_off) {
   return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off);
 }

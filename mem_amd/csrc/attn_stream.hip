@@ -75,7 +75,7 @@ __global__ __launch_bounds__(512) void attn_fwd_stream_kernel(const __bf16* __re
       stage_chunk(imgs + (cur ^ 1) * 2 * IMG + IMG, s0 + 2 * D, ldq, (c + 1) * CT, T, CT);
     }
     if (!active) continue;
-    const int cq4 = codeQ[qc];
+    const int cq4 = codeQ[qc] + (int)lds_addr_of(reinterpret_cast<const char*>(tabX));   // absolute LDS address of the lane's table window
     f32x16 s[CKB];
 #pragma unroll
     for (int kb = 0; kb < CKB; ++kb) {
@@ -96,7 +96,7 @@ __global__ __launch_bounds__(512) void attn_fwd_stream_kernel(const __bf16* __re
         bfr2(s[kb], 4 * g + 2);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          float v = fmaf(s[kb][4 * g + e], kLog2e, lds_f32_at(tabX, cq4 - kcs[e]));
+          float v = fmaf(s[kb][4 * g + e], kLog2e, lds_f32_abs(cq4 - kcs[e]));
           if (key0 + e >= T) v = -INFINITY;
           s[kb][4 * g + e] = v;
           cmax = fmaxf(cmax, v);
@@ -235,7 +235,7 @@ __global__ __launch_bounds__(512) void attn_bwd_kv_stream_kernel(
       stage_chunk(imgs + (cur ^ 1) * 2 * IMG + IMG, d0, ldo, (c + 1) * CT, T, CT);
     }
     if (!active) continue;
-    const int ck4 = codeK[kc_tok];
+    const int ck4 = codeK[kc_tok] - (int)lds_addr_of(reinterpret_cast<const char*>(tabX));   // (folds the table's LDS base)
     const float* lseC = lseS + cur * CT;
     const float* delC = delS + cur * CT;
 #pragma unroll
@@ -264,7 +264,7 @@ __global__ __launch_bounds__(512) void attn_bwd_kv_stream_kernel(
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int i = 4 * g + e;
-          const float sv = fmaf(S[i], kLog2e, lds_f32_at(tabX, qcs[e] - ck4));
+          const float sv = fmaf(S[i], kLog2e, lds_f32_abs(qcs[e] - ck4));
           float p = fexp2(sv - ll[e]) * kmask;                 // kmask = 0 for padding keys
           if (q0 + e >= T) p = 0.f;
           S[i] = p;
@@ -409,7 +409,8 @@ __global__ __launch_bounds__(512) void attn_bwd_q_stream_kernel(
         stage_chunk(imgs + (cur ^ 1) * 2 * IMG + IMG, s0 + 2 * D, ldq, (c + 1) * CT, T, CT);
       }
       if (!active) continue;
-      const int cq4 = codeQ[qc];
+      const int cq4 = codeQ[qc] + (int)lds_addr_of(reinterpret_cast<const char*>(tabX));   // absolute LDS address of the lane's table window
+      const int bins_delta = (int)(lds_addr_of(reinterpret_cast<const char*>(binsi)) - lds_addr_of(reinterpret_cast<const char*>(tabX)));
 #pragma unroll
       for (int kb = 0; kb < CKB; ++kb) {
         f32x16 St, dPt;
@@ -433,12 +434,12 @@ __global__ __launch_bounds__(512) void attn_bwd_q_stream_kernel(
           for (int e = 0; e < 4; ++e) {
             const int i = 4 * g + e;
             const int idx4 = cq4 - kcs[e];
-            const float sv = fmaf(St[i], kLog2e, lds_f32_at(tabX, idx4));
+            const float sv = fmaf(St[i], kLog2e, lds_f32_abs(idx4));
             float p = fexp2(sv - lq) * qmask;                   // qmask = 0 for padding queries
             if (key0 + e >= T) p = 0.f;
             const float ds = p * (dPt[i] - dq_);
             dPt[i] = ds;
-            if (DT) atomicAdd(reinterpret_cast<int*>(reinterpret_cast<char*>(binsi) + idx4), __float2int_rn(ds * fx));
+            if (DT) lds_add_i32_abs(idx4 + bins_delta, __float2int_rn(ds * fx));
           }
         }
         bf16x8 ckf[2][2];
