@@ -258,6 +258,12 @@ def main():
                 roof = {"bound": "mfma", "kernel": "bf16 MFMA GEMM family", "achieved": round(ach, 1),
                         "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
                         "traffic": None}
+            # MFMA-pipe utilisation from the SQ counters (tools/prof_mfma.sh -> profiles/mfma_util.json, own PMC passes):
+            # SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x 1024 SIMDs), per kernel family and over the whole step
+            upath = os.path.join(ROOT, "profiles", "mfma_util.json")
+            if os.path.exists(upath):
+                uj = json.load(open(upath))
+                roof["mfma_util_pmc"] = {k.lstrip("_"): v["mfma_util"] for k, v in uj.items() if "mfma_util" in v}
             roof["gemm_family"] = {"kernels": "gemm_p8_kernel<EPI>, gemm_nt_kernel<EPI>, gemm_tn_p8_kernel",
                                    "achieved": round(ach, 1), "frac": round(ach / PEAK_BF16_TFLOPS, 4),
                                    "launches": len(timer), "avg_launch_us": round(tot_ms / len(timer) * 1e3, 2),
