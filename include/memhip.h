@@ -362,6 +362,14 @@ int memhip_adamw(float* p, const float* g, float* m, float* v, int64_t n, const 
                  double lr, double beta1, double beta2, double eps, double weight_decay, int step,
                  const float* gnorm, double max_norm, memhip_stream_t stream);
 
+/* The same step with per-group learning rates / weight decay (layer-wise lr decay of finetuning:
+ * replaces get_parameter_groups + LayerDecayValueAssigner   mem/optim_factory.py:31-100 feeding optim.AdamW).
+ * group_of_chunk u8 [n/1024]; group_table f32 [n_groups][2] (device) = {1 - lr_g*wd_g, lr_g / (1 - beta1^step)},
+ * computed by the caller in double and rounded once, like torch's Python-side scalars. */
+int memhip_adamw_groups(float* p, const float* g, float* m, float* v, int64_t n, const uint8_t* group_of_chunk,
+                        const float* group_table, int n_groups, double beta1, double beta2, double eps, int step,
+                        const float* gnorm, double max_norm, memhip_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -77,6 +77,45 @@ __global__ __launch_bounds__(kT) void adamw_kernel(float* __restrict__ p, const 
   }
 }
 
+// The same update with PER-GROUP learning rates (layer-wise lr decay of finetuning: every parameter group has its
+// own lr = schedule x lr_scale and weight decay, mem/optim_factory.py:31-53,56-100).  group_of_chunk[c] indexes a
+// small device table of {1 - lr_g*wd_g, lr_g / bias_correction1}, both computed on the host in double like torch.
+__global__ __launch_bounds__(kT) void adamw_groups_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                          float* __restrict__ m, float* __restrict__ v,
+                                                          long long nchunks, const unsigned char* __restrict__ group_of_chunk,
+                                                          const float2* __restrict__ group_table, float b1, float b2,
+                                                          float eps, float bc2_sqrt, const float* __restrict__ gnorm,
+                                                          float max_norm) {
+  float coef = 1.0f;
+  if (max_norm > 0.f) {
+    coef = max_norm / (gnorm[0] + 1e-6f);
+    coef = coef < 1.0f ? coef : 1.0f;
+  }
+  for (long long c = blockIdx.x; c < nchunks; c += gridDim.x) {
+    const float2 gt = group_table[group_of_chunk[c]];
+    const float decay = gt.x, step_size = gt.y;
+    const long long i = c * (kChunk / 4) + threadIdx.x;
+    float4 pp = reinterpret_cast<float4*>(p)[i];
+    float4 gg = reinterpret_cast<const float4*>(g)[i];
+    float4 mm = reinterpret_cast<float4*>(m)[i];
+    float4 vv = reinterpret_cast<float4*>(v)[i];
+#define UPD(f)                                                        \
+    {                                                                 \
+      const float gr = gg.f * coef;                                   \
+      pp.f *= decay;                                                  \
+      mm.f = mm.f + (gr - mm.f) * (1.0f - b1);                        \
+      vv.f = vv.f * b2 + (1.0f - b2) * gr * gr;                       \
+      const float denom = sqrtf(vv.f) / bc2_sqrt + eps;               \
+      pp.f = pp.f - step_size * (mm.f / denom);                       \
+    }
+    UPD(x) UPD(y) UPD(z) UPD(w)
+#undef UPD
+    reinterpret_cast<float4*>(p)[i] = pp;
+    reinterpret_cast<float4*>(m)[i] = mm;
+    reinterpret_cast<float4*>(v)[i] = vv;
+  }
+}
+
 }  // namespace
 
 extern "C" size_t memhip_grad_norm_workspace(void) { return 1024 * sizeof(double); }
@@ -115,4 +154,22 @@ extern "C" int memhip_adamw(float* p, const float* g, float* m, float* v, int64_
                      wd_flag_per_chunk, (float)(1.0 - lr * weight_decay), (float)beta1, (float)beta2,
                      (float)eps, step_size, bc2_sqrt, gnorm, (float)max_norm);
   return check_launch("adamw");
+}
+
+extern "C" int memhip_adamw_groups(float* p, const float* g, float* m, float* v, int64_t n,
+                                   const uint8_t* group_of_chunk, const float* group_table, int n_groups,
+                                   double beta1, double beta2, double eps, int step, const float* gnorm,
+                                   double max_norm, memhip_stream_t stream) {
+  MEMHIP_REQUIRE(n >= 0 && n % kChunk == 0, "adamw_groups: n must be a multiple of %d", kChunk);
+  if (n == 0) return MEMHIP_OK;
+  MEMHIP_REQUIRE(p && g && m && v && group_of_chunk && group_table && n_groups >= 1 && n_groups <= 256 && step >= 1,
+                 "adamw_groups: bad arguments");
+  MEMHIP_REQUIRE(max_norm <= 0.0 || gnorm, "adamw_groups: clipping needs gnorm");
+  const double bc2 = 1.0 - pow(beta2, (double)step);
+  const long long nchunks = n / kChunk;
+  int blocks = (int)(nchunks < 8192 ? nchunks : 8192);
+  hipLaunchKernelGGL(adamw_groups_kernel, dim3(blocks), dim3(kT), 0, as_stream(stream), p, g, m, v, nchunks,
+                     group_of_chunk, reinterpret_cast<const float2*>(group_table), (float)beta1, (float)beta2, (float)eps,
+                     (float)sqrt(bc2), gnorm, (float)max_norm);
+  return check_launch("adamw_groups");
 }

@@ -1,5 +1,6 @@
 """ViT building blocks -- mirror of /root/reference/mem/modeling_finetune.py:42-247
-(DropPath, Mlp, Attention, Block, PatchEmbed, RelativePositionBias).
+(DropPath, Mlp, Attention, Block, PatchEmbed, RelativePositionBias) -- and the finetuning model
+``VisionTransformer`` / ``ft_vit`` (:250-385).
 
 These classes keep the reference's constructor arguments, attribute names and therefore its
 state-dict keys and its torch-RNG initialisation order, but they are PARAMETER CONTAINERS: the
@@ -58,7 +59,6 @@ class Attention(nn.Module):
             head_dim = attn_head_dim
         all_head_dim = head_dim * num_heads
         assert head_dim == 64 and all_head_dim == dim, "fused attention kernel: head_dim 64 (ViT-B / ViT-L)"
-        assert window_size is None, "per-block rel-pos tables (use_rel_pos_bias) are unused by the pretraining configs"
         assert attn_drop == 0.0 and proj_drop == 0.0
         self.scale = qk_scale or head_dim ** -0.5
         self.qkv = nn.Linear(dim, all_head_dim * 3, bias=False)
@@ -68,9 +68,18 @@ class Attention(nn.Module):
         else:
             self.q_bias = None
             self.v_bias = None
-        self.window_size = None
-        self.relative_position_bias_table = None
-        self.relative_position_index = None
+        if window_size:
+            # use_rel_pos_bias: this block's own bucket table + index buffer (modeling_finetune.py:96-124), same
+            # parameter / buffer names; the fused attention kernel gathers from the table directly
+            self.window_size = window_size
+            rp = RelativePositionBias(window_size, num_heads)
+            self.num_relative_distance = rp.num_relative_distance
+            self.relative_position_bias_table = nn.Parameter(torch.zeros(self.num_relative_distance, num_heads))
+            self.register_buffer("relative_position_index", rp.relative_position_index)
+        else:
+            self.window_size = None
+            self.relative_position_bias_table = None
+            self.relative_position_index = None
         self.attn_drop = nn.Dropout(attn_drop)
         self.proj = nn.Linear(all_head_dim, dim)
         self.proj_drop = nn.Dropout(proj_drop)
@@ -135,3 +144,168 @@ class RelativePositionBias(nn.Module):
         self.register_buffer("relative_position_index", idx)
 
     forward = _fused
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Finetuning model (modeling_finetune.py:250-385).  The trunk (patch embedding, position embedding, blocks with
+# per-block or shared relative-position bias, layer scale, stochastic depth) runs in the fused HIP engine; the
+# O(B x D) tail -- mean pooling over the patch tokens, fc_norm, head -- is ordinary torch modules under bf16
+# autocast, connected to the engine by one autograd Function.
+import math                                   # noqa: E402
+from functools import partial                 # noqa: E402
+
+
+def _trunc_normal_(tensor, mean=0.0, std=1.0):
+    # modeling_finetune.py:17 imports timm's trunc_normal_ itself (absolute cut-offs a=-2, b=2), unlike
+    # modeling_pretrain.py:19-20 which wraps it with a=-std, b=std
+    nn.init.trunc_normal_(tensor, mean=mean, std=std, a=-2.0, b=2.0)
+
+
+class _TrunkFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, model, x, dp_masks, anchor):
+        ctx.model = model
+        eng = model.engine
+        xl = eng.forward_trunk(x, None, dp_masks)
+        return xl[: x.shape[0] * eng.T].view(x.shape[0], eng.T, eng.D).clone()
+
+    @staticmethod
+    def backward(ctx, dxl):
+        eng = ctx.model.engine
+        eng.attach_grads()
+        eng.backward_trunk(dxl.float().contiguous())
+        return None, None, None, None
+
+
+class VisionTransformer(nn.Module):
+    """modeling_finetune.py:250-369: same constructor keywords, state-dict keys, init order and forward()."""
+
+    def __init__(self, img_size=(224, 224), patch_size=(16, 16), in_chans=3, num_classes=1000, embed_dim=768, depth=12,
+                 num_heads=12, mlp_ratio=4.0, qkv_bias=False, qk_scale=None, drop_rate=0.0, attn_drop_rate=0.0,
+                 drop_path_rate=0.0, norm_layer=nn.LayerNorm, init_values=None, use_abs_pos_emb=True,
+                 use_rel_pos_bias=False, use_shared_rel_pos_bias=False, use_mean_pooling=True, init_scale=0.001,
+                 use_batch_norm=False, **kwargs):
+        super().__init__()
+        assert qkv_bias and drop_rate == 0.0 and attn_drop_rate == 0.0, "fused path: qkv_bias, no dropout"
+        assert not use_batch_norm, "linear-probe BatchNorm head: not in the fused path"
+        self.num_classes = num_classes
+        self.num_features = self.embed_dim = embed_dim
+        self.patch_embed = PatchEmbed(img_size=img_size, patch_size=patch_size, in_chans=in_chans, embed_dim=embed_dim)
+        num_patches = self.patch_embed.num_patches
+        self.cls_token = nn.Parameter(torch.zeros(1, 1, embed_dim))
+        self.pos_embed = nn.Parameter(torch.zeros(1, num_patches + 1, embed_dim)) if use_abs_pos_emb else None
+        self.pos_drop = nn.Dropout(p=drop_rate)
+        if use_shared_rel_pos_bias:
+            self.rel_pos_bias = RelativePositionBias(window_size=self.patch_embed.patch_shape, num_heads=num_heads)
+        else:
+            self.rel_pos_bias = None
+        dpr = [x.item() for x in torch.linspace(0, drop_path_rate, depth)]
+        self.use_rel_pos_bias = use_rel_pos_bias
+        self.blocks = nn.ModuleList([
+            Block(dim=embed_dim, num_heads=num_heads, mlp_ratio=mlp_ratio, qkv_bias=qkv_bias, qk_scale=qk_scale,
+                  drop=drop_rate, attn_drop=attn_drop_rate, drop_path=dpr[i], norm_layer=norm_layer,
+                  init_values=init_values, window_size=self.patch_embed.patch_shape if use_rel_pos_bias else None)
+            for i in range(depth)])
+        self.norm = nn.Identity() if use_mean_pooling else norm_layer(embed_dim)
+        self.fc_norm = norm_layer(embed_dim) if use_mean_pooling else None
+        self.head = nn.Linear(embed_dim, num_classes) if num_classes > 0 else nn.Identity()
+        if self.pos_embed is not None:
+            _trunc_normal_(self.pos_embed, std=0.02)
+        _trunc_normal_(self.cls_token, std=0.02)
+        if isinstance(self.head, nn.Linear):
+            _trunc_normal_(self.head.weight, std=0.02)
+        self.apply(self._init_weights)
+        self.fix_init_weight()
+        if isinstance(self.head, nn.Linear):
+            self.head.weight.data.mul_(init_scale)
+            self.head.bias.data.mul_(init_scale)
+        self._engine = None
+        self._anchor = None
+
+    def fix_init_weight(self):
+        for layer_id, layer in enumerate(self.blocks):
+            layer.attn.proj.weight.data.div_(math.sqrt(2.0 * (layer_id + 1)))
+            layer.mlp.fc2.weight.data.div_(math.sqrt(2.0 * (layer_id + 1)))
+
+    def _init_weights(self, m):
+        if isinstance(m, nn.Linear):
+            _trunc_normal_(m.weight, std=0.02)
+            if m.bias is not None:
+                nn.init.constant_(m.bias, 0)
+        elif isinstance(m, nn.LayerNorm):
+            nn.init.constant_(m.bias, 0)
+            nn.init.constant_(m.weight, 1.0)
+
+    def get_num_layers(self):
+        return len(self.blocks)
+
+    @torch.jit.ignore
+    def no_weight_decay(self):
+        return {"pos_embed", "cls_token"}
+
+    def get_classifier(self):
+        return self.head
+
+    def reset_classifier(self, num_classes, global_pool=""):
+        raise NotImplementedError("reset_classifier after the engine is built: construct the model with num_classes")
+
+    @property
+    def engine(self):
+        if self._engine is None:
+            from ._lib import require_gpu
+            from .vit_engine import ViTEngine
+            require_gpu()
+            self._engine = ViTEngine(self)
+        return self._engine
+
+    def load_state_dict(self, *a, **k):
+        r = super().load_state_dict(*a, **k)
+        if self._engine is not None:
+            self._engine.weights_dirty = True
+        return r
+
+    def draw_drop_path(self, B):
+        eng = self.engine
+        probs = torch.tensor([b.drop_prob for b in self.blocks for _ in range(2)], device=eng.dev)
+        if float(probs.max()) == 0.0:
+            return None
+        u = torch.rand((2 * eng.depth, B), device=eng.dev)
+        return torch.floor((1.0 - probs).view(-1, 1) + u).contiguous()
+
+    def _trunk(self, x, drop_path_masks=None):
+        eng = self.engine
+        x = x.to(device=eng.dev, dtype=torch.float32).contiguous()
+        if self.training and drop_path_masks is None:
+            drop_path_masks = self.draw_drop_path(x.shape[0])
+        if not self.training:
+            drop_path_masks = None
+        if torch.is_grad_enabled() and self.training:
+            if self._anchor is None:
+                self._anchor = torch.zeros(1, device=x.device, requires_grad=True)
+            return _TrunkFunction.apply(self, x, drop_path_masks, self._anchor)
+        B = x.shape[0]
+        return eng.forward_trunk(x, None, drop_path_masks)[: B * eng.T].view(B, eng.T, eng.D).clone()
+
+    def forward_features(self, x, drop_path_masks=None):
+        t = self._trunk(x, drop_path_masks)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            t = self.norm(t)
+            if self.fc_norm is not None:
+                return self.fc_norm(t[:, 1:, :].mean(1))
+            return t[:, 0]
+
+    def forward(self, x, drop_path_masks=None):
+        x = self.forward_features(x, drop_path_masks)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            return self.head(x)
+
+    def get_intermediate_layers(self, x):
+        raise NotImplementedError("per-block features are not exported by the fused engine")
+
+
+def ft_vit(pretrained=False, **kwargs):
+    """modeling_finetune.py:372-378."""
+    model = VisionTransformer(qkv_bias=True, norm_layer=partial(nn.LayerNorm, eps=1e-6), **kwargs)
+    model.default_cfg = {"url": "", "num_classes": 2, "input_size": (3, 128, 128), "pool_size": None, "crop_pct": 1,
+                         "interpolation": "bicubic", "mean": (0.5, 0, 0.5), "std": (0.5, 0, 0.5)}
+    return model

@@ -209,6 +209,10 @@ class VisionTransformerForMaskedImageModeling(nn.Module):
         self.engine.backward()
 
 
+from .modeling_finetune import ft_vit as _ft_vit   # noqa: E402
+ft_vit = register_model(_ft_vit)
+
+
 @register_model
 def pt_vit(pretrained=False, **kwargs):
     init_ckpt = kwargs.pop("init_ckpt", None)

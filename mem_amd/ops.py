@@ -93,6 +93,7 @@ declare({
     "memhip_grad_norm_workspace": (sz, []),
     "memhip_grad_norm": (i32, [vp, i64, vp, vp, sz, vp]),
     "memhip_adamw": (i32, [vp, vp, vp, vp, i64, vp, f64, f64, f64, f64, f64, i32, vp, f64, vp]),
+    "memhip_adamw_groups": (i32, [vp, vp, vp, vp, i64, vp, vp, i32, f64, f64, f64, i32, vp, f64, vp]),
 })
 
 
@@ -217,6 +218,11 @@ def grad_norm(g, n, norm_out, ws):
 def adamw(p, g, m, v, n, wd_flags, lr, beta1, beta2, eps, wd, step, gnorm=None, max_norm=0.0):
     check(lib.memhip_adamw(ptr(p), ptr(g), ptr(m), ptr(v), n, ptr(wd_flags), lr, beta1, beta2, eps, wd, step,
                            ptr(gnorm), max_norm if max_norm else 0.0, stream_ptr()), "adamw")
+
+
+def adamw_groups(p, g, m, v, n, group_of_chunk, group_table, n_groups, beta1, beta2, eps, step, gnorm=None, max_norm=0.0):
+    check(lib.memhip_adamw_groups(ptr(p), ptr(g), ptr(m), ptr(v), n, ptr(group_of_chunk), ptr(group_table), n_groups, beta1,
+                                  beta2, eps, step, ptr(gnorm), max_norm if max_norm else 0.0, stream_ptr()), "adamw_groups")
 
 
 declare({

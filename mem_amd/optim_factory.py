@@ -11,8 +11,36 @@ import json
 import torch
 
 
+def get_num_layer_for_vit(var_name, num_max_layer):
+    """optim_factory.py:31-43: the layer id that decides a parameter's lr scale under layer-wise lr decay."""
+    if var_name in ("cls_token", "mask_token", "pos_embed"):
+        return 0
+    elif var_name.startswith("patch_embed"):
+        return 0
+    elif var_name.startswith("rel_pos_bias"):
+        return num_max_layer - 1
+    elif var_name.startswith("blocks"):
+        return int(var_name.split(".")[1]) + 1
+    else:
+        return num_max_layer - 1
+
+
+class LayerDecayValueAssigner(object):
+    """optim_factory.py:46-53."""
+
+    def __init__(self, values):
+        self.values = values
+
+    def get_scale(self, layer_id):
+        return self.values[layer_id]
+
+    def get_layer_id(self, var_name):
+        return get_num_layer_for_vit(var_name, len(self.values))
+
+
 def get_parameter_groups(model, weight_decay=1e-5, skip_list=(), get_num_layer=None, get_layer_scale=None):
-    assert get_num_layer is None and get_layer_scale is None, "layer-decay groups belong to finetuning"
+    """optim_factory.py:56-100: decay / no_decay, split per layer id (``layer_%d_decay`` ...) with an ``lr_scale``
+    when the finetuning entry point passes a LayerDecayValueAssigner's methods."""
     names = {}
     groups = {}
     for name, param in model.named_parameters():
@@ -22,9 +50,15 @@ def get_parameter_groups(model, weight_decay=1e-5, skip_list=(), get_num_layer=N
             gname, wd = "no_decay", 0.0
         else:
             gname, wd = "decay", weight_decay
+        if get_num_layer is not None:
+            layer_id = get_num_layer(name)
+            gname = "layer_%d_%s" % (layer_id, gname)
+        else:
+            layer_id = None
         if gname not in groups:
-            names[gname] = {"weight_decay": wd, "params": [], "lr_scale": 1.0}
-            groups[gname] = {"weight_decay": wd, "params": [], "lr_scale": 1.0}
+            scale = get_layer_scale(layer_id) if get_layer_scale is not None else 1.0
+            names[gname] = {"weight_decay": wd, "params": [], "lr_scale": scale}
+            groups[gname] = {"weight_decay": wd, "params": [], "lr_scale": scale}
         groups[gname]["params"].append(param)
         names[gname]["params"].append(name)
     print("Param groups = %s" % json.dumps(names, indent=2))
@@ -48,8 +82,10 @@ class FlatAdamW:
             g.setdefault("betas", tuple(betas))
             g.setdefault("eps", eps)
             self.param_groups.append(g)
-        assert all(g.get("lr_scale", 1.0) == 1.0 for g in self.param_groups), "pretraining uses lr_scale 1"
         e = self.engine
+        # chunk -> group map for the grouped update (layer-wise lr decay); built lazily on the first step that needs it
+        self._group_of_chunk = None
+        self._group_table = None
         self.exp_avg = torch.zeros(e.nflat, dtype=torch.float32, device=e.dev)
         self.exp_avg_sq = torch.zeros(e.nflat, dtype=torch.float32, device=e.dev)
         self.steps = 0
@@ -61,13 +97,56 @@ class FlatAdamW:
 
     def step(self):
         lrs = {g["lr"] for g in self.param_groups}
-        assert len(lrs) == 1, "flat AdamW: one learning rate for all groups (lr_scale == 1)"
-        wds = [g["weight_decay"] for g in self.param_groups if g["weight_decay"] > 0]
-        wd = wds[0] if wds else 0.0
+        wdset = {g["weight_decay"] for g in self.param_groups if g["weight_decay"] > 0}
         g0 = self.param_groups[0]
         self.steps += 1
-        self.engine.adamw_step(self.exp_avg, self.exp_avg_sq, lrs.pop(), wd, self.steps, betas=g0["betas"],
-                               eps=g0["eps"], max_norm=self.max_norm)
+        if len(lrs) == 1 and len(wdset) <= 1 and self._covers_flag_layout():
+            wd = wdset.pop() if wdset else 0.0
+            self.engine.adamw_step(self.exp_avg, self.exp_avg_sq, lrs.pop(), wd, self.steps, betas=g0["betas"],
+                                   eps=g0["eps"], max_norm=self.max_norm)
+        else:
+            self._grouped_step(g0)
+
+    def _covers_flag_layout(self):
+        """True when the groups' decay / no_decay split is the engine's built-in one (pretraining)."""
+        if not hasattr(self, "_flag_ok"):
+            e = self.engine
+            name_of = {id(p): n for n, p in e.named.items()}
+            dec = {name_of[id(p)] for g in self.param_groups if g["weight_decay"] > 0 for p in g["params"]}
+            allp = {name_of[id(p)] for g in self.param_groups for p in g["params"]}
+            self._flag_ok = dec == set(e.decay_names) and allp == set(e.named)
+        return self._flag_ok
+
+    def _grouped_step(self, g0):
+        """Per-group lr / weight decay (finetuning with layer decay, frozen parameters): memhip_adamw_groups.  Chunks
+        that belong to no group (frozen parameters, padding) map to a group with lr 0 and no decay."""
+        import numpy as np
+        from . import ops
+        e = self.engine
+        ng = len(self.param_groups)
+        assert ng < 255, "grouped AdamW: at most 254 parameter groups"
+        if self._group_of_chunk is None:
+            name_of = {id(p): n for n, p in e.named.items()}
+            goc = np.full(e.nflat // 1024, ng, dtype=np.uint8)             # ng = the "frozen" group
+            for gi, g in enumerate(self.param_groups):
+                for p in g["params"]:
+                    o, k = e.segs[name_of[id(p)]]
+                    goc[o // 1024:(o + k + 1023) // 1024] = gi
+            # (q_bias and v_bias share one padded [q_bias | 0 | v_bias] segment and one group: same layer, no decay)
+            self._group_of_chunk = torch.from_numpy(goc).to(e.dev)
+            self._group_table = torch.zeros((ng + 1, 2), dtype=torch.float32, device=e.dev)
+        b1 = g0["betas"][0]
+        bc1 = 1.0 - b1 ** self.steps
+        tab = np.empty((ng + 1, 2), dtype=np.float32)
+        for gi, g in enumerate(self.param_groups):
+            tab[gi, 0] = np.float32(1.0 - g["lr"] * g["weight_decay"])
+            tab[gi, 1] = np.float32(g["lr"] / bc1)
+        tab[ng] = (1.0, 0.0)
+        self._group_table.copy_(torch.from_numpy(tab), non_blocking=True)
+        ops.adamw_groups(e.flat_p, e.flat_g, self.exp_avg, self.exp_avg_sq, e.nflat, self._group_of_chunk, self._group_table,
+                         ng + 1, g0["betas"][0], g0["betas"][1], g0["eps"], self.steps, gnorm=e.gnorm,
+                         max_norm=self.max_norm or 0.0)
+        e.weights_dirty = True
 
     # ---- torch-format state for checkpoints (utils.save_model / auto_load_model)
     def _param_list(self):

@@ -47,13 +47,23 @@ class ViTEngine:
         self.heads = model.blocks[0].attn.num_heads
         self.scale = float(model.blocks[0].attn.scale)
         self.hidden = model.blocks[0].mlp.fc1.weight.shape[0]
-        self.V = model.lm_head.weight.shape[0]
+        # "mlm": masked-token head of the pretraining model (lm_head on the masked rows);  "cls": the finetuning
+        # model (modeling_finetune.VisionTransformer) -- the engine runs the trunk, the O(B*D) pooling / fc_norm / head
+        # tail stays in torch autograd
+        self.head_kind = "mlm" if hasattr(model, "lm_head") else "cls"
+        self.V = model.lm_head.weight.shape[0] if self.head_kind == "mlm" else 0
         self.Kpe = self.C * self.ph * self.pw
         assert self.D % 64 == 0 and self.hidden % 64 == 0 and self.Kpe % 64 == 0, "GEMM K dims must be multiples of 64"
-        assert model.pos_embed is None, "use_abs_pos_emb is off in every pretraining config; not in the fused path"
-        assert model.rel_pos_bias is not None, "fused attention expects the shared relative position bias"
+        self.has_pos = model.pos_embed is not None
+        self.window = tuple(pe.patch_shape)
+        self.nrd = (2 * self.window[0] - 1) * (2 * self.window[1] - 1) + 3
+        if model.rel_pos_bias is not None:
+            self.rel = "shared"                      # one table for all blocks (pretraining; --disable_rel_pos_bias off)
+        elif getattr(model.blocks[0].attn, "relative_position_bias_table", None) is not None:
+            self.rel = "block"                       # use_rel_pos_bias: one table per block (finetuning default)
+        else:
+            self.rel = "none"
         self.TP = ops.attn_tokens_padded(self.T)
-        self.nrd = model.rel_pos_bias.num_relative_distance
         self._pack_parameters()
         self._build_static()
         self.B = 0
@@ -67,15 +77,17 @@ class ViTEngine:
         named = dict(m.named_parameters())
         skip = m.no_weight_decay()
         order = []                                    # (bucket, [names]) in reverse-layer order
-        order.append(("head", ["lm_head.weight", "lm_head.bias", "norm.weight", "norm.bias"]))
+        order.append(("head", ["lm_head.weight", "lm_head.bias", "head.weight", "head.bias", "fc_norm.weight", "fc_norm.bias",
+                               "norm.weight", "norm.bias"]))
         for i in reversed(range(self.depth)):
             pre = f"blocks.{i}."
             names = [pre + n for n in ("mlp.fc2.weight", "mlp.fc2.bias", "gamma_2", "mlp.fc1.weight", "mlp.fc1.bias",
                                        "norm2.weight", "norm2.bias", "attn.proj.weight", "attn.proj.bias", "gamma_1",
-                                       "attn.qkv.weight", "QKVBIAS", "norm1.weight", "norm1.bias")]
+                                       "attn.qkv.weight", "QKVBIAS", "attn.relative_position_bias_table", "norm1.weight",
+                                       "norm1.bias")]
             order.append((f"block{i}", names))
         order.append(("embed", ["rel_pos_bias.relative_position_bias_table", "patch_embed.proj.weight",
-                                "patch_embed.proj.bias", "mask_token", "cls_token"]))
+                                "patch_embed.proj.bias", "mask_token", "cls_token", "pos_embed"]))
         segs, off = {}, 0
         buckets, flags = [], []
         for bname, names in order:
@@ -147,8 +159,10 @@ class ViTEngine:
                               proj=torch.empty((D, D), dtype=bf, device=dev),
                               fc1=torch.empty((D, Hd), dtype=bf, device=dev),
                               fc2=torch.empty((Hd, D), dtype=bf, device=dev))
-        self.wT_lm = torch.empty((D, V), dtype=bf, device=dev)
-        self.window = tuple(self.model.rel_pos_bias.window_size)
+        self.wT_lm = torch.empty((D, V), dtype=bf, device=dev) if self.head_kind == "mlm" else None
+        self.zero_table = torch.zeros((self.nrd, self.heads), dtype=torch.float32, device=dev)   # rel == "none"
+        self.zero_vec = torch.zeros(D, dtype=torch.float32, device=dev)                           # no mask_token
+        self.head_end = self.buckets[0][2]           # flat offset where the head bucket ends
         # MEMHIP_GELU_DG=1: fc1 keeps gelu'(h) (bf16) for the backward instead of h, so that erf / exp are evaluated
         # once and the GELU backward is a plain product.  Measured gain 0.2 ms per step for one extra bf16 rounding
         # of gelu' -- off by default (the reference evaluates gelu' in fp32 from the stored pre-activation)
@@ -177,11 +191,14 @@ class ViTEngine:
                                  a=e(M, Hd), lse=e(B, self.heads, self.TP, dt=f32),
                                  mean1=e(M, dt=f32), rstd1=e(M, dt=f32), mean2=e(M, dt=f32), rstd2=e(M, dt=f32)))
         # head
-        self.hN = e(Mm_cap, D)
-        self.meanN, self.rstdN = e(Mm_cap, dt=f32), e(Mm_cap, dt=f32)
-        self.logits = e(Mm_cap, V)
-        self.row_loss, self.row_ok = e(Mm_cap, dt=f32), torch.empty(Mm_cap, dtype=torch.int32, device=dev)
-        self.dhN = e(Mm_cap, D)
+        if self.head_kind == "mlm":
+            self.hN = e(Mm_cap, D)
+            self.meanN, self.rstdN = e(Mm_cap, dt=f32), e(Mm_cap, dt=f32)
+            self.logits = e(Mm_cap, V)
+            self.row_loss, self.row_ok = e(Mm_cap, dt=f32), torch.empty(Mm_cap, dtype=torch.int32, device=dev)
+            self.dhN = e(Mm_cap, D)
+        else:
+            self.zero_mask = torch.zeros(B * self.L, dtype=torch.uint8, device=dev)
         # backward temporaries (shared by all blocks)
         self.dx = torch.zeros((M, D), dtype=f32, device=dev)
         self.dY, self.dh_small = e(M, D), e(M, D)
@@ -205,8 +222,24 @@ class ViTEngine:
             ops.transpose_cast(self.P(pre + "attn.proj.weight").view(D, D), D, D, self.wT[i]["proj"])
             ops.transpose_cast(self.P(pre + "mlp.fc1.weight").view(Hd, D), Hd, D, self.wT[i]["fc1"])
             ops.transpose_cast(self.P(pre + "mlp.fc2.weight").view(D, Hd), D, Hd, self.wT[i]["fc2"])
-        ops.transpose_cast(self.P("lm_head.weight").view(self.V, D), self.V, D, self.wT_lm)
+        if self.head_kind == "mlm":
+            ops.transpose_cast(self.P("lm_head.weight").view(self.V, D), self.V, D, self.wT_lm)
         self.weights_dirty = False
+
+    def table(self, i):
+        """Relative-position bucket table of block i ([nrd, heads] fp32 master)."""
+        if self.rel == "shared":
+            return self.P("rel_pos_bias.relative_position_bias_table")
+        if self.rel == "block":
+            return self.P(f"blocks.{i}.attn.relative_position_bias_table")
+        return self.zero_table
+
+    def dtable(self, i):
+        if self.rel == "shared":
+            return self.G("rel_pos_bias.relative_position_bias_table")
+        if self.rel == "block":
+            return self.G(f"blocks.{i}.attn.relative_position_bias_table")
+        return None
 
     # ------------------------------------------------------------------ forward
     def forward(self, x, mask_u8, rows_idx, labels=None, dp_masks=None, all_tokens=False):
@@ -221,21 +254,50 @@ class ViTEngine:
             f"Input image size ({x.shape[2]}*{x.shape[3]}) doesn't match model ({self.H}*{self.W})."
         Mm = rows_idx.numel()
         self.ensure_batch(B, Mm)
-        if self.weights_dirty:
-            self.sync_weights()
+        xl = self.forward_trunk(x, mask_u8, dp_masks)
         D, Hd, T, L, V = self.D, self.hidden, self.T, self.L, self.V
         M = B * T
-        self.cur = dict(B=B, M=M, Mm=Mm, mask=mask_u8, rows=rows_idx, dp=dp_masks, labels=labels)
+        self.cur.update(Mm=Mm, rows=rows_idx, labels=labels)
+        # final norm on exactly the rows that reach the head (x[:,1:][bool_masked_pos])
+        ops.layernorm_fwd(xl, self.P("norm.weight"), self.P("norm.bias"), self.hN, self.meanN, self.rstdN, Mm, D,
+                          row_idx=rows_idx)
+        ops.gemm_nt(self.hN, self.W16("lm_head.weight", V, D), Mm, V, D, ops.EPI_BIAS_BF16, out0=self.logits,
+                    bias=self.P("lm_head.bias"))
+        if labels is not None:
+            ops.cross_entropy(self.logits, labels, Mm, V, 1.0 / Mm, self.row_loss, self.row_ok, self.loss_acc,
+                              write_grad=True)
+        return self.logits[:Mm]
+
+    def forward_trunk(self, x, mask_u8=None, dp_masks=None):
+        """Patch embedding (+ mask-token blend, + abs. position embedding) and the blocks: x f32 [B,C,H,W] ->
+        the fp32 residual stream after the last block, [B*T, D] (engine-owned, valid until the next forward)."""
+        assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous()
+        B = x.shape[0]
+        assert tuple(x.shape[1:]) == (self.C, self.H, self.W), \
+            f"Input image size ({x.shape[2]}*{x.shape[3]}) doesn't match model ({self.H}*{self.W})."
+        self.ensure_batch(B, getattr(self, "Mm_cap", 0))
+        if self.weights_dirty:
+            self.sync_weights()
+        if mask_u8 is None:
+            mask_u8 = self.zero_mask[: B * self.L]
+        D, Hd, T, L = self.D, self.hidden, self.T, self.L
+        M = B * T
+        self.cur = dict(B=B, M=M, Mm=0, mask=mask_u8, rows=None, dp=dp_masks, labels=None)
+        if self.head_kind == "cls":
+            self.flat_g[: self.head_end].zero_()        # the torch tail accumulates its gradients here before backward_trunk
         ops.im2col(x, B, self.C, self.H, self.W, self.ph, self.pw, self.patches)
         x0 = self.x[0]
         ops.fill_cls(x0, B, T, D, self.P("cls_token"))
         ops.gemm_nt(self.patches, self.W16("patch_embed.proj.weight", D, self.Kpe), B * L, D, self.Kpe,
-                    ops.EPI_PATCH_EMBED, bias=self.P("patch_embed.proj.bias"), vec1=self.P("mask_token"),
+                    ops.EPI_PATCH_EMBED, bias=self.P("patch_embed.proj.bias"),
+                    vec1=self.P("mask_token") if "mask_token" in self.segs else self.zero_vec,
                     resid=x0, aux=mask_u8, rows_per_sample=L, ldaux=0)
-        table = self.P("rel_pos_bias.relative_position_bias_table")
+        if self.has_pos:
+            x0[:M].view(B, T, D).add_(self.P("pos_embed").view(1, T, D))
         for i in range(self.depth):
             pre = f"blocks.{i}."
             a = self.act[i]
+            table = self.table(i)
             blk = self.model.blocks[i]
             keep = 1.0 - blk.drop_prob
             use_dp = dp_masks is not None and blk.drop_prob > 0.0
@@ -257,16 +319,7 @@ class ViTEngine:
             ops.gemm_nt(a["a"], self.W16(pre + "mlp.fc2.weight", D, Hd), M, D, Hd, ops.EPI_RESIDUAL, out0=None,
                         bias=self.P(pre + "mlp.fc2.bias"), vec1=g2, resid=xout, aux=xmid, ldaux=D,
                         rowmask=dp_masks[2 * i + 1] if use_dp else None, keep_prob=keep, rows_per_sample=T)
-        xl = self.x[2 * self.depth]
-        # final norm on exactly the rows that reach the head (x[:,1:][bool_masked_pos])
-        ops.layernorm_fwd(xl, self.P("norm.weight"), self.P("norm.bias"), self.hN, self.meanN, self.rstdN, Mm, D,
-                          row_idx=rows_idx)
-        ops.gemm_nt(self.hN, self.W16("lm_head.weight", V, D), Mm, V, D, ops.EPI_BIAS_BF16, out0=self.logits,
-                    bias=self.P("lm_head.bias"))
-        if labels is not None:
-            ops.cross_entropy(self.logits, labels, Mm, V, 1.0 / Mm, self.row_loss, self.row_ok, self.loss_acc,
-                              write_grad=True)
-        return self.logits[:Mm]
+        return self.x[2 * self.depth]
 
     # ------------------------------------------------------------------ backward
     def _wgrad(self, dY, X, R, n_out, n_in, gname, bias_grads=()):
@@ -297,10 +350,24 @@ class ViTEngine:
         self._wgrad(dl, self.hN, Mm, V, D, "lm_head.weight", bias_grads=((self.G("lm_head.bias"), 0, V),))
         ops.layernorm_bwd(self.dhN, self.x[2 * self.depth], self.P("norm.weight"), self.meanN, self.rstdN, dx,
                           self.G("norm.weight"), self.G("norm.bias"), Mm, D, accumulate=False, row_idx=c["rows"])
+        self._backward_trunk()
+
+    def backward_trunk(self, dxl):
+        """Finetuning: gradient of the loss w.r.t. the trunk output (f32 [B*T, D] or [B,T,D]) -> every trunk parameter."""
+        c = self.cur
+        M, D = c["M"], self.D
+        self.flat_g[self.head_end:].zero_()
+        self.dx[:M].copy_(dxl.reshape(M, D))
+        self._backward_trunk()
+
+    def _backward_trunk(self):
+        c = self.cur
+        B, M = c["B"], c["M"]
+        D, Hd, T, L = self.D, self.hidden, self.T, self.L
+        dp_masks = c["dp"]
+        dx = self.dx
         if self.grad_hook:
             self.grad_hook(0)
-        dtable = self.G("rel_pos_bias.relative_position_bias_table")
-        table = self.P("rel_pos_bias.relative_position_bias_table")
         fuse = D <= 1024 and os.environ.get("MEMHIP_FUSE_LN_BRANCH", "1") != "0"
         for i in reversed(range(self.depth)):
             pre = f"blocks.{i}."
@@ -310,6 +377,7 @@ class ViTEngine:
             use_dp = dp_masks is not None and blk.drop_prob > 0.0
             xin, xmid = self.x[2 * i], self.x[2 * i + 1]
             has_g = (pre + "gamma_1") in self.segs
+            table, dtable = self.table(i), self.dtable(i)
             # -- MLP branch (for every block but the last this already ran fused into the norm1 backward of
             # block i+1, see below)
             if i == self.depth - 1 or not fuse:
@@ -374,7 +442,10 @@ class ViTEngine:
             if self.grad_hook:
                 self.grad_hook(self.depth - i)
         # ---- embedding
-        ops.embed_bwd(dx, c["mask"], B, L, D, self.dYpe, self.G("cls_token"), self.G("mask_token"))
+        if self.has_pos:
+            self.G("pos_embed").view(T, D).copy_(dx[:M].view(B, T, D).sum(0))
+        ops.embed_bwd(dx, c["mask"], B, L, D, self.dYpe, self.G("cls_token"),
+                      self.G("mask_token") if "mask_token" in self.segs else self.zero_vec)
         self._wgrad(self.dYpe, self.patches, B * L, D, self.Kpe, "patch_embed.proj.weight",
                     bias_grads=((self.G("patch_embed.proj.bias"), 0, D),))
         if self.grad_hook:

@@ -42,13 +42,18 @@ def rel_pos_index(window):
 
 
 class _Attn(nn.Module):
-    def __init__(self, dim, heads):
+    def __init__(self, dim, heads, window=None):
         super().__init__()
         self.heads = heads
         self.scale = (dim // heads) ** -0.5
         self.qkv = nn.Linear(dim, 3 * dim, bias=False)
         self.q_bias = nn.Parameter(torch.zeros(dim))
         self.v_bias = nn.Parameter(torch.zeros(dim))
+        self.window = window
+        if window:                               # use_rel_pos_bias: the block's own table (modeling_finetune.py:96-120)
+            idx, nrd = rel_pos_index(window)
+            self.relative_position_bias_table = nn.Parameter(torch.zeros(nrd, heads))
+            self.register_buffer("relative_position_index", idx)
         self.proj = nn.Linear(dim, dim)
 
     def forward(self, x, bias):
@@ -60,6 +65,10 @@ class _Attn(nn.Module):
         q, k, v = qkv[0], qkv[1], qkv[2]
         q = q * self.scale
         a = q @ k.transpose(-2, -1)
+        if self.window:                          # modeling_finetune.py:140-146
+            n = self.window[0] * self.window[1] + 1
+            own = self.relative_position_bias_table[self.relative_position_index.view(-1)].view(n, n, -1)
+            a = a + own.permute(2, 0, 1).contiguous().unsqueeze(0)
         if bias is not None:
             a = a + bias
         a = a.softmax(dim=-1)
@@ -79,10 +88,10 @@ class _Mlp(nn.Module):
 
 
 class _Block(nn.Module):
-    def __init__(self, dim, heads, mlp_ratio, drop_path, init_values, eps):
+    def __init__(self, dim, heads, mlp_ratio, drop_path, init_values, eps, window=None):
         super().__init__()
         self.norm1 = nn.LayerNorm(dim, eps=eps)
-        self.attn = _Attn(dim, heads)
+        self.attn = _Attn(dim, heads, window)
         self.norm2 = nn.LayerNorm(dim, eps=eps)
         self.mlp = _Mlp(dim, int(dim * mlp_ratio))
         self.drop_prob = float(drop_path)
@@ -227,6 +236,96 @@ class RefViT(nn.Module):
         if return_all_tokens:
             return self.lm_head(x)
         return self.lm_head(x[bool_masked_pos])
+
+
+class RefFtViT(nn.Module):
+    """== VisionTransformer as built by ft_vit (modeling_finetune.py:250-378: qkv_bias=True, LayerNorm eps=1e-6,
+    dropouts 0): trunk + mean pooling over the patch tokens + fc_norm + head (or cls token + norm)."""
+
+    def __init__(self, img_size=(224, 224), patch_size=(16, 16), in_chans=3, num_classes=1000, embed_dim=768, depth=12,
+                 num_heads=12, mlp_ratio=4.0, drop_path_rate=0.0, init_values=None, use_abs_pos_emb=True,
+                 use_rel_pos_bias=False, use_shared_rel_pos_bias=False, use_mean_pooling=True, init_scale=0.001):
+        super().__init__()
+        self.embed_dim = embed_dim
+        self.patch_embed = _PatchEmbed(img_size, patch_size, in_chans, embed_dim)
+        self.cls_token = nn.Parameter(torch.zeros(1, 1, embed_dim))
+        self.pos_embed = (nn.Parameter(torch.zeros(1, self.patch_embed.num_patches + 1, embed_dim))
+                          if use_abs_pos_emb else None)
+        self.rel_pos_bias = (_RelPos(self.patch_embed.patch_shape, num_heads) if use_shared_rel_pos_bias else None)
+        dpr = [v.item() for v in torch.linspace(0, drop_path_rate, depth)]
+        self.blocks = nn.ModuleList([_Block(embed_dim, num_heads, mlp_ratio, dpr[i], init_values, 1e-6,
+                                            self.patch_embed.patch_shape if use_rel_pos_bias else None)
+                                     for i in range(depth)])
+        self.norm = nn.Identity() if use_mean_pooling else nn.LayerNorm(embed_dim, eps=1e-6)
+        self.fc_norm = nn.LayerNorm(embed_dim, eps=1e-6) if use_mean_pooling else None
+        self.head = nn.Linear(embed_dim, num_classes)
+        def tn(t, std):          # timm 0.4.12 trunc_normal_(tensor, std=std): ABSOLUTE cut-offs a=-2, b=2 (un-vendored)
+            nn.init.trunc_normal_(t, mean=0.0, std=std, a=-2.0, b=2.0)
+        if self.pos_embed is not None:
+            tn(self.pos_embed, 0.02)
+        tn(self.cls_token, 0.02)
+        tn(self.head.weight, 0.02)
+
+        def visit(m):                     # nn.Module.apply order: children first (modeling_finetune.py:311-318)
+            for c in m.children():
+                visit(c)
+            if isinstance(m, nn.Linear):
+                tn(m.weight, 0.02)
+                if m.bias is not None:
+                    nn.init.constant_(m.bias, 0)
+            elif isinstance(m, nn.LayerNorm):
+                nn.init.constant_(m.bias, 0)
+                nn.init.constant_(m.weight, 1.0)
+        visit(self)
+        with torch.no_grad():
+            for i, blk in enumerate(self.blocks):
+                blk.attn.proj.weight.div_(math.sqrt(2.0 * (i + 1)))
+                blk.mlp.fc2.weight.div_(math.sqrt(2.0 * (i + 1)))
+            self.head.weight.mul_(init_scale)
+            self.head.bias.mul_(init_scale)
+
+    def no_weight_decay(self):
+        return {"pos_embed", "cls_token"}
+
+    def forward(self, x, keep=None):
+        # modeling_finetune.py:334-356
+        x = self.patch_embed(x)
+        B = x.shape[0]
+        x = torch.cat((self.cls_token.expand(B, -1, -1), x), dim=1)
+        if self.pos_embed is not None:
+            x = x + self.pos_embed
+        bias = self.rel_pos_bias() if self.rel_pos_bias is not None else None
+        for i, blk in enumerate(self.blocks):
+            k1 = k2 = None
+            if keep is not None:
+                k1, k2 = keep[i]
+            x = blk(x, bias, k1, k2)
+        x = self.norm(x)
+        x = self.fc_norm(x[:, 1:, :].mean(1)) if self.fc_norm is not None else x[:, 0]
+        return self.head(x)
+
+
+def layer_decay_groups(model, weight_decay, layer_decay):
+    """optim_factory.py:31-100 + run_class_finetuning.py:550-552: group name -> (weight_decay, lr_scale, [names])."""
+    depth = len(model.blocks)
+    values = [layer_decay ** (depth + 1 - i) for i in range(depth + 2)]
+
+    def layer_id(n):
+        if n in ("cls_token", "mask_token", "pos_embed") or n.startswith("patch_embed"):
+            return 0
+        if n.startswith("rel_pos_bias"):
+            return len(values) - 1
+        if n.startswith("blocks"):
+            return int(n.split(".")[1]) + 1
+        return len(values) - 1
+    skip = model.no_weight_decay()
+    out = {}
+    for n, p in model.named_parameters():
+        nd = p.ndim == 1 or n.endswith(".bias") or n in skip
+        lid = layer_id(n)
+        g = "layer_%d_%s" % (lid, "no_decay" if nd else "decay")
+        out.setdefault(g, {"weight_decay": 0.0 if nd else weight_decay, "lr_scale": values[lid], "params": []})["params"].append(n)
+    return out
 
 
 def param_groups(model, weight_decay=0.05):

@@ -157,6 +157,79 @@ def test_vit_large_480x640_step():
         assert rel <= 2e-2, (k, rel.item())          # table-gradient / bias atomics reorder fp32 sums
 
 
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_finetune_model_vs_reference_golden(tag):
+    """f3: ft_vit on the fused engine (trunk in HIP, pooling / fc_norm / head in torch autograd) against the
+    reference's bf16-autocast outputs: (a) per-block relative-position tables + mean pooling + layer scale (the
+    finetuning default), (b) shared table + abs. position embedding + cls-token head, no layer scale."""
+    from mem_amd.modeling_finetune import ft_vit
+    from oracle.gen_golden_ft import FT_A, FT_B, ft_inputs
+    from oracle.vit_ref import fill_by_name
+    cfg = FT_A if tag == "a" else FT_B
+    g = np.load(os.path.join(GOLDEN, "vit_ft.npz"))
+    meta = json.load(open(os.path.join(GOLDEN, "vit_ft_meta.json")))
+    m = ft_vit(**cfg)
+    assert list(m.state_dict().keys()) == meta[f"{tag}_state_keys"]
+    m.load_state_dict(fill_by_name(m.state_dict(), seed=5))
+    m = m.cuda().train()
+    x, y = ft_inputs(cfg, 5, 31)
+    lo = m(x.cuda())
+    assert np.abs(lo.detach().float().cpu().numpy() - g[f"{tag}__logits"]).max() <= 0.03
+    loss = torch.nn.CrossEntropyLoss()(lo.float(), y.cuda())
+    assert abs(loss.item() - float(g[f"{tag}__loss"])) <= 3e-3
+    loss.backward()
+    for k, p in m.named_parameters():
+        ref = torch.from_numpy(g[f"{tag}__grad__{k}"]).cuda()
+        rel = (p.grad - ref).norm() / (ref.norm() + 1e-12)
+        assert rel <= 4e-2, (k, rel.item())
+    flat_g = torch.cat([p.grad.flatten() for _, p in m.named_parameters()])
+    flat_r = torch.cat([torch.from_numpy(g[f"{tag}__grad__{k}"]).flatten() for k, _ in m.named_parameters()]).cuda()
+    assert torch.nn.functional.cosine_similarity(flat_g, flat_r, dim=0).item() >= 0.999
+    m.eval()
+    with torch.no_grad():
+        lo2 = m(x.cuda())
+    assert np.abs(lo2.float().cpu().numpy() - g[f"{tag}__logits"]).max() <= 0.03
+
+
+def test_finetune_layer_decay_adamw_vs_torch():
+    """Layer-wise lr decay: FlatAdamW's grouped update (memhip_adamw_groups) against torch.optim.AdamW with the same
+    parameter groups, 3 steps with gradient clipping, on the finetuning model's parameters."""
+    import contextlib
+    import io
+    from mem_amd import optim_factory as OF
+    from mem_amd.modeling_finetune import ft_vit
+    from oracle.gen_golden_ft import FT_A, ft_inputs
+    from oracle.vit_ref import fill_by_name
+    m = ft_vit(**FT_A)
+    m.load_state_dict(fill_by_name(m.state_dict(), seed=5))
+    m = m.cuda().train()
+    depth = FT_A["depth"]
+    assigner = OF.LayerDecayValueAssigner(list(0.75 ** (depth + 1 - i) for i in range(depth + 2)))
+    with contextlib.redirect_stdout(io.StringIO()):
+        groups = OF.get_parameter_groups(m, 0.05, m.no_weight_decay(), assigner.get_layer_id, assigner.get_scale)
+    opt = OF.FlatAdamW(m, groups, lr=1e-3)
+    opt.max_norm = 1.0
+    shadow = {k: p.detach().clone().requires_grad_(True) for k, p in m.named_parameters()}
+    name_of = {id(p): n for n, p in m.named_parameters()}
+    tgroups = [{"params": [shadow[name_of[id(p)]] for p in gr["params"]], "weight_decay": gr["weight_decay"],
+                "lr": 1e-3 * gr["lr_scale"]} for gr in groups]
+    topt = torch.optim.AdamW(tgroups, lr=1e-3, betas=(0.9, 0.95), eps=1e-8)
+    x, y = ft_inputs(FT_A, 5, 31)
+    for it in range(3):
+        for gr in opt.param_groups:
+            gr["lr"] = 1e-3 * gr["lr_scale"]
+        loss = torch.nn.CrossEntropyLoss()(m(x.cuda()).float(), y.cuda())
+        loss.backward()
+        for k, p in m.named_parameters():
+            shadow[k].grad = p.grad.detach().clone()
+        torch.nn.utils.clip_grad_norm_(list(shadow.values()), 1.0)
+        topt.step()
+        m.engine.grad_norm()
+        opt.step()
+        for k, p in m.named_parameters():
+            torch.testing.assert_close(p.detach(), shadow[k].detach(), rtol=2e-5, atol=2e-6, msg=lambda s_, k=k: f"{k}: {s_}")
+
+
 def test_drop_path_masks_vs_oracle():
     """Stochastic depth with the keep masks fed in: product vs the CPU oracle under bf16 autocast."""
     from mem_amd.modeling_pretrain import pt_vit

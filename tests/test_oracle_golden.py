@@ -137,6 +137,42 @@ def test_vit_long_nonsquare_golden():
         assert np.array_equal(m(x, mask).numpy(), g["fp32__logits"])
 
 
+def test_finetune_model_golden_and_layer_decay_groups():
+    """f3: the oracle's finetuning model (RefFtViT) against the reference outputs of oracle/gen_golden_ft.py, bit for
+    bit under bf16 autocast, in both head configurations; the layer-decay parameter groups of the oracle AND of the
+    product's optim_factory (pure host logic) against the reference's assignment."""
+    from oracle.gen_golden_ft import FT_A, FT_B, ft_inputs
+    torch.set_num_threads(1)
+    g = np.load(os.path.join(GOLDEN, "vit_ft.npz"))
+    meta = json.load(open(os.path.join(GOLDEN, "vit_ft_meta.json")))
+    for tag, cfg in (("a", FT_A), ("b", FT_B)):
+        m = V.RefFtViT(**cfg)
+        assert list(m.state_dict().keys()) == meta[f"{tag}_state_keys"]
+        m.load_state_dict(V.fill_by_name(m.state_dict(), seed=5))
+        x, y = ft_inputs(cfg, 5, 31)
+        with torch.autocast("cpu", dtype=torch.bfloat16):
+            lo = m(x)
+            loss = torch.nn.CrossEntropyLoss()(lo, y)
+        loss.backward()
+        assert np.array_equal(lo.detach().float().numpy(), g[f"{tag}__logits"])
+        assert np.array_equal(loss.detach().numpy(), g[f"{tag}__loss"])
+        for k, p in m.named_parameters():
+            assert np.array_equal(p.grad.numpy(), g[f"{tag}__grad__{k}"]), (tag, k)
+        want = meta[f"{tag}_layer_decay_groups"]
+        assert V.layer_decay_groups(m, 0.05, 0.75) == want
+        # the product's host-side group builder (no GPU needed: it only looks at names and shapes)
+        import contextlib
+        import io
+        from mem_amd import optim_factory as OF
+        depth = cfg["depth"]
+        assigner = OF.LayerDecayValueAssigner(list(0.75 ** (depth + 1 - i) for i in range(depth + 2)))
+        name_of = {id(p): n for n, p in m.named_parameters()}
+        with contextlib.redirect_stdout(io.StringIO()):
+            groups = OF.get_parameter_groups(m, 0.05, m.no_weight_decay(), assigner.get_layer_id, assigner.get_scale)
+        got = {json.dumps([name_of[id(p)] for p in gr["params"]]): (gr["weight_decay"], gr["lr_scale"]) for gr in groups}
+        assert got == {json.dumps(v["params"]): (v["weight_decay"], v["lr_scale"]) for v in want.values()}
+
+
 def test_vit_tiny_train_golden():
     """First 20 of the 100 golden steps (the full 100 are checked against the HIP path on the GPU)."""
     torch.set_num_threads(1)
