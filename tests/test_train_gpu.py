@@ -99,3 +99,75 @@ def test_cli_entrypoint_two_epochs_synthetic(tmp_path):
     assert len(log) == 2 and all("train_loss" in e and "train_mlm_acc" in e and e["epoch"] in (0, 1) for e in log)
     assert all(e["train_loss"] == e["train_loss"] for e in log)                 # finite
     assert any(p.name.startswith("checkpoint-") for p in out.iterdir())
+
+
+def test_pretrain_checkpoint_to_finetune_loop(tmp_path, capsys):
+    """f3 end to end: a pretraining checkpoint ({'model': ...}, shared relative-position table, mask token, lm head)
+    initialises the finetuning model through utils.finetune (table expanded to every block, head / mask token
+    reported), then engine_for_finetuning.train_one_epoch with layer-wise lr decay fits a small synthetic
+    classification set and evaluate() reports the reference's meters."""
+    import contextlib
+    import io
+    from mem_amd import engine_for_finetuning as EF
+    from mem_amd import optim_factory as OF
+    from mem_amd import utils as U
+    from mem_amd.modeling_finetune import ft_vit
+    from mem_amd.modeling_pretrain import pt_vit
+    from oracle.vit_ref import fill_by_name
+    geo = dict(img_size=(64, 96), patch_size=(16, 16), in_chans=3, embed_dim=128, depth=3, num_heads=2, mlp_ratio=4)
+    pre = pt_vit(vocab_size=512, drop_path_rate=0.0, use_shared_rel_pos_bias=True, use_abs_pos_emb=False, init_values=0.1,
+                 **geo)
+    sd = fill_by_name(pre.state_dict(), seed=2)
+    ckpt = os.path.join(tmp_path, "checkpoint-9.pth")
+    torch.save({"model": sd, "epoch": 9}, ckpt)
+    torch.manual_seed(0)
+    m = ft_vit(num_classes=4, drop_path_rate=0.1, init_values=0.1, use_abs_pos_emb=False, use_rel_pos_bias=True,
+               use_mean_pooling=True, **geo)
+
+    class Args:
+        finetune = ckpt; model_key = "model|module"; model_prefix = ""
+    U.finetune(Args(), m)
+    out = capsys.readouterr().out
+    assert "Expand the shared relative position embedding" in out
+    assert "lm_head.weight" in out and "mask_token" in out and "head.weight" in out     # unexpected / missing report
+    for i in range(3):
+        assert torch.equal(m.state_dict()[f"blocks.{i}.attn.relative_position_bias_table"],
+                           sd["rel_pos_bias.relative_position_bias_table"])
+    assert torch.equal(m.state_dict()["patch_embed.proj.weight"], sd["patch_embed.proj.weight"])
+    assert torch.equal(m.state_dict()["blocks.2.mlp.fc2.weight"], sd["blocks.2.mlp.fc2.weight"])
+    m = m.cuda()
+    # synthetic 4-class set: the class decides which quadrant of the canvas carries events
+    g = torch.Generator().manual_seed(3)
+    data = []
+    for _ in range(6):
+        y = torch.randint(0, 4, (16,), generator=g)
+        x = torch.zeros(16, 3, 64, 96)
+        for b in range(16):
+            r, c = divmod(int(y[b]), 2)
+            x[b, :, r * 32:(r + 1) * 32, c * 48:(c + 1) * 48] = (torch.rand(3, 32, 48, generator=g) < 0.3).float()
+        data.append((x, y))
+    depth = m.get_num_layers()
+    assigner = OF.LayerDecayValueAssigner(list(0.75 ** (depth + 1 - i) for i in range(depth + 2)))
+
+    class OA:
+        opt = "adamw"; weight_decay = 0.05; lr = 2e-3; opt_eps = 1e-8
+    with contextlib.redirect_stdout(io.StringIO()):
+        opt = OF.create_optimizer(OA(), m, skip_list=m.no_weight_decay(), get_num_layer=assigner.get_layer_id,
+                                  get_layer_scale=assigner.get_scale)
+    assert len(opt.param_groups) > 2 and len({gr["lr_scale"] for gr in opt.param_groups}) == depth + 2
+    scaler = U.NativeScalerWithGradNormCount()
+    lr_sched = U.cosine_scheduler(2e-3, 1e-5, 8, len(data), warmup_epochs=1)
+    crit = torch.nn.CrossEntropyLoss()
+    first = last = None
+    with contextlib.redirect_stdout(io.StringIO()):
+        for ep in range(8):
+            st = EF.train_one_epoch(None, m, crit, data, opt, torch.device("cuda"), ep, scaler, max_norm=5.0,
+                                    start_steps=ep * len(data), lr_schedule_values=lr_sched,
+                                    num_training_steps_per_epoch=len(data), update_freq=1)
+            first = st if first is None else first
+            last = st
+        ev = EF.evaluate(data, m, torch.device("cuda"))
+    assert {"loss", "class_acc", "lr", "min_lr", "grad_norm", "weight_decay", "loss_scale"} <= set(last)
+    assert last["min_lr"] < last["lr"]                                  # layer decay: different lrs per group
+    assert last["loss"] < 0.5 * first["loss"], (first["loss"], last["loss"])
+    assert set(ev) == {"loss", "acc1", "acc5"} and ev["acc1"] >= 90.0, ev
