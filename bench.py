@@ -167,7 +167,7 @@ def main():
     # ---- secondary figure: the frozen tokenizer forward that the reference runs every step to make the
     # labels (engine_for_pretraining.py:144); not part of `value` (BASELINE: tokenizer outside the timed set)
     tok_ms = tok_torch_ms = None
-    if not a.no_tokenizer_figure:
+    if not a.no_tokenizer_figure and world == 1:                      # N=1 figures only: ranks must reach the teardown together
         try:
             from mem_amd.vae_model import DiscreteVAE, HipTokenizer
             vae = DiscreteVAE(input_H=H, input_W=W, num_tokens=8192, codebook_dim=512, num_layers=4,
@@ -192,7 +192,7 @@ def main():
     # ---- secondary figure: BASELINE configs[3], the rasterizer alone at N-ImageNet scale (1 M events per
     # sample, 480 x 640 canvas): HBM-bound, algorithmic bytes = 32 B per event + 3*H*W output bytes
     raster_fig = None
-    if rank == 0 and not a.no_raster_figure:
+    if world == 1 and not a.no_raster_figure:
         try:
             from mem_amd import datasets as D
             rb, rn, rh, rw = 32, 1_000_000, 480, 640
