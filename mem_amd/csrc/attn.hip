@@ -116,6 +116,9 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(const __bf16* __restrict_
     for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
+        // groups of 8 keys that lie completely in the padding of the last block (27 of its 32 keys at 197 tokens):
+        // wave-uniform skip of the exp work
+        if (kb == NKB - 1 && kb * 32 + 8 * (i >> 2) >= T) { s[kb][i] = 0.f; continue; }
         const float p = fexp2(s[kb][i] - mx);
         s[kb][i] = p;
         sum += p;
@@ -265,6 +268,11 @@ __global__ __launch_bounds__(512) void attn_bwd_kv_kernel(const __bf16* __restri
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int q0 = qb * 32 + 8 * g + 4 * hh;
+        if (qb == NKB - 1 && qb * 32 + 8 * g >= T) {          // 8 padded queries: P = dS = 0 (wave-uniform skip)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { S[4 * g + e] = 0.f; dP[4 * g + e] = 0.f; }
+          continue;
+        }
         const int4 qcv = *reinterpret_cast<const int4*>(codeQ + q0);
         const float4 lv = *reinterpret_cast<const float4*>(lseC + q0);
         const float4 dv = *reinterpret_cast<const float4*>(delC + q0);
@@ -449,6 +457,11 @@ __global__ __launch_bounds__(512) void attn_bwd_q_kernel(const __bf16* __restric
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const int key0 = kb * 32 + 8 * g + 4 * hh;
+          if (kb == NKB - 1 && kb * 32 + 8 * g >= T) {        // 8 padded keys: dS = 0, nothing for the buckets
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dPt[4 * g + e] = 0.f;
+            continue;
+          }
           const int4 kc = *reinterpret_cast<const int4*>(codeK + key0);
           const int kcs[4] = {kc.x, kc.y, kc.z, kc.w};
           bfr2(St, 4 * g);
@@ -465,7 +478,7 @@ __global__ __launch_bounds__(512) void attn_bwd_q_kernel(const __bf16* __restric
             const float ds = p * (dPt[i] - dq_);
             dPt[i] = ds;
             // masked elements add 0 (their codes are valid): no divergent branch around the atomic
-            if (DT) lds_add_i32_abs(idx4 + bins_delta, __float2int_rn(ds * fx));
+            if (DT) lds_add_i32_abs(idx4 + bins_delta, fx_round(ds, fx));
           }
         }
         bf16x8 ckf[2][2];

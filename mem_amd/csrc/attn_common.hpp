@@ -170,6 +170,11 @@ __device__ __forceinline__ void rel_setup(float* tabX, int* codeQ, int* codeK, c
 __device__ __forceinline__ float lds_f32_abs(int lds_byte_addr) {
   return *reinterpret_cast<const __attribute__((address_space(3))) float*>((unsigned)lds_byte_addr);
 }
+// round(x * scale) to int with ONE fma + ONE integer subtract: adding 1.5 * 2^23 leaves the rounded (nearest-even)
+// integer in the low mantissa bits for |x * scale| < 2^22 (v_mul + v_rndne + v_cvt_i32 are three instructions)
+__device__ __forceinline__ int fx_round(float x, float scale) {
+  return __float_as_int(fmaf(x, scale, 12582912.0f)) - 0x4B400000;
+}
 __device__ __forceinline__ void lds_add_i32_abs(int lds_byte_addr, int v) {       // ds_add_u32, no return
   __hip_atomic_fetch_add(reinterpret_cast<__attribute__((address_space(3))) int*>((unsigned)lds_byte_addr), v,
                          __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);

@@ -439,7 +439,7 @@ __global__ __launch_bounds__(512) void attn_bwd_q_stream_kernel(
             if (key0 + e >= T) p = 0.f;
             const float ds = p * (dPt[i] - dq_);
             dPt[i] = ds;
-            if (DT) lds_add_i32_abs(idx4 + bins_delta, __float2int_rn(ds * fx));
+            if (DT) lds_add_i32_abs(idx4 + bins_delta, fx_round(ds, fx));
           }
         }
         bf16x8 ckf[2][2];
