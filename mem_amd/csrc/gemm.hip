@@ -188,7 +188,6 @@ int launch(const GemmArgs& p, hipStream_t s) {
 }  // namespace
 
 namespace memhip {
-int gemm_ring_dispatch(const GemmArgs& p, hipStream_t s);
 int gemm256_dispatch(const GemmArgs& p, hipStream_t s);
 int gemm_p8_dispatch(const GemmArgs& p, hipStream_t s);
 int gemm_p8_split_rows(const GemmArgs& p);
@@ -220,10 +219,9 @@ extern "C" int memhip_gemm_bf16_nt(const memhip_gemm_args_t* a, memhip_stream_t 
     case MEMHIP_EPI_PATCH_EMBED: MEMHIP_REQUIRE(p.resid && p.vec1 && p.aux, "gemm: patch args"); break;
     default: return fail(MEMHIP_EINVAL, "gemm: unknown epilogue %d", p.epilogue);
   }
-  // large token-dimension products: persistent 256x256-tile structure (gemm256.hip); the 256x128
-  // ring variant (gemm_ring.hip) is kept for A/B measurements only (MEMHIP_GEMM_RING=1)
+  // large token-dimension products: the phase-interleaved persistent kernel (gemm_p8.hip); the lockstep 256x256
+  // kernel (gemm256.hip) takes shapes it does not (K a multiple of 64 but not of 128, or MEMHIP_GEMM_P8=0)
   static const bool k256_on = !(getenv("MEMHIP_GEMM256") && atoi(getenv("MEMHIP_GEMM256")) == 0);
-  static const bool ring_on = getenv("MEMHIP_GEMM_RING") && atoi(getenv("MEMHIP_GEMM_RING")) == 1;
   static const bool p8_on = !(getenv("MEMHIP_GEMM_P8") && atoi(getenv("MEMHIP_GEMM_P8")) == 0);
   if (p8_on) {
     // A persistent 256x256-tile launch whose last round would be poorly filled (N = 768: 591 tiles on
@@ -269,10 +267,6 @@ extern "C" int memhip_gemm_bf16_nt(const memhip_gemm_args_t* a, memhip_stream_t 
   }
   if (k256_on) {
     const int rc = gemm256_dispatch(p, s);
-    if (rc != MEMHIP_EUNSUPPORTED) return rc;
-  }
-  if (ring_on) {
-    const int rc = gemm_ring_dispatch(p, s);
     if (rc != MEMHIP_EUNSUPPORTED) return rc;
   }
   switch (p.epilogue) {

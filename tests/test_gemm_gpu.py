@@ -169,8 +169,9 @@ def test_gemm_tn_weight_gradient(R, N, K):
 @pytest.mark.parametrize("M,N,K", [(2048, 128, 64), (4000, 768, 768), (2304 + 17, 2304, 768), (5000, 384, 3072),
                                    (4096, 256, 64), (4096 + 100, 768, 768), (9000, 2304, 128), (4500, 512, 3072),
                                    (25600 + 13, 768, 1536)])       # last: 303 tiles -> row-split launch (p8 + 128x128)
-def test_ring_gemm_large_m_all_epilogues(M, N, K):
-    """M >= 2048 and N % 128 == 0 dispatch to the persistent ring-pipelined kernel (gemm_ring.hip):
+def test_persistent_gemm_large_m_all_epilogues(M, N, K):
+    """Large-M shapes dispatch to the persistent 256-row-tile kernels (gemm_p8.hip, row-split launches with 128-row
+    tiles for the left-over rows; gemm256.hip when K is not a multiple of 128; the 128x128 kernel otherwise):
     exact-integer layout check + every fused epilogue against torch."""
     from mem_amd import ops
     g = torch.Generator(device="cuda").manual_seed(M + N)
