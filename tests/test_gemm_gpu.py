@@ -1,4 +1,5 @@
 """-m gpu: bf16 MFMA GEMM + fused epilogues vs plain torch fp32 references of the same op."""
+import numpy as np
 import pytest
 import torch
 
@@ -234,3 +235,36 @@ def test_gelu_with_stored_derivative(M, N, K):
     da = (G.float() @ W2.float().t()).bfloat16().float()
     torch.testing.assert_close(o.float(), (da * dg.float()).bfloat16().float(), rtol=2e-2, atol=2e-2)
     torch.testing.assert_close(cs, o.float().sum(0), rtol=1e-3, atol=5e-2)
+
+
+def test_gemm_dispatch_fuzz_exact():
+    """Randomised shapes across every dispatch boundary (128x128 kernel, gemm256, gemm_p8 full launches, row-split
+    launches with 128-row tiles, weight-gradient kernels with and without the workspace): small-integer operands, so
+    fp32 accumulation is exact and any mis-addressed tile / dropped row / double-counted split shows as a bit
+    difference."""
+    from mem_amd import ops
+    rng = np.random.default_rng(123)
+    g = torch.Generator(device="cuda").manual_seed(9)
+    shapes = []
+    for _ in range(14):
+        shapes.append((int(rng.integers(1, 9000)), 8 * int(rng.integers(1, 200)), 64 * int(rng.integers(1, 20))))
+    shapes += [(4096, 256, 128), (4095, 1024, 192), (12289, 1024, 1024), (19216, 4096, 1024), (19216, 1024, 4096),
+               (8193, 768, 64), (50432, 256, 128), (4097, 3072, 320)]
+    for (M, N, K) in shapes:
+        A = torch.randint(-2, 3, (M, K), generator=g, device="cuda").float()
+        B = torch.randint(-2, 3, (N, K), generator=g, device="cuda").float()
+        C = torch.full((M + 3, N), 5.0, dtype=torch.float32, device="cuda")
+        ops.gemm_nt(A.bfloat16(), B.bfloat16(), M, N, K, ops.EPI_F32, out0=C)
+        assert torch.equal(C[:M], A @ B.t()), (M, N, K)
+        assert (C[M:] == 5.0).all(), (M, N, K)
+    for _ in range(10):
+        R, N, K = int(rng.integers(1, 9000)), 8 * int(rng.integers(1, 160)), 8 * int(rng.integers(1, 160))
+        dY = torch.randint(-2, 3, (R, N), generator=g, device="cuda").float()
+        X = torch.randint(-2, 3, (R, K), generator=g, device="cuda").float()
+        want = dY.t() @ X
+        out = torch.ones((N, K), dtype=torch.float32, device="cuda")
+        ops.gemm_tn(dY.bfloat16(), X.bfloat16(), R, N, K, out, accumulate=True)
+        assert torch.equal(out, want + 1.0), (R, N, K)
+        ws = torch.empty(max(ops.gemm_tn_workspace(R, N, K), 16), dtype=torch.uint8, device="cuda")
+        ops.gemm_tn(dY.bfloat16(), X.bfloat16(), R, N, K, out, accumulate=False, workspace=ws)
+        assert torch.equal(out, want), (R, N, K)
