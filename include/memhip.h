@@ -330,6 +330,13 @@ int memhip_cast_f32_bf16(const float* in, void* out_bf16, int64_t n, memhip_stre
 /* out bf16 [Cc, ldout] = in f32 [R, Cc]^T (the [in,out]-major copy of a Linear weight used by dgrad) */
 int memhip_transpose_cast_f32_bf16(const float* in, int64_t ldin, int R, int Cc, void* out_bf16,
                                    int64_t ldout, memhip_stream_t stream);
+/* n weight transposes (fp32 [R,C] -> bf16 [C, ldout], rows beyond R zero-filled up to min(ldout, 64-padded R))
+ * in one launch: desc = device array of n records {const float* in; int64 ldin; int64 R; int64 C; bf16* out;
+ * int64 ldout} (48 bytes each), tile_prefix = device i32 [n+1] with the first 64x64 tile index of every matrix
+ * (tile_prefix[n] = total_tiles).  Same result as n calls of memhip_transpose_cast_f32_bf16. */
+int memhip_transpose_cast_batched(const void* desc, const int32_t* tile_prefix, int n, int total_tiles,
+                                  memhip_stream_t stream);
+
 /* out bf16 [Cc, ldout] = in bf16 [R, Cc]^T, columns [R, R_pad) zero-filled (R_pad % 64 == 0);
  * optional fused column sums of `in` (Linear bias gradients) over two column ranges. */
 int memhip_transpose_bf16(const void* in, int64_t ldin, int R, int Cc, void* out, int64_t ldout, int R_pad,

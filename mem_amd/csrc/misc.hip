@@ -67,6 +67,49 @@ __global__ __launch_bounds__(256) void transpose_kernel(const IN* __restrict__ i
   }
 }
 
+// All weight transposes of a step in ONE launch (49 launches of ~8 us each otherwise): desc[i] = {in, ldin, R, Cc,
+// out, ldout}, tile_prefix[i] = first 64x64 tile of matrix i (tile_prefix[n] = total).  Vectorised: a thread reads
+// 8 consecutive fp32 of a row (two 16-byte loads) when the tile is interior.
+struct TransposeDesc { const float* in; long long ldin; long long R; long long Cc; __bf16* out; long long ldout; };
+__global__ __launch_bounds__(256) void transpose_cast_batched_kernel(const TransposeDesc* __restrict__ desc,
+                                                                     const int* __restrict__ tile_prefix, int n) {
+  __shared__ __bf16 tile[64][66];
+  int mi = 0;
+  while (mi + 1 < n && (int)blockIdx.x >= tile_prefix[mi + 1]) ++mi;          // n <= a few dozen
+  const TransposeDesc d = desc[mi];
+  const int local = blockIdx.x - tile_prefix[mi];
+  const int R = (int)d.R, Cc = (int)d.Cc;
+  const int tr = (R + 63) / 64;
+  const int r0 = (local % tr) * 64, c0 = (local / tr) * 64;
+  const int t = threadIdx.x;
+  const int R_pad = (int)(d.ldout < (long long)tr * 64 ? d.ldout : (long long)tr * 64);
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    const int rl = (t >> 3) + pass * 32, cl = (t & 7) * 8;
+    const int r = r0 + rl, c = c0 + cl;
+    const float* src = d.in + (long long)r * d.ldin + c;
+    if (r < R && c + 8 <= Cc && ((d.ldin & 3) == 0) && (((unsigned long long)d.in & 15) == 0)) {
+      const float4 a = reinterpret_cast<const float4*>(src)[0], b = reinterpret_cast<const float4*>(src)[1];
+      const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+      for (int k = 0; k < 8; ++k) tile[rl][cl + k] = (__bf16)v[k];
+    } else {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) tile[rl][cl + k] = (r < R && c + k < Cc) ? (__bf16)src[k] : (__bf16)0.f;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    const int cl = (t >> 3) + pass * 32, rl = (t & 7) * 8;
+    const int c = c0 + cl;
+    bf16x8 o;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) o[k] = tile[rl + k][cl];
+    if (c < Cc && r0 + rl < R_pad) *reinterpret_cast<bf16x8*>(d.out + (long long)c * d.ldout + r0 + rl) = o;
+  }
+}
+
 // x f32 [B,C,H,W] -> patches bf16 [B*L, C*ph*pw], k = c*ph*pw + py*pw + px (Conv2d weight order)
 __global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ x, int B, int C, int H, int W,
                                                      int ph, int pw, __bf16* __restrict__ out) {
@@ -161,6 +204,17 @@ extern "C" int memhip_transpose_cast_f32_bf16(const float* in, int64_t ldin, int
                      (long long)ldin, R, Cc, (__bf16*)out, (long long)ldout, R_pad, (float*)nullptr, 0, 0,
                      (float*)nullptr, 0, 0);
   return check_launch("transpose_cast");
+}
+
+extern "C" int memhip_transpose_cast_batched(const void* desc, const int32_t* tile_prefix, int n, int total_tiles,
+                                             memhip_stream_t stream) {
+  MEMHIP_REQUIRE(n >= 0 && total_tiles >= 0, "transpose_cast_batched: bad arguments");
+  if (n == 0 || total_tiles == 0) return MEMHIP_OK;
+  MEMHIP_REQUIRE(desc && tile_prefix, "transpose_cast_batched: null pointer");
+  static_assert(sizeof(TransposeDesc) == 48, "descriptor = 6 x 8 bytes");
+  hipLaunchKernelGGL(transpose_cast_batched_kernel, dim3(total_tiles), dim3(256), 0, as_stream(stream),
+                     (const TransposeDesc*)desc, tile_prefix, n);
+  return check_launch("transpose_cast_batched");
 }
 
 extern "C" int memhip_transpose_bf16(const void* in, int64_t ldin, int R, int Cc, void* out, int64_t ldout,

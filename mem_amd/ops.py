@@ -93,6 +93,7 @@ declare({
     "memhip_grad_norm_workspace": (sz, []),
     "memhip_grad_norm": (i32, [vp, i64, vp, vp, sz, vp]),
     "memhip_adamw": (i32, [vp, vp, vp, vp, i64, vp, f64, f64, f64, f64, f64, i32, vp, f64, vp]),
+    "memhip_transpose_cast_batched": (i32, [vp, vp, i32, i32, vp]),
     "memhip_adamw_groups": (i32, [vp, vp, vp, vp, i64, vp, vp, i32, f64, f64, f64, i32, vp, f64, vp]),
 })
 
@@ -195,6 +196,11 @@ def transpose_cast(src_f32, R, Cc, dst_bf16, ldout=None):
     check(lib.memhip_transpose_cast_f32_bf16(ptr(src_f32), src_f32.stride(0), R, Cc, ptr(dst_bf16),
                                              dst_bf16.stride(0) if ldout is None else ldout, stream_ptr()),
           "transpose_cast")
+
+
+def transpose_cast_batched(desc_dev, prefix_dev, n, total_tiles):
+    check(lib.memhip_transpose_cast_batched(ptr(desc_dev), ptr(prefix_dev), n, total_tiles, stream_ptr()),
+          "transpose_cast_batched")
 
 
 def transpose_bf16(src, R, Cc, dst, R_pad, colsum0=None, c0=(0, 0), colsum1=None, c1=(0, 0)):

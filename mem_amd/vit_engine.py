@@ -163,6 +163,7 @@ class ViTEngine:
         self.zero_table = torch.zeros((self.nrd, self.heads), dtype=torch.float32, device=dev)   # rel == "none"
         self.zero_vec = torch.zeros(D, dtype=torch.float32, device=dev)                           # no mask_token
         self.head_end = self.buckets[0][2]           # flat offset where the head bucket ends
+        self._tdesc = None
         # MEMHIP_GELU_DG=1: fc1 keeps gelu'(h) (bf16) for the backward instead of h, so that erf / exp are evaluated
         # once and the GELU backward is a plain product.  Measured gain 0.2 ms per step for one extra bf16 rounding
         # of gelu' -- off by default (the reference evaluates gelu' in fp32 from the stored pre-activation)
@@ -215,16 +216,32 @@ class ViTEngine:
     def sync_weights(self):
         """fp32 masters -> bf16 shadows (+ [in,out]-major copies for the dgrad GEMMs)."""
         ops.cast_f32_bf16(self.flat_p, self.flat_w16, self.nflat)
+        if self._tdesc is None:
+            self._build_transpose_descs()
+        ops.transpose_cast_batched(self._tdesc, self._tprefix, self._tn, self._ttiles)
+        self.weights_dirty = False
+
+    def _build_transpose_descs(self):
+        """Descriptors of the [in,out]-major bf16 weight copies (one batched launch per step, memhip_transpose_cast_batched)."""
+        import numpy as np
         D, Hd = self.D, self.hidden
+        items = []
         for i in range(self.depth):
             pre = f"blocks.{i}."
-            ops.transpose_cast(self.P(pre + "attn.qkv.weight").view(3 * D, D), 3 * D, D, self.wT[i]["qkv"])
-            ops.transpose_cast(self.P(pre + "attn.proj.weight").view(D, D), D, D, self.wT[i]["proj"])
-            ops.transpose_cast(self.P(pre + "mlp.fc1.weight").view(Hd, D), Hd, D, self.wT[i]["fc1"])
-            ops.transpose_cast(self.P(pre + "mlp.fc2.weight").view(D, Hd), D, Hd, self.wT[i]["fc2"])
+            items += [(self.P(pre + "attn.qkv.weight"), 3 * D, D, self.wT[i]["qkv"]),
+                      (self.P(pre + "attn.proj.weight"), D, D, self.wT[i]["proj"]),
+                      (self.P(pre + "mlp.fc1.weight"), Hd, D, self.wT[i]["fc1"]),
+                      (self.P(pre + "mlp.fc2.weight"), D, Hd, self.wT[i]["fc2"])]
         if self.head_kind == "mlm":
-            ops.transpose_cast(self.P("lm_head.weight").view(self.V, D), self.V, D, self.wT_lm)
-        self.weights_dirty = False
+            items.append((self.P("lm_head.weight"), self.V, D, self.wT_lm))
+        desc = np.zeros((len(items), 6), dtype=np.int64)
+        prefix = np.zeros(len(items) + 1, dtype=np.int32)
+        for k, (src, R, Cc, dst) in enumerate(items):
+            desc[k] = (src.data_ptr(), Cc, R, Cc, dst.data_ptr(), dst.stride(0))
+            prefix[k + 1] = prefix[k] + ((R + 63) // 64) * ((Cc + 63) // 64)
+        self._tdesc = torch.from_numpy(desc).to(self.dev)
+        self._tprefix = torch.from_numpy(prefix).to(self.dev)
+        self._tn, self._ttiles = len(items), int(prefix[-1])
 
     def table(self, i):
         """Relative-position bucket table of block i ([nrd, heads] fp32 master)."""
