@@ -74,8 +74,14 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", 1))
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # MEMHIP_BENCH_FORCE_DIST=1: run the RCCL path (process group, parameter broadcast, per-bucket async all-reduce hooked
+    # into backward, join before the optimizer) in a ONE-rank group -- a single-GPU dry run of what N > 1 executes
+    force_dist = world == 1 and os.environ.get("MEMHIP_BENCH_FORCE_DIST") == "1"
+    if world > 1 or force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl")
 
@@ -99,8 +105,8 @@ def main():
     opt = FlatAdamW(model, groups, lr=5e-4)
     opt.max_norm = 30.0
     reducer = None
-    if world > 1:
-        reducer = GradReducer(eng.flat_g, eng.buckets, flat_p=eng.flat_p)
+    if world > 1 or force_dist:
+        reducer = GradReducer(eng.flat_g, eng.buckets, flat_p=eng.flat_p, force=force_dist)
         eng.grad_hook = reducer
         eng.weights_dirty = True
 
@@ -139,7 +145,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if world > 1 or force_dist:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -292,9 +298,20 @@ def main():
             out["rasterizer_1m_events"] = raster_fig
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(out), flush=True)
-    if world > 1:
+        result_line = json.dumps(out)
+    else:
+        result_line = None
+    if world > 1 or force_dist:
         dist.destroy_process_group()
+    # RCCL prints its version banner through C stdio (buffered until exit when stdout is a pipe): flush it first so that
+    # the JSON line is the LAST line on stdout
+    import ctypes
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except OSError:
+        pass
+    if result_line is not None:
+        print(result_line, flush=True)
 
 
 if __name__ == "__main__":

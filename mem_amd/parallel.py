@@ -15,18 +15,21 @@ import torch.distributed as dist
 
 
 class GradReducer:
-    def __init__(self, flat_g, buckets, flat_p=None, group=None, coalesce_small=0):
+    def __init__(self, flat_g, buckets, flat_p=None, group=None, coalesce_small=0, force=False):
         self.flat_g, self.buckets, self.group = flat_g, buckets, group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        # force: issue the collectives even in a one-rank group (single-GPU dry run of the RCCL path: bench.py
+        # with MEMHIP_BENCH_FORCE_DIST=1)
+        self.active = (self.world > 1 or force) and dist.is_initialized()
         self.handles = []
         # SUM then divide (on the compute stream, after the join): ReduceOp.AVG needs ncclAvg support in the
         # installed RCCL and saves one 0.1 ms pass over the buckets -- not worth a hard dependency
         self.use_avg = False
-        if flat_p is not None and self.world > 1:
+        if flat_p is not None and self.active:
             dist.broadcast(flat_p, src=0, group=group)          # rank-0 weights everywhere (DDP ctor)
 
     def __call__(self, bucket_index):
-        if self.world == 1:
+        if not self.active:
             return
         _, b0, b1 = self.buckets[bucket_index]
         view = self.flat_g[b0:b1]

@@ -171,3 +171,26 @@ def test_pretrain_checkpoint_to_finetune_loop(tmp_path, capsys):
     assert last["min_lr"] < last["lr"]                                  # layer decay: different lrs per group
     assert last["loss"] < 0.5 * first["loss"], (first["loss"], last["loss"])
     assert set(ev) == {"loss", "acc1", "acc5"} and ev["acc1"] >= 90.0, ev
+
+
+def test_bench_contract_and_rccl_dry_run():
+    """bench.py prints ONE JSON line and it is the LAST line of stdout, also when RCCL is initialised (its version
+    banner goes through C stdio).  MEMHIP_BENCH_FORCE_DIST=1 runs the N > 1 code path -- process group, parameter
+    broadcast, per-bucket async all-reduce hooked into backward, join before AdamW -- in a one-rank RCCL group."""
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ, MEMHIP_BENCH_FORCE_DIST="1", MASTER_PORT="29577")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--batch", "16", "--steps", "3", "--warmup", "1",
+                        "--no-tokenizer-figure", "--no-raster-figure", "--no-cpu-baseline"], env=env, capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    out = json.loads(lines[-1])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert k in out, k
+    assert out["n_gpus"] == 1 and out["steps"] == 3 and out["scaling"] == "weak" and out["dtype"] == "bf16"
+    assert out["roofline"]["bound"] == "mfma" and 0 < out["roofline"]["frac"] < 1
+    assert sum(ln.lstrip().startswith("{") for ln in lines) == 1
