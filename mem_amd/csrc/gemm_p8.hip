@@ -39,6 +39,10 @@
 #ifndef P8_EPI_AHEAD
 #define P8_EPI_AHEAD 2
 #endif
+#ifndef P8_REALIGN
+#define P8_REALIGN 1   // 1: all eight waves run a tile's epilogue together (waves 0-3 wait, waves 4-7 re-stagger after it);
+                       // 0 (each group enters the epilogue when it is done) measured 8-12 % slower on the K = 768 shapes
+#endif
 #ifndef P8_EPI_RESID_LATE
 #define P8_EPI_RESID_LATE 2
 #endif
@@ -271,7 +275,7 @@ __global__ __launch_bounds__(kThreads) void gemm_p8_kernel(GemmArgs p, int ntm, 
     if (c_k == nk - 2) {
       // waves 0-3 wait for the last compute segment of waves 4-7, so that all eight waves run the
       // (VALU-bound, barrier-free) epilogue together; waves 4-7 fall half a phase behind again after it
-      if (wr == 0) P8_BARRIER();
+      if (P8_REALIGN && wr == 0) P8_BARRIER();
       // ---- epilogue of tile c_tile straight out of the accumulators: the MFMAs ran with swapped
       // operands, so a lane holds 4 consecutive columns (registers) of one row (lane & 15)
       int tm, tn;
@@ -343,7 +347,7 @@ __global__ __launch_bounds__(kThreads) void gemm_p8_kernel(GemmArgs p, int ntm, 
             for (int r = 0; r < 4; ++r) acc[q][mf][nf][r] = 0.f;
       c_k = 0;
       c_tile += gridDim.x;
-      if (wr == 1) P8_BARRIER();
+      if (P8_REALIGN && wr == 1) P8_BARRIER();
     } else {
       c_k += 2;
     }
