@@ -225,6 +225,10 @@ def main():
                                        "achieved": round(byts / rdt / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
                                        "frac": round(byts / rdt / 8e12, 4), "algorithmic_bytes_per_sample": 32 * rn + 3 * rh * rw,
                                        "traffic": None}}
+            # HBM bytes per launch from the PMC passes (tools/prof_pmc_raster.sh -> profiles/raster_traffic.json)
+            rpath = os.path.join(ROOT, "profiles", "raster_traffic.json")
+            if os.path.exists(rpath):
+                raster_fig["roofline"]["traffic"] = json.load(open(rpath))["hbm_bytes_per_sample"] * rb
             del ev
         except Exception as e:                                        # the figure is optional
             print(f"[bench] rasterizer figure skipped: {e}", file=sys.stderr)
