@@ -209,12 +209,14 @@ __global__ __launch_bounds__(kLdsThreads) void raster_lds_kernel(
 
 // ---- long streams (N-ImageNet scale, ~1 M events per sample) on canvases whose counters do not fit one
 // workgroup's LDS: two streaming passes instead of one global atomic per event.
-//   pass 1 (raster_bin_keys): every event is read ONCE (32 B), reduced to a 4-byte key (pixel inside its
-//     band of rows | polarity << 31) and the keys of each chunk of kBinChunk events are written back sorted
-//     by band (counting sort in LDS), with the band boundaries of the chunk in a small header.
-//   pass 2 (raster_bin_accum): one workgroup per (sample, band) walks the headers, reads only its own
-//     segments (contiguous, 4 B per event), counts in LDS and writes the wrapped uint8 planes.
-// HBM traffic per event: 32 B read + 4 B written + 4 B read, against 32 B algorithmic.
+//   pass 1 (raster_bin_keys): every event is read ONCE (32 B), reduced to a 2-byte key (pixel inside its band
+//     | polarity << 15) and the keys of each chunk of kBinChunk events are written back sorted by band (counting
+//     sort in LDS).  Every band's segment starts at a multiple of 8 keys (padded with 0xFFFF), so that pass 2
+//     reads 16 bytes per lane; the segment boundaries of the chunk go to a small header.
+//   pass 2 (raster_bin_accum): one workgroup per (sample, band) walks the headers, reads only its own segments
+//     (one 16-byte load per lane covers the average segment; the next chunk's load is in flight while the current
+//     keys are counted), counts in LDS and writes the wrapped uint8 planes.
+// HBM traffic per event: 32 B read + ~2.3 B written + ~2.3 B read, against 32 B algorithmic.
 // Counters: ONE u32 per pixel = [neg count : 16 | pos count : 16].  Only counts mod 256 are observable, so
 // 16 bits are enough provided the carry out of the low half is undone: the low half changes only by +1, so
 // exactly the add that sees 0xFFFF there carries, and that thread takes the carry back out of the high half.
@@ -222,18 +224,18 @@ constexpr int kBinThreads = 512;
 constexpr int kBinEvPerThread = 8;
 constexpr int kBinChunk = kBinThreads * kBinEvPerThread;   // 4096 events
 constexpr int kBinMaxBands = 64;
-constexpr int kBinBandPixels = 40000;                      // 156.25 KiB of LDS
+constexpr int kBinBandPixels = 32764;                      // 15-bit pixel index inside a band (0xFFFF is the pad key)
+constexpr int kBinSlots = kBinChunk + 8 * kBinMaxBands;    // key slots of a chunk: events + padding of every segment to 8
 constexpr int kAccThreads = 1024;
-constexpr int kAccUnroll = 8;                              // keys per lane in flight in pass 2
 constexpr int kBinOverflow = 1 << 30;                      // status flag: n_events smaller than the offsets say
 
 __global__ __launch_bounds__(kBinThreads) void raster_bin_keys(
     const double* __restrict__ ev, const int64_t* __restrict__ offsets,
     const memhip_event_aug_t* __restrict__ augs, int H, int W, int band_px, int nb, long long n_cap,
-    unsigned int* __restrict__ keys, unsigned int* __restrict__ hdr, int32_t* __restrict__ status) {
+    unsigned short* __restrict__ keys, unsigned int* __restrict__ hdr, int32_t* __restrict__ status) {
   __shared__ unsigned int cnt[kBinMaxBands];
   __shared__ unsigned int base[kBinMaxBands + 1];
-  __shared__ unsigned int sorted[kBinChunk];
+  __shared__ __attribute__((aligned(16))) unsigned short sorted[kBinSlots];
   const int b = blockIdx.y, tid = threadIdx.x;
   const long long beg = offsets[b], n = offsets[b + 1] - beg, rel = beg - offsets[0];
   const long long HW = (long long)H * W;
@@ -248,6 +250,8 @@ __global__ __launch_bounds__(kBinThreads) void raster_bin_keys(
   int bad = 0;
   for (long long c = blockIdx.x; c < nchunks; c += gridDim.x) {
     if (tid < nb) cnt[tid] = 0u;
+    for (int i = tid; i < kBinSlots / 8; i += kBinThreads)                     // pad key everywhere first
+      reinterpret_cast<uint4*>(sorted)[i] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
     __syncthreads();
     unsigned int key[kBinEvPerThread], where[kBinEvPerThread];
 #pragma unroll
@@ -265,12 +269,12 @@ __global__ __launch_bounds__(kBinThreads) void raster_bin_keys(
       const bool isneg = e.p == -1.0;
       if (!(e.p == 1.0) && !isneg) continue;
       const int band = (int)(flat / band_px);
-      key[k] = (unsigned int)(flat - (long long)band * band_px) | (isneg ? 0x80000000u : 0u);
+      key[k] = (unsigned int)(flat - (long long)band * band_px) | (isneg ? 0x8000u : 0u);
       where[k] = ((unsigned int)band << 16) | atomicAdd(&cnt[band], 1u);   // slot inside the band's segment
     }
     __syncthreads();
-    if (tid < 64) {                          // exclusive scan of <= 64 band counts in one wave
-      const unsigned int v = tid < nb ? cnt[tid] : 0u;
+    if (tid < 64) {                          // exclusive scan of <= 64 band counts (rounded up to 8) in one wave
+      const unsigned int v = tid < nb ? ((cnt[tid] + 7u) & ~7u) : 0u;
       unsigned int inc = v;
       for (int o = 1; o < 64; o <<= 1) {
         const unsigned int u = __shfl_up(inc, o);
@@ -282,20 +286,38 @@ __global__ __launch_bounds__(kBinThreads) void raster_bin_keys(
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < kBinEvPerThread; ++k)
-      if (where[k] != 0xFFFFFFFFu) sorted[base[where[k] >> 16] + (where[k] & 0xFFFFu)] = key[k];
+      if (where[k] != 0xFFFFFFFFu) sorted[base[where[k] >> 16] + (where[k] & 0xFFFFu)] = (unsigned short)key[k];
     __syncthreads();
-    const unsigned int total = base[nb];
-    unsigned int* kout = keys + rel + c * kBinChunk;
-    for (unsigned int j = tid; j < total; j += kBinThreads) kout[j] = sorted[j];
-    if (tid <= nb) hdr[(hbase + c) * (kBinMaxBands + 1) + tid] = base[tid];
+    const unsigned int total8 = base[nb] >> 3;                                  // 16-byte groups to write
+    uint4* kout = reinterpret_cast<uint4*>(keys + (hbase + c) * kBinSlots);
+    for (unsigned int j = tid; j < total8; j += kBinThreads) kout[j] = reinterpret_cast<const uint4*>(sorted)[j];
+    if (tid <= nb) hdr[(hbase + c) * (kBinMaxBands + 1) + tid] = base[tid] >> 3;   // boundaries in 16-byte groups
     __syncthreads();
   }
   if (bad) atomicAdd(status + b, bad);
 }
 
+__device__ __forceinline__ void bin_count8(unsigned int* cnt, const uint4& q) {
+  const unsigned int w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int hhalf = 0; hhalf < 2; ++hhalf) {
+      const unsigned int key = hhalf ? (w[i] >> 16) : (w[i] & 0xFFFFu);
+      if (key == 0xFFFFu) continue;                                             // segment padding
+      const unsigned int l = key & 0x7FFFu;
+      if (key & 0x8000u) {
+        atomicAdd(cnt + l, 0x10000u);
+      } else {
+        const unsigned int old = atomicAdd(cnt + l, 1u);
+        if ((old & 0xFFFFu) == 0xFFFFu) atomicSub(cnt + l, 0x10000u);           // undo the carry into the neg half
+      }
+    }
+}
+
 __global__ __launch_bounds__(kAccThreads) void raster_bin_accum(
     const int64_t* __restrict__ offsets, int H, int W, int band_px, long long n_cap,
-    const unsigned int* __restrict__ keys, const unsigned int* __restrict__ hdr, uint8_t* __restrict__ out) {
+    const unsigned short* __restrict__ keys, const unsigned int* __restrict__ hdr, uint8_t* __restrict__ out) {
   extern __shared__ unsigned int cnt[];       // [band_px]: neg << 16 | pos
   const int band = blockIdx.x, b = blockIdx.y;
   const long long HW = (long long)H * W;
@@ -306,38 +328,28 @@ __global__ __launch_bounds__(kAccThreads) void raster_bin_accum(
   const long long beg = offsets[b], n = offsets[b + 1] - beg, rel = beg - offsets[0];
   if (rel + n <= n_cap) {
     const long long nchunks = (n + kBinChunk - 1) / kBinChunk;
-    const unsigned int* h = hdr + (rel / kBinChunk + b) * (kBinMaxBands + 1) + band;
+    const long long hbase = rel / kBinChunk + b;
+    const unsigned int* h = hdr + hbase * (kBinMaxBands + 1) + band;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     constexpr int kWaves = kAccThreads / 64;
+    const uint4 kPad = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+    // software pipeline over this wave's chunks: header two chunks ahead, first 16-byte group one chunk ahead
     long long c = wave;
-    unsigned int s = 0, e = 0;
+    unsigned int s = 0, e = 0, s1 = 0, e1 = 0;
     if (c < nchunks) { s = h[c * (kBinMaxBands + 1)]; e = h[c * (kBinMaxBands + 1) + 1]; }
+    if (c + kWaves < nchunks) { s1 = h[(c + kWaves) * (kBinMaxBands + 1)]; e1 = h[(c + kWaves) * (kBinMaxBands + 1) + 1]; }
+    uint4 q = kPad;
+    if (c < nchunks && s + lane < e) q = reinterpret_cast<const uint4*>(keys + (hbase + c) * kBinSlots)[s + lane];
     while (c < nchunks) {
-      const long long cn = c + kWaves;
+      const long long c1 = c + kWaves, c2 = c + 2 * kWaves;
       unsigned int s2 = 0, e2 = 0;
-      if (cn < nchunks) { s2 = h[cn * (kBinMaxBands + 1)]; e2 = h[cn * (kBinMaxBands + 1) + 1]; }   // next header in flight
-      const unsigned int* kin = keys + rel + c * kBinChunk;
-      for (unsigned int j0 = s + lane; j0 < e + lane; j0 += 64 * kAccUnroll) {   // wave-uniform trip count
-        unsigned int kv[kAccUnroll];
-#pragma unroll
-        for (int k = 0; k < kAccUnroll; ++k) {                // all loads of the batch in flight before the atomics
-          const unsigned int j = j0 + 64 * k;
-          kv[k] = j < e ? kin[j] : 0xFFFFFFFFu;
-        }
-#pragma unroll
-        for (int k = 0; k < kAccUnroll; ++k) {
-          const unsigned int key = kv[k];
-          if (key == 0xFFFFFFFFu) continue;                   // (a valid key never has all low bits set: l < band_px)
-          const unsigned int l = key & 0x7FFFFFFFu;
-          if (key >> 31) {
-            atomicAdd(cnt + l, 0x10000u);
-          } else {
-            const unsigned int old = atomicAdd(cnt + l, 1u);
-            if ((old & 0xFFFFu) == 0xFFFFu) atomicSub(cnt + l, 0x10000u);   // undo the carry into the neg half
-          }
-        }
-      }
-      c = cn; s = s2; e = e2;
+      if (c2 < nchunks) { s2 = h[c2 * (kBinMaxBands + 1)]; e2 = h[c2 * (kBinMaxBands + 1) + 1]; }
+      uint4 qn = kPad;
+      if (c1 < nchunks && s1 + lane < e1) qn = reinterpret_cast<const uint4*>(keys + (hbase + c1) * kBinSlots)[s1 + lane];
+      bin_count8(cnt, q);
+      const uint4* kin = reinterpret_cast<const uint4*>(keys + (hbase + c) * kBinSlots);
+      for (unsigned int j = s + 64 + lane; j < e; j += 64) bin_count8(cnt, kin[j]);   // segments beyond 512 keys
+      c = c1; s = s1; e = e1; s1 = s2; e1 = e2; q = qn;
     }
   }
   __syncthreads();
@@ -503,8 +515,9 @@ extern "C" int memhip_events_extent(const double* ev, const int64_t* offsets,
 extern "C" size_t memhip_rasterize_binned_workspace(int B, int H, int W, int64_t n_events) {
   (void)H; (void)W;
   if (B <= 0 || n_events < 0) return 0;
-  const size_t keys = (((size_t)n_events + kBinChunk) * sizeof(unsigned int) + 15) & ~(size_t)15;
-  const size_t hdr = ((size_t)n_events / kBinChunk + (size_t)B + 1) * (kBinMaxBands + 1) * sizeof(unsigned int);
+  const size_t chunks = (size_t)n_events / kBinChunk + (size_t)B + 1;
+  const size_t keys = (chunks * kBinSlots * sizeof(unsigned short) + 15) & ~(size_t)15;
+  const size_t hdr = chunks * (kBinMaxBands + 1) * sizeof(unsigned int);
   return keys + hdr;
 }
 
@@ -523,8 +536,8 @@ extern "C" int memhip_rasterize_binned_f64(const double* ev, const int64_t* offs
   if (workspace_bytes < need)
     return memhip::fail(MEMHIP_EWORKSPACE, "rasterize_binned: workspace %zu < %zu", workspace_bytes, need);
   hipStream_t s = memhip::as_stream(stream);
-  unsigned int* keys = (unsigned int*)workspace;
-  const size_t keys_bytes = (((size_t)n_events + kBinChunk) * sizeof(unsigned int) + 15) & ~(size_t)15;
+  unsigned short* keys = (unsigned short*)workspace;
+  const size_t keys_bytes = ((((size_t)n_events / kBinChunk + (size_t)B + 1) * kBinSlots * sizeof(unsigned short)) + 15) & ~(size_t)15;
   unsigned int* hdr = (unsigned int*)((char*)workspace + keys_bytes);
   MEMHIP_HIP(hipMemsetAsync(status, 0, (size_t)B * sizeof(int32_t), s));
   static bool attr_done = false;

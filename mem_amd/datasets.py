@@ -33,7 +33,7 @@ declare({
 # single-pass LDS kernel (more than 6 bands of 14336 pixels) or the streams are long; the time surface keeps
 # the global-atomic form
 _BINNED_MIN_EVENTS_PER_SAMPLE = 200_000
-_BINNED_MAX_PIXELS = 64 * 40000
+_BINNED_MAX_PIXELS = 64 * 32764
 
 
 def _lds_fits(H, W):
