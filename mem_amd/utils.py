@@ -308,93 +308,84 @@ def auto_load_model(args, model, model_without_ddp, optimizer, loss_scaler, mode
 
 
 def load_state_dict(model, state_dict, prefix="", ignore_missing="relative_position_index"):
-    """utils.py:302-348: non-strict load through ``_load_from_state_dict`` with the reference's report lines."""
-    missing_keys, unexpected_keys, error_msgs = [], [], []
+    """utils.py:302-348: non-strict load, module by module through ``_load_from_state_dict`` (so buffers / parameters
+    missing on either side are collected instead of raised), with the reference's four report lines; missing keys
+    that contain one of the ``|``-separated ``ignore_missing`` patterns are listed separately."""
+    missing, unexpected, errors = [], [], []
     metadata = getattr(state_dict, "_metadata", None)
-    state_dict = state_dict.copy()
+    sd = state_dict.copy()
     if metadata is not None:
-        state_dict._metadata = metadata
-
-    def load(module, prefix=""):
-        local_metadata = {} if metadata is None else metadata.get(prefix[:-1], {})
-        module._load_from_state_dict(state_dict, prefix, local_metadata, True, missing_keys, unexpected_keys, error_msgs)
-        for name, child in module._modules.items():
-            if child is not None:
-                load(child, prefix + name + ".")
-
-    load(model, prefix=prefix)
-    warn_missing_keys, ignore_missing_keys = [], []
-    for key in missing_keys:
-        if any(ig in key for ig in ignore_missing.split("|")):
-            ignore_missing_keys.append(key)
-        else:
-            warn_missing_keys.append(key)
-    if len(warn_missing_keys) > 0:
-        print("Weights of {} not initialized from pretrained model: {}".format(model.__class__.__name__, warn_missing_keys))
-    if len(unexpected_keys) > 0:
-        print("Weights from pretrained model not used in {}: {}".format(model.__class__.__name__, unexpected_keys))
-    if len(ignore_missing_keys) > 0:
-        print("Ignored weights of {} not initialized from pretrained model: {}".format(
-            model.__class__.__name__, ignore_missing_keys))
-    if len(error_msgs) > 0:
-        print("\n".join(error_msgs))
+        sd._metadata = metadata
+    stack = [(model, prefix)]
+    while stack:                                                   # pre-order, children in registration order
+        module, pre = stack.pop()
+        module._load_from_state_dict(sd, pre, {} if metadata is None else metadata.get(pre[:-1], {}), True, missing,
+                                     unexpected, errors)
+        stack.extend(reversed([(child, pre + name + ".") for name, child in module._modules.items() if child is not None]))
+    patterns = ignore_missing.split("|")
+    ignored = [k for k in missing if any(pat in k for pat in patterns)]
+    warned = [k for k in missing if k not in ignored]
+    cls = model.__class__.__name__
+    for keys, text in ((warned, "Weights of {} not initialized from pretrained model: {}"),
+                       (unexpected, "Weights from pretrained model not used in {}: {}"),
+                       (ignored, "Ignored weights of {} not initialized from pretrained model: {}")):
+        if keys:
+            print(text.format(cls, keys))
+    if errors:
+        print("\n".join(errors))
     if getattr(model, "_engine", None) is not None:
         model._engine.weights_dirty = True
+
+
+def _resize_pos_embed(pos_embed_checkpoint, model):
+    """Bicubic resize of the patch part of an absolute position embedding to the model's grid (utils.py:703-721)."""
+    dim = pos_embed_checkpoint.shape[-1]
+    n_extra = model.pos_embed.shape[-2] - model.patch_embed.num_patches
+    src = int((pos_embed_checkpoint.shape[-2] - n_extra) ** 0.5)
+    dst = int(model.patch_embed.num_patches ** 0.5)
+    if src == dst:
+        return pos_embed_checkpoint
+    print("Position interpolate from %dx%d to %dx%d" % (src, src, dst, dst))
+    grid = pos_embed_checkpoint[:, n_extra:].reshape(-1, src, src, dim).permute(0, 3, 1, 2)
+    grid = torch.nn.functional.interpolate(grid, size=(dst, dst), mode="bicubic", align_corners=False)
+    return torch.cat((pos_embed_checkpoint[:, :n_extra], grid.permute(0, 2, 3, 1).flatten(1, 2)), dim=1)
 
 
 def finetune(args, model):
     """utils.py:613-723: initialise a finetuning model from a pretraining checkpoint -- pick the state dict by
     ``args.model_key``, drop a head of another shape, EXPAND the shared relative-position table to every block when
     the model keeps per-block tables, drop the index buffers, then the non-strict load.  The two resampling
-    branches (geometric-progression resize of the bias tables, bicubic resize of pos_embed) apply only when the
-    finetuning resolution differs from the pretraining one; the table one needs scipy's removed ``interp2d`` and
-    raises here."""
+    branches apply only when the finetuning resolution differs from the pretraining one: pos_embed is resized
+    (bicubic); the bias tables would need scipy's removed ``interp2d`` and raise here."""
     checkpoint = torch.load(args.finetune, map_location="cpu", weights_only=False)
     print("Load ckpt from %s" % args.finetune)
-    checkpoint_model = None
+    ckpt = checkpoint
     for model_key in getattr(args, "model_key", "model|module").split("|"):
         if model_key in checkpoint:
-            checkpoint_model = checkpoint[model_key]
+            ckpt = checkpoint[model_key]
             print("Load state_dict by model_key = %s" % model_key)
             break
-    if checkpoint_model is None:
-        checkpoint_model = checkpoint
-    state_dict = model.state_dict()
-    for k in ["head.weight", "head.bias"]:
-        if k in checkpoint_model and checkpoint_model[k].shape != state_dict[k].shape:
+    own = model.state_dict()
+    for k in ("head.weight", "head.bias"):
+        if k in ckpt and ckpt[k].shape != own[k].shape:
             print(f"Removing key {k} from pretrained checkpoint")
-            del checkpoint_model[k]
-    if model.use_rel_pos_bias and "rel_pos_bias.relative_position_bias_table" in checkpoint_model:
+            del ckpt[k]
+    shared = "rel_pos_bias.relative_position_bias_table"
+    if model.use_rel_pos_bias and shared in ckpt:
         print("Expand the shared relative position embedding to each transformer block. ")
-        rel_pos_bias = checkpoint_model["rel_pos_bias.relative_position_bias_table"]
+        table = ckpt.pop(shared)
         for i in range(model.get_num_layers()):
-            checkpoint_model["blocks.%d.attn.relative_position_bias_table" % i] = rel_pos_bias.clone()
-        checkpoint_model.pop("rel_pos_bias.relative_position_bias_table")
-    for key in list(checkpoint_model.keys()):
-        if "relative_position_index" in key:
-            checkpoint_model.pop(key)
-        if "relative_position_bias_table" in key and key in state_dict:
-            if checkpoint_model[key].shape != state_dict[key].shape:
-                raise NotImplementedError(
-                    "relative-position tables of another window size: the reference resamples them with "
-                    "scipy.interpolate.interp2d (removed from SciPy); finetune at the pretraining resolution")
-    if "pos_embed" in checkpoint_model and model.pos_embed is not None:
-        pos_embed_checkpoint = checkpoint_model["pos_embed"]
-        embedding_size = pos_embed_checkpoint.shape[-1]
-        num_patches = model.patch_embed.num_patches
-        num_extra_tokens = model.pos_embed.shape[-2] - num_patches
-        orig_size = int((pos_embed_checkpoint.shape[-2] - num_extra_tokens) ** 0.5)
-        new_size = int(num_patches ** 0.5)
-        if orig_size != new_size:
-            print("Position interpolate from %dx%d to %dx%d" % (orig_size, orig_size, new_size, new_size))
-            extra_tokens = pos_embed_checkpoint[:, :num_extra_tokens]
-            pos_tokens = pos_embed_checkpoint[:, num_extra_tokens:]
-            pos_tokens = pos_tokens.reshape(-1, orig_size, orig_size, embedding_size).permute(0, 3, 1, 2)
-            pos_tokens = torch.nn.functional.interpolate(pos_tokens, size=(new_size, new_size), mode="bicubic",
-                                                         align_corners=False)
-            pos_tokens = pos_tokens.permute(0, 2, 3, 1).flatten(1, 2)
-            checkpoint_model["pos_embed"] = torch.cat((extra_tokens, pos_tokens), dim=1)
-    load_state_dict(model, checkpoint_model, prefix=getattr(args, "model_prefix", ""))
+            ckpt["blocks.%d.attn.relative_position_bias_table" % i] = table.clone()
+    for key in [k for k in ckpt if "relative_position_index" in k]:
+        ckpt.pop(key)
+    for key in [k for k in ckpt if "relative_position_bias_table" in k and k in own]:
+        if ckpt[key].shape != own[key].shape:
+            raise NotImplementedError(
+                "relative-position tables of another window size: the reference resamples them with "
+                "scipy.interpolate.interp2d (removed from SciPy); finetune at the pretraining resolution")
+    if "pos_embed" in ckpt and model.pos_embed is not None:
+        ckpt["pos_embed"] = _resize_pos_embed(ckpt["pos_embed"], model)
+    load_state_dict(model, ckpt, prefix=getattr(args, "model_prefix", ""))
 
 
 def create_d_vae(weight_path, d_vae_type, image_size, device):
