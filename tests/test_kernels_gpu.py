@@ -238,11 +238,11 @@ def test_grad_norm_and_adamw_match_torch():
 
 def test_attention_full_size_properties():
     """BASELINE size (B=256, 197 tokens, 12 heads): size-independent properties instead of a reference tensor.
-    (1) softmax rows sum to one: with V == const the output is that constant; (2) exp(lse) is the row sum of
-    exp(score): recomputed from lse on a few sampled (sample, head, query) rows; (3) backward with dO == 0 gives
-    exactly zero gradients; (4) the table gradient sums to zero over all buckets of a head when the upstream
-    gradient is orthogonal to V's row space ... replaced by the always-true identity: sum over buckets of dtable ==
-    sum over (b,q,k) of dS == 0 for every head (softmax-backward rows sum to zero)."""
+    (1) softmax rows sum to one: with V == const the output is that constant; (2) lse is the log of the row sum of
+    exp(score): recomputed on a few sampled (sample, head, query) rows; (3) backward with dO == 0 gives exactly zero
+    gradients (and overwrites stale output); (4) softmax-backward rows sum to zero, so the bucket gradients of every
+    head sum to zero up to fixed-point / bf16 noise (random V: with V == const the true gradient itself vanishes and
+    only the rounding difference between bf16 dP and the flash-form delta would be left)."""
     from mem_amd import ops
     from oracle.vit_ref import rel_pos_index
     B, T, H, win = 256, 197, 12, (14, 14)
