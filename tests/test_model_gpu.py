@@ -324,3 +324,46 @@ def test_batch_is_token_weighted_mean_of_samples():
     for k in g_all:
         rel = (g_all[k] - acc[k]).norm() / (acc[k].norm() + 1e-12)
         assert rel <= 2e-2, (k, rel.item())           # bf16 dlogits scale differently (1/M vs 1/M_b): rounding noise only
+
+
+def test_vit_base_full_batch_is_weighted_mean_of_halves():
+    """BASELINE configs[1] size (ViT-B/16, C=2, B=256, ~98 masked patches per sample): the batch loss / gradients equal
+    the masked-token-weighted mean of the two half batches -- exercises the row-split GEMM launches, the 13-samples-
+    per-workgroup attention grids and every batched reduction at the size the benchmark runs."""
+    from mem_amd.modeling_pretrain import pt_vit
+    from oracle.gen_golden import BASE, vit_inputs
+    from oracle.vit_ref import fill_by_name
+    cfg = dict(BASE, in_chans=2)
+    m = pt_vit(**cfg)
+    m.load_state_dict(fill_by_name(m.state_dict(), seed=1))
+    m = m.cuda().train()
+    B = 256
+    x, mask, labels = vit_inputs(cfg, B, 5, 98)
+    counts = mask.sum(1)
+    xs, ms, ls = x.cuda(), mask.cuda(), labels.cuda()
+    la = m.forward_loss(xs, ms, ls)
+    m.backward()
+    loss_all = la[0].item()
+    assert abs(loss_all - float(np.log(8192))) < 1.5          # recipe-filled weights: ln V plus half the logit variance
+    names = ["blocks.0.attn.qkv.weight", "blocks.11.mlp.fc2.weight", "blocks.5.norm1.weight", "blocks.7.attn.q_bias",
+             "rel_pos_bias.relative_position_bias_table", "patch_embed.proj.weight", "lm_head.bias", "blocks.3.gamma_1",
+             "cls_token", "mask_token"]
+    P = dict(m.named_parameters())
+    g_all = {k: P[k].grad.detach().clone() for k in names}
+    for k, p in P.items():
+        assert torch.isfinite(p.grad).all(), k
+    acc = {k: torch.zeros_like(v) for k, v in g_all.items()}
+    loss_acc, off = 0.0, 0
+    for lo, hi in ((0, 128), (128, 256)):
+        nb = int(counts[lo:hi].sum())
+        l1 = m.forward_loss(xs[lo:hi], ms[lo:hi], ls[off:off + nb])
+        m.backward()
+        off += nb
+        w = nb / int(counts.sum())
+        loss_acc += w * l1[0].item()
+        for k in names:
+            acc[k] += w * P[k].grad
+    assert abs(loss_all - loss_acc) <= 2e-4, (loss_all, loss_acc)
+    for k in names:
+        rel = (g_all[k] - acc[k]).norm() / (acc[k].norm() + 1e-12)
+        assert rel <= 2e-2, (k, rel.item())
