@@ -22,9 +22,9 @@ class GradReducer:
         # with MEMHIP_BENCH_FORCE_DIST=1)
         self.active = (self.world > 1 or force) and dist.is_initialized()
         self.handles = []
-        # SUM then divide (on the compute stream, after the join): ReduceOp.AVG needs ncclAvg support in the
-        # installed RCCL and saves one 0.1 ms pass over the buckets -- not worth a hard dependency
-        self.use_avg = False
+        # RCCL (ncclAvg, RCCL >= 2.10) averages inside the collective; gloo (CPU tests) has no AVG: SUM, then divide
+        # on the compute stream after the join (one extra pass over the buckets)
+        self.use_avg = dist.is_initialized() and dist.get_backend(group) == "nccl"
         if flat_p is not None and self.active:
             dist.broadcast(flat_p, src=0, group=group)          # rank-0 weights everywhere (DDP ctor)
 
