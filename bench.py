@@ -20,6 +20,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FLOP_PER_SAMPLE = {2: 108.85e9, 3: 109.08e9}      # BASELINE.md section 2 (GEMMs only, fwd+bwd)
+TIMER_EVERY = 8                                    # every 8th timed step carries the per-GEMM HIP events
 PEAK_BF16_TFLOPS = 2500.0                          # MI355X dense bf16 (MI355X_MICROARCH.md)
 
 
@@ -151,18 +152,43 @@ def main():
 
     for it in range(a.warmup):
         step(it)
+    # CPython's cyclic collector walks every tracked object of the process (model, optimizer, torch internals) when its
+    # allocation counters trip: ~14 ms of host stall every few steps, which the GPU sees as an idle gap because the
+    # host runs only a few ms ahead.  Freeze what exists now into the permanent generation (gc stays enabled).
+    import gc
+    gc.collect()
+    gc.freeze()
     fence()
     # Live per-launch GEMM timing (HIP events on the launch stream) for the roofline object.  Two event
     # records around each of the 149 GEMM products of a step cost ~1.2 ms of dispatch bubbles per step
-    # (measured), so only every 4th timed step is instrumented: still >= 5 steps x 149 launches by default.
+    # (measured), so only every 8th timed step is instrumented: 3 steps x 149 launches by default (0.18 ms on the mean).
     timer_log = [] if not a.no_gemm_timer else None
+    if timer_log is not None:
+        # pre-create and pre-record the timer's events (2 per GEMM product, ~150 products per instrumented step)
+        need = 2 * 160 * len(range(0, a.steps, TIMER_EVERY))
+        ops.GEMM_EVENT_POOL = [torch.cuda.Event(enable_timing=True) for _ in range(need)]
+        for e in ops.GEMM_EVENT_POOL:
+            e.record()
+        torch.cuda.synchronize()
+    # per-step durations for the median: one event per step boundary on the launch stream, read after the timed region
+    step_ev = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]
     t0 = time.perf_counter()
+    step_ev[0].record()
+    host_t = [time.perf_counter()]
     for it in range(a.steps):
-        ops.GEMM_TIMER = timer_log if (timer_log is not None and it % 4 == 0) else None
+        ops.GEMM_TIMER = timer_log if (timer_log is not None and it % TIMER_EVERY == 0) else None
         la = step(a.warmup + it)
+        step_ev[it + 1].record()
+        host_t.append(time.perf_counter())
     ops.GEMM_TIMER = timer_log
     fence()
     dt = time.perf_counter() - t0
+    if os.environ.get("MEMHIP_BENCH_STEP_TIMES") == "1":
+        print("[bench] host per-step ms:", [round((host_t[i + 1] - host_t[i]) * 1e3, 1) for i in range(a.steps)], file=sys.stderr)
+        print("[bench] per-step ms:", [round(step_ev[i].elapsed_time(step_ev[i + 1]), 2) for i in range(a.steps)], file=sys.stderr)
+    step_ms = sorted(step_ev[i].elapsed_time(step_ev[i + 1]) for i in range(a.steps))
+    # un-instrumented steps only: the GEMM event pairs of an instrumented step cost ~1.2 ms
+    plain = sorted(step_ev[i].elapsed_time(step_ev[i + 1]) for i in range(a.steps) if timer_log is None or i % TIMER_EVERY != 0)
     timer, ops.GEMM_TIMER = ops.GEMM_TIMER, None
     loss_last = float(la[0].item())
     if world > 1:
@@ -237,7 +263,7 @@ def main():
         value = world * B * a.steps / dt
         roof = None
         if timer:
-            n_inst = len(range(0, a.steps, 4))
+            n_inst = len(range(0, a.steps, TIMER_EVERY))
             tot_ms, tot_fl, per = 0.0, 0.0, {}
             for e0, e1, fl, epi in timer:
                 d = e0.elapsed_time(e1)
@@ -281,7 +307,9 @@ def main():
                                    "traffic": {k: v.get("hbm_bytes_per_launch") for k, v in tj.items() if k.startswith("gemm")}}
         out = {"metric": "pretrain samples/sec (ViT-B, 224^2 event voxels)", "value": round(value, 1),
                "unit": "samples/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-               "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "ms_per_step": round(ms, 3), "ms_per_step_p50": round(step_ms[len(step_ms) // 2], 3),
+               "ms_per_step_p50_uninstrumented": round(plain[len(plain) // 2], 3) if plain else None,
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": "bf16", "data": "synthetic",
                "config": {"workload": "MEM pretrain ViT-Base/16, 224^2 2-bin event voxels, bf16, batch 256 per GPU "
                                       "(BASELINE configs[1]); step = rasterize 256x30k events + event_norm + masks "

@@ -33,6 +33,13 @@ def _p(t):
 # Optional live timing of every GEMM launch with HIP events on the launch stream (bench.py's
 # roofline leg): set GEMM_TIMER to a list; entries are (start_event, end_event, flops, epilogue).
 GEMM_TIMER = None
+# Events for the timer, created AND recorded once before the timed region (bench.py): creating / first-recording a few
+# hundred timing events inside the region grows the runtime's signal pool there, seen as ~14 ms stalls some steps later.
+GEMM_EVENT_POOL = []
+
+
+def _timer_event():
+    return GEMM_EVENT_POOL.pop() if GEMM_EVENT_POOL else torch.cuda.Event(enable_timing=True)
 
 
 def gemm_nt(A, B, M, N, K, epi, out0=None, out1=None, bias=None, vec1=None, resid=None, aux=None,
@@ -59,7 +66,7 @@ def gemm_nt(A, B, M, N, K, epi, out0=None, out1=None, bias=None, vec1=None, resi
     if GEMM_TIMER is None:
         check(lib.memhip_gemm_bf16_nt(C.byref(a), stream_ptr()), "gemm_bf16_nt")
     else:
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0, e1 = _timer_event(), _timer_event()
         e0.record()
         check(lib.memhip_gemm_bf16_nt(C.byref(a), stream_ptr()), "gemm_bf16_nt")
         e1.record()
@@ -251,7 +258,7 @@ def gemm_tn(A, B, R, N, K, out, accumulate=True, workspace=None):
         check(lib.memhip_gemm_bf16_tn_ws(ptr(A), A.stride(0), ptr(B), B.stride(0), R, N, K, ptr(out), out.stride(0),
                                          int(accumulate), ws, wsb, stream_ptr()), "gemm_bf16_tn")
     else:
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0, e1 = _timer_event(), _timer_event()
         e0.record()
         check(lib.memhip_gemm_bf16_tn_ws(ptr(A), A.stride(0), ptr(B), B.stride(0), R, N, K, ptr(out), out.stride(0),
                                          int(accumulate), ws, wsb, stream_ptr()), "gemm_bf16_tn")
