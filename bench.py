@@ -7,7 +7,12 @@ One "step" = one pass of the hot path over one synthetic batch that is already r
   MT19937, overlapped) -> ViT-B masked forward + CE -> backward (RCCL all-reduce overlapped when
   N>1) -> grad-norm/clip + AdamW.
 Launch:  python bench.py [--gpus N --steps K --warmup W]
-         (N>1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+  N>1, either form works:
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N ...                (the driver's form: RANK / LOCAL_RANK / WORLD_SIZE come from the env)
+    python bench.py --gpus N ...             (self-launching: with no WORLD_SIZE in the env this process starts
+        exactly that torchrun command as a CHILD before anything touches the GPU, relays its output, prints rank 0's
+        JSON line last and exits with the child's return code -- no exec of a GPU-initialised process)
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -51,6 +56,41 @@ def cpu_baseline(batch=8, budget_s=15.0, max_threads=32):
                                       f"after 1 warm-up in {dt:.1f} s, {threads} threads of {os.cpu_count()} cores"}
 
 
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def self_launch(a, argv):
+    """`python bench.py --gpus N` from a bare shell: start one fresh rank process per GPU through torchrun as a child
+    (this process has imported neither torch nor HIP), relay the children's output, print rank 0's JSON line LAST."""
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    env["MEMHIP_BENCH_CHILD"] = "1"
+    port = int(os.environ.get("MASTER_PORT") or _free_port())
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    print("[bench] self-launch:", " ".join(cmd), file=sys.stderr, flush=True)
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=None, text=True)
+    result = None
+    for line in proc.stdout:
+        line = line.rstrip("\n")
+        if line.startswith("{") and '"metric"' in line:
+            result = line
+        elif line:
+            print(line, file=sys.stderr, flush=True)
+    rc = proc.wait()
+    if result is not None:
+        print(result, flush=True)
+    sys.exit(rc if rc != 0 or result is not None else 1)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -64,7 +104,12 @@ def main():
                     help="skip the secondary figure that adds the frozen dVAE tokenizer forward (stock PyTorch-ROCm)")
     ap.add_argument("--no-raster-figure", action="store_true",
                     help="skip the secondary figure for BASELINE configs[3] (rasterizer at 1 M events per sample)")
+    ap.add_argument("--rendezvous-only", action="store_true",
+                    help="launch plumbing check without a GPU (tests/test_bench_launch.py): start the ranks, form a gloo "
+                         "group, all-reduce one number, print a stub JSON line; measures nothing")
     a = ap.parse_args()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(a, sys.argv[1:])                  # never returns
 
     import numpy as np
     import torch
@@ -73,7 +118,23 @@ def main():
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
-    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    if world != a.gpus:
+        sys.exit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world} (launch with --nproc-per-node {a.gpus}, or unset "
+                 "WORLD_SIZE and let bench.py start the ranks itself)")
+    if a.rendezvous_only:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+        dist.init_process_group("gloo")
+        t = torch.tensor([float(rank + 1)])
+        dist.all_reduce(t)
+        dist.barrier()
+        dist.destroy_process_group()
+        if rank == 0:
+            print(json.dumps({"metric": "rendezvous-only (no measurement)", "value": None, "n_gpus": world,
+                              "rank_sum": float(t.item())}), flush=True)
+        return
     torch.cuda.set_device(local_rank)
     # MEMHIP_BENCH_FORCE_DIST=1: run the RCCL path (process group, parameter broadcast, per-bucket async all-reduce hooked
     # into backward, join before the optimizer) in a ONE-rank group -- a single-GPU dry run of what N > 1 executes

@@ -44,6 +44,12 @@ int memhip_abi_version(void);
 const char* memhip_last_error(void);
 /* Name of the device code object this library was built for ("gfx950"). */
 const char* memhip_arch(void);
+/* Kernel-selection switches for A/B measurements (tools/): the library reads NO environment variable; the only
+ * process-wide state is this explicit table.  Names: "gemm_p8", "gemm256", "gemm_split", "gemm_p8_half", "tn_p8",
+ * "tn256", "raster_lds" (0/1, default 1 = shipped dispatch), "gemm_p8_min_n" (768), "gemm256_min_n" (1024).
+ * Unknown name: MEMHIP_EINVAL.  Results do not depend on any option (same contract, different kernel). */
+int memhip_set_option(const char* name, int value);
+int memhip_get_option(const char* name, int* value);
 
 /* ------------------------------------------------------------------------
  * Event stream -> voxel/histogram image

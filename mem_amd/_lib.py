@@ -42,6 +42,8 @@ declare({
     "memhip_abi_version": (i32, []),
     "memhip_last_error": (C.c_char_p, []),
     "memhip_arch": (C.c_char_p, []),
+    "memhip_set_option": (i32, [C.c_char_p, i32]),
+    "memhip_get_option": (i32, [C.c_char_p, C.POINTER(i32)]),
 })
 
 if lib.memhip_abi_version() != ABI_VERSION:
@@ -51,6 +53,17 @@ if lib.memhip_abi_version() != ABI_VERSION:
 def check(rc, what=""):
     if rc != 0:
         raise MemhipError(f"{what} failed ({rc}): {lib.memhip_last_error().decode()}")
+
+
+def set_option(name, value):
+    """Kernel-selection switch of the library (include/memhip.h: memhip_set_option) -- A/B tools only."""
+    check(lib.memhip_set_option(name.encode(), int(value)), "set_option")
+
+
+def get_option(name):
+    v = i32(0)
+    check(lib.memhip_get_option(name.encode(), C.byref(v)), "get_option")
+    return v.value
 
 
 def ptr(t):

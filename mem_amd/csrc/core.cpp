@@ -1,10 +1,43 @@
-// ABI bookkeeping: version, arch, thread-local error string.
+// ABI bookkeeping: version, arch, thread-local error string, kernel-selection options.
 #include "common.h"
+#include <atomic>
+#include <cstring>
 
-namespace memhip { thread_local char g_err[512] = ""; }
+namespace memhip {
+thread_local char g_err[512] = "";
+
+// Kernel-selection switches for A/B measurements (tools/): set ONLY through memhip_set_option() -- the library
+// reads no environment variable.  Defaults = the shipped dispatch.
+static std::atomic<int> g_opt[OPT_COUNT_] = {
+    /*gemm_p8*/ {1}, /*gemm256*/ {1}, /*gemm_split*/ {1}, /*gemm_p8_half*/ {1}, /*gemm_p8_min_n*/ {768},
+    /*gemm256_min_n*/ {1024}, /*tn_p8*/ {1}, /*tn256*/ {1}, /*raster_lds*/ {1}};
+static const char* const g_opt_name[OPT_COUNT_] = {"gemm_p8", "gemm256", "gemm_split", "gemm_p8_half", "gemm_p8_min_n",
+                                                   "gemm256_min_n", "tn_p8", "tn256", "raster_lds"};
+int opt(int id) { return g_opt[id].load(std::memory_order_relaxed); }
+}  // namespace memhip
 
 extern "C" {
 int memhip_abi_version(void) { return MEMHIP_ABI_VERSION; }
 const char* memhip_last_error(void) { return memhip::g_err; }
 const char* memhip_arch(void) { return "gfx950"; }
+
+int memhip_set_option(const char* name, int value) {
+  MEMHIP_REQUIRE(name, "set_option: null name");
+  for (int i = 0; i < memhip::OPT_COUNT_; ++i)
+    if (!strcmp(name, memhip::g_opt_name[i])) {
+      memhip::g_opt[i].store(value, std::memory_order_relaxed);
+      return MEMHIP_OK;
+    }
+  return memhip::fail(MEMHIP_EINVAL, "set_option: unknown option '%s'", name);
+}
+
+int memhip_get_option(const char* name, int* value) {
+  MEMHIP_REQUIRE(name && value, "get_option: null argument");
+  for (int i = 0; i < memhip::OPT_COUNT_; ++i)
+    if (!strcmp(name, memhip::g_opt_name[i])) {
+      *value = memhip::opt(i);
+      return MEMHIP_OK;
+    }
+  return memhip::fail(MEMHIP_EINVAL, "get_option: unknown option '%s'", name);
+}
 }

@@ -10,7 +10,6 @@
 // through the *source* address (LDS-DMA writes lane-linear) so that every ds_read_b128 fragment
 // read is bank-conflict free.  Workgroup ids are remapped so that the 8 XCDs each walk a
 // contiguous range of tiles (A row-panel reuse in the XCD-private L2).
-#include <cstdlib>
 #include <cstddef>
 #include "common.h"
 #include "gemm_epilogue.hpp"
@@ -221,14 +220,14 @@ extern "C" int memhip_gemm_bf16_nt(const memhip_gemm_args_t* a, memhip_stream_t 
   }
   // large token-dimension products: the phase-interleaved persistent kernel (gemm_p8.hip); the lockstep 256x256
   // kernel (gemm256.hip) takes shapes it does not (K a multiple of 64 but not of 128, or MEMHIP_GEMM_P8=0)
-  static const bool k256_on = !(getenv("MEMHIP_GEMM256") && atoi(getenv("MEMHIP_GEMM256")) == 0);
-  static const bool p8_on = !(getenv("MEMHIP_GEMM_P8") && atoi(getenv("MEMHIP_GEMM_P8")) == 0);
+  const bool k256_on = opt(OPT_GEMM256) != 0;
+  const bool p8_on = opt(OPT_GEMM_P8) != 0;
   if (p8_on) {
     // A persistent 256x256-tile launch whose last round would be poorly filled (N = 768: 591 tiles on
     // 256 CUs) only takes the rows of the full rounds; the remaining rows go to the 128x128 kernel
     // below (finer tiles, 2-3 workgroups per CU).  Rows are independent, so this is two launches of
     // the same contract on two row ranges.
-    static const bool split_on = !(getenv("MEMHIP_GEMM_SPLIT") && atoi(getenv("MEMHIP_GEMM_SPLIT")) == 0);
+    const bool split_on = opt(OPT_GEMM_SPLIT) != 0;
     const int split = split_on ? gemm_p8_split_rows(p) : 0;
     if (split > 0 && split < p.M && p.epilogue != MEMHIP_EPI_PATCH_EMBED) {
       GemmArgs head = p;
@@ -244,7 +243,7 @@ extern "C" int memhip_gemm_bf16_nt(const memhip_gemm_args_t* a, memhip_stream_t 
         p.M -= split;
         p.m_base = split;
         // the left-over rows: the same phase structure on 128-row tiles (MEMHIP_GEMM_P8_HALF=0: 128x128 kernel)
-        static const bool half_on = !(getenv("MEMHIP_GEMM_P8_HALF") && atoi(getenv("MEMHIP_GEMM_P8_HALF")) == 0);
+        const bool half_on = opt(OPT_GEMM_P8_HALF) != 0;
         if (half_on) {
           const int rch = gemm_p8_half_dispatch(p, s);
           if (rch != MEMHIP_EUNSUPPORTED) return rch;

@@ -13,7 +13,6 @@
 // across tile boundaries.  8 waves as 2(M) x 4(N); fragment addresses are per-lane constants plus
 // immediates (no VALU address math in the loop).  The epilogue transposes through the ring slot
 // that is free at that moment (refill deferred), 16 rows per pass, 16-byte global accesses.
-#include <cstdlib>
 #include "common.h"
 #include "gemm_epilogue.hpp"
 
@@ -193,7 +192,7 @@ int gemm256_dispatch(const GemmArgs& p, hipStream_t s) {
   // N = 768 (3 tiles wide) leaves the third round of 591 tiles 31 % full on 256 CUs and measures
   // 5-10 % below the 128x128 kernel (tools/bench_gemm.py); wide N gains 12-25 %.  MEMHIP_GEMM256_MIN_N
   // overrides the threshold for experiments.
-  static const int min_n = getenv("MEMHIP_GEMM256_MIN_N") ? atoi(getenv("MEMHIP_GEMM256_MIN_N")) : 1024;
+  const int min_n = opt(OPT_GEMM256_MIN_N);
   if (p.M < 4096 || p.N < min_n || p.N % BN != 0 || p.K % BK != 0 || !vec) return MEMHIP_EUNSUPPORTED;
   static int num_cu = 0;
   if (!num_cu) {

@@ -32,7 +32,6 @@
 // consecutive output columns of one row, and the B rows are interleaved so that its two n-fragments
 // are 8 consecutive columns: the epilogue runs straight out of the registers with 16-byte accesses
 // (no LDS transposition, no barrier) while the prefetch stream keeps running under it.
-#include <cstdlib>
 #include "common.h"
 #include "gemm_epilogue.hpp"
 
@@ -390,7 +389,7 @@ static bool p8_fits(const GemmArgs& p) {
   const bool vec = ((p.ldo0 | p.ldo1 | p.ldr | p.ldaux | p.colscale_n) & 7) == 0;      // host twin of vec_ok()
   // Narrow outputs (N = 768: 591 tiles on 256 CUs) are taken too: the launcher hands the rows of a
   // poorly filled last round to the 128x128 kernel (gemm_p8_split_rows).  MEMHIP_GEMM_P8_MIN_N overrides.
-  static const int min_n = getenv("MEMHIP_GEMM_P8_MIN_N") ? atoi(getenv("MEMHIP_GEMM_P8_MIN_N")) : 768;
+  const int min_n = opt(OPT_GEMM_P8_MIN_N);
   const bool wide = p.N >= min_n;
   return p.M >= 4096 && wide && p.N % BN == 0 && p.K % (2 * BK) == 0 && vec;
 }

@@ -15,7 +15,6 @@
 // The output is small (<= 3072 x 768) and the reduction long (50 432 tokens), so the grid is
 // split-K: S slices of the token range per output tile, combined with fp32 atomics into the
 // (pre-zeroed) gradient buffer -- S is chosen so that tiles * S fills the 256 CUs.
-#include <cstdlib>
 #include "common.h"
 
 namespace {
@@ -203,13 +202,13 @@ extern "C" int memhip_gemm_bf16_tn_ws(const void* A, int64_t lda, const void* B,
   MEMHIP_REQUIRE(N % 8 == 0 && K % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0 && ((uintptr_t)A & 15) == 0 &&
                      ((uintptr_t)B & 15) == 0, "gemm_tn: operands must be 16-byte aligned, N/K/ld %% 8 == 0");
   hipStream_t s = as_stream(stream);
-  static const bool p8_on = !(getenv("MEMHIP_TN_P8") && atoi(getenv("MEMHIP_TN_P8")) == 0);
+  const bool p8_on = opt(OPT_TN_P8) != 0;
   if (p8_on) {
     const int rc = gemm_tn_p8_dispatch(A, lda, B, ldb, R, N, K, out, ldo, accumulate, (float*)workspace,
                                        workspace_bytes, s);
     if (rc != MEMHIP_EUNSUPPORTED) return rc;
   }
-  static const bool k256_on = !(getenv("MEMHIP_TN256") && atoi(getenv("MEMHIP_TN256")) == 0);
+  const bool k256_on = opt(OPT_TN256) != 0;
   if (k256_on) {
     const int rc = gemm_tn256_dispatch(A, lda, B, ldb, R, N, K, out, ldo, accumulate, s);
     if (rc != MEMHIP_EUNSUPPORTED) return rc;

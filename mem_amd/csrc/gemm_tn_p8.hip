@@ -14,7 +14,6 @@
 // The fp32 partial tile is either added to the gradient with atomics shaped as two 128-byte runs
 // per wave-instruction, or (with a caller workspace) stored to a slab and summed by a reduction pass;
 // both are staged through the idle ring.
-#include <cstdlib>
 #include "common.h"
 
 namespace {

@@ -48,6 +48,10 @@ __global__ __launch_bounds__(kT) void adamw_kernel(float* __restrict__ p, const 
                                                    float decay_mul, float b1, float b2, float eps,
                                                    float step_size, float bc2_sqrt,
                                                    const float* __restrict__ gnorm, float max_norm) {
+  // Non-finite guard on the device: a NaN/Inf loss gives a NaN/Inf gradient norm; the update is then skipped as a whole
+  // (parameters and both moments untouched), so the host's deferred isfinite(loss) abort
+  // (engine_for_pretraining.py:219-228 in the reference, checked here at the next meter flush) finds clean weights.
+  if (gnorm && !isfinite(gnorm[0])) return;
   float coef = 1.0f;
   if (max_norm > 0.f) {                          // clip_grad_norm_: g *= clamp(max_norm/(norm+1e-6), max=1)
     coef = max_norm / (gnorm[0] + 1e-6f);
@@ -86,6 +90,7 @@ __global__ __launch_bounds__(kT) void adamw_groups_kernel(float* __restrict__ p,
                                                           const float2* __restrict__ group_table, float b1, float b2,
                                                           float eps, float bc2_sqrt, const float* __restrict__ gnorm,
                                                           float max_norm) {
+  if (gnorm && !isfinite(gnorm[0])) return;      // see adamw_kernel
   float coef = 1.0f;
   if (max_norm > 0.f) {
     coef = max_norm / (gnorm[0] + 1e-6f);

@@ -4,7 +4,6 @@
 // once with two 16-B loads per lane (a wave covers 2 KiB contiguous), binned with u32 atomics
 // that resolve in the XCD L2 / memory side, and a second streaming pass folds the u32 bins to
 // the reference's wrap-around uint8 counts.  Algorithmic bytes: 32*N + 3*H*W per sample.
-#include <cstdlib>
 #include "common.h"
 
 static_assert(sizeof(memhip_event_aug_t) == 56, "memhip_event_aug_t ABI layout");
@@ -411,7 +410,7 @@ extern "C" int memhip_rasterize_aug_f64(const double* ev, const int64_t* offsets
     // privatised-counter path (see raster_lds_kernel): small canvas, no time surface
     int rpb = kBandPixels / W;
     const int bands = rpb > 0 ? memhip::cdiv(H, rpb) : kMaxBands + 1;
-    static const bool lds_on = !(getenv("MEMHIP_RASTER_LDS") && atoi(getenv("MEMHIP_RASTER_LDS")) == 0);
+    const bool lds_on = memhip::opt(memhip::OPT_RASTER_LDS) != 0;
     if (lds_on && !time_surface && bands <= kMaxBands && ((uintptr_t)out & 3) == 0) {
       rpb = memhip::cdiv(H, bands);                        // even bands
       MEMHIP_HIP(hipMemsetAsync(status, 0, (size_t)B * sizeof(int32_t), s));

@@ -266,11 +266,14 @@ class VisionTransformer(nn.Module):
 
     def draw_drop_path(self, B):
         eng = self.engine
-        probs = torch.tensor([b.drop_prob for b in self.blocks for _ in range(2)], device=eng.dev)
-        if float(probs.max()) == 0.0:
+        probs = [float(b.drop_prob) for b in self.blocks for _ in range(2)]
+        if max(probs) == 0.0:                         # decided on the host: no device read-back per step
             return None
+        keep = getattr(self, "_dp_keep", None)
+        if keep is None or keep[0] != probs:          # the static (1 - p) column lives on the device once
+            keep = self._dp_keep = (probs, (1.0 - torch.tensor(probs, device=eng.dev)).view(-1, 1))
         u = torch.rand((2 * eng.depth, B), device=eng.dev)
-        return torch.floor((1.0 - probs).view(-1, 1) + u).contiguous()
+        return torch.floor(keep[1] + u).contiguous()
 
     def _trunk(self, x, drop_path_masks=None):
         eng = self.engine

@@ -170,11 +170,14 @@ class VisionTransformerForMaskedImageModeling(nn.Module):
         """Per-sample stochastic-depth keep masks for one step: f32 [2*depth, B] of 0/1 with
         P(1) = 1 - drop_prob of the block (timm drop_path: floor(keep_prob + U[0,1)))."""
         eng = self.engine
-        probs = torch.tensor([b.drop_prob for b in self.blocks for _ in range(2)], device=eng.dev)
-        if float(probs.max()) == 0.0:
+        probs = [float(b.drop_prob) for b in self.blocks for _ in range(2)]
+        if max(probs) == 0.0:                         # decided on the host: no device read-back per step
             return None
+        keep = getattr(self, "_dp_keep", None)
+        if keep is None or keep[0] != probs:          # the static (1 - p) column lives on the device once
+            keep = self._dp_keep = (probs, (1.0 - torch.tensor(probs, device=eng.dev)).view(-1, 1))
         u = torch.rand((2 * eng.depth, B), device=eng.dev)
-        return torch.floor((1.0 - probs).view(-1, 1) + u).contiguous()
+        return torch.floor(keep[1] + u).contiguous()
 
     def forward(self, x, bool_masked_pos, return_all_tokens=False, drop_path_masks=None):
         x, mask_u8, rows = self._prep(x, bool_masked_pos, return_all_tokens)

@@ -17,8 +17,6 @@ MI355X-first structure (not an autograd graph):
 """
 import math
 
-import os
-
 import torch
 
 from . import ops
@@ -164,14 +162,17 @@ class ViTEngine:
         self.zero_vec = torch.zeros(D, dtype=torch.float32, device=dev)                           # no mask_token
         self.head_end = self.buckets[0][2]           # flat offset where the head bucket ends
         self._tdesc = None
-        # MEMHIP_GELU_DG=1: fc1 keeps gelu'(h) (bf16) for the backward instead of h, so that erf / exp are evaluated
-        # once and the GELU backward is a plain product.  Measured gain 0.2 ms per step for one extra bf16 rounding
-        # of gelu' -- off by default (the reference evaluates gelu' in fp32 from the stored pre-activation)
-        dg = os.environ.get("MEMHIP_GELU_DG", "0") == "1"
-        self.epi_gelu, self.epi_dgelu = (ops.EPI_BIAS_GELU_DG, ops.EPI_MUL_AUX) if dg else (ops.EPI_BIAS_GELU, ops.EPI_DGELU)
+        # gelu_dg: fc1 keeps gelu'(h) (bf16) for the backward instead of h, so that erf / exp are evaluated once and the
+        # GELU backward is a plain product.  Measured gain 0.2 ms per step for one extra bf16 rounding of gelu' -- off
+        # (the reference evaluates gelu' in fp32 from the stored pre-activation); set engine.set_gelu_dg(True) to try
+        self.set_gelu_dg(False)
+        self.fuse_ln_branch = True       # LayerNorm backward fused with the following branch backward (D <= 1024)
         self.gn_ws = torch.zeros(1024, dtype=torch.float64, device=dev)
         self.gnorm = torch.zeros(1, dtype=torch.float32, device=dev)
         self.loss_acc = torch.zeros(2, dtype=torch.float32, device=dev)
+
+    def set_gelu_dg(self, on):
+        self.epi_gelu, self.epi_dgelu = (ops.EPI_BIAS_GELU_DG, ops.EPI_MUL_AUX) if on else (ops.EPI_BIAS_GELU, ops.EPI_DGELU)
 
     # ------------------------------------------------------------------ buffers per batch size
     def ensure_batch(self, B, Mm_max):
@@ -385,7 +386,10 @@ class ViTEngine:
         dx = self.dx
         if self.grad_hook:
             self.grad_hook(0)
-        fuse = D <= 1024 and os.environ.get("MEMHIP_FUSE_LN_BRANCH", "1") != "0"
+        # both ping-pong rows of the proj-bias scratch start clean: block i accumulates into row i&1 and clears the
+        # other one, which leaves row (depth-1)&1 dirty for the next backward when depth is odd
+        self.bias_scr.zero_()
+        fuse = D <= 1024 and self.fuse_ln_branch
         for i in reversed(range(self.depth)):
             pre = f"blocks.{i}."
             a = self.act[i]

@@ -43,3 +43,21 @@ def test_no_oracle_in_product():
             if f.endswith(".py"):
                 txt = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M), f
+
+
+def test_options_table_and_no_environment_reads():
+    """Kernel-selection switches exist only behind memhip_set_option; the shared object imports no getenv."""
+    import subprocess
+    from mem_amd import _lib
+    assert _lib.get_option("gemm_p8") == 1 and _lib.get_option("gemm_p8_min_n") == 768
+    _lib.set_option("gemm_p8", 0)
+    assert _lib.get_option("gemm_p8") == 0
+    _lib.set_option("gemm_p8", 1)
+    try:
+        _lib.set_option("no_such_option", 1)
+        raise AssertionError("unknown option accepted")
+    except _lib.MemhipError as e:
+        assert "unknown option" in str(e)
+    syms = subprocess.run(["nm", "-D", "--undefined-only", os.path.join(ROOT, "mem_amd", "libmemhip.so")],
+                          capture_output=True, text=True).stdout
+    assert "getenv" not in syms

@@ -1,5 +1,6 @@
-"""-m "not gpu": the native (libmemhip.so, host C++) mask generators are bit-exact against the
-reference goldens and against the oracle on long streams (host code: runs without a GPU)."""
+"""The native (libmemhip.so, host C++) mask generators are bit-exact against the reference goldens and against the
+oracle on long streams.  Host code: every test here runs twice -- under -m "not gpu" in the build container and
+under -m gpu on the GPU box (same binary, so the driver's GPU record covers SURVEY section 8 row a5 too)."""
 import contextlib
 import io
 import json
@@ -11,6 +12,13 @@ import numpy as np
 from conftest import GOLDEN
 from mem_amd.masking_generator import MaskingGenerator, MaskingGeneratorRandomLocation
 from oracle import masking_py as MP
+
+import pytest
+
+
+@pytest.fixture(autouse=True, params=["host", pytest.param("gpu_box", marks=pytest.mark.gpu)])
+def _where(request):
+    return request.param
 
 
 def _unpack(a, n, shape):

@@ -367,3 +367,36 @@ def test_vit_base_full_batch_is_weighted_mean_of_halves():
     for k in names:
         rel = (g_all[k] - acc[k]).norm() / (acc[k].norm() + 1e-12)
         assert rel <= 2e-2, (k, rel.item())
+
+
+def test_odd_depth_repeated_backward_vs_oracle():
+    """Depth 3 (odd): the proj-bias / v_bias ping-pong scratch of the backward must start clean on EVERY backward
+    (round-1 defect: from the second backward on, the last block's attn.proj.bias / attn.v_bias gradients carried
+    block 0's column sums of the previous step).  Checker: the oracle model on the host CPU under bf16 autocast."""
+    from mem_amd.modeling_pretrain import pt_vit
+    from oracle.gen_golden import vit_inputs
+    from oracle.vit_ref import RefViT, fill_by_name
+    cfg = dict(TINY, depth=3)
+    m = pt_vit(**cfg)
+    sd = fill_by_name(m.state_dict(), seed=5)
+    m.load_state_dict(sd)
+    m = m.cuda().train()
+    o = RefViT(**cfg)
+    o.load_state_dict(sd)
+    o.train()
+    for step in range(3):                                   # different inputs each time, no optimizer step
+        x, mask, labels = vit_inputs(cfg, 4, 900 + step, 6)
+        for p in o.parameters():
+            p.grad = None
+        with torch.autocast("cpu", dtype=torch.bfloat16):
+            lo = o(x, mask)
+        loss_o = torch.nn.CrossEntropyLoss()(lo.float(), labels)
+        loss_o.backward()
+        la = m.forward_loss(x.cuda(), mask.cuda(), labels.cuda())
+        m.backward()
+        assert abs(la[0].item() - loss_o.item()) <= 2e-3
+        og = dict(o.named_parameters())
+        for k, p in m.named_parameters():
+            ref = og[k].grad.cuda()
+            rel = (p.grad - ref).norm() / (ref.norm() + 1e-12)
+            assert rel <= 3e-2, (step, k, rel.item())
