@@ -120,6 +120,38 @@ int memhip_events_extent(const double* ev, const int64_t* offsets, const memhip_
                          int B, double* extent, memhip_stream_t stream);
 
 /* ------------------------------------------------------------------------
+ * Event record contract: raw dataset records -> the (N,4) float64 rows [x, y, t, p]
+ * replaces the N-Caltech101 decode loop        process_data/process_dataset.py:48-63
+ *          imgnet_npy_loader                   mem/dataset_folder.py:285-292
+ *          dsec_npy_loader                     mem/dataset_folder.py:275-283
+ * ------------------------------------------------------------------------
+ * decode_ncaltech101: raw u8 [n_bytes] (device, 4-byte aligned) of 5-byte records: byte0 -> column 0,
+ *   byte1 -> column 1, p = bit 7 of byte2 -> 2p-1, t = (byte2 & 0x7f):byte3:byte4 big-endian (23 bits);
+ *   ev f64 [n_bytes/5, 4].  n_bytes % 5 != 0 -> MEMHIP_EINVAL (the reference's loop raises on the short read).
+ * events_from_columns: four device column arrays of n elements with a dtype code each ->
+ *   ev[i] = [x[i], y[i], t[i], int8(int8(p[i]) * 2 - 1)] as float64 (the int8 wrap-around of
+ *   `data['p'].astype(np.int8) * 2 - 1` kept; p must be bool / integer).
+ * events_dsec: in [n,4] row-major of `dtype` -> out f64 rows [x, y, t, 2p-1] of the rows with y < y_limit
+ *   (440 in the reference), order kept; n_out i64 (device) = number of rows written; out has room for n rows. */
+#define MEMHIP_DT_U8 0
+#define MEMHIP_DT_I8 1
+#define MEMHIP_DT_U16 2
+#define MEMHIP_DT_I16 3
+#define MEMHIP_DT_U32 4
+#define MEMHIP_DT_I32 5
+#define MEMHIP_DT_U64 6
+#define MEMHIP_DT_I64 7
+#define MEMHIP_DT_F32 8
+#define MEMHIP_DT_F64 9
+#define MEMHIP_DT_BOOL 10
+int memhip_decode_ncaltech101(const uint8_t* raw, int64_t n_bytes, double* ev, memhip_stream_t stream);
+int memhip_events_from_columns(const void* x, int x_dtype, const void* y, int y_dtype, const void* t, int t_dtype,
+                               const void* p, int p_dtype, int64_t n, double* ev, memhip_stream_t stream);
+size_t memhip_events_dsec_workspace(int64_t n);
+int memhip_events_dsec(const void* in, int dtype, int64_t n, double y_limit, double* out, int64_t* n_out,
+                       void* workspace, size_t workspace_bytes, memhip_stream_t stream);
+
+/* ------------------------------------------------------------------------
  * Tensor-level event transforms, fused
  * replaces ToTensor (/255), RemoveTimesurface, RemoveHotPixels, LogTransform,
  * GammaTransform, NormalizeEvent            mem/transforms.py:200-275

@@ -51,6 +51,22 @@ def test_ncaltech_decode_golden():
     assert np.array_equal(E.decode_ncaltech101(g["raw"].tobytes()), g["events"])
 
 
+def test_record_goldens_from_reference():
+    """oracle/gen_golden_records.py: outputs of the reference's own ncaltech101() / imgnet_npy_loader / dsec_npy_loader."""
+    g = np.load(os.path.join(GOLDEN, "records.npz"))
+    names = sorted({k.split("__")[1] for k in g.files if k.startswith("ncaltech__")})
+    assert len(names) == 4
+    for n in names:
+        assert np.array_equal(E.decode_ncaltech101(g[f"ncaltech__{n}__raw"].tobytes()), g[f"ncaltech__{n}__events"])
+    for tag in ("u16_i64_bool", "i32_f64_u8", "i16_u32_i16wrap"):
+        got = E.imgnet_struct_to_events(*(g[f"imgnet__{tag}__{k}"] for k in "xytp"))
+        assert np.array_equal(got, g[f"imgnet__{tag}__events"])
+    rec = g["imgnet__struct__rec"]
+    assert np.array_equal(E.imgnet_struct_to_events(rec["x"], rec["y"], rec["t"], rec["p"]), g["imgnet__struct__events"])
+    for tag in ("f64", "i64", "u16"):
+        assert np.array_equal(E.dsec_to_events(g[f"dsec__{tag}__in"]), g[f"dsec__{tag}__events"])
+
+
 def test_transform_goldens():
     g = np.load(os.path.join(GOLDEN, "transforms.npz"))
     for name in ("s32", "s224", "zeros"):
