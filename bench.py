@@ -259,14 +259,13 @@ def main():
 
     # ---- secondary figure: the frozen tokenizer forward that the reference runs every step to make the
     # labels (engine_for_pretraining.py:144); not part of `value` (BASELINE: tokenizer outside the timed set)
-    tok_ms = tok_torch_ms = None
+    tok_ms = tok_bf16_ms = tok_torch_ms = None
     if not a.no_tokenizer_figure and world == 1:                      # N=1 figures only: ranks must reach the teardown together
         try:
             from mem_amd.vae_model import DiscreteVAE, HipTokenizer
             vae = DiscreteVAE(input_H=H, input_W=W, num_tokens=8192, codebook_dim=512, num_layers=4,
                               num_resnet_blocks=3, hidden_dim=384, channels=3).cuda().eval()
             img = torch.rand(B, 3, H, W, device="cuda")
-            tok = HipTokenizer(vae, max_batch=B)
 
             def _time(fn, n):
                 for _ in range(2):
@@ -277,7 +276,11 @@ def main():
                     fn()
                 torch.cuda.synchronize()
                 return (time.perf_counter() - t1) / n * 1e3
-            tok_ms = _time(lambda: tok.get_codebook_indices(img), 5)
+            tok = HipTokenizer(vae, max_batch=B)                       # default mode: fp32 operands, exact labels
+            tok_ms = _time(lambda: tok.get_codebook_indices(img), 3)
+            del tok
+            tok = HipTokenizer(vae, max_batch=B, precision="bf16")
+            tok_bf16_ms = _time(lambda: tok.get_codebook_indices(img), 5)
             tok_torch_ms = _time(lambda: vae.get_codebook_indices(img), 2)
             del vae, img, tok
         except Exception as e:                                        # the figure is optional
@@ -382,11 +385,16 @@ def main():
         if tok_ms is not None:
             out["with_tokenizer"] = {"value": round(world * B / ((ms + tok_ms) * 1e-3), 1), "unit": "samples/sec",
                                      "tokenizer_ms_per_step": round(tok_ms, 3),
-                                     "tokenizer_ms_stock_torch_fp32": round(tok_torch_ms, 3),
+                                     "tokenizer_tflops": round(B * 24.4e9 / (tok_ms * 1e-3) / 1e12, 1),
+                                     "tokenizer_fp32_peak_tflops": 157.3,
+                                     "tokenizer_ms_bf16_mode": round(tok_bf16_ms, 3) if tok_bf16_ms else None,
+                                     "tokenizer_ms_stock_torch_fp32": round(tok_torch_ms, 3) if tok_torch_ms else None,
                                      "note": "secondary figure (SURVEY section 8d): the same step plus the frozen dVAE "
                                              "tokenizer forward (4 conv + 3 ResBlocks + 1x1 -> 8192, 24.4 GFLOP/sample, "
-                                             "random weights) on the HIP implicit-GEMM path (csrc/conv.hip, bf16); the "
-                                             "fp32 torch module on stock PyTorch-ROCm is timed beside it"}
+                                             "random weights) on the HIP fp32 implicit-GEMM path (csrc/conv_f32.hip, "
+                                             "v_mfma_f32_16x16x4_f32: fp32 operands like the reference, exact labels); the "
+                                             "opt-in bf16-operand mode (csrc/conv.hip, 1-3 % of labels differ) and the fp32 "
+                                             "torch module on stock PyTorch-ROCm are timed beside it"}
         if raster_fig is not None:
             out["rasterizer_1m_events"] = raster_fig
         if world == 1 and not a.no_cpu_baseline:

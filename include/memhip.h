@@ -361,6 +361,20 @@ int memhip_nchw_to_padded_nhwc4(const float* x, int B, int C, int H, int W, cons
 /* ids i64 [M] = argmax over the N columns of logits bf16 [M, ld] (first maximum) */
 int memhip_argmax_rows_bf16(const void* logits, int64_t ld, int M, int N, int64_t* ids, memhip_stream_t stream);
 
+/* The same three entry points in fp32 -- the EXACT-label mode (default): the reference computes the tokenizer in fp32
+ * (mem/engine_for_pretraining.py:140-145 is outside the autocast block at :147) and its output is an integer, so the
+ * labels are produced with fp32 operands and fp32 accumulation (v_mfma_f32_16x16x4_f32, an fmaf chain over k).
+ * Activations fp32 NHWC with the one-pixel zero border, weight fp32 [C_out, k*k*C_in] (ky, kx, c)-major; any kernel
+ * size 1..4, stride >= 1, pad 0/1; C_in, C_out multiples of 4, k*k*C_in a multiple of 32.
+ * argmax_rows_f32: ids = first maximum of each row; top2_gap (f32 [M], may be NULL) = best - runner-up logit. */
+int memhip_conv2d_nhwc_f32(const float* in, const float* weight, const float* bias, const float* add, float* out,
+                           int B, int H, int W, int Cin, int Cout, int ksize, int stride, int pad, int relu,
+                           int out_padded, memhip_stream_t stream);
+int memhip_nchw_to_padded_nhwc4_f32(const float* x, int B, int C, int H, int W, const float* mean, const float* stdv,
+                                    float* out, memhip_stream_t stream);
+int memhip_argmax_rows_f32(const float* logits, int64_t ld, int M, int N, int64_t* ids, float* top2_gap,
+                           memhip_stream_t stream);
+
 /* ------------------------------------------------------------------------
  * Layout / dtype movers
  * ------------------------------------------------------------------------ */

@@ -1,0 +1,279 @@
+// fp32 implicit-GEMM convolutions for the EXACT-label mode of the frozen dVAE tokenizer forward
+// (reference: eventvae/vae/vae_model.py:29-42,86-101,153-158).  The reference runs the tokenizer in fp32 --
+// mem/engine_for_pretraining.py:140-145 sits outside the autocast block at :147 -- and its output is an INTEGER
+// (argmax ids), so the labels must come from fp32 arithmetic: v_mfma_f32_16x16x4_f32 (f32 operands, f32
+// accumulate, bitwise an fmaf chain over k; 64 FLOP/clk/SIMD = the fp32 vector peak, 157 TFLOP/s chip-wide).
+// The bf16 kernels of conv.hip remain as the fast approximate mode.
+//
+// Same layout idea as conv.hip: activations fp32 NHWC with a one-pixel ZERO border ([B, H+2, W+2, C]), weights
+// [C_out][ky][kx][c] K-contiguous, A gathered through per-row base addresses + a per-chunk tap offset (any
+// C_in % 4 == 0: a 16-byte chunk never straddles a tap).  128x128x32 tiles, 4 waves of 64x64 (4x4 MFMA blocks),
+// register-staged double buffer; LDS rows have a pitch of 34 floats so that the fragment reads (16 rows x 2 k per
+// 32-lane group) touch 32 distinct banks.  Epilogue: + bias, ReLU, residual add, fp32 float4 stores.
+#include "common.h"
+
+namespace {
+
+using namespace memhip;
+
+constexpr int BM = 128, BN = 128, BK = 32;
+constexpr int kThreads = 256;
+constexpr int PITCH = BK + 2;                       // floats; 8-byte aligned rows, bank(row, k) = 2 row + k
+constexpr int kTileFloats = BM * PITCH;
+constexpr int kStageFloats = 2 * kTileFloats;       // A tile + B tile
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+struct ConvArgsF32 {
+  const float* in;      // [B, Hp, Wp, Cin] padded
+  const float* w;       // [Cout, K]
+  const float* bias;    // [Cout] or null
+  const float* add;     // residual, laid out like `out`, or null
+  float* out;
+  int B, Hp, Wp, Cin, Ho, Wo, Cout, kw, stride, off, K;
+  int out_padded, relu;
+};
+
+__global__ __launch_bounds__(kThreads, 2) void conv_gemm_f32_kernel(ConvArgsF32 p) {
+  extern __shared__ __attribute__((aligned(16))) float smem_f[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wr = wave >> 1, wc = wave & 1;
+  const int M = p.B * p.Ho * p.Wo;
+  const int nwg = gridDim.x;
+  int pid = blockIdx.x;
+  {                                                  // XCD-aware bijective remap, n fastest
+    const int q = nwg >> 3, r = nwg & 7, xcd = pid & 7, idx = pid >> 3;
+    pid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int ntn = (p.Cout + BN - 1) / BN;
+  const int m0 = (pid / ntn) * BM, n0 = (pid % ntn) * BN;
+
+  // global -> register staging: load j of this thread covers row (wave*4 + j)*8 + lane/8, chunk lane%8 (4 floats)
+  long long abase[4], bbase[4];
+  const int chunk = lane & 7;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int row = (wave * 4 + j) * 8 + (lane >> 3);
+    int m = m0 + row;
+    m = m < M ? m : M - 1;
+    const int hw = p.Ho * p.Wo;
+    const int b = m / hw, r = m - b * hw;
+    const int oy = r / p.Wo, ox = r - oy * p.Wo;
+    abase[j] = (((long long)b * p.Hp + oy * p.stride + p.off) * p.Wp + ox * p.stride + p.off) * p.Cin;
+    int n = n0 + row;
+    n = n < p.Cout ? n : p.Cout - 1;
+    bbase[j] = (long long)n * p.K;
+  }
+  float4 ra[4], rb[4];
+  auto fetch = [&](int t) {
+    const int k = t * BK + chunk * 4;
+    const int tap = k / p.Cin, c0 = k - tap * p.Cin;
+    const int ky = tap / p.kw, kx = tap - ky * p.kw;
+    const long long koff = ((long long)ky * p.Wp + kx) * p.Cin + c0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      ra[j] = *reinterpret_cast<const float4*>(p.in + abase[j] + koff);
+      rb[j] = *reinterpret_cast<const float4*>(p.w + bbase[j] + k);
+    }
+  };
+  auto commit = [&](float* dst) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int row = (wave * 4 + j) * 8 + (lane >> 3);
+      float2* a = reinterpret_cast<float2*>(dst + row * PITCH + chunk * 4);
+      a[0] = make_float2(ra[j].x, ra[j].y);
+      a[1] = make_float2(ra[j].z, ra[j].w);
+      float2* b = reinterpret_cast<float2*>(dst + kTileFloats + row * PITCH + chunk * 4);
+      b[0] = make_float2(rb[j].x, rb[j].y);
+      b[1] = make_float2(rb[j].z, rb[j].w);
+    }
+  };
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nk = p.K / BK;
+  fetch(0);
+  commit(smem_f);
+  __syncthreads();
+  int cur = 0;
+  const int frow = lane & 15, fk = lane >> 4;        // fragment: row = lane % 16, k = lane / 16
+  for (int t = 0; t < nk; ++t) {
+    if (t + 1 < nk) fetch(t + 1);
+    const float* At = smem_f + cur * kStageFloats + (wr * 64 + frow) * PITCH + fk;
+    const float* Bt = smem_f + cur * kStageFloats + kTileFloats + (wc * 64 + frow) * PITCH + fk;
+#pragma unroll
+    for (int kk = 0; kk < BK / 4; ++kk) {
+      float af[4], bf[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) af[i] = At[i * 16 * PITCH + kk * 4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bf[j] = Bt[j * 16 * PITCH + kk * 4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+    }
+    if (t + 1 < nk) commit(smem_f + (cur ^ 1) * kStageFloats);
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  // ---- epilogue: the wave's 64x64 sub-tile through LDS, 32 rows at a time; lane -> (row, 4 columns)
+  const int mw = m0 + wr * 64, nw = n0 + wc * 64;
+  constexpr int LS = 68;
+  float* wreg = smem_f + wave * (32 * LS);
+  const int c4 = (lane & 15) * 4;
+  const int n = nw + c4;
+  float bias[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) bias[k] = (p.bias && n + k < p.Cout) ? p.bias[n + k] : 0.f;
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    __syncthreads();
+#pragma unroll
+    for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          wreg[(ii * 16 + (lane >> 4) * 4 + r) * LS + j * 16 + (lane & 15)] = acc[half * 2 + ii][j][r];
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int row = it * 4 + (lane >> 4);
+      const int m = mw + half * 32 + row;
+      if (m >= M || n >= p.Cout) continue;
+      long long mo = m;
+      if (p.out_padded) {
+        const int hw = p.Ho * p.Wo;
+        const int b = m / hw, r = m - b * hw;
+        const int oy = r / p.Wo, ox = r - oy * p.Wo;
+        mo = ((long long)b * (p.Ho + 2) + oy + 1) * (p.Wo + 2) + ox + 1;
+      }
+      const float4 v0 = *reinterpret_cast<const float4*>(wreg + row * LS + c4);
+      float v[4] = {v0.x + bias[0], v0.y + bias[1], v0.z + bias[2], v0.w + bias[3]};
+      if (p.relu) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k], 0.f);
+      }
+      if (p.add) {                                    // ResBlock: net(x) + x
+        const float4 xv = *reinterpret_cast<const float4*>(p.add + mo * p.Cout + n);
+        v[0] += xv.x; v[1] += xv.y; v[2] += xv.z; v[3] += xv.w;
+      }
+      *reinterpret_cast<float4*>(p.out + mo * p.Cout + n) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+  }
+}
+
+// images f32 NCHW [B, C<=4, H, W] -> fp32 padded NHWC4 interior, optional (x - mean) / std
+__global__ __launch_bounds__(256) void nchw_to_padded_nhwc4_f32_kernel(const float* __restrict__ x, int B, int C, int H,
+                                                                       int W, const float* __restrict__ mean,
+                                                                       const float* __restrict__ stdv,
+                                                                       float* __restrict__ out) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long long)B * H * W) return;
+  const int xw = (int)(i % W);
+  const long long t = i / W;
+  const int y = (int)(t % H), b = (int)(t / H);
+  float v[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int c = 0; c < C; ++c) {
+    float u = x[(((long long)b * C + c) * H + y) * W + xw];
+    if (mean) u = (u - mean[c]) / stdv[c];
+    v[c] = u;
+  }
+  *reinterpret_cast<float4*>(out + (((long long)b * (H + 2) + y + 1) * (W + 2) + xw + 1) * 4) =
+      make_float4(v[0], v[1], v[2], v[3]);
+}
+
+// ids[m] = argmax_n logits[m, n] (first maximum; NaN never wins, like a comparison chain), one wave per row
+__global__ __launch_bounds__(256) void argmax_rows_f32_kernel(const float* __restrict__ logits, long long ld, int M, int N,
+                                                              long long* __restrict__ ids, float* __restrict__ gap) {
+  const int lane = threadIdx.x & 63;
+  const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (m >= M) return;
+  float best = -INFINITY, second = -INFINITY;
+  int bi = 0x7fffffff;
+  for (int n = lane * 4; n < N; n += 256) {
+    const float4 v = *reinterpret_cast<const float4*>(logits + (long long)m * ld + n);
+    const float f[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (f[k] > best) { second = best; best = f[k]; bi = n + k; }
+      else if (f[k] > second) second = f[k];
+    }
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ob = __shfl_xor(best, o), os = __shfl_xor(second, o);
+    const int oi = __shfl_xor(bi, o);
+    if (ob > best || (ob == best && oi < bi)) {
+      second = fmaxf(best, os);                       // the displaced maximum may be the runner-up (ties: gap 0)
+      best = ob; bi = oi;
+    } else {
+      second = fmaxf(second, ob);
+    }
+  }
+  if (lane == 0) {
+    ids[m] = bi;
+    if (gap) gap[m] = best - second;
+  }
+}
+
+}  // namespace
+
+extern "C" int memhip_conv2d_nhwc_f32(const float* in, const float* weight, const float* bias, const float* add, float* out,
+                                      int B, int H, int W, int Cin, int Cout, int ksize, int stride, int pad, int relu,
+                                      int out_padded, memhip_stream_t stream) {
+  MEMHIP_REQUIRE(B >= 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "conv2d_f32: bad shape");
+  if (B == 0) return MEMHIP_OK;
+  MEMHIP_REQUIRE(in && weight && out, "conv2d_f32: null pointer");
+  MEMHIP_REQUIRE(ksize >= 1 && ksize <= 4 && stride >= 1 && pad >= 0 && pad <= 1,
+                 "conv2d_f32: kernel size 1..4, padding 0 or 1 (one-pixel border layout)");
+  MEMHIP_REQUIRE(Cin % 4 == 0 && Cout % 4 == 0, "conv2d_f32: C_in and C_out must be multiples of 4");
+  ConvArgsF32 p;
+  p.in = in; p.w = weight; p.bias = bias; p.add = add; p.out = out;
+  p.B = B; p.Hp = H + 2; p.Wp = W + 2; p.Cin = Cin;
+  p.Ho = (H + 2 * pad - ksize) / stride + 1; p.Wo = (W + 2 * pad - ksize) / stride + 1;
+  p.Cout = Cout; p.kw = ksize; p.stride = stride; p.off = 1 - pad; p.K = ksize * ksize * Cin;
+  p.out_padded = out_padded; p.relu = relu;
+  MEMHIP_REQUIRE(p.Ho > 0 && p.Wo > 0, "conv2d_f32: empty output");
+  MEMHIP_REQUIRE(p.K % BK == 0, "conv2d_f32: K = %d must be a multiple of %d", p.K, BK);
+  const long long M = (long long)B * p.Ho * p.Wo;
+  MEMHIP_REQUIRE(M < (1LL << 31), "conv2d_f32: too many output pixels");
+  const int grid = cdiv(M, BM) * cdiv(Cout, BN);
+  const size_t lds = 2 * kStageFloats * sizeof(float);
+  static bool attr_done = false;
+  if (!attr_done) {
+    MEMHIP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_gemm_f32_kernel),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(conv_gemm_f32_kernel, dim3(grid), dim3(kThreads), lds, as_stream(stream), p);
+  return check_launch("conv2d_nhwc_f32");
+}
+
+extern "C" int memhip_nchw_to_padded_nhwc4_f32(const float* x, int B, int C, int H, int W, const float* mean,
+                                               const float* stdv, float* out, memhip_stream_t stream) {
+  MEMHIP_REQUIRE(B >= 0 && C >= 1 && C <= 4 && H > 0 && W > 0, "nchw_to_padded_nhwc4_f32: bad shape");
+  if (B == 0) return MEMHIP_OK;
+  MEMHIP_REQUIRE(x && out && (!mean == !stdv), "nchw_to_padded_nhwc4_f32: null pointer");
+  const long long n = (long long)B * H * W;
+  hipLaunchKernelGGL(nchw_to_padded_nhwc4_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream),
+                     x, B, C, H, W, mean, stdv, out);
+  return check_launch("nchw_to_padded_nhwc4_f32");
+}
+
+extern "C" int memhip_argmax_rows_f32(const float* logits, int64_t ld, int M, int N, int64_t* ids, float* top2_gap,
+                                      memhip_stream_t stream) {
+  MEMHIP_REQUIRE(M >= 0 && N > 0 && N % 4 == 0 && ld % 4 == 0, "argmax_rows_f32: N and ld must be multiples of 4");
+  if (M == 0) return MEMHIP_OK;
+  MEMHIP_REQUIRE(logits && ids, "argmax_rows_f32: null pointer");
+  hipLaunchKernelGGL(argmax_rows_f32_kernel, dim3((M + 3) / 4), dim3(256), 0, as_stream(stream), logits, (long long)ld, M, N,
+                     (long long*)ids, top2_gap);
+  return check_launch("argmax_rows_f32");
+}

@@ -97,6 +97,9 @@ declare({
     "memhip_conv2d_nhwc_bf16": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
     "memhip_nchw_to_padded_nhwc4": (i32, [vp, i32, i32, i32, i32, vp, vp, vp, vp]),
     "memhip_argmax_rows_bf16": (i32, [vp, i64, i32, i32, vp, vp]),
+    "memhip_conv2d_nhwc_f32": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
+    "memhip_nchw_to_padded_nhwc4_f32": (i32, [vp, i32, i32, i32, i32, vp, vp, vp, vp]),
+    "memhip_argmax_rows_f32": (i32, [vp, i64, i32, i32, vp, vp, vp]),
     "memhip_grad_norm_workspace": (sz, []),
     "memhip_grad_norm": (i32, [vp, i64, vp, vp, sz, vp]),
     "memhip_adamw": (i32, [vp, vp, vp, vp, i64, vp, f64, f64, f64, f64, f64, i32, vp, f64, vp]),
@@ -145,18 +148,31 @@ def gemv_acc(W, N, K, x, y, x_acc=None, zero=None):
 
 
 def conv2d_nhwc(x_pad, weight, bias, out, B, H, W, Cin, Cout, ksize, stride, pad, relu=False, add=None, out_padded=True):
-    """x_pad bf16 [B,H+2,W+2,Cin] -> out bf16 [B,Ho+2,Wo+2,Cout] interior (or dense [B*Ho*Wo,Cout])."""
+    """x_pad [B,H+2,W+2,Cin] -> out [B,Ho+2,Wo+2,Cout] interior (or dense [B*Ho*Wo,Cout]); bf16 or fp32 by x_pad.dtype."""
+    if x_pad.dtype == torch.float32:
+        assert weight.dtype == torch.float32 and out.dtype == torch.float32 and (add is None or add.dtype == torch.float32)
+        check(lib.memhip_conv2d_nhwc_f32(ptr(x_pad), ptr(weight), ptr(bias), ptr(add), ptr(out), B, H, W, Cin, Cout, ksize,
+                                         stride, pad, int(relu), int(out_padded), stream_ptr()), "conv2d_nhwc_f32")
+        return
     check(lib.memhip_conv2d_nhwc_bf16(ptr(x_pad), ptr(weight), ptr(bias), ptr(add), ptr(out), B, H, W, Cin, Cout, ksize,
                                       stride, pad, int(relu), int(out_padded), stream_ptr()), "conv2d_nhwc_bf16")
 
 
 def nchw_to_padded_nhwc4(x, out, mean=None, std=None):
     B, Cc, H, W = x.shape
+    if out.dtype == torch.float32:
+        check(lib.memhip_nchw_to_padded_nhwc4_f32(ptr(x), B, Cc, H, W, ptr(mean), ptr(std), ptr(out), stream_ptr()),
+              "nchw_to_padded_nhwc4_f32")
+        return
     check(lib.memhip_nchw_to_padded_nhwc4(ptr(x), B, Cc, H, W, ptr(mean), ptr(std), ptr(out), stream_ptr()),
           "nchw_to_padded_nhwc4")
 
 
-def argmax_rows(logits, M, N, ids):
+def argmax_rows(logits, M, N, ids, gap=None):
+    if logits.dtype == torch.float32:
+        check(lib.memhip_argmax_rows_f32(ptr(logits), logits.stride(0), M, N, ptr(ids), ptr(gap), stream_ptr()),
+              "argmax_rows_f32")
+        return
     check(lib.memhip_argmax_rows_bf16(ptr(logits), logits.stride(0), M, N, ptr(ids), stream_ptr()), "argmax_rows_bf16")
 
 

@@ -73,18 +73,23 @@ class DiscreteVAE(nn.Module):
 
 
 class HipTokenizer:
-    """`DiscreteVAE.get_codebook_indices` on the hand-written HIP path (csrc/conv.hip): bf16 NHWC
-    activations with a one-pixel zero border, implicit-GEMM convolutions on the MFMA GEMM tile with
-    fused bias / ReLU / residual, argmax over the token logits.  Built from a (frozen) `DiscreteVAE`
-    whose weights it packs once; the torch module stays the fp32 reference-exact form.
+    """`DiscreteVAE.get_codebook_indices` on the hand-written HIP path: NHWC activations with a one-pixel zero
+    border, implicit-GEMM convolutions on MFMA tiles with fused bias / ReLU / residual, argmax over the token logits.
+    Built from a (frozen) `DiscreteVAE` whose weights it packs once.
 
-    Precision: bf16 operands with fp32 accumulation where the reference runs fp32 convolutions
-    (TF32 on the GPUs it was written for); labels are discrete, the parity bar is token agreement
-    (tests/test_tokenizer_gpu.py)."""
+    precision="fp32" (default, csrc/conv_f32.hip): fp32 operands and accumulation (v_mfma_f32_16x16x4_f32), i.e. the
+      reference's arithmetic -- it runs the tokenizer in fp32, outside the autocast block
+      (mem/engine_for_pretraining.py:140-147).  The ids are integers: the parity bar is EQUALITY with the fp32
+      reference (tests/test_tokenizer_gpu.py).
+    precision="bf16" (csrc/conv.hip): bf16 operands, fp32 accumulation; ~7x faster, 97-99 % of the ids agree (the rest
+      are near ties) -- an explicit opt-in (`--tokenizer_impl hip_bf16`), never the default."""
 
-    def __init__(self, vae: "DiscreteVAE", max_batch=256):
+    def __init__(self, vae: "DiscreteVAE", max_batch=256, precision="fp32"):
         from . import ops
         self.ops = ops
+        assert precision in ("fp32", "bf16")
+        self.precision = precision
+        self.dt = torch.float32 if precision == "fp32" else torch.bfloat16
         dev = next(vae.parameters()).device
         assert dev.type == "cuda", "HipTokenizer needs the model on the GPU"
         self.dev, self.H, self.W = dev, vae.input_H, vae.input_W
@@ -111,15 +116,14 @@ class HipTokenizer:
         self.max_batch = 0
         self._alloc(max_batch)
 
-    @staticmethod
-    def _pack(conv):
+    def _pack(self, conv):
         w = conv.weight.detach()                           # [Cout, Cin, k, k]
         co, ci, k, _ = w.shape
         w = w.permute(0, 2, 3, 1)                          # (ky, kx, c)-major
         if ci < 4:
             w = torch.nn.functional.pad(w, (0, 4 - ci))
             ci = 4
-        wp = w.reshape(co, k * k * ci).to(torch.bfloat16).contiguous()
+        wp = w.reshape(co, k * k * ci).to(self.dt).contiguous()
         b = conv.bias.detach().float().contiguous() if conv.bias is not None else None
         return (wp, b, ci, co, k, conv.stride[0], conv.padding[0])
 
@@ -127,7 +131,7 @@ class HipTokenizer:
         """Zero-bordered activation buffers for batch B (allocated once; only interiors are written)."""
         if B <= self.max_batch:
             return
-        dev, bf = self.dev, torch.bfloat16
+        dev, bf = self.dev, self.dt
         self.max_batch = B
         H, W = self.H, self.W
         self.x0 = torch.zeros((B, H + 2, W + 2, 4), dtype=bf, device=dev)
@@ -138,8 +142,8 @@ class HipTokenizer:
                 _, wp, b, ci, co, k, s, p, _ = L
                 h, w = (h + 2 * p - k) // s + 1, (w + 2 * p - k) // s + 1
                 key = (h, w, co)
-                if key not in self.bufs:
-                    self.bufs[key] = [torch.zeros((B, h + 2, w + 2, co), dtype=bf, device=dev) for _ in range(3)]
+                if key not in self.bufs:                  # one buffer per strided level; the ResBlocks' level gets 3 below
+                    self.bufs[key] = [torch.zeros((B, h + 2, w + 2, co), dtype=bf, device=dev)]
             elif L[0] == "res":
                 key = (h, w, L[1][3])
                 if key not in self.bufs:
@@ -149,6 +153,7 @@ class HipTokenizer:
         self.hw_out = (h, w)
         self.logits = torch.empty((B * h * w, self.num_tokens), dtype=bf, device=dev)
         self.ids = torch.empty((B * h * w,), dtype=torch.int64, device=dev)
+        self.gap = torch.empty((B * h * w,), dtype=torch.float32, device=dev) if self.precision == "fp32" else None
 
     @torch.no_grad()
     def get_codebook_indices(self, images):
@@ -180,5 +185,11 @@ class HipTokenizer:
                 _, wp, b, ci, co, k, s, p, _ = L
                 ops.conv2d_nhwc(cur, wp, b, self.logits, B, h, w, ci, co, k, s, p, relu=False, out_padded=False)
         M = B * h * w
-        ops.argmax_rows(self.logits, M, self.num_tokens, self.ids)
+        ops.argmax_rows(self.logits, M, self.num_tokens, self.ids, self.gap)
         return self.ids[:M].view(B, h * w).clone()
+
+    def last_top2_gap(self, B):
+        """fp32 mode: best-minus-runner-up logit of every token of the last call (f32 [B, h*w]) -- how far each label
+        is from flipping under a different fp32 summation order."""
+        h, w = self.hw_out
+        return self.gap[: B * h * w].view(B, h * w).clone()

@@ -59,6 +59,12 @@ TINY_VAE = dict(input_H=64, input_W=64, num_tokens=512, codebook_dim=32, num_lay
                 hidden_dim=64, channels=3)
 
 
+# the MEM tokenizer at ViT-B pretraining shape (run_mem_pretraining.py:183-186 defaults + configs/ncaltech.conf):
+# 4 stride-2 layers, hidden 384, 3 ResBlocks, 8192 tokens, 224 x 224 -> 14 x 14 ids
+BASE_VAE = dict(input_H=224, input_W=224, num_tokens=8192, codebook_dim=512, num_layers=4, num_resnet_blocks=3,
+                hidden_dim=384, channels=3)
+
+
 def vae_inputs(cfg, batch, seed):
     g = torch.Generator().manual_seed(seed)
     return torch.rand(batch, cfg["channels"], cfg["input_H"], cfg["input_W"], generator=g)

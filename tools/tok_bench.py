@@ -19,7 +19,7 @@ with torch.autocast("cuda", dtype=torch.bfloat16):
     ids16 = vae.get_codebook_indices(img[:32])
 print("agreement fp32 vs bf16 (random weights):", (ids32 == ids16).float().mean().item())
 from mem_amd.vae_model import HipTokenizer
-tok = HipTokenizer(vae, max_batch=B)
+tok = HipTokenizer(vae, max_batch=B, precision=sys.argv[1] if len(sys.argv) > 1 else "fp32")
 print("HIP tokenizer ms", t(lambda: tok.get_codebook_indices(img)))
 ids = tok.get_codebook_indices(img[:32]); ref = vae.get_codebook_indices(img[:32])
 print("agreement HIP vs fp32:", (ids == ref).float().mean().item())
