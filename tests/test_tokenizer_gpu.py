@@ -64,7 +64,7 @@ def test_argmax_rows_first_maximum():
                                               (2, 2, 0, 8, 12, 10)])
 def test_conv_f32_layers_vs_torch(k, s, p, cin, cout, h):
     """fp32 implicit GEMM (v_mfma_f32_16x16x4_f32) vs torch's fp32 convolution in float64: relative error at the fp32
-    accumulation level (<= 2e-6 of the output scale), ragged M / N tiles, bias + ReLU + residual, dense output."""
+    accumulation level (<= 4e-7 sqrt(K) of the output scale), ragged M / N tiles, bias + ReLU + residual, dense output."""
     from mem_amd import ops
     g = torch.Generator(device="cuda").manual_seed(k * 100 + cin)
     B = 3
@@ -81,7 +81,8 @@ def test_conv_f32_layers_vs_torch(k, s, p, cin, cout, h):
     out = torch.zeros(B, ho + 2, ho + 2, cout, device="cuda")
     add = torch.zeros_like(out)
     add[:, 1:-1, 1:-1] = torch.randn(B, ho, ho, cout, generator=g, device="cuda")
-    tol = 2e-6 * float(ref.abs().max())
+    # fp32 accumulation over K = k*k*cin terms: error ~ sqrt(K) * 2^-24 * scale (measured 1.1e-6 at K = 3456)
+    tol = 4e-7 * max(4.0, (k * k * cin) ** 0.5) * float(ref.abs().max())
     ops.conv2d_nhwc(xp, wp, b, out, B, h, h, cin, cout, k, s, p, relu=True)
     assert (out[:, 1:-1, 1:-1].permute(0, 3, 1, 2).double() - torch.relu(ref)).abs().max().item() <= tol
     assert out[:, 0].abs().max() == 0 and out[:, :, 0].abs().max() == 0 and out[:, -1].abs().max() == 0
