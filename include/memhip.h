@@ -93,8 +93,11 @@ typedef struct memhip_event_aug {
   int32_t shift_x, shift_y;
   int32_t do_filter;         /* 0/1: apply the bounds filter of Aug_RandomShiftEvs */
   int32_t filt_w, filt_h;
-  int32_t pad_;
+  int32_t infer;             /* MEMHIP_AUG_INFER_* bits: fields that memhip_aug_resolve fills from the data (0 = none) */
 } memhip_event_aug_t;
+#define MEMHIP_AUG_INFER_FLIP_W 1
+#define MEMHIP_AUG_INFER_FILT_W 2
+#define MEMHIP_AUG_INFER_FILT_H 4
 int memhip_rasterize_aug_f64(const double* ev, const int64_t* offsets, const memhip_event_aug_t* aug,
                              int B, int H, int W, int time_surface, uint8_t* out, int32_t* status,
                              void* workspace, size_t workspace_bytes, memhip_stream_t stream);
@@ -111,6 +114,19 @@ size_t memhip_rasterize_binned_workspace(int B, int H, int W, int64_t n_events);
 int memhip_rasterize_binned_f64(const double* ev, const int64_t* offsets, const memhip_event_aug_t* aug,
                                 int B, int H, int W, int64_t n_events, uint8_t* out, int32_t* status,
                                 void* workspace, size_t workspace_bytes, memhip_stream_t stream);
+
+/* Data-dependent canvases without a host round trip (mem/datasets.py:516,537-540,572-575: "W = x.max() + 1"):
+ *   memhip_events_extent(raw window) -> memhip_aug_resolve(stage 0) fills the inferred flip / filter sizes of aug[b];
+ *   memhip_events_extent(with aug)   -> memhip_aug_resolve(stage 1) writes the canvas dims[b] = (H_b, W_b)
+ *   (fixed_h / fixed_w > 0 override; empty samples or canvases beyond hmax x wmax: dims (0,0), status |= 1 << 29);
+ *   memhip_rasterize_var_f64 rasterizes sample b on its own canvas, stored densely ([3, H_b, W_b]) at the start of
+ *   its slot of 3 * Hmax * Wmax bytes of `out` (rest of the slot zero).  Semantics per sample = memhip_rasterize_aug_f64;
+ *   workspace = memhip_rasterize_workspace(B, Hmax, Wmax). */
+int memhip_aug_resolve(const double* extent, memhip_event_aug_t* aug, int B, int stage, int fixed_h, int fixed_w,
+                       int hmax, int wmax, int32_t* dims, int32_t* status, memhip_stream_t stream);
+int memhip_rasterize_var_f64(const double* ev, const int64_t* offsets, const memhip_event_aug_t* aug,
+                             const int32_t* dims, int B, int Hmax, int Wmax, int time_surface, uint8_t* out,
+                             int32_t* status, void* workspace, size_t workspace_bytes, memhip_stream_t stream);
 
 /* Per-sample extent of the (augmented) events, for the reference's data-dependent
  * canvas "W = xs.max()+1" (mem/datasets.py:516,538-540,572-575).
@@ -150,6 +166,36 @@ int memhip_events_from_columns(const void* x, int x_dtype, const void* y, int y_
 size_t memhip_events_dsec_workspace(int64_t n);
 int memhip_events_dsec(const void* in, int dtype, int64_t n, double y_limit, double* out, int64_t* n_out,
                        void* workspace, size_t workspace_bytes, memhip_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * Image-space augmentation chain, batched with per-sample parameters (host draws, device arithmetic)
+ * replaces ToTensor + Resize(bilinear, antialias=True) / RandomCrop(pad_if_needed)   mem/datasets.py:637-642
+ *          ToUnit8 -> EventRandAugment(num_ops=2, 14 ops) -> ToFloat32               mem/datasets.py:655-658,
+ *                                                                                    mem/transforms.py:292-484
+ *          ColorJitter(brightness, 0, saturation)                                    mem/datasets.py:34-38
+ * (torchvision tensor ops in the reference: uint8 images, float32 arithmetic, truncating casts, torch.round after
+ * resampling; restated in oracle/aug_t.py.)
+ * ------------------------------------------------------------------------
+ * resample_to_f32: in u8 = B slots of slot_bytes, sample b stored densely as [3, h_b, w_b] (dims i32 [B,2], or
+ *   fixed_h / fixed_w when dims is NULL) -> out f32 [B,3,OH,OW] = value / 255 resampled:
+ *   mode 0 Resize((OH,OW), BILINEAR, antialias=True) per sample (separable triangle filter, horizontal first);
+ *   mode 1 crop window (OH,OW) at offs[b] = (top, left) (NULL = 0,0) of the image zero-padded on BOTH sides by the
+ *          deficit when it is smaller than the window (RandomCrop(pad_if_needed=True)).
+ * to_uint8: y = (255 * x).to(uint8)  (ToUnit8, transforms.py:341-348).
+ * rand_augment_u8: one op per sample on u8 [B,3,H,W] (out != in); ops = device array of B records
+ *   { int32 op (index into ['Identity','ShearX','ShearY','TranslateX','TranslateY','Rotate','Brightness','Color',
+ *   'Contrast','Sharpness','Posterize','Solarize','AutoContrast','Equalize']); float mag (Posterize bits / Solarize
+ *   threshold); float theta[6] }: affine ops: theta = torchvision's inverse affine matrix as float32; blend ops
+ *   (Brightness/Color/Contrast/Sharpness): theta[1] = float32(ratio), theta[0] = float32(1 - ratio), ratio = 1 + magnitude.
+ * color_jitter: in u8 (value / 255 first = ToFloat32) or f32 [B,3,H,W] -> out f32 [B,out_chans,H,W] (2 = [pos,neg]);
+ *   params = device array of B records { int32 order (0 none, 1 brightness, 2 saturation, 3 b then s, 4 s then b);
+ *   float bf, 1-bf, sf, 1-sf } or NULL (conversion / channel drop only). */
+int memhip_resample_to_f32(const uint8_t* in, const int32_t* dims, int64_t slot_bytes, int fixed_h, int fixed_w, int mode,
+                           const int32_t* offs, int B, int OH, int OW, float* out, memhip_stream_t stream);
+int memhip_to_uint8(const float* x, int64_t n, uint8_t* y, memhip_stream_t stream);
+int memhip_rand_augment_u8(const uint8_t* in, uint8_t* out, const void* ops, int B, int H, int W, memhip_stream_t stream);
+int memhip_color_jitter(const void* in, int in_is_u8, int B, int H, int W, const void* params, float* out, int out_chans,
+                        memhip_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * Tensor-level event transforms, fused

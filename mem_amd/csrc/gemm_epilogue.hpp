@@ -137,6 +137,9 @@ __device__ __forceinline__ ef32x2 splat2(float v) { return ef32x2{v, v}; }
 // bias+GELU product, which writes 620 MB per launch: the lines do not linger in L2 as dirty data)
 typedef __attribute__((ext_vector_type(4))) unsigned eu32x4;
 __device__ __forceinline__ void st_stream16(void* base, long long elem_off, unsigned a, unsigned b, unsigned c, unsigned d) {
+#ifdef MEMHIP_EXP_NOSTORE
+  if ((a ^ b ^ c ^ d) != 0x12345677u) return;
+#endif
   __builtin_nontemporal_store(eu32x4{a, b, c, d}, reinterpret_cast<eu32x4*>(reinterpret_cast<__bf16*>(base) + elem_off));
 }
 
@@ -213,6 +216,10 @@ struct EpiRow<MEMHIP_EPI_RESIDUAL> { float x[8]; };
 template <int EPI>
 __device__ __forceinline__ void epi_row_load(const GemmArgs& p, int m, int n, EpiRow<EPI>& r) {
   if constexpr (EPI == MEMHIP_EPI_DGELU || EPI == MEMHIP_EPI_MUL_AUX) {
+#ifdef MEMHIP_EXP_NOLOAD
+    r.h = uint4{0x3f803f80u + (unsigned)m, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u + (unsigned)n};
+    return;
+#endif
     r.h = *reinterpret_cast<const uint4*>(reinterpret_cast<const __bf16*>(p.aux) + (long long)m * p.ldaux + n);
   } else if constexpr (EPI == MEMHIP_EPI_RESIDUAL) {
     if (p.aux) ld8(reinterpret_cast<const float*>(p.aux) + (long long)m * p.ldaux + n, r.x);

@@ -286,7 +286,11 @@ __global__ __launch_bounds__(kThreads) void gemm_p8_kernel(GemmArgs p, int ntm, 
       // a CU has 32 KB outstanding, i.e. ~20 GB/s per CU at ~1.5 us latency -- the epilogue was latency
       // bound, not HBM bound.  Row indices are clamped instead of branched, so that nothing orders the loads.
       // (the residual epilogue carries 8 registers per row: no room for a second batch beside 128 accumulators)
+#ifdef P8_RESID_AHEAD
+      constexpr int kAhead = (EPI == MEMHIP_EPI_RESIDUAL || EPI == MEMHIP_EPI_PATCH_EMBED) ? P8_RESID_AHEAD : kEpiAhead;
+#else
       constexpr int kAhead = (EPI == MEMHIP_EPI_RESIDUAL || EPI == MEMHIP_EPI_PATCH_EMBED) ? 0 : kEpiAhead;
+#endif
       EpiRow<EPI> rows[4][MF];
       auto load_batch = [&](int b) {
         const int jj = b >> 1, ii = b & 1;
@@ -298,7 +302,11 @@ __global__ __launch_bounds__(kThreads) void gemm_p8_kernel(GemmArgs p, int ntm, 
       };
       // residual epilogue: batch 0 alone; batches 1 and 2 go out together once batch 0 has released its
       // accumulators and row registers (the accumulators are re-zeroed after the loop, not inside it)
+#ifdef P8_RESID_AHEAD
+      constexpr bool kLate = false;
+#else
       constexpr bool kLate = (EPI == MEMHIP_EPI_RESIDUAL || EPI == MEMHIP_EPI_PATCH_EMBED) && P8_EPI_RESID_LATE;
+#endif
 #pragma unroll
       for (int b = 0; b < kAhead && b < 4; ++b) load_batch(b);
       float cs[8];

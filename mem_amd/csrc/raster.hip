@@ -53,11 +53,13 @@ __global__ __launch_bounds__(kThreads) void raster_count(
     const double* __restrict__ ev, const int64_t* __restrict__ offsets,
     const memhip_event_aug_t* __restrict__ augs, int H, int W,
     int time_surface, unsigned int* __restrict__ bins, unsigned long long* __restrict__ tstat,
-    int32_t* __restrict__ status) {
+    int32_t* __restrict__ status, const int32_t* __restrict__ dims, long long slot_px) {
   const int b = blockIdx.y;
   const long long beg = offsets[b], end = offsets[b + 1];
+  if (dims) { H = dims[2 * b]; W = dims[2 * b + 1]; }       // per-sample canvas (memhip_rasterize_var_f64)
   const long long HW = (long long)H * W;
-  unsigned int* pos = bins + (size_t)b * 3 * HW;
+  if (HW <= 0) return;
+  unsigned int* pos = bins + (size_t)b * 3 * (dims ? slot_px : HW);
   unsigned int* tss = pos + HW;
   unsigned int* neg = tss + HW;
   unsigned long long tmax = 0ull, tmin_inv = 0ull;
@@ -107,13 +109,15 @@ __global__ __launch_bounds__(kThreads) void raster_finalize(
     const double* __restrict__ ev, const int64_t* __restrict__ offsets,
     const memhip_event_aug_t* __restrict__ augs, int H, int W,
     int time_surface, const unsigned int* __restrict__ bins,
-    const unsigned long long* __restrict__ tstat, uint8_t* __restrict__ out) {
+    const unsigned long long* __restrict__ tstat, uint8_t* __restrict__ out,
+    const int32_t* __restrict__ dims, long long slot_px) {
   const int b = blockIdx.y;
+  if (dims) { H = dims[2 * b]; W = dims[2 * b + 1]; }
   const long long HW = (long long)H * W;
-  const unsigned int* pos = bins + (size_t)b * 3 * HW;
+  const unsigned int* pos = bins + (size_t)b * 3 * (dims ? slot_px : HW);
   const unsigned int* tss = pos + HW;
   const unsigned int* neg = tss + HW;
-  uint8_t* o = out + (size_t)b * 3 * HW;
+  uint8_t* o = out + (size_t)b * 3 * (dims ? slot_px : HW);
   double tmin = 0.0, trange = 0.0;
   if (time_surface) {
     const double tmax = dec_f64(tstat[2 * b]);
@@ -434,14 +438,94 @@ extern "C" int memhip_rasterize_aug_f64(const double* ev, const int64_t* offsets
   int bx = B >= 256 ? 8 : (B >= 32 ? 32 : 256);
   dim3 g1(bx, B);
   hipLaunchKernelGGL(raster_count, g1, dim3(kThreads), 0, s, ev, offsets, aug, H, W, time_surface,
-                     bins, tstat, status);
+                     bins, tstat, status, (const int32_t*)nullptr, 0LL);
   long long HW = (long long)H * W;
   int fx = (int)((HW + kThreads - 1) / kThreads);
   if (fx > 64) fx = 64;
   dim3 g2(fx, B);
   hipLaunchKernelGGL(raster_finalize, g2, dim3(kThreads), 0, s, ev, offsets, aug, H, W,
-                     time_surface, bins, tstat, out);
+                     time_surface, bins, tstat, out, (const int32_t*)nullptr, 0LL);
   return memhip::check_launch("rasterize");
+}
+
+// Per-sample canvases (the reference's data-dependent "W = xs.max() + 1", datasets.py:572-575): sample b is
+// rasterized on dims[b] = (H_b, W_b) and stored DENSELY ([3, H_b, W_b], pitch W_b) at the start of its slot of
+// 3 * Hmax * Wmax bytes.  Global-atomic form (any canvas, time surface supported).
+extern "C" int memhip_rasterize_var_f64(const double* ev, const int64_t* offsets, const memhip_event_aug_t* aug,
+                                        const int32_t* dims, int B, int Hmax, int Wmax, int time_surface, uint8_t* out,
+                                        int32_t* status, void* workspace, size_t workspace_bytes,
+                                        memhip_stream_t stream) {
+  MEMHIP_REQUIRE(B >= 0 && Hmax > 0 && Wmax > 0, "rasterize_var: bad shape B=%d Hmax=%d Wmax=%d", B, Hmax, Wmax);
+  if (B == 0) return MEMHIP_OK;
+  MEMHIP_REQUIRE(ev && offsets && dims && out && status && workspace, "rasterize_var: null pointer");
+  MEMHIP_REQUIRE(((uintptr_t)ev & 15) == 0, "rasterize_var: ev must be 16-byte aligned");
+  const size_t need = memhip_rasterize_workspace(B, Hmax, Wmax);
+  if (workspace_bytes < need)
+    return memhip::fail(MEMHIP_EWORKSPACE, "rasterize_var: workspace %zu < %zu", workspace_bytes, need);
+  hipStream_t s = memhip::as_stream(stream);
+  const long long slot = (long long)Hmax * Wmax;
+  size_t bins_bytes = ((size_t)B * 3 * slot * sizeof(unsigned int) + 15) & ~(size_t)15;
+  unsigned int* bins = (unsigned int*)workspace;
+  unsigned long long* tstat = (unsigned long long*)((char*)workspace + bins_bytes);
+  MEMHIP_HIP(hipMemsetAsync(workspace, 0, need, s));
+  MEMHIP_HIP(hipMemsetAsync(status, 0, (size_t)B * sizeof(int32_t), s));
+  MEMHIP_HIP(hipMemsetAsync(out, 0, (size_t)B * 3 * slot, s));
+  int bx = B >= 256 ? 8 : (B >= 32 ? 32 : 256);
+  hipLaunchKernelGGL(raster_count, dim3(bx, B), dim3(kThreads), 0, s, ev, offsets, aug, Hmax, Wmax, time_surface,
+                     bins, tstat, status, dims, slot);
+  int fx = (int)((slot + kThreads - 1) / kThreads);
+  if (fx > 64) fx = 64;
+  hipLaunchKernelGGL(raster_finalize, dim3(fx, B), dim3(kThreads), 0, s, ev, offsets, aug, Hmax, Wmax,
+                     time_surface, bins, tstat, out, dims, slot);
+  return memhip::check_launch("rasterize_var");
+}
+
+namespace {
+// Resolution of the reference's data-dependent widths / heights ON THE DEVICE (no host sync), from the extent of the
+// events (memhip_events_extent): truncation toward zero like ndarray.astype(np.int64).
+//   stage 0 (extent of the RAW window): Aug_FlipEvsAlongX W = int(max x) + 1 (datasets.py:516); Aug_RandomShiftEvs
+//            W = int(max x') + 1 after the flip, H = int(max y) + 1 (:537-540) -> aug[b].flip_w / filt_w / filt_h for the
+//            fields whose MEMHIP_AUG_INFER_* bit is set in aug[b].infer.
+//   stage 1 (extent AFTER the whole chain incl. the bounds filter): EventArrToImg canvas W = xs.max() + 1,
+//            H = ys.max() + 1 (:572-575) -> dims[b]; fixed_h / fixed_w > 0 override.  Empty samples (the reference raises
+//            ValueError on max() of an empty array) and canvases beyond (hmax, wmax) get dims (0, 0) and status |= 1 << 29.
+__global__ void aug_resolve_kernel(const double* __restrict__ ext, memhip_event_aug_t* __restrict__ aug, int B, int stage,
+                                   int fixed_h, int fixed_w, int hmax, int wmax, int32_t* __restrict__ dims,
+                                   int32_t* __restrict__ status) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const double maxx = ext[4 * b], maxy = ext[4 * b + 1], minx = ext[4 * b + 2];
+  const bool empty = !(maxx >= minx);
+  if (stage == 0) {
+    memhip_event_aug_t a = aug[b];
+    if (empty) return;
+    double mx = maxx;
+    if (a.infer & MEMHIP_AUG_INFER_FLIP_W) a.flip_w = (long long)maxx + 1;
+    if (a.flip_x) mx = (double)(a.flip_w - 1) - minx;                 // max of W - 1 - x
+    if (a.infer & MEMHIP_AUG_INFER_FILT_W) a.filt_w = (int)((long long)mx + 1);
+    if (a.infer & MEMHIP_AUG_INFER_FILT_H) a.filt_h = (int)((long long)maxy + 1);
+    aug[b] = a;
+  } else {
+    long long h = fixed_h > 0 ? fixed_h : (empty ? 0 : (long long)maxy + 1);
+    long long w = fixed_w > 0 ? fixed_w : (empty ? 0 : (long long)maxx + 1);
+    if (h <= 0 || w <= 0 || h > hmax || w > wmax || h * w > (long long)hmax * wmax) {
+      h = w = 0;
+      if (status) atomicOr(status + b, 1 << 29);
+    }
+    dims[2 * b] = (int)h;
+    dims[2 * b + 1] = (int)w;
+  }
+}
+}  // namespace
+
+extern "C" int memhip_aug_resolve(const double* extent, memhip_event_aug_t* aug, int B, int stage, int fixed_h, int fixed_w,
+                                  int hmax, int wmax, int32_t* dims, int32_t* status, memhip_stream_t stream) {
+  MEMHIP_REQUIRE(B >= 0 && (stage == 0 || stage == 1), "aug_resolve: bad arguments");
+  if (B == 0) return MEMHIP_OK;
+  MEMHIP_REQUIRE(extent && (stage == 0 ? aug != nullptr : dims != nullptr), "aug_resolve: null pointer");
+  hipLaunchKernelGGL(aug_resolve_kernel, dim3((B + 255) / 256), dim3(256), 0, memhip::as_stream(stream), extent, aug, B, stage,
+                     fixed_h, fixed_w, hmax, wmax, dims, status);
+  return memhip::check_launch("aug_resolve");
 }
 
 extern "C" int memhip_rasterize_f64(const double* ev, const int64_t* offsets, int B, int H, int W,

@@ -8,7 +8,9 @@ reference's (N,4) float64 rows); ``EventArrToImg`` then runs ONE fused HIP pass
 (csrc/raster.hip) that applies the whole chain while it reads each event once.  The random
 draws are made on the host with the same generators, in the same order, as the reference
 (``random.choice``, ``np.random.random``, ``np.random.randint``), so results are equal draw
-for draw.  ``EventBatchPipeline`` is the batched form used by training / bench.
+for draw.  ``augment.BatchAugPipeline`` is the batched form training uses (raw events + per-sample draw records are collated
+and the whole chain runs on the GPU once per batch); ``EventBatchPipeline`` is its fixed-canvas special case that
+bench.py times.
 """
 import ctypes as C
 import random
@@ -40,7 +42,7 @@ class EventAug(C.Structure):
     _fields_ = [("scale_x", C.c_double), ("scale_y", C.c_double), ("time_flip", C.c_int32),
                 ("flip_x", C.c_int32), ("flip_w", C.c_int64), ("shift_x", C.c_int32),
                 ("shift_y", C.c_int32), ("do_filter", C.c_int32), ("filt_w", C.c_int32),
-                ("filt_h", C.c_int32), ("pad_", C.c_int32)]
+                ("filt_h", C.c_int32), ("infer", C.c_int32)]
 
     def __init__(self):
         super().__init__()
@@ -49,7 +51,7 @@ class EventAug(C.Structure):
 
 AUG_DTYPE = np.dtype([("scale_x", "<f8"), ("scale_y", "<f8"), ("time_flip", "<i4"), ("flip_x", "<i4"),
                       ("flip_w", "<i8"), ("shift_x", "<i4"), ("shift_y", "<i4"), ("do_filter", "<i4"),
-                      ("filt_w", "<i4"), ("filt_h", "<i4"), ("pad_", "<i4")])
+                      ("filt_w", "<i4"), ("filt_h", "<i4"), ("infer", "<i4")])
 assert AUG_DTYPE.itemsize == C.sizeof(EventAug) == 56
 
 
@@ -272,46 +274,57 @@ class Compose:
         return "Compose(" + ", ".join(type(t).__name__ for t in self.transforms) + ")"
 
 
+class TransformNPY:
+    """What build_transformNPY returns (datasets.py:611-660): the per-sample chain events (N,4) -> f32 [3,H,W].
+
+    ``__call__`` keeps the reference's per-sample surface (it runs the batched GPU chain with B = 1 and returns a CPU
+    tensor like the reference's transform does); training does NOT go through it: the dataset hands out raw events +
+    ``draw()`` records and the whole batch runs through ``augment.BatchAugPipeline`` once per step (collate_raw)."""
+
+    def __init__(self, is_train, args, with_jitter=False, out_chans=3):
+        from .augment import BatchAugPipeline, ChainConfig
+        self.cfg = ChainConfig(args, is_train)
+        self.cfg.apply_jitter = with_jitter
+        self.pipe = BatchAugPipeline(self.cfg, out_chans)
+        if self.cfg.slice_max:
+            assert 5000 <= self.cfg.slice_max < 200000
+            print(f"Slicing max {self.cfg.slice_max} num evs.")
+        if self.cfg.time_surface:
+            print("Using Time Surface!")
+
+    def draw(self, n_events):
+        from .augment import draw_sample
+        return draw_sample(self.cfg, n_events)
+
+    def __call__(self, x):
+        ev = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float64)).cuda() if isinstance(x, np.ndarray) else x.cuda()
+        d = self.draw(ev.shape[0])
+        out, st = self.pipe(ev, [0, ev.shape[0]], [d], return_stages=True)
+        if int(st["status"].sum().item()) != 0:
+            raise ValueError("empty sample or canvas beyond the sensor bound (reference: max() of an empty array)")
+        return out[0].cpu()
+
+    def __repr__(self):
+        c = self.cfg
+        return (f"TransformNPY(canvas={c.canvas or 'from events'}, scale={c.scale}, resize={c.resize}, crop={c.crop}, "
+                f"flags={c.flags}, rand_aug={c.rand_aug}, color_jitter={c.color_jitter if c.apply_jitter else None})")
+
+
 def build_transformNPY(is_train, args):
-    """datasets.py:611-660.  Not in this round (torchvision arithmetic):
-    Resize for data-dependent canvases, EventRandAugment, ColorJitter -- requested combinations
-    raise NotImplementedError instead of silently differing."""
-    t = []
-    H, W = None, None
-    if "imagenet" in args.data_path:
-        H, W = args.input_H, args.input_W
-        t += [ReshapeScaleXandY(newH=H, newW=W, oldH=480, oldW=640, is_train=is_train)]
-        if is_train:
-            H, W = int(480 * (256 / 480)), int(640 * (256 / 480))
-    elif any(k in args.data_path for k in ("SS_final", "dsec", "DSEC")):
-        H, W = 440, 640
-    elif getattr(args, "fixed_canvas", False):
-        H, W = args.input_H, args.input_W
-    t += [SliceRandomMaxEvs(args.slice_max_evs)]
-    if is_train:
-        t += [RandomTimeFlip(), Aug_FlipEvsAlongX(H=H, W=W),
-              Aug_RandomShiftEvs(H=H, W=W, max_shift=args.max_random_shift_evs)]
-    t += [EventArrToImg(H, W, args.timesurface), ToTensor()]
-    if (H, W) != (args.input_H, args.input_W):
-        raise NotImplementedError("Resize/RandomCrop to the model size is torchvision arithmetic "
-                                  "(SURVEY.md 8 f2): only canvases equal to (input_H, input_W) this round")
-    t.append(T.EventChain(timesurface=args.timesurface, hotpixfilter=args.hotpixfilter,
-                          num_stds=args.hotpix_num_stds, logtrafo=args.logtrafo, gammatrafo=args.gammatrafo,
-                          gamma=args.gamma, normalize=args.normalize_events))
-    if is_train and args.rand_aug:
-        raise NotImplementedError("EventRandAugment is torchvision arithmetic (SURVEY.md 8 f2); pass --rand_aug 0")
-    return Compose(t)
+    """datasets.py:611-660."""
+    return TransformNPY(is_train, args)
 
 
 class DataAugmentationForPT:
     """datasets.py:26-82: returns (patches, visual_tokens (same tensor), mask)."""
 
     def __init__(self, args, is_train=True):
-        if getattr(args, "color_jitter", 0):
-            raise NotImplementedError("ColorJitter is torchvision arithmetic (SURVEY.md 8 f2); pass --color_jitter 0")
         if args.discrete_vae_type != "event":
             raise NotImplementedError()
-        self.common_transform = Compose([build_transformNPY(is_train, args), T.CreateTwoPic()])
+        if getattr(args, "data_set", "npy") == "dsec_semseg":
+            raise NotImplementedError("build_transform_dsec (segmentation) is outside the pretraining path")
+        # build_transformNPY + ColorJitter(color_jitter, 0, color_jitter) + CreateTwoPic (:33-37)
+        self.common_transform = TransformNPY(is_train, args, with_jitter=True)
         if args.masking == "random":
             self.masked_position_generator = MaskingGeneratorRandomLocation(
                 args.window_size, num_masking_patches=args.num_mask_patches)
@@ -323,47 +336,158 @@ class DataAugmentationForPT:
         else:
             raise ValueError(f"Need to chose proper masking scheme. {args.masking} does not exist.")
 
+    def draw(self, n_events):
+        """(transform draws, mask) in the reference's per-sample order: transform chain first, mask last (:71-75)."""
+        return self.common_transform.draw(n_events), self.masked_position_generator()
+
     def __call__(self, image):
-        for_patches, for_visual_tokens = self.common_transform(image)
-        return for_patches, for_visual_tokens, self.masked_position_generator()
+        x = self.common_transform(image)
+        return x, x, self.masked_position_generator()
 
     def __repr__(self):
         return ("(DataAugmentationForPT,\n  common_transform = %s,\n  Masked position generator = %s,\n)"
                 % (self.common_transform, self.masked_position_generator))
 
 
+class RawEventDataset(torch.utils.data.Dataset):
+    """(events, draws, mask) per sample: CPU only (DataLoader workers never touch the GPU).  ``source(i)`` -> (N,4)
+    float64 ndarray; ``aug`` = DataAugmentationForPT.  The slice window of SliceRandomMaxEvs is applied here (a view),
+    so the collated batch is one contiguous CSR buffer."""
+
+    def __init__(self, n, source, aug):
+        self.n, self.source, self.aug = n, source, aug
+
+    def __len__(self):
+        return self.n
+
+    def __getitem__(self, i):
+        ev = self.source(i)
+        d, mask = self.aug.draw(len(ev))
+        ev = ev[d.beg:d.end]
+        d.beg, d.end = 0, len(ev)
+        return (ev, d, mask), 0
+
+    def collate(self, batch):
+        evs = [b[0][0] for b in batch]
+        lens = np.array([0] + [len(e) for e in evs], dtype=np.int64)
+        return {"events": torch.from_numpy(np.ascontiguousarray(np.concatenate(evs, 0), dtype=np.float64)),
+                "offsets": np.cumsum(lens), "draws": [b[0][1] for b in batch],
+                "masks": np.stack([b[0][2] for b in batch]), "pipe": self.aug.common_transform.pipe}, \
+            torch.zeros(len(batch), dtype=torch.int64)
+
+
+# sensor geometry of the synthetic stand-ins, by data_path keyword (W, H)
+_SENSOR = {"caltech": (240, 180), "Caltech": (240, 180), "ncars": (120, 100), "N-Cars": (120, 100), "imagenet": (640, 480),
+           "dsec": (640, 480), "DSEC": (640, 480), "SS_final": (640, 480)}
+
+
+class SyntheticEventSource:
+    """Seeded synthetic (N,4) event streams with the layout of dataset_folder.py:275-302.  With ``vary_extent`` every
+    sample occupies its own sub-rectangle of the sensor (like N-Caltech101 recordings, whose canvas the reference
+    infers per sample from the data)."""
+
+    def __init__(self, n_events, W, H, seed=1234, vary_extent=False):
+        self.ne, self.W, self.H, self.seed, self.vary = n_events, W, H, seed, vary_extent
+
+    def __call__(self, i):
+        g = np.random.default_rng(self.seed + i)
+        W, H = self.W, self.H
+        if self.vary:
+            W, H = int(g.integers(max(100, (2 * W) // 3), W + 1)), int(g.integers(max(100, (2 * H) // 3), H + 1))
+        n = self.ne
+        return np.stack([g.integers(0, W, n), g.integers(0, H, n), np.sort(g.integers(0, 300000, n)),
+                         g.integers(0, 2, n) * 2 - 1], 1).astype(np.float64)
+
+
 class SyntheticEventDataset(torch.utils.data.Dataset):
-    """Seeded synthetic (N,4) event streams with the layout of dataset_folder.py:275-302 -- the
-    stand-in for npyFolder when no dataset is on disk (all BASELINE configs are synthetic)."""
+    """Per-sample form (transform applied in __getitem__ through the B = 1 compat path; tests / small tools)."""
 
     def __init__(self, n_samples, n_events, H, W, transform=None, seed=1234):
-        self.n, self.ne, self.H, self.W, self.transform, self.seed = n_samples, n_events, H, W, transform, seed
+        self.n, self.transform = n_samples, transform
+        self.src = SyntheticEventSource(n_events, W, H, seed)
 
     def __len__(self):
         return self.n
 
     def events(self, i):
-        g = np.random.default_rng(self.seed + i)
-        n = self.ne
-        return np.stack([g.integers(0, self.W, n), g.integers(0, self.H, n),
-                         np.sort(g.integers(0, 300000, n)), g.integers(0, 2, n) * 2 - 1], 1).astype(np.float64)
+        return self.src(i)
 
     def __getitem__(self, i):
         x = self.events(i)
         return (self.transform(x) if self.transform is not None else x), 0
 
 
+class NpyFolderSource:
+    """root/<class>/<file>.npy|npz in sorted order (dataset_folder.py:npyFolder) with the reference's loader choice
+    (datasets.py:158-172); events are loaded to host memory (the conversion kernels of process_data run per batch)."""
+
+    def __init__(self, root, loader):
+        import os
+        self.files = []
+        for cls in sorted(d for d in os.listdir(root) if os.path.isdir(os.path.join(root, d))):
+            for f in sorted(os.listdir(os.path.join(root, cls))):
+                if f.endswith((".npy", ".npz")):
+                    self.files.append(os.path.join(root, cls, f))
+        self.loader = loader
+
+    def __len__(self):
+        return len(self.files)
+
+    def __call__(self, i):
+        return self.loader(self.files[i])
+
+
+def _host_loader(args):
+    """CPU forms of the loaders (DataLoader workers): (N,4) float64 ndarrays, same arithmetic as dataset_folder.py:275-302
+    (the GPU forms live in process_data.py)."""
+    dp = args.data_path
+    if getattr(args, "data_set", "npy") == "dsec_semseg":
+        def dsec(path):
+            data = np.load(path).astype(float)
+            data[:, 3] = 2 * data[:, 3] - 1
+            return data[data[:, 1] < 440]
+        return dsec
+    if "imagenet" in dp and "npy" in dp:
+        def imgnet(path):
+            data = np.load(path)
+            ps = data["p"].astype(np.int8) * 2 - 1
+            return np.vstack([data["x"], data["y"], data["t"], ps]).T.astype(float)
+        return imgnet
+    return lambda path: np.load(path)
+
+
 def build_pretraining_dataset(args, is_train=True):
-    """datasets.py:146-174.  Folder walking / .npy loading is I/O plumbing outside the hot path
-    (SURVEY.md 2.1 row 8); ``--data_path synthetic`` builds the seeded synthetic stand-in."""
-    if args.data_path != "synthetic":
-        raise NotImplementedError("only --data_path synthetic this round (dataset folder I/O is out of scope)")
-    args.fixed_canvas = True                  # synthetic streams are generated on the model's own canvas
+    """datasets.py:146-174.  A data_path that exists is read like the reference reads it (root/train|val/<class>/*.npy);
+    otherwise -- there are no datasets in this environment -- seeded synthetic streams of the geometry the data_path
+    names (N-Caltech101: per-sample extents inside 240 x 180) stand in, loudly."""
+    import os
     transform = DataAugmentationForPT(args, is_train)
     print("Data Aug = %s" % str(transform))
+    root = None
+    for a, b in (("train", "val"), ("extracted_train", "extracted_val"), ("train_events", "test_events")):
+        r = os.path.join(args.data_path, a if is_train else b)
+        if os.path.exists(r):
+            root = r
+            break
+    if root is not None:
+        src = NpyFolderSource(root, _host_loader(args))
+        return RawEventDataset(len(src), src, transform)
+    if args.data_path != "synthetic" and not getattr(args, "synthetic_if_missing", 1):
+        raise AssertionError(f"{args.data_path} not found")
     n = getattr(args, "synthetic_samples", 64)
-    return SyntheticEventDataset(n if is_train else max(2, n // 8), args.slice_max_evs, args.input_H, args.input_W,
-                                 transform=transform, seed=1234 if is_train else 4321)
+    n = n if is_train else max(2, n // 8)
+    cfg = transform.common_transform.cfg
+    key = next((k for k in _SENSOR if k in args.data_path), None)
+    if key is None:                                   # "synthetic": streams on the model's own canvas
+        W, H, vary = args.input_W, args.input_H, False
+        cfg.canvas = cfg.canvas or (args.input_H, args.input_W)
+    else:
+        (W, H), vary = _SENSOR[key], cfg.canvas is None
+        print(f"WARNING: {args.data_path} does not exist here -- using seeded synthetic event streams with the "
+              f"{key} sensor geometry ({W}x{H})")
+        cfg.canvas_max = (max(cfg.canvas_max[0], H), max(cfg.canvas_max[1], W))
+    src = SyntheticEventSource(args.slice_max_evs, W, H, seed=1234 if is_train else 4321, vary_extent=vary)
+    return RawEventDataset(n, src, transform)
 
 
 class EventBatchPipeline:

@@ -20,10 +20,19 @@ from . import utils
 
 
 def _prep_batch(batch, device, model, d_vae):
-    samples, images, bool_masked_pos = batch
-    images = images.to(device, non_blocking=True)
-    samples = samples.to(device, non_blocking=True)
-    bool_masked_pos = bool_masked_pos.to(device, non_blocking=True)
+    if isinstance(batch, dict):
+        # raw batch (datasets.RawEventDataset.collate): one upload of the events, then the whole transform chain of
+        # build_transformNPY + ColorJitter on the GPU (augment.BatchAugPipeline); patches IS visual_tokens for
+        # discrete_vae_type == "event" (datasets.py:49-51)
+        ev = batch["events"].to(device, non_blocking=True)
+        samples = batch["pipe"](ev, batch["offsets"], batch["draws"])
+        images = samples
+        bool_masked_pos = torch.from_numpy(batch["masks"]).to(device, non_blocking=True)
+    else:
+        samples, images, bool_masked_pos = batch
+        images = images.to(device, non_blocking=True)
+        samples = samples.to(device, non_blocking=True)
+        bool_masked_pos = bool_masked_pos.to(device, non_blocking=True)
     with torch.no_grad():
         bool_masked_pos = bool_masked_pos.flatten(1).to(torch.bool)
         input_ids = d_vae.get_codebook_indices(images).flatten(1)       # (B, 14*14)

@@ -122,6 +122,11 @@ def get_args(argv=None):
     p.set_defaults(auto_resume=True)
     p.add_argument("--start_epoch", default=0, type=int, metavar="N")
     p.add_argument("--num_workers", default=0, type=int)
+    p.add_argument("--synthetic_if_missing", default=1, type=int,
+                   help="1: a --data_path that does not exist is replaced (loudly) by seeded synthetic event streams of the "
+                        "sensor geometry its name implies; 0: fail like the reference's assert")
+    p.add_argument("--canvas_max_H", default=0, type=int, help="bound of data-dependent canvases (0: 480)")
+    p.add_argument("--canvas_max_W", default=0, type=int, help="bound of data-dependent canvases (0: 640)")
     p.add_argument("--pin_mem", action="store_true")
     p.add_argument("--no_pin_mem", action="store_false", dest="pin_mem")
     p.set_defaults(pin_mem=False)
@@ -200,12 +205,16 @@ def main(args):
     if dataset_val is not None:
         sampler_val = (torch.utils.data.DistributedSampler(dataset_val, num_replicas=num_tasks, rank=global_rank, shuffle=False)
                        if args.dist_eval else torch.utils.data.SequentialSampler(dataset_val))
+    # datasets hand out raw events + draw records (CPU only: DataLoader workers are safe); collate builds one CSR batch
+    # and train_one_epoch runs the whole transform chain on the GPU once per batch (augment.BatchAugPipeline)
     data_loader_train = torch.utils.data.DataLoader(dataset_train, sampler=sampler_train, batch_size=args.batch_size,
-                                                    num_workers=args.num_workers, pin_memory=args.pin_mem, drop_last=True)
+                                                    num_workers=args.num_workers, pin_memory=args.pin_mem, drop_last=True,
+                                                    collate_fn=getattr(dataset_train, "collate", None))
     data_loader_val = None
     if dataset_val is not None:
         data_loader_val = torch.utils.data.DataLoader(dataset_val, sampler=sampler_val, batch_size=int(1.5 * args.batch_size),
-                                                      num_workers=args.num_workers, pin_memory=args.pin_mem, drop_last=False)
+                                                      num_workers=args.num_workers, pin_memory=args.pin_mem, drop_last=False,
+                                                      collate_fn=getattr(dataset_val, "collate", None))
     model.to(device)
     model_without_ddp = model
     n_parameters = sum(p.numel() for p in model.parameters() if p.requires_grad)
