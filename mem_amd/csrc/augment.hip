@@ -10,6 +10,11 @@
 // elementwise; statistics ops (Contrast mean, AutoContrast min/max, Equalize histograms) reduce in LDS.
 #include "common.h"
 
+// torch evaluates these chains as separate float32 tensor ops (mul, mul, add ...): no fused multiply-add anywhere.
+// hipcc contracts a * b + c by default (and __fmul_rn / __fadd_rn are plain operators in the HIP headers), so this
+// translation unit is built with -ffp-contract=off (csrc/Makefile; the pragma alone leaves inlined lambdas contracted).
+#pragma clang fp contract(off)
+
 namespace {
 
 using namespace memhip;

@@ -6,7 +6,8 @@ name=$1; shift
 cd "$(dirname "$0")/../mem_amd/csrc"
 mkdir -p _build_$name ../exp
 for f in core.cpp mask.cpp *.hip; do
-  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function -fno-fast-math "$@" -c $f -o _build_$name/$f.o &
+  extra=""; case $f in augment.hip|raster.hip|event_norm.hip|records.hip) extra="-ffp-contract=off";; esac
+  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function -fno-fast-math $extra "$@" -c $f -o _build_$name/$f.o &
   while [ $(jobs -r | wc -l) -ge 8 ]; do sleep 0.2; done
 done
 wait
