@@ -225,6 +225,16 @@ BASE = dict(img_size=(224, 224), patch_size=(16, 16), in_chans=2, vocab_size=819
             use_abs_pos_emb=False, init_values=0.1)
 
 
+# (parameter, row stride) of the ViT-B gradient tensors stored in vit_base_c*.npz
+BASE_GRAD_SAMPLES = [("rel_pos_bias.relative_position_bias_table", 1), ("cls_token", 1), ("mask_token", 1),
+                     ("patch_embed.proj.weight", 16), ("patch_embed.proj.bias", 1), ("blocks.0.attn.q_bias", 1),
+                     ("blocks.0.attn.v_bias", 1), ("blocks.0.attn.qkv.weight", 48), ("blocks.0.norm1.weight", 1),
+                     ("blocks.5.gamma_1", 1), ("blocks.5.attn.proj.weight", 24), ("blocks.6.mlp.fc1.weight", 96),
+                     ("blocks.6.mlp.fc1.bias", 1), ("blocks.11.mlp.fc2.weight", 24), ("blocks.11.gamma_2", 1),
+                     ("blocks.11.mlp.fc2.bias", 1), ("norm.weight", 1), ("norm.bias", 1), ("lm_head.weight", 128),
+                     ("lm_head.bias", 1)]
+
+
 def vit_inputs(cfg, B, seed, nmask):
     g = torch.Generator().manual_seed(seed)
     C, (H, W) = cfg["in_chans"], cfg["img_size"]
@@ -366,6 +376,11 @@ def gen_vit():
             g[f"{mode}__gradnorms"] = np.array([p.grad.norm().item() for _, p in refb.named_parameters()])
             for (k, p), (_, q) in zip(refb.named_parameters(), orab.named_parameters()):
                 assert torch.equal(p.grad, q.grad), k
+            # full gradient TENSORS of a cross-section of parameters (whole small tensors, strided rows of the big
+            # matrices): direction checks at ViT-B size, not only norms
+            pd = dict(refb.named_parameters())
+            for k, st in BASE_GRAD_SAMPLES:
+                g[f"{mode}__grad__{k}"] = pd[k].grad.detach()[::st].contiguous().numpy()
             res[f"base_c{C}_param_names"] = names
         if C == 3:
             # config #1: 10 fp32 steps, B=2, drop_path=0, ncaltech.conf hyper-parameters

@@ -289,6 +289,22 @@ def test_vit_base_vs_reference_golden(C):
     assert np.abs(gn[big] / ref[big] - 1).max() <= 0.08, np.abs(gn[big] / ref[big] - 1).max()
     tot = np.sqrt((gn ** 2).sum()) / np.sqrt((ref ** 2).sum())
     assert abs(tot - 1) <= 0.02, tot
+    # direction at ViT-B size: full gradient tensors of a cross-section of parameters (whole small tensors, strided
+    # rows of the big matrices) against the reference's bf16-autocast gradients: rel-L2 <= 3e-2 each, cosine >= 0.999
+    from oracle.gen_golden import BASE_GRAD_SAMPLES
+    pd = dict(m.named_parameters())
+    got_all, ref_all = [], []
+    for k, st in BASE_GRAD_SAMPLES:
+        r = torch.from_numpy(g[f"bf16__grad__{k}"]).cuda()
+        q = pd[k].grad[::st]
+        rel = ((q - r).norm() / (r.norm() + 1e-12)).item()
+        cos = torch.nn.functional.cosine_similarity(q.flatten(), r.flatten(), dim=0).item()
+        assert rel <= 3e-2 and cos >= 0.999, (k, rel, cos)
+        got_all.append(q.flatten()); ref_all.append(r.flatten())
+        r32 = torch.from_numpy(g[f"fp32__grad__{k}"]).cuda()
+        assert torch.nn.functional.cosine_similarity(q.flatten(), r32.flatten(), dim=0).item() >= 0.995, k
+    cos = torch.nn.functional.cosine_similarity(torch.cat(got_all), torch.cat(ref_all), dim=0).item()
+    assert cos >= 0.9995, cos
 
 
 def test_batch_is_token_weighted_mean_of_samples():
