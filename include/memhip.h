@@ -387,6 +387,39 @@ int memhip_attn_bwd(const void* qkv, int64_t ldqkv, const void* dout, int64_t ld
                     float* dv_bias, memhip_stream_t stream);
 
 /* ------------------------------------------------------------------------
+ * fp32 PARITY MODE (`--precision fp32`): the ViT path with fp32 operands / accumulation and no bf16 rounding points --
+ * the reference's arithmetic without autocast (same reference lines as the bf16 entry points above).  For loss-curve
+ * parity against the reference's fp32 CPU run (north star: step-100 loss within 1e-4); speed is secondary.
+ * ------------------------------------------------------------------------
+ * f32_gemm_nt: memhip_gemm_args_t with A, B, out0, out1 and (DGELU) aux as fp32; epilogues BIAS_BF16 (= plain bias,
+ *   fp32 out), BIAS_GELU (exact erf), RESIDUAL, DGELU, F32, PATCH_EMBED; K and ld multiples of 4 (K is zero-extended to
+ *   the next multiple of 32 inside).  f32_transpose: out [C, ldout] = in [R, C]^T, columns >= R zero.
+ * f32_attn_*: generic attention (head_dim 32 or 64, T <= 256): bias[h,i,j] = table[index[i*T+j], h] (index NULL: none);
+ *   bwd zeroes dqkv, then dq (times scale) by stores, dk / dv / dtable by fp32 atomics; delta = sum_j P dP. */
+int memhip_f32_gemm_nt(const memhip_gemm_args_t* args, memhip_stream_t stream);
+int memhip_f32_transpose(const float* in, int64_t ldin, int R, int C, float* out, int64_t ldout, memhip_stream_t stream);
+int memhip_f32_layernorm_fwd(const float* x, int64_t ldx, const int32_t* row_idx, int R, int D, const float* gamma,
+                             const float* beta, float eps, float* y, int64_t ldy, float* mean, float* rstd,
+                             memhip_stream_t stream);
+int memhip_f32_layernorm_bwd(const float* dy, int64_t lddy, const float* x, int64_t ldx, const int32_t* row_idx, int R, int D,
+                             const float* gamma, const float* mean, const float* rstd, float* dres, int64_t lddres,
+                             int accumulate, float* dgamma, float* dbeta, memhip_stream_t stream);
+int memhip_f32_branch_bwd(const float* dx, int64_t lddx, const float* y, int64_t ldy, const float* gamma, const float* rowmask,
+                          float keep_prob, int rows_per_sample, int M, int D, float* dy, int64_t lddy, float* dgamma,
+                          float* dbias, memhip_stream_t stream);
+int memhip_f32_embed_bwd(const float* dx, int64_t lddx, const uint8_t* mask, int B, int L, int D, float* dy, int64_t lddy,
+                         float* dcls, float* dmask_token, memhip_stream_t stream);
+int memhip_f32_cross_entropy(float* logits, int64_t ld, const int64_t* labels, int M, int V, float grad_scale,
+                             float* row_loss, int32_t* row_correct, int write_grad, float* out2, memhip_stream_t stream);
+int memhip_f32_colsum(const float* in, int64_t ld, int R, int C, float* out, memhip_stream_t stream);
+int memhip_f32_im2col(const float* x, int B, int C, int H, int W, int ph, int pw, float* out, memhip_stream_t stream);
+int memhip_f32_attn_fwd(const float* qkv, int64_t ldqkv, int B, int T, int D, int heads, const float* table,
+                        const int32_t* index, float* out, int64_t ldo, float* lse, memhip_stream_t stream);
+int memhip_f32_attn_bwd(const float* qkv, int64_t ldqkv, const float* dout, int64_t ldo, int B, int T, int D, int heads,
+                        float scale, const float* table, const int32_t* index, float* dqkv, int64_t lddqkv, float* dtable,
+                        memhip_stream_t stream);
+
+/* ------------------------------------------------------------------------
  * Frozen dVAE tokenizer forward
  * replaces DiscreteVAE.get_codebook_indices          eventvae/vae/vae_model.py:153-158
  *          encoder stack / ResBlock                   eventvae/vae/vae_model.py:29-42,86-101

@@ -64,7 +64,8 @@ class _ViTFunction(torch.autograd.Function):
     def backward(ctx, dlogits):
         m = ctx.model
         m.engine.attach_grads()
-        m.engine.backward(dlogits.to(torch.bfloat16).contiguous())
+        dt = torch.float32 if getattr(m, "precision", "bf16") == "fp32" else torch.bfloat16
+        m.engine.backward(dlogits.to(dt).contiguous())
         return None, None, None, None, None, None
 
 
@@ -142,7 +143,11 @@ class VisionTransformerForMaskedImageModeling(nn.Module):
     def engine(self):
         if self._engine is None:
             require_gpu()
-            self._engine = ViTEngine(self)
+            if getattr(self, "precision", "bf16") == "fp32":     # --precision fp32: the parity mode (vit_engine_f32.py)
+                from .vit_engine_f32 import ViTEngineF32
+                self._engine = ViTEngineF32(self)
+            else:
+                self._engine = ViTEngine(self)
         return self._engine
 
     def load_state_dict(self, *a, **k):
@@ -219,8 +224,11 @@ ft_vit = register_model(_ft_vit)
 @register_model
 def pt_vit(pretrained=False, **kwargs):
     init_ckpt = kwargs.pop("init_ckpt", None)
+    precision = kwargs.pop("precision", "bf16")
+    assert precision in ("bf16", "fp32")
     model = VisionTransformerForMaskedImageModeling(qkv_bias=True, norm_layer=partial(nn.LayerNorm, eps=1e-6),
                                                     **kwargs)
+    model.precision = precision      # "fp32": parity mode (fp32 operands, no bf16 rounding points; slow)
     model.default_cfg = {"url": "", "num_classes": 2, "input_size": (3, 128, 128), "pool_size": None, "crop_pct": 1,
                          "interpolation": "bicubic", "mean": (0.5, 0, 0.5), "std": (0.5, 0, 0.5)}
     if pretrained:

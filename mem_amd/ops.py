@@ -284,3 +284,87 @@ def gemm_tn(A, B, R, N, K, out, accumulate=True, workspace=None):
 
 def colsum_bf16(x, R, Cc, out):
     check(lib.memhip_colsum_bf16(ptr(x), x.stride(0), R, Cc, ptr(out), stream_ptr()), "colsum_bf16")
+
+
+# ---------------------------------------------------------------- fp32 parity mode (csrc/fp32_path.hip)
+declare({
+    "memhip_f32_gemm_nt": (i32, [C.POINTER(GemmArgs), vp]),
+    "memhip_f32_transpose": (i32, [vp, i64, i32, i32, vp, i64, vp]),
+    "memhip_f32_layernorm_fwd": (i32, [vp, i64, vp, i32, i32, vp, vp, f32, vp, i64, vp, vp, vp]),
+    "memhip_f32_layernorm_bwd": (i32, [vp, i64, vp, i64, vp, i32, i32, vp, vp, vp, vp, i64, i32, vp, vp, vp]),
+    "memhip_f32_branch_bwd": (i32, [vp, i64, vp, i64, vp, vp, f32, i32, i32, i32, vp, i64, vp, vp, vp]),
+    "memhip_f32_embed_bwd": (i32, [vp, i64, vp, i32, i32, i32, vp, i64, vp, vp, vp]),
+    "memhip_f32_cross_entropy": (i32, [vp, i64, vp, i32, i32, f32, vp, vp, i32, vp, vp]),
+    "memhip_f32_colsum": (i32, [vp, i64, i32, i32, vp, vp]),
+    "memhip_f32_im2col": (i32, [vp, i32, i32, i32, i32, i32, i32, vp, vp]),
+    "memhip_f32_attn_fwd": (i32, [vp, i64, i32, i32, i32, i32, vp, vp, vp, i64, vp, vp]),
+    "memhip_f32_attn_bwd": (i32, [vp, i64, vp, i64, i32, i32, i32, i32, f32, vp, vp, vp, i64, vp, vp]),
+})
+
+
+def f32_gemm_nt(A, B, M, N, K, epi, out0=None, out1=None, bias=None, vec1=None, resid=None, aux=None, rowmask=None,
+                keep_prob=1.0, colscale=1.0, colscale_n=0, rows_per_sample=1, accumulate=False, colsum=None, ldaux=None):
+    """fp32 twin of gemm_nt (A, B, out0, out1, DGELU aux are fp32)."""
+    a = GemmArgs()
+    a.A, a.B, a.lda, a.ldb = _p(A), _p(B), A.stride(0), B.stride(0)
+    a.M, a.N, a.K, a.epilogue = M, N, K, epi
+    a.out0, a.ldo0 = _p(out0), (out0.stride(0) if out0 is not None else 0)
+    a.out1, a.ldo1 = _p(out1), (out1.stride(0) if out1 is not None else 0)
+    a.bias, a.vec1, a.resid = _p(bias), _p(vec1), _p(resid)
+    a.ldr = resid.stride(0) if resid is not None else 0
+    a.aux = _p(aux)
+    a.ldaux = (aux.stride(0) if (aux is not None and aux.dim() > 1) else 0) if ldaux is None else ldaux
+    a.rowmask = _p(rowmask)
+    a.keep_prob, a.colscale, a.colscale_n = keep_prob, colscale, colscale_n
+    a.rows_per_sample, a.accumulate = rows_per_sample, int(accumulate)
+    a.colsum = _p(colsum)
+    check(lib.memhip_f32_gemm_nt(C.byref(a), stream_ptr()), "f32_gemm_nt")
+
+
+def f32_transpose(src, R, Cc, dst):
+    check(lib.memhip_f32_transpose(ptr(src), src.stride(0), R, Cc, ptr(dst), dst.stride(0), stream_ptr()), "f32_transpose")
+
+
+def f32_layernorm_fwd(x, gamma, beta, y, mean, rstd, R, D, eps=1e-6, row_idx=None):
+    check(lib.memhip_f32_layernorm_fwd(ptr(x), x.stride(0), ptr(row_idx), R, D, ptr(gamma), ptr(beta), eps, ptr(y),
+                                       y.stride(0), ptr(mean), ptr(rstd), stream_ptr()), "f32_layernorm_fwd")
+
+
+def f32_layernorm_bwd(dy, x, gamma, mean, rstd, dres, dgamma, dbeta, R, D, accumulate=True, row_idx=None):
+    check(lib.memhip_f32_layernorm_bwd(ptr(dy), dy.stride(0), ptr(x), x.stride(0), ptr(row_idx), R, D, ptr(gamma), ptr(mean),
+                                       ptr(rstd), ptr(dres), dres.stride(0), int(accumulate), ptr(dgamma), ptr(dbeta),
+                                       stream_ptr()), "f32_layernorm_bwd")
+
+
+def f32_branch_bwd(dx, y, gamma, dy, dgamma, dbias, M, D, rowmask=None, keep_prob=1.0, rows_per_sample=1):
+    check(lib.memhip_f32_branch_bwd(ptr(dx), dx.stride(0), ptr(y), y.stride(0) if y is not None else 0, ptr(gamma), ptr(rowmask),
+                                    keep_prob, rows_per_sample, M, D, ptr(dy), dy.stride(0), ptr(dgamma), ptr(dbias),
+                                    stream_ptr()), "f32_branch_bwd")
+
+
+def f32_embed_bwd(dx, mask_u8, B, L, D, dy, dcls, dmask_token):
+    check(lib.memhip_f32_embed_bwd(ptr(dx), dx.stride(0), ptr(mask_u8), B, L, D, ptr(dy), dy.stride(0), ptr(dcls),
+                                   ptr(dmask_token), stream_ptr()), "f32_embed_bwd")
+
+
+def f32_cross_entropy(logits, labels, M, V, grad_scale, row_loss, row_correct, out2, write_grad=True):
+    check(lib.memhip_f32_cross_entropy(ptr(logits), logits.stride(0), ptr(labels), M, V, grad_scale, ptr(row_loss),
+                                       ptr(row_correct), int(write_grad), ptr(out2), stream_ptr()), "f32_cross_entropy")
+
+
+def f32_colsum(x, R, Cc, out):
+    check(lib.memhip_f32_colsum(ptr(x), x.stride(0), R, Cc, ptr(out), stream_ptr()), "f32_colsum")
+
+
+def f32_im2col(x, B, Cc, H, W, ph, pw, out):
+    check(lib.memhip_f32_im2col(ptr(x), B, Cc, H, W, ph, pw, ptr(out), stream_ptr()), "f32_im2col")
+
+
+def f32_attn_fwd(qkv, B, T, D, heads, table, index, out, lse=None):
+    check(lib.memhip_f32_attn_fwd(ptr(qkv), qkv.stride(0), B, T, D, heads, ptr(table), ptr(index), ptr(out), out.stride(0),
+                                  ptr(lse), stream_ptr()), "f32_attn_fwd")
+
+
+def f32_attn_bwd(qkv, dout, B, T, D, heads, scale, table, index, dqkv, dtable):
+    check(lib.memhip_f32_attn_bwd(ptr(qkv), qkv.stride(0), ptr(dout), dout.stride(0), B, T, D, heads, scale, ptr(table),
+                                  ptr(index), ptr(dqkv), dqkv.stride(0), ptr(dtable), stream_ptr()), "f32_attn_bwd")

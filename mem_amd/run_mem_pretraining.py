@@ -121,6 +121,10 @@ def get_args(argv=None):
     p.add_argument("--no_auto_resume", action="store_false", dest="auto_resume")
     p.set_defaults(auto_resume=True)
     p.add_argument("--start_epoch", default=0, type=int, metavar="N")
+    p.add_argument("--precision", default="bf16", choices=["bf16", "fp32"],
+                   help="bf16: the reference's autocast placement (bf16 GEMM operands, fp32 accumulate / residual / softmax); "
+                        "fp32: parity mode, fp32 operands everywhere like the reference without autocast (slow; for loss-curve "
+                        "parity against the reference's fp32 run)")
     p.add_argument("--num_workers", default=0, type=int)
     p.add_argument("--synthetic_if_missing", default=1, type=int,
                    help="1: a --data_path that does not exist is replaced (loudly) by seeded synthetic event streams of the "
@@ -158,7 +162,7 @@ def get_model(args):
         init_values=args.layer_scale_init_value, in_chans=2 if args.voxel == 0 else args.voxel,
         img_size=(args.input_H, args.input_W), patch_size=(2 ** args.num_layers, 2 ** args.num_layers),
         embed_dim=args.transformer_emb, depth=args.transformer_depth, num_heads=args.transformer_heads,
-        mlp_ratio=args.transformer_mlp_ratio, vocab_size=args.num_tokens)
+        mlp_ratio=args.transformer_mlp_ratio, vocab_size=args.num_tokens, precision=args.precision)
 
 
 def main(args):
