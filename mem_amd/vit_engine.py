@@ -68,6 +68,13 @@ class ViTEngine:
         self.step_masks = None
         self.weights_dirty = True
         self.grad_hook = None            # called as grad_hook(bucket_index) when a bucket's grads are final
+        # Weight-gradient products on a second HIP stream (backward only): every dgrad GEMM has an independent wgrad
+        # GEMM beside it (both only read dY), and both are persistent one-workgroup-per-CU launches, so the CUs that a
+        # launch leaves idle in its last partial round of tiles (N = 768: 591 tiles on 256 CUs) pick up workgroups of
+        # the other stream's launch instead of waiting.  Results are identical (same kernels, same operands).
+        self.wgrad_side_stream = True
+        self._side = None
+        self._ev_pool, self._ev_i = [], 0
 
     # ------------------------------------------------------------------ parameter packing
     def _pack_parameters(self):
@@ -204,6 +211,7 @@ class ViTEngine:
         # backward temporaries (shared by all blocks)
         self.dx = torch.zeros((M, D), dtype=f32, device=dev)
         self.dY, self.dh_small = e(M, D), e(M, D)
+        self.dY2 = e(M, D)                                    # attention-branch twin of dY (the side stream reads both)
         self.dbig = e(M, Hd)
         self.dqkv = e(M, 3 * D)
         self.dao = e(M, D)
@@ -350,6 +358,65 @@ class ViTEngine:
         for gv, c0, c1 in bias_grads:
             ops.colsum_bf16(dY[:, c0:c1], R, c1 - c0, gv)
 
+    # ---- second stream for the weight-gradient products
+    def _event(self):
+        if self._ev_i == len(self._ev_pool):
+            self._ev_pool.append(torch.cuda.Event())
+        e = self._ev_pool[self._ev_i]
+        self._ev_i += 1
+        return e
+
+    def _side_begin(self):
+        """Start of a backward: decide whether the side stream is used (not under the per-launch GEMM timer of
+        bench.py, whose HIP events must see one kernel at a time)."""
+        self._use_side = bool(self.wgrad_side_stream) and ops.GEMM_TIMER is None
+        self._ev_i = 0
+        self._side_reads = {}
+        if self._use_side and self._side is None:
+            self._side = torch.cuda.Stream(device=self.dev)
+            # the wgrad workspace is sized once so that it is never reallocated while the side stream uses it
+            D, Hd = self.D, self.hidden
+            M = self.B * self.T
+            need = max(ops.gemm_tn_workspace(M, 3 * D, D), ops.gemm_tn_workspace(M, Hd, D), ops.gemm_tn_workspace(M, D, Hd),
+                       ops.gemm_tn_workspace(M, D, D), ops.gemm_tn_workspace(getattr(self, "Mm_cap", 0) or M, max(self.V, 1), D),
+                       ops.gemm_tn_workspace(self.B * self.L, D, self.Kpe))
+            if need > self._tn_ws.numel():
+                self._tn_ws = torch.empty(need, dtype=torch.uint8, device=self.dev)
+
+    def _on_side(self, fn):
+        """Run fn() (weight-gradient work that only READS what the main stream has produced so far) on the side stream."""
+        if not self._use_side:
+            fn()
+            return
+        e = self._event()
+        e.record()                                           # everything enqueued on the main stream so far
+        with torch.cuda.stream(self._side):
+            self._side.wait_event(e)
+            fn()
+
+    def _side_read_done(self, name):
+        """Mark the side stream's position after its (last) read of buffer `name`."""
+        if self._use_side:
+            e = self._event()
+            e.record(self._side)
+            self._side_reads[name] = e
+
+    def _before_overwrite(self, name):
+        """Main stream: wait until the side stream has finished reading buffer `name`."""
+        if self._use_side:
+            e = self._side_reads.pop(name, None)
+            if e is not None:
+                torch.cuda.current_stream().wait_event(e)
+
+    def _side_join(self):
+        """Main stream waits for the side stream (before a buffer the side stream reads is overwritten, before a
+        gradient bucket is handed to the reducer, at the end of backward)."""
+        if not self._use_side:
+            return
+        e = self._event()
+        e.record(self._side)
+        torch.cuda.current_stream().wait_event(e)
+
     def backward(self, dlogits=None):
         """Gradients of mean-CE (dlogits already in self.logits after forward(labels=...)) or of a
         caller-supplied dlogits (bf16 [Mm,V]) w.r.t. every parameter, into the flat grad buffer."""
@@ -364,8 +431,9 @@ class ViTEngine:
         dx[:M].zero_()
         dl = self.logits
         # ---- head
+        self._side_begin()
         ops.gemm_nt(dl, self.wT_lm, Mm, D, V, ops.EPI_BIAS_BF16, out0=self.dhN)
-        self._wgrad(dl, self.hN, Mm, V, D, "lm_head.weight", bias_grads=((self.G("lm_head.bias"), 0, V),))
+        self._on_side(lambda: self._wgrad(dl, self.hN, Mm, V, D, "lm_head.weight", bias_grads=((self.G("lm_head.bias"), 0, V),)))
         ops.layernorm_bwd(self.dhN, self.x[2 * self.depth], self.P("norm.weight"), self.meanN, self.rstdN, dx,
                           self.G("norm.weight"), self.G("norm.bias"), Mm, D, accumulate=False, row_idx=c["rows"])
         self._backward_trunk()
@@ -376,6 +444,7 @@ class ViTEngine:
         M, D = c["M"], self.D
         self.flat_g[self.head_end:].zero_()
         self.dx[:M].copy_(dxl.reshape(M, D))
+        self._side_begin()
         self._backward_trunk()
 
     def _backward_trunk(self):
@@ -385,6 +454,7 @@ class ViTEngine:
         dp_masks = c["dp"]
         dx = self.dx
         if self.grad_hook:
+            self._side_join()
             self.grad_hook(0)
         # both ping-pong rows of the proj-bias scratch start clean: block i accumulates into row i&1 and clears the
         # other one, which leaves row (depth-1)&1 dirty for the next backward when depth is odd
@@ -400,27 +470,36 @@ class ViTEngine:
             has_g = (pre + "gamma_1") in self.segs
             table, dtable = self.table(i), self.dtable(i)
             # -- MLP branch (for every block but the last this already ran fused into the norm1 backward of
-            # block i+1, see below)
+            # block i+1, see below).  dY = gradient of the MLP branch output, dY2 = of the attention branch output.
+            dY, dY2 = self.dY, self.dY2
             if i == self.depth - 1 or not fuse:
-                ops.branch_bwd(dx, None, self.P(pre + "gamma_2") if has_g else None, self.dY,
+                self._before_overwrite("dY")
+                ops.branch_bwd(dx, None, self.P(pre + "gamma_2") if has_g else None, dY,
                                None, self.G(pre + "mlp.fc2.bias"), M, D,
                                rowmask=dp_masks[2 * i + 1] if use_dp else None, keep_prob=keep, rows_per_sample=T)
-            ops.gemm_nt(self.dY, self.wT[i]["fc2"], M, Hd, D, self.epi_dgelu, out0=self.dbig, aux=a["hpre"],
+            self._before_overwrite("dbig")
+            ops.gemm_nt(dY, self.wT[i]["fc2"], M, Hd, D, self.epi_dgelu, out0=self.dbig, aux=a["hpre"],
                         colsum=self.G(pre + "mlp.fc1.bias"))        # fc1 bias grad = column sums of dh
-            self._wgrad(self.dY, a["a"], M, D, Hd, pre + "mlp.fc2.weight")
-            if has_g:
-                # layer-scale gradient from the weight gradient (no branch output y kept): memhip_layerscale_grad
-                ops.layerscale_grad(self.W16(pre + "mlp.fc2.weight", D, Hd), self.G(pre + "mlp.fc2.weight").view(D, Hd),
-                                    self.P(pre + "mlp.fc2.bias"), self.G(pre + "mlp.fc2.bias"),
-                                    self.P(pre + "gamma_2"), D, Hd, self.G(pre + "gamma_2"))
-            self._wgrad(self.dbig, a["h2"], M, Hd, D, pre + "mlp.fc1.weight")
+
+            def wg_mlp(i=i, pre=pre, a=a, has_g=has_g):
+                self._wgrad(dY, a["a"], M, D, Hd, pre + "mlp.fc2.weight")
+                self._side_read_done("dY")
+                if has_g:
+                    # layer-scale gradient from the weight gradient (no branch output y kept): memhip_layerscale_grad
+                    ops.layerscale_grad(self.W16(pre + "mlp.fc2.weight", D, Hd), self.G(pre + "mlp.fc2.weight").view(D, Hd),
+                                        self.P(pre + "mlp.fc2.bias"), self.G(pre + "mlp.fc2.bias"),
+                                        self.P(pre + "gamma_2"), D, Hd, self.G(pre + "gamma_2"))
+                self._wgrad(self.dbig, a["h2"], M, Hd, D, pre + "mlp.fc1.weight")
+                self._side_read_done("dbig")
+            self._on_side(wg_mlp)
             ops.gemm_nt(self.dbig, self.wT[i]["fc1"], M, D, Hd, ops.EPI_BIAS_BF16, out0=self.dh_small)
             scr = self.bias_scr[i & 1]
             if fuse:
                 # norm2 backward + attention-branch backward in one pass over dx (proj.bias column sums -> scr)
+                self._before_overwrite("dY2")
                 ops.layernorm_bwd_branch(self.dh_small, xmid, self.P(pre + "norm2.weight"), a["mean2"], a["rstd2"], dx,
                                          self.G(pre + "norm2.weight"), self.G(pre + "norm2.bias"), M, D, None,
-                                         self.P(pre + "gamma_1") if has_g else None, self.dY, None, scr,
+                                         self.P(pre + "gamma_1") if has_g else None, dY2, None, scr,
                                          rowmask=dp_masks[2 * i] if use_dp else None, keep_prob=keep, rows_per_sample=T)
             else:
                 ops.layernorm_bwd(self.dh_small, xmid, self.P(pre + "norm2.weight"), a["mean2"], a["rstd2"], dx,
@@ -431,29 +510,40 @@ class ViTEngine:
             # v_bias.grad = colsum(d attn_out) = colsum(dY) @ W_proj: one 768x768 GEMV instead of column
             # sums inside the attention kernel (which cost it 32 VGPRs and its occupancy).
             if not fuse:
-                ops.branch_bwd(dx, None, self.P(pre + "gamma_1") if has_g else None, self.dY, None, scr, M, D,
+                self._before_overwrite("dY2")
+                ops.branch_bwd(dx, None, self.P(pre + "gamma_1") if has_g else None, dY2, None, scr, M, D,
                                rowmask=dp_masks[2 * i] if use_dp else None, keep_prob=keep, rows_per_sample=T)
-            ops.gemm_nt(self.dY, self.wT[i]["proj"], M, D, D, ops.EPI_BIAS_BF16, out0=self.dao)
+            ops.gemm_nt(dY2, self.wT[i]["proj"], M, D, D, ops.EPI_BIAS_BF16, out0=self.dao)
             ops.gemv_acc(self.wT[i]["proj"], D, D, scr, self.G(pre + "attn.v_bias"),
                          x_acc=self.G(pre + "attn.proj.bias"), zero=self.bias_scr[(i & 1) ^ 1])
-            self._wgrad(self.dY, a["ao"], M, D, D, pre + "attn.proj.weight")
-            if has_g:
-                ops.layerscale_grad(self.W16(pre + "attn.proj.weight", D, D), self.G(pre + "attn.proj.weight").view(D, D),
-                                    self.P(pre + "attn.proj.bias"), self.G(pre + "attn.proj.bias"),
-                                    self.P(pre + "gamma_1"), D, D, self.G(pre + "gamma_1"))
+
+            def wg_proj(pre=pre, a=a, has_g=has_g):
+                self._wgrad(dY2, a["ao"], M, D, D, pre + "attn.proj.weight")
+                self._side_read_done("dY2")
+                if has_g:
+                    ops.layerscale_grad(self.W16(pre + "attn.proj.weight", D, D), self.G(pre + "attn.proj.weight").view(D, D),
+                                        self.P(pre + "attn.proj.bias"), self.G(pre + "attn.proj.bias"),
+                                        self.P(pre + "gamma_1"), D, D, self.G(pre + "gamma_1"))
+            self._on_side(wg_proj)
             ops.attn_delta(self.dao, a["ao"], M, self.heads, self.delta_ws)
+            self._before_overwrite("dqkv")
             ops.attn_bwd(a["qkv"], self.dao, a["lse"], self.delta_ws, table, self.window, B, T, D, self.heads,
                          self.scale, self.dqkv, dtable, dq_bias=self.G(pre + "attn.q_bias"))
-            self._wgrad(self.dqkv, a["h1"], M, 3 * D, D, pre + "attn.qkv.weight")
+
+            def wg_qkv(pre=pre, a=a):
+                self._wgrad(self.dqkv, a["h1"], M, 3 * D, D, pre + "attn.qkv.weight")
+                self._side_read_done("dqkv")
+            self._on_side(wg_qkv)
             ops.gemm_nt(self.dqkv, self.wT[i]["qkv"], M, D, 3 * D, ops.EPI_BIAS_BF16, out0=self.dh_small)
             if fuse and i > 0:
                 # norm1 backward of block i + MLP-branch backward of block i-1 in one pass over dx
                 pb, ab_, bb_ = f"blocks.{i - 1}.", self.act[i - 1], self.model.blocks[i - 1]
                 has_gb = (pb + "gamma_1") in self.segs
                 use_dpb = dp_masks is not None and bb_.drop_prob > 0.0
+                self._before_overwrite("dY")
                 ops.layernorm_bwd_branch(self.dh_small, xin, self.P(pre + "norm1.weight"), a["mean1"], a["rstd1"], dx,
                                          self.G(pre + "norm1.weight"), self.G(pre + "norm1.bias"), M, D, None,
-                                         self.P(pb + "gamma_2") if has_gb else None, self.dY, None,
+                                         self.P(pb + "gamma_2") if has_gb else None, dY, None,
                                          self.G(pb + "mlp.fc2.bias"),
                                          rowmask=dp_masks[2 * (i - 1) + 1] if use_dpb else None,
                                          keep_prob=1.0 - bb_.drop_prob, rows_per_sample=T)
@@ -461,14 +551,16 @@ class ViTEngine:
                 ops.layernorm_bwd(self.dh_small, xin, self.P(pre + "norm1.weight"), a["mean1"], a["rstd1"], dx,
                                   self.G(pre + "norm1.weight"), self.G(pre + "norm1.bias"), M, D, accumulate=True)
             if self.grad_hook:
+                self._side_join()
                 self.grad_hook(self.depth - i)
         # ---- embedding
         if self.has_pos:
             self.G("pos_embed").view(T, D).copy_(dx[:M].view(B, T, D).sum(0))
         ops.embed_bwd(dx, c["mask"], B, L, D, self.dYpe, self.G("cls_token"),
                       self.G("mask_token") if "mask_token" in self.segs else self.zero_vec)
-        self._wgrad(self.dYpe, self.patches, B * L, D, self.Kpe, "patch_embed.proj.weight",
-                    bias_grads=((self.G("patch_embed.proj.bias"), 0, D),))
+        self._on_side(lambda: self._wgrad(self.dYpe, self.patches, B * L, D, self.Kpe, "patch_embed.proj.weight",
+                                          bias_grads=((self.G("patch_embed.proj.bias"), 0, D),)))
+        self._side_join()                                     # every gradient is final on the main stream from here on
         if self.grad_hook:
             self.grad_hook(self.depth + 1)
 
