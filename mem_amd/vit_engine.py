@@ -73,6 +73,7 @@ class ViTEngine:
         # launch leaves idle in its last partial round of tiles (N = 768: 591 tiles on 256 CUs) pick up workgroups of
         # the other stream's launch instead of waiting.  Results are identical (same kernels, same operands).
         self.wgrad_side_stream = True
+        self.fwd_two_streams = True       # forward: the two halves of the batch on two streams (see forward_trunk)
         self._side = None
         self._ev_pool, self._ev_i = [], 0
 
@@ -294,6 +295,37 @@ class ViTEngine:
                               write_grad=True)
         return self.logits[:Mm]
 
+    def _block_fwd(self, i, b0, b1, dp_masks):
+        """Block i on the samples [b0, b1) (mem/modeling_finetune.py:160-189)."""
+        D, Hd, T = self.D, self.hidden, self.T
+        r0, r1 = b0 * T, b1 * T
+        M, Bs = r1 - r0, b1 - b0
+        pre = f"blocks.{i}."
+        a = self.act[i]
+        table = self.table(i)
+        blk = self.model.blocks[i]
+        keep = 1.0 - blk.drop_prob
+        use_dp = dp_masks is not None and blk.drop_prob > 0.0
+        xin, xmid, xout = self.x[2 * i][r0:r1], self.x[2 * i + 1][r0:r1], self.x[2 * i + 2][r0:r1]
+        g1 = self.P(pre + "gamma_1") if (pre + "gamma_1") in self.segs else None
+        g2 = self.P(pre + "gamma_2") if (pre + "gamma_2") in self.segs else None
+        h1, qkv, ao, h2, hpre, aa = (a[k][r0:r1] for k in ("h1", "qkv", "ao", "h2", "hpre", "a"))
+        ops.layernorm_fwd(xin, self.P(pre + "norm1.weight"), self.P(pre + "norm1.bias"), h1, a["mean1"][r0:r1],
+                          a["rstd1"][r0:r1], M, D)
+        ops.gemm_nt(h1, self.W16(pre + "attn.qkv.weight", 3 * D, D), M, 3 * D, D, ops.EPI_BIAS_BF16,
+                    out0=qkv, bias=self.P(pre + "attn.qkvbias3"), colscale=self.scale, colscale_n=D)
+        ops.attn_fwd(qkv, Bs, T, D, self.heads, table, self.window, ao, a["lse"][b0:b1])
+        ops.gemm_nt(ao, self.W16(pre + "attn.proj.weight", D, D), M, D, D, ops.EPI_RESIDUAL, out0=None,
+                    bias=self.P(pre + "attn.proj.bias"), vec1=g1, resid=xmid, aux=xin, ldaux=D,
+                    rowmask=dp_masks[2 * i][b0:b1] if use_dp else None, keep_prob=keep, rows_per_sample=T)
+        ops.layernorm_fwd(xmid, self.P(pre + "norm2.weight"), self.P(pre + "norm2.bias"), h2, a["mean2"][r0:r1],
+                          a["rstd2"][r0:r1], M, D)
+        ops.gemm_nt(h2, self.W16(pre + "mlp.fc1.weight", Hd, D), M, Hd, D, self.epi_gelu, out0=hpre,
+                    out1=aa, bias=self.P(pre + "mlp.fc1.bias"))
+        ops.gemm_nt(aa, self.W16(pre + "mlp.fc2.weight", D, Hd), M, D, Hd, ops.EPI_RESIDUAL, out0=None,
+                    bias=self.P(pre + "mlp.fc2.bias"), vec1=g2, resid=xout, aux=xmid, ldaux=D,
+                    rowmask=dp_masks[2 * i + 1][b0:b1] if use_dp else None, keep_prob=keep, rows_per_sample=T)
+
     def forward_trunk(self, x, mask_u8=None, dp_masks=None):
         """Patch embedding (+ mask-token blend, + abs. position embedding) and the blocks: x f32 [B,C,H,W] ->
         the fp32 residual stream after the last block, [B*T, D] (engine-owned, valid until the next forward)."""
@@ -320,31 +352,27 @@ class ViTEngine:
                     resid=x0, aux=mask_u8, rows_per_sample=L, ldaux=0)
         if self.has_pos:
             x0[:M].view(B, T, D).add_(self.P("pos_embed").view(1, T, D))
-        for i in range(self.depth):
-            pre = f"blocks.{i}."
-            a = self.act[i]
-            table = self.table(i)
-            blk = self.model.blocks[i]
-            keep = 1.0 - blk.drop_prob
-            use_dp = dp_masks is not None and blk.drop_prob > 0.0
-            xin, xmid, xout = self.x[2 * i], self.x[2 * i + 1], self.x[2 * i + 2]
-            g1 = self.P(pre + "gamma_1") if (pre + "gamma_1") in self.segs else None
-            g2 = self.P(pre + "gamma_2") if (pre + "gamma_2") in self.segs else None
-            ops.layernorm_fwd(xin, self.P(pre + "norm1.weight"), self.P(pre + "norm1.bias"), a["h1"], a["mean1"],
-                              a["rstd1"], M, D)
-            ops.gemm_nt(a["h1"], self.W16(pre + "attn.qkv.weight", 3 * D, D), M, 3 * D, D, ops.EPI_BIAS_BF16,
-                        out0=a["qkv"], bias=self.P(pre + "attn.qkvbias3"), colscale=self.scale, colscale_n=D)
-            ops.attn_fwd(a["qkv"], B, T, D, self.heads, table, self.window, a["ao"], a["lse"])
-            ops.gemm_nt(a["ao"], self.W16(pre + "attn.proj.weight", D, D), M, D, D, ops.EPI_RESIDUAL, out0=None,
-                        bias=self.P(pre + "attn.proj.bias"), vec1=g1, resid=xmid, aux=xin, ldaux=D,
-                        rowmask=dp_masks[2 * i] if use_dp else None, keep_prob=keep, rows_per_sample=T)
-            ops.layernorm_fwd(xmid, self.P(pre + "norm2.weight"), self.P(pre + "norm2.bias"), a["h2"], a["mean2"],
-                              a["rstd2"], M, D)
-            ops.gemm_nt(a["h2"], self.W16(pre + "mlp.fc1.weight", Hd, D), M, Hd, D, self.epi_gelu, out0=a["hpre"],
-                        out1=a["a"], bias=self.P(pre + "mlp.fc1.bias"))
-            ops.gemm_nt(a["a"], self.W16(pre + "mlp.fc2.weight", D, Hd), M, D, Hd, ops.EPI_RESIDUAL, out0=None,
-                        bias=self.P(pre + "mlp.fc2.bias"), vec1=g2, resid=xout, aux=xmid, ldaux=D,
-                        rowmask=dp_masks[2 * i + 1] if use_dp else None, keep_prob=keep, rows_per_sample=T)
+        # Two sample-halves on two HIP streams (forward ops are independent per sample): the halves' persistent GEMM
+        # launches interleave on the CUs, so the workgroups of one launch fill the partial last round of the other and
+        # the HBM-bound epilogue phase of one half runs beside the MFMA-bound main loop of the other.  Same kernels on
+        # the same rows: results are identical to the single-stream order.
+        split = (self.fwd_two_streams and B >= 64 and B % 2 == 0 and ops.GEMM_TIMER is None)
+        if split:
+            if self._side is None:
+                self._side = torch.cuda.Stream(device=self.dev)
+            e0 = torch.cuda.Event()
+            e0.record()
+            self._side.wait_event(e0)
+            for i in range(self.depth):
+                self._block_fwd(i, 0, B // 2, dp_masks)
+                with torch.cuda.stream(self._side):
+                    self._block_fwd(i, B // 2, B, dp_masks)
+            e1 = torch.cuda.Event()
+            e1.record(self._side)
+            torch.cuda.current_stream().wait_event(e1)
+        else:
+            for i in range(self.depth):
+                self._block_fwd(i, 0, B, dp_masks)
         return self.x[2 * self.depth]
 
     # ------------------------------------------------------------------ backward
@@ -374,6 +402,8 @@ class ViTEngine:
         self._side_reads = {}
         if self._use_side and self._side is None:
             self._side = torch.cuda.Stream(device=self.dev)
+        if self._use_side and getattr(self, "_ws_for", None) != (self.B, getattr(self, "Mm_cap", 0)):
+            self._ws_for = (self.B, getattr(self, "Mm_cap", 0))
             # the wgrad workspace is sized once so that it is never reallocated while the side stream uses it
             D, Hd = self.D, self.hidden
             M = self.B * self.T
