@@ -419,6 +419,26 @@ int memhip_f32_attn_bwd(const float* qkv, int64_t ldqkv, const float* dout, int6
                         float scale, const float* table, const int32_t* index, float* dqkv, int64_t lddqkv, float* dtable,
                         memhip_stream_t stream);
 
+/* MAE variant (`--mae 1`), fp32 path: token plumbing and loss around the generic blocks above
+ * replaces random_masking gather / mask-token unshuffle / forward_loss     mem/modeling_mae.py:204-292
+ *   enc_assemble: out [B,(K+1),D]: row (b,0) = cls + pos[0]; row (b,1+j) = xe[b, ids_keep[b,j]] + pos[1 + ids_keep[b,j]]
+ *   dec_assemble: out [B,(L+1),D]: row (b,0) = y[b,0] + dpos[0]; row (b,1+l) = (r < K ? y[b,1+r] : mask_token) + dpos[1+l],
+ *                 r = ids_restore[b,l]
+ *   *_bwd: the exact transposes (dxe is zeroed inside; dcls / dmask_token accumulate)
+ *   mae_loss: pred [B,(L+1),p*p*C] (cls row ignored) vs patchify(img) ('nchpwq->nhwpqc'); row_loss [B,L] = per-patch mean
+ *             squared error times its weight (only_masked: mask / sum(mask), else 1), dpred = gradient of the summed loss;
+ *             scratch2[0] = sum(mask), scratch2[1] = loss. */
+int memhip_mae_enc_assemble(const float* xe, const float* pos, const float* cls, const int64_t* ids_keep, int B, int L, int K,
+                            int D, float* out, memhip_stream_t stream);
+int memhip_mae_enc_assemble_bwd(const float* dx, const int64_t* ids_keep, int B, int L, int K, int D, float* dxe, float* dcls,
+                                memhip_stream_t stream);
+int memhip_mae_dec_assemble(const float* y, const float* mask_token, const float* dpos, const int64_t* ids_restore, int B, int L,
+                            int K, int D, float* out, memhip_stream_t stream);
+int memhip_mae_dec_assemble_bwd(const float* dxd, const int64_t* ids_restore, int B, int L, int K, int D, float* dy,
+                                float* dmask_token, memhip_stream_t stream);
+int memhip_mae_loss(const float* pred, const float* img, const float* mask, int B, int C, int H, int W, int patch,
+                    int only_masked, float* row_loss, float* dpred, float* scratch2, memhip_stream_t stream);
+
 /* ------------------------------------------------------------------------
  * Frozen dVAE tokenizer forward
  * replaces DiscreteVAE.get_codebook_indices          eventvae/vae/vae_model.py:153-158

@@ -565,3 +565,157 @@ extern "C" int memhip_f32_attn_bwd(const float* qkv, int64_t ldqkv, const float*
   else return fail(MEMHIP_EUNSUPPORTED, "attn_bwd_f32: head_dim %d (32 or 64)", hd);
   return check_launch("attn_bwd_f32");
 }
+
+// ---------------------------------------------------------------- MAE token plumbing + loss (mem/modeling_mae.py:204-292)
+namespace {
+
+// encoder input: row (b, 0) = cls + pos[0]; row (b, 1 + j) = xe[b, ids_keep[b, j]] + pos[1 + ids_keep[b, j]]
+__global__ __launch_bounds__(256) void mae_enc_assemble_kernel(const float* __restrict__ xe, const float* __restrict__ pos,
+                                                               const float* __restrict__ cls, const long long* __restrict__ ids_keep,
+                                                               int B, int L, int K, int D, float* __restrict__ out) {
+  const int row = blockIdx.x;                       // b * (K + 1) + t
+  const int b = row / (K + 1), t = row - b * (K + 1);
+  float* o = out + (long long)row * D;
+  if (t == 0) {
+    for (int c = threadIdx.x; c < D; c += 256) o[c] = cls[c] + pos[c];
+  } else {
+    const long long l = ids_keep[(long long)b * K + t - 1];
+    const float* s = xe + ((long long)b * L + l) * D;
+    const float* p = pos + (1 + l) * D;
+    for (int c = threadIdx.x; c < D; c += 256) o[c] = s[c] + p[c];
+  }
+}
+// backward: dxe[b, ids_keep[b, j]] = dx[b, 1 + j] (dxe pre-zeroed), dcls += dx[b, 0]
+__global__ __launch_bounds__(256) void mae_enc_assemble_bwd_kernel(const float* __restrict__ dx, const long long* __restrict__ ids_keep,
+                                                                   int B, int L, int K, int D, float* __restrict__ dxe,
+                                                                   float* __restrict__ dcls) {
+  const int row = blockIdx.x;
+  const int b = row / (K + 1), t = row - b * (K + 1);
+  const float* g = dx + (long long)row * D;
+  if (t == 0) {
+    for (int c = threadIdx.x; c < D; c += 256) atomicAdd(dcls + c, g[c]);
+  } else {
+    float* o = dxe + ((long long)b * L + ids_keep[(long long)b * K + t - 1]) * D;
+    for (int c = threadIdx.x; c < D; c += 256) o[c] = g[c];
+  }
+}
+// decoder input: row (b, 0) = y[b, 0] + dpos[0]; row (b, 1 + l) = (r < K ? y[b, 1 + r] : mask_token) + dpos[1 + l], r = ids_restore[b, l]
+__global__ __launch_bounds__(256) void mae_dec_assemble_kernel(const float* __restrict__ y, const float* __restrict__ mask_token,
+                                                               const float* __restrict__ dpos, const long long* __restrict__ ids_restore,
+                                                               int B, int L, int K, int D, float* __restrict__ out) {
+  const int row = blockIdx.x;                       // b * (L + 1) + t
+  const int b = row / (L + 1), t = row - b * (L + 1);
+  float* o = out + (long long)row * D;
+  const float* p = dpos + (long long)t * D;
+  const float* s;
+  if (t == 0) s = y + (long long)b * (K + 1) * D;
+  else {
+    const long long r = ids_restore[(long long)b * L + t - 1];
+    s = r < K ? y + ((long long)b * (K + 1) + 1 + r) * D : mask_token;
+  }
+  for (int c = threadIdx.x; c < D; c += 256) o[c] = s[c] + p[c];
+}
+__global__ __launch_bounds__(256) void mae_dec_assemble_bwd_kernel(const float* __restrict__ dxd, const long long* __restrict__ ids_restore,
+                                                                   int B, int L, int K, int D, float* __restrict__ dy,
+                                                                   float* __restrict__ dmask_token) {
+  const int row = blockIdx.x;
+  const int b = row / (L + 1), t = row - b * (L + 1);
+  const float* g = dxd + (long long)row * D;
+  if (t == 0) {
+    float* o = dy + (long long)b * (K + 1) * D;
+    for (int c = threadIdx.x; c < D; c += 256) o[c] = g[c];
+  } else {
+    const long long r = ids_restore[(long long)b * L + t - 1];
+    if (r < K) {
+      float* o = dy + ((long long)b * (K + 1) + 1 + r) * D;
+      for (int c = threadIdx.x; c < D; c += 256) o[c] = g[c];
+    } else {
+      for (int c = threadIdx.x; c < D; c += 256) atomicAdd(dmask_token + c, g[c]);
+    }
+  }
+}
+// loss: pred [B*(L+1), P] (row (b,0) = cls, ignored), target = patchify(imgs) ('nchpwq->nhwpqc'); per-patch mean squared
+// error; only_masked: sum(loss * mask) / sum(mask), else sum over all patches.  dpred written in place of nothing: separate buffer.
+__global__ __launch_bounds__(256) void mae_loss_kernel(const float* __restrict__ pred, const float* __restrict__ img,
+                                                       const float* __restrict__ mask, int B, int C, int H, int W, int p,
+                                                       int only_masked, const float* __restrict__ mask_sum,
+                                                       float* __restrict__ row_loss, float* __restrict__ dpred) {
+  const int gw = W / p, L = (H / p) * gw, P = p * p * C;
+  const int row = blockIdx.x;                       // b * (L + 1) + t
+  const int b = row / (L + 1), t = row - b * (L + 1);
+  float* d = dpred + (long long)row * P;
+  if (t == 0) {
+    for (int k = threadIdx.x; k < P; k += 256) d[k] = 0.f;
+    return;
+  }
+  const int l = t - 1, gy = l / gw, gx = l - gy * gw;
+  const float m = mask[(long long)b * L + l];
+  const float wgt = only_masked ? m / mask_sum[0] : 1.0f;
+  const float* pr = pred + (long long)row * P;
+  float s = 0.f;
+  for (int k = threadIdx.x; k < P; k += 256) {
+    const int c = k % C, q = (k / C) % p, py = k / (C * p);
+    const float tg = img[(((long long)b * C + c) * H + gy * p + py) * W + gx * p + q];
+    const float e = pr[k] - tg;
+    s += e * e;
+    d[k] = 2.0f * e / (float)P * wgt;
+  }
+  __shared__ float sh[4];
+  s = wsumf(s);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) row_loss[(long long)b * L + l] = (sh[0] + sh[1] + sh[2] + sh[3]) / (float)P * wgt;
+}
+__global__ __launch_bounds__(256) void sum_f32_kernel(const float* __restrict__ x, long long n, float* __restrict__ out) {
+  __shared__ double sh[256];
+  double s = 0.0;
+  for (long long i = threadIdx.x; i < n; i += 256) s += x[i];
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) { double t = 0; for (int i = 0; i < 256; ++i) t += sh[i]; out[0] = (float)t; }
+}
+
+}  // namespace
+
+extern "C" int memhip_mae_enc_assemble(const float* xe, const float* pos, const float* cls, const int64_t* ids_keep, int B, int L,
+                                       int K, int D, float* out, memhip_stream_t stream) {
+  MEMHIP_REQUIRE(B > 0 && L > 0 && K > 0 && K <= L && D > 0 && xe && pos && cls && ids_keep && out, "mae_enc_assemble: bad arguments");
+  hipLaunchKernelGGL(mae_enc_assemble_kernel, dim3(B * (K + 1)), dim3(256), 0, as_stream(stream), xe, pos, cls,
+                     (const long long*)ids_keep, B, L, K, D, out);
+  return check_launch("mae_enc_assemble");
+}
+extern "C" int memhip_mae_enc_assemble_bwd(const float* dx, const int64_t* ids_keep, int B, int L, int K, int D, float* dxe,
+                                           float* dcls, memhip_stream_t stream) {
+  MEMHIP_REQUIRE(B > 0 && L > 0 && K > 0 && D > 0 && dx && ids_keep && dxe && dcls, "mae_enc_assemble_bwd: bad arguments");
+  hipStream_t s = as_stream(stream);
+  MEMHIP_HIP(hipMemsetAsync(dxe, 0, (size_t)B * L * D * sizeof(float), s));
+  hipLaunchKernelGGL(mae_enc_assemble_bwd_kernel, dim3(B * (K + 1)), dim3(256), 0, s, dx, (const long long*)ids_keep, B, L, K, D,
+                     dxe, dcls);
+  return check_launch("mae_enc_assemble_bwd");
+}
+extern "C" int memhip_mae_dec_assemble(const float* y, const float* mask_token, const float* dpos, const int64_t* ids_restore, int B,
+                                       int L, int K, int D, float* out, memhip_stream_t stream) {
+  MEMHIP_REQUIRE(B > 0 && L > 0 && K > 0 && D > 0 && y && mask_token && dpos && ids_restore && out, "mae_dec_assemble: bad arguments");
+  hipLaunchKernelGGL(mae_dec_assemble_kernel, dim3(B * (L + 1)), dim3(256), 0, as_stream(stream), y, mask_token, dpos,
+                     (const long long*)ids_restore, B, L, K, D, out);
+  return check_launch("mae_dec_assemble");
+}
+extern "C" int memhip_mae_dec_assemble_bwd(const float* dxd, const int64_t* ids_restore, int B, int L, int K, int D, float* dy,
+                                           float* dmask_token, memhip_stream_t stream) {
+  MEMHIP_REQUIRE(B > 0 && L > 0 && K > 0 && D > 0 && dxd && ids_restore && dy && dmask_token, "mae_dec_assemble_bwd: bad arguments");
+  hipLaunchKernelGGL(mae_dec_assemble_bwd_kernel, dim3(B * (L + 1)), dim3(256), 0, as_stream(stream), dxd,
+                     (const long long*)ids_restore, B, L, K, D, dy, dmask_token);
+  return check_launch("mae_dec_assemble_bwd");
+}
+extern "C" int memhip_mae_loss(const float* pred, const float* img, const float* mask, int B, int C, int H, int W, int patch,
+                               int only_masked, float* row_loss, float* dpred, float* scratch2, memhip_stream_t stream) {
+  MEMHIP_REQUIRE(B > 0 && C > 0 && H % patch == 0 && W % patch == 0 && pred && img && mask && row_loss && dpred && scratch2,
+                 "mae_loss: bad arguments");
+  hipStream_t s = as_stream(stream);
+  const int L = (H / patch) * (W / patch);
+  hipLaunchKernelGGL(sum_f32_kernel, dim3(1), dim3(256), 0, s, mask, (long long)B * L, scratch2);          // sum(mask)
+  hipLaunchKernelGGL(mae_loss_kernel, dim3(B * (L + 1)), dim3(256), 0, s, pred, img, mask, B, C, H, W, patch, only_masked,
+                     scratch2, row_loss, dpred);
+  hipLaunchKernelGGL(sum_f32_kernel, dim3(1), dim3(256), 0, s, row_loss, (long long)B * L, scratch2 + 1);  // the loss
+  return check_launch("mae_loss");
+}

@@ -19,7 +19,7 @@ import torch
 from . import utils
 
 
-def _prep_batch(batch, device, model, d_vae):
+def _prep_batch(batch, device, model, d_vae, MAE=False):
     if isinstance(batch, dict):
         # raw batch (datasets.RawEventDataset.collate): one upload of the events, then the whole transform chain of
         # build_transformNPY + ColorJitter on the GPU (augment.BatchAugPipeline); patches IS visual_tokens for
@@ -33,6 +33,8 @@ def _prep_batch(batch, device, model, d_vae):
         images = images.to(device, non_blocking=True)
         samples = samples.to(device, non_blocking=True)
         bool_masked_pos = bool_masked_pos.to(device, non_blocking=True)
+    if MAE:                                          # engine_for_pretraining.py:141-142: no tokenizer, 3-channel images
+        return samples, images, bool_masked_pos.flatten(1).to(torch.bool), None
     with torch.no_grad():
         bool_masked_pos = bool_masked_pos.flatten(1).to(torch.bool)
         input_ids = d_vae.get_codebook_indices(images).flatten(1)       # (B, 14*14)
@@ -71,8 +73,6 @@ def train_one_epoch(model: torch.nn.Module, d_vae: torch.nn.Module, data_loader:
                     device: torch.device, epoch: int, loss_scaler, max_norm: float = 0, log_writer=None,
                     lr_scheduler=None, start_steps=None, lr_schedule_values=None, wd_schedule_values=None,
                     run=None, args=None, plotting=False, MAE=False):
-    if MAE:
-        raise NotImplementedError("--mae 1 (modeling_mae.py) is outside this round (SURVEY.md section 8 row f4)")
     model.train()
     metric_logger = utils.MetricLogger(delimiter="  ")
     metric_logger.add_meter("lr", utils.SmoothedValue(window_size=1, fmt="{value:.6f}"))
@@ -90,8 +90,11 @@ def train_one_epoch(model: torch.nn.Module, d_vae: torch.nn.Module, data_loader:
                     param_group["lr"] = lr_schedule_values[it] * param_group["lr_scale"]
                 if wd_schedule_values is not None and param_group["weight_decay"] > 0:
                     param_group["weight_decay"] = wd_schedule_values[it]
-        samples, images, bool_masked_pos, labels = _prep_batch(batch, device, model, d_vae)
-        loss_acc = model.forward_loss(samples, bool_masked_pos, labels)
+        samples, images, bool_masked_pos, labels = _prep_batch(batch, device, model, d_vae, MAE)
+        if MAE:
+            loss_acc = model.forward_loss(samples)                  # loss, pred, mask = model(samples) (:149); mlm_acc = 0
+        else:
+            loss_acc = model.forward_loss(samples, bool_masked_pos, labels)
         model._fused_loss_pending = True
         grad_norm = loss_scaler(loss_acc, optimizer, clip_grad=max_norm, parameters=model.parameters(),
                                 model=model, reducer=reducer)
@@ -118,14 +121,12 @@ def train_one_epoch(model: torch.nn.Module, d_vae: torch.nn.Module, data_loader:
 
 @torch.no_grad()
 def evaluate(data_loader, model, d_vae, device, args, plotting=False, MAE=False):
-    if MAE:
-        raise NotImplementedError("--mae 1 is outside this round (SURVEY.md section 8 row f4)")
     metric_logger = utils.MetricLogger(delimiter="  ")
     header = "Test:"
     model.eval()
     for batch in metric_logger.log_every(data_loader, 10, header):
-        samples, images, bool_masked_pos, labels = _prep_batch(batch[0], device, model, d_vae)
-        la = model.forward_loss(samples, bool_masked_pos, labels).tolist()
+        samples, images, bool_masked_pos, labels = _prep_batch(batch[0], device, model, d_vae, MAE)
+        la = (model.forward_loss(samples) if MAE else model.forward_loss(samples, bool_masked_pos, labels)).tolist()
         metric_logger.update(loss=la[0])
         metric_logger.meters["mlm_acc"].update(la[1])
     metric_logger.synchronize_between_processes()

@@ -368,3 +368,36 @@ def f32_attn_fwd(qkv, B, T, D, heads, table, index, out, lse=None):
 def f32_attn_bwd(qkv, dout, B, T, D, heads, scale, table, index, dqkv, dtable):
     check(lib.memhip_f32_attn_bwd(ptr(qkv), qkv.stride(0), ptr(dout), dout.stride(0), B, T, D, heads, scale, ptr(table),
                                   ptr(index), ptr(dqkv), dqkv.stride(0), ptr(dtable), stream_ptr()), "f32_attn_bwd")
+
+
+# ---------------------------------------------------------------- MAE plumbing (csrc/fp32_path.hip)
+declare({
+    "memhip_mae_enc_assemble": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, vp, vp]),
+    "memhip_mae_enc_assemble_bwd": (i32, [vp, vp, i32, i32, i32, i32, vp, vp, vp]),
+    "memhip_mae_dec_assemble": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, vp, vp]),
+    "memhip_mae_dec_assemble_bwd": (i32, [vp, vp, i32, i32, i32, i32, vp, vp, vp]),
+    "memhip_mae_loss": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp]),
+})
+
+
+def mae_enc_assemble(xe, pos, cls, ids_keep, B, L, K, D, out):
+    check(lib.memhip_mae_enc_assemble(ptr(xe), ptr(pos), ptr(cls), ptr(ids_keep), B, L, K, D, ptr(out), stream_ptr()), "mae_enc_assemble")
+
+
+def mae_enc_assemble_bwd(dx, ids_keep, B, L, K, D, dxe, dcls):
+    check(lib.memhip_mae_enc_assemble_bwd(ptr(dx), ptr(ids_keep), B, L, K, D, ptr(dxe), ptr(dcls), stream_ptr()), "mae_enc_assemble_bwd")
+
+
+def mae_dec_assemble(y, mask_token, dpos, ids_restore, B, L, K, D, out):
+    check(lib.memhip_mae_dec_assemble(ptr(y), ptr(mask_token), ptr(dpos), ptr(ids_restore), B, L, K, D, ptr(out), stream_ptr()),
+          "mae_dec_assemble")
+
+
+def mae_dec_assemble_bwd(dxd, ids_restore, B, L, K, D, dy, dmask_token):
+    check(lib.memhip_mae_dec_assemble_bwd(ptr(dxd), ptr(ids_restore), B, L, K, D, ptr(dy), ptr(dmask_token), stream_ptr()),
+          "mae_dec_assemble_bwd")
+
+
+def mae_loss(pred, img, mask, B, Cc, H, W, patch, only_masked, row_loss, dpred, scratch2):
+    check(lib.memhip_mae_loss(ptr(pred), ptr(img), ptr(mask), B, Cc, H, W, patch, int(only_masked), ptr(row_loss), ptr(dpred),
+                              ptr(scratch2), stream_ptr()), "mae_loss")

@@ -169,8 +169,6 @@ def main(args):
     utils.init_distributed_mode(args)
     print("Running", f"{args.expweek}_{args.expname}")
     print(args)
-    if args.MAE:
-        raise NotImplementedError("--mae 1 is outside this round (SURVEY.md section 8 row f4)")
     if bool(args.pretrained):
         raise NotImplementedError("--pretrained 1 downloads timm ImageNet weights: no network here")
     device = torch.device(args.device)
@@ -180,6 +178,11 @@ def main(args):
     input_size = (args.input_H, args.input_W)
     second_input_size = (args.input_H2, args.input_W2)
     model = get_model(args)
+    if args.MAE:                                         # run_mem_pretraining.py:231-232,275-276
+        from .modeling_mae import mae_vit_base_patch16_dec512d8b
+        assert args.input_H == args.input_W, "the MAE variant patchifies square images (modeling_mae.py:169)"
+        model = mae_vit_base_patch16_dec512d8b(norm_pix_loss=0, LOSS_ONLY_MASKED_MAE=True, img_size=args.input_H)
+        print("Using MAE loss (fp32 kernels: mem_amd/modeling_mae.py)")
     patch_size = model.patch_embed.patch_size
     print("Patch size = %s" % str(patch_size))
     args.window_size = (input_size[0] // patch_size[0], input_size[1] // patch_size[1])
