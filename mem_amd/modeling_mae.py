@@ -288,7 +288,7 @@ class MaeEngineF32:
         o, k = self.segs[name]
         return self.flat_g[o:o + k]
 
-    def W(self, name):
+    def Wm(self, name):
         p = self.named[name]
         o, k = self.segs[name]
         return self.flat_p[o:o + k].view(p.shape[0], -1)
@@ -308,7 +308,7 @@ class MaeEngineF32:
 
     def sync_weights(self):
         for n in self._lin_names():
-            w = self.W(n)
+            w = self.Wm(n)
             if n not in self.wT:
                 self.wT[n] = torch.empty((w.shape[1], w.shape[0]), dtype=torch.float32, device=self.dev)
             ops.f32_transpose(w, w.shape[0], w.shape[1], self.wT[n])
@@ -351,14 +351,14 @@ class MaeEngineF32:
         xin, xmid, xout = acts["x"][2 * i], acts["x"][2 * i + 1], acts["x"][2 * i + 2]
         scale = (D // heads) ** -0.5
         ops.f32_layernorm_fwd(xin, P(pre + "norm1.weight"), P(pre + "norm1.bias"), a["h1"], a["mean1"], a["rstd1"], M, D, eps=self.eps)
-        G(a["h1"], self.W(pre + "attn.qkv.weight"), M, 3 * D, D, ops.EPI_BIAS_BF16, out0=a["qkv"], bias=P(pre + "attn.qkv.bias"),
+        G(a["h1"], self.Wm(pre + "attn.qkv.weight"), M, 3 * D, D, ops.EPI_BIAS_BF16, out0=a["qkv"], bias=P(pre + "attn.qkv.bias"),
           colscale=scale, colscale_n=D)
         ops.f32_attn_fwd(a["qkv"], B, T, D, heads, None, None, a["ao"])
-        G(a["ao"], self.W(pre + "attn.proj.weight"), M, D, D, ops.EPI_RESIDUAL, bias=P(pre + "attn.proj.bias"), resid=xmid,
+        G(a["ao"], self.Wm(pre + "attn.proj.weight"), M, D, D, ops.EPI_RESIDUAL, bias=P(pre + "attn.proj.bias"), resid=xmid,
           aux=xin, ldaux=D, rows_per_sample=T)
         ops.f32_layernorm_fwd(xmid, P(pre + "norm2.weight"), P(pre + "norm2.bias"), a["h2"], a["mean2"], a["rstd2"], M, D, eps=self.eps)
-        G(a["h2"], self.W(pre + "mlp.fc1.weight"), M, Hd, D, ops.EPI_BIAS_GELU, out0=a["hpre"], out1=a["a"], bias=P(pre + "mlp.fc1.bias"))
-        G(a["a"], self.W(pre + "mlp.fc2.weight"), M, D, Hd, ops.EPI_RESIDUAL, bias=P(pre + "mlp.fc2.bias"), resid=xout, aux=xmid,
+        G(a["h2"], self.Wm(pre + "mlp.fc1.weight"), M, Hd, D, ops.EPI_BIAS_GELU, out0=a["hpre"], out1=a["a"], bias=P(pre + "mlp.fc1.bias"))
+        G(a["a"], self.Wm(pre + "mlp.fc2.weight"), M, D, Hd, ops.EPI_RESIDUAL, bias=P(pre + "mlp.fc2.bias"), resid=xout, aux=xmid,
           ldaux=D, rows_per_sample=T)
 
     def _wgrad(self, dY, X, R, n_out, n_in, gname):
@@ -410,20 +410,20 @@ class MaeEngineF32:
         L, T, D, Dd = self.L, self.T, self.D, self.Dd
         self.cur = dict(B=B, K=K, ids_keep=ids_keep, ids_restore=ids_restore, mask=mask, imgs=imgs)
         ops.f32_im2col(imgs, B, self.C, self.H, self.W, self.ph, self.pw, self.patches)
-        G(self.patches, self.W("patch_embed.proj.weight"), B * L, D, self.Kpe, ops.EPI_BIAS_BF16, out0=self.xe,
+        G(self.patches, self.Wm("patch_embed.proj.weight"), B * L, D, self.Kpe, ops.EPI_BIAS_BF16, out0=self.xe,
           bias=P("patch_embed.proj.bias"))
         ops.mae_enc_assemble(self.xe, m.pos_embed.data.view(T, D), P("cls_token"), ids_keep, B, L, K, D, self.ea["x"][0])
         for i in range(self.enc["depth"]):
             self._blk_fwd(self.enc, self.ea, i, B, K + 1)
         Me, Md = B * (K + 1), B * T
         ops.f32_layernorm_fwd(self.ea["x"][-1], P("norm.weight"), P("norm.bias"), self.latent, self.meanE, self.rstdE, Me, D, eps=self.eps)
-        G(self.latent, self.W("decoder_embed.weight"), Me, Dd, D, ops.EPI_BIAS_BF16, out0=self.yd, bias=P("decoder_embed.bias"))
+        G(self.latent, self.Wm("decoder_embed.weight"), Me, Dd, D, ops.EPI_BIAS_BF16, out0=self.yd, bias=P("decoder_embed.bias"))
         ops.mae_dec_assemble(self.yd, P("mask_token"), m.decoder_pos_embed.data.view(T, Dd), ids_restore, B, L, K, Dd, self.da["x"][0])
         for i in range(self.dec["depth"]):
             self._blk_fwd(self.dec, self.da, i, B, T)
         ops.f32_layernorm_fwd(self.da["x"][-1], P("decoder_norm.weight"), P("decoder_norm.bias"), self.hdn, self.meanD, self.rstdD,
                               Md, Dd, eps=self.eps)
-        G(self.hdn, self.W("decoder_pred.weight"), Md, self.Pp, Dd, ops.EPI_BIAS_BF16, out0=self.pred, bias=P("decoder_pred.bias"))
+        G(self.hdn, self.Wm("decoder_pred.weight"), Md, self.Pp, Dd, ops.EPI_BIAS_BF16, out0=self.pred, bias=P("decoder_pred.bias"))
         ops.mae_loss(self.pred, imgs, mask, B, self.C, self.H, self.W, self.ph, m.LOSS_ONLY_MASKED_MAE, self.row_loss, self.dpred,
                      self.scratch2)
         self.loss_acc[0:1].copy_(self.scratch2[1:2])
