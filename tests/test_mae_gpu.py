@@ -88,3 +88,21 @@ def test_mae_training_loop_and_factory(tmp_path):
     assert sd["pos_embed"].shape == (1, 197, 768) and sd["decoder_pos_embed"].shape == (1, 197, 512)
     assert sd["decoder_blocks.7.attn.qkv.weight"].shape == (1536, 512) and sd["decoder_pred.weight"].shape == (768, 512)
     assert len(b.blocks) == 12 and b.decoder_blocks[0].attn.num_heads == 16 and b.norm.eps == 1e-6
+
+
+def test_cli_mae_flag(tmp_path):
+    """`--mae 1` through the entrypoint (run_mem_pretraining.py:231-232,275-276): ViT-B MAE factory on 112^2 synthetic
+    event frames, one short epoch + eval, checkpoint and log written."""
+    import json
+    from mem_amd.run_mem_pretraining import get_args, main
+    out = tmp_path / "run"
+    out.mkdir()
+    args = get_args(["--expweek", "t", "--mae", "1", "--data_path", "synthetic", "--input_H", "112", "--input_W", "112",
+                     "--batch_size", "4", "--epochs", "1", "--warmup_epochs", "0", "--synthetic_samples", "8",
+                     "--num_workers", "0", "--output_dir", str(out), "--color_jitter", "0", "--rand_aug", "0",
+                     "--slice_max_evs", "5000", "--clip_grad", "3.0"])
+    main(args)
+    log = [json.loads(l) for l in open(out / "log.txt")]
+    assert len(log) == 1 and np.isfinite(log[0]["train_loss"]) and log[0]["train_mlm_acc"] == 0
+    sd = torch.load(next(p for p in out.iterdir() if p.name.startswith("checkpoint-")), map_location="cpu", weights_only=False)
+    assert "decoder_blocks.7.mlp.fc2.weight" in sd["model"] and "pos_embed" in sd["model"]
