@@ -73,7 +73,8 @@ class ViTEngine:
         # launch leaves idle in its last partial round of tiles (N = 768: 591 tiles on 256 CUs) pick up workgroups of
         # the other stream's launch instead of waiting.  Results are identical (same kernels, same operands).
         self.wgrad_side_stream = True
-        self.fwd_two_streams = True       # forward: the two halves of the batch on two streams (see forward_trunk)
+        self.fwd_two_streams = False      # forward: the two halves of the batch on two streams (see forward_trunk);
+                                          # measured -0.08 ms at B = 256 (within noise): off by default
         self._side = None
         self._ev_pool, self._ev_i = [], 0
 
