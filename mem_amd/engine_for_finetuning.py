@@ -50,8 +50,7 @@ def train_one_epoch(args, model: torch.nn.Module, criterion: torch.nn.Module, da
                     device: torch.device, epoch: int, loss_scaler, max_norm: float = 0, model_ema=None,
                     mixup_fn=None, log_writer=None, start_steps=None, lr_schedule_values=None,
                     wd_schedule_values=None, num_training_steps_per_epoch=None, update_freq=None):
-    if (update_freq or 1) != 1:
-        raise NotImplementedError("update_freq > 1: the fused engine's flat gradient buffer is rewritten every step")
+    update_freq = update_freq or 1
     if loss_scaler is None:
         raise NotImplementedError("the deepspeed branch (loss_scaler=None) is not part of the fused path")
     first_it = start_steps or 0
@@ -59,8 +58,14 @@ def train_one_epoch(args, model: torch.nn.Module, criterion: torch.nn.Module, da
     meters = utils.MetricLogger(delimiter="  ")
     for name in ("lr", "min_lr"):
         meters.add_meter(name, utils.SmoothedValue(window_size=1, fmt="{value:.6f}"))
+    eng = getattr(model, "engine", None)
+    if eng is not None:
+        # update_freq > 1 (engine_for_finetuning.py:78,117-124): micro-batch gradients ADD into the flat buffer; the
+        # optimizer.zero_grad() below is what clears it
+        eng.accumulate_grads = update_freq > 1
     optimizer.zero_grad()
-    for step, (samples, targets) in enumerate(meters.log_every(data_loader, 10, "Epoch: [{}]".format(epoch))):
+    for data_iter_step, (samples, targets) in enumerate(meters.log_every(data_loader, 10, "Epoch: [{}]".format(epoch))):
+        step = data_iter_step // update_freq
         if num_training_steps_per_epoch is not None and step >= num_training_steps_per_epoch:
             continue
         _apply_schedules(optimizer, first_it + step, lr_schedule_values, wd_schedule_values)
@@ -73,11 +78,14 @@ def train_one_epoch(args, model: torch.nn.Module, criterion: torch.nn.Module, da
             print("Loss is {}, stopping training".format(loss_value))
             sys.exit(1)
         # bf16: no loss scaling -- backward, fused clip, (grouped) AdamW; returns the pre-clip gradient norm
+        do_update = (data_iter_step + 1) % update_freq == 0
+        loss = loss / update_freq
         grad_norm = loss_scaler(loss, optimizer, clip_grad=max_norm, parameters=model.parameters(), create_graph=False,
-                                update_grad=True)
-        optimizer.zero_grad()
-        if model_ema is not None:
-            model_ema.update(model)
+                                update_grad=do_update)
+        if do_update:
+            optimizer.zero_grad()
+            if model_ema is not None:
+                model_ema.update(model)
         torch.cuda.synchronize()
         min_lr, max_lr, wd_now = _optimizer_stats(optimizer)
         stats = {"loss": loss_value,
@@ -90,6 +98,8 @@ def train_one_epoch(args, model: torch.nn.Module, criterion: torch.nn.Module, da
             for k, v in stats.items():
                 log_writer.update(head="loss" if k in ("loss", "class_acc") else "opt", **{k: v})
             log_writer.set_step()
+    if eng is not None:
+        eng.accumulate_grads = False
     meters.synchronize_between_processes()
     print("Averaged stats:", meters)
     return {k: meter.global_avg for k, meter in meters.meters.items()}

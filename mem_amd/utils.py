@@ -351,12 +351,50 @@ def _resize_pos_embed(pos_embed_checkpoint, model):
     return torch.cat((pos_embed_checkpoint[:, :n_extra], grid.permute(0, 2, 3, 1).flatten(1, 2)), dim=1)
 
 
+def _resample_rel_pos_table(table, src_size, dst_size, num_extra_tokens):
+    """utils.py:657-699: relative-position tables of another window size.  Source positions follow a geometric
+    progression (bisection of the ratio so that the progression spans the target half-width), every head's
+    src x src grid is resampled by a bicubic spline at the integer target positions, the extra (cls) rows are kept.
+    The reference calls scipy.interpolate.interp2d(x, y, z, kind='cubic'), removed in SciPy 1.14; on a regular grid
+    that function was FITPACK's regrid_smth(kx = ky = 3, s = 0) -- the call RectBivariateSpline makes (third party,
+    parity unpinned: the reference's own call cannot run on this SciPy)."""
+    import numpy as np
+    from scipy.interpolate import RectBivariateSpline
+    extra = table[-num_extra_tokens:, :]
+    body = table[:-num_extra_tokens, :]
+
+    def geometric_progression(a, r, n):
+        return a * (1.0 - r ** n) / (1.0 - r)
+    left, right = 1.01, 1.5
+    while right - left > 1e-6:
+        q = (left + right) / 2.0
+        if geometric_progression(1, q, src_size // 2) > dst_size // 2:
+            right = q
+        else:
+            left = q
+    dis, cur = [], 1
+    for i in range(src_size // 2):
+        dis.append(cur)
+        cur += q ** (i + 1)
+    x = [-v for v in reversed(dis)] + [0] + dis
+    t = dst_size // 2.0
+    dx = np.arange(-t, t + 0.1, 1.0)
+    print("Original positions = %s" % str(x))
+    print("Target positions = %s" % str(dx))
+    heads = []
+    for i in range(body.shape[1]):
+        z = body[:, i].view(src_size, src_size).float().numpy()           # z[iy, ix]
+        f = RectBivariateSpline(x, x, z.T.astype(np.float64), kx=3, ky=3, s=0)
+        heads.append(torch.Tensor(f(dx, dx).T.copy()).contiguous().view(-1, 1).to(table.device))   # interp2d returns [len(y), len(x)]
+    return torch.cat((torch.cat(heads, dim=-1), extra), dim=0)
+
+
 def finetune(args, model):
     """utils.py:613-723: initialise a finetuning model from a pretraining checkpoint -- pick the state dict by
     ``args.model_key``, drop a head of another shape, EXPAND the shared relative-position table to every block when
     the model keeps per-block tables, drop the index buffers, then the non-strict load.  The two resampling
     branches apply only when the finetuning resolution differs from the pretraining one: pos_embed is resized
-    (bicubic); the bias tables would need scipy's removed ``interp2d`` and raise here."""
+    (bicubic), the bias tables are resampled on the geometric-progression grid (_resample_rel_pos_table)."""
     checkpoint = torch.load(args.finetune, map_location="cpu", weights_only=False)
     print("Load ckpt from %s" % args.finetune)
     ckpt = checkpoint
@@ -379,10 +417,14 @@ def finetune(args, model):
     for key in [k for k in ckpt if "relative_position_index" in k]:
         ckpt.pop(key)
     for key in [k for k in ckpt if "relative_position_bias_table" in k and k in own]:
-        if ckpt[key].shape != own[key].shape:
-            raise NotImplementedError(
-                "relative-position tables of another window size: the reference resamples them with "
-                "scipy.interpolate.interp2d (removed from SciPy); finetune at the pretraining resolution")
+        src_num_pos, dst_num_pos = ckpt[key].shape[0], own[key].shape[0]
+        ps = model.patch_embed.patch_shape
+        num_extra = dst_num_pos - (ps[0] * 2 - 1) * (ps[1] * 2 - 1)
+        src_size, dst_size = int((src_num_pos - num_extra) ** 0.5), int((dst_num_pos - num_extra) ** 0.5)
+        print(ps, src_size, dst_size)
+        if src_size != dst_size:
+            print("Position interpolate for %s from %dx%d to %dx%d" % (key, src_size, src_size, dst_size, dst_size))
+            ckpt[key] = _resample_rel_pos_table(ckpt[key], src_size, dst_size, num_extra)
     if "pos_embed" in ckpt and model.pos_embed is not None:
         ckpt["pos_embed"] = _resize_pos_embed(ckpt["pos_embed"], model)
     load_state_dict(model, ckpt, prefix=getattr(args, "model_prefix", ""))

@@ -72,6 +72,10 @@ class ViTEngine:
         # GEMM beside it (both only read dY), and both are persistent one-workgroup-per-CU launches, so the CUs that a
         # launch leaves idle in its last partial round of tiles (N = 768: 591 tiles on 256 CUs) pick up workgroups of
         # the other stream's launch instead of waiting.  Results are identical (same kernels, same operands).
+        # gradient accumulation (finetuning with update_freq > 1): backward ADDS into the flat gradient buffer and the
+        # caller's optimizer.zero_grad() clears it (every gradient kernel accumulates; the layer-scale gradient is a
+        # linear function of the accumulated weight gradient)
+        self.accumulate_grads = False
         self.wgrad_side_stream = True
         self.fwd_two_streams = False      # forward: the two halves of the batch on two streams (see forward_trunk);
                                           # measured -0.08 ms at B = 256 (within noise): off by default
@@ -342,7 +346,7 @@ class ViTEngine:
         D, Hd, T, L = self.D, self.hidden, self.T, self.L
         M = B * T
         self.cur = dict(B=B, M=M, Mm=0, mask=mask_u8, rows=None, dp=dp_masks, labels=None)
-        if self.head_kind == "cls":
+        if self.head_kind == "cls" and not self.accumulate_grads:
             self.flat_g[: self.head_end].zero_()        # the torch tail accumulates its gradients here before backward_trunk
         ops.im2col(x, B, self.C, self.H, self.W, self.ph, self.pw, self.patches)
         x0 = self.x[0]
@@ -457,7 +461,8 @@ class ViTEngine:
         dp_masks = c["dp"]
         if dlogits is not None:
             self.logits[:Mm].copy_(dlogits)
-        self.flat_g.zero_()
+        if not self.accumulate_grads:
+            self.flat_g.zero_()
         dx = self.dx
         dx[:M].zero_()
         dl = self.logits
@@ -473,7 +478,8 @@ class ViTEngine:
         """Finetuning: gradient of the loss w.r.t. the trunk output (f32 [B*T, D] or [B,T,D]) -> every trunk parameter."""
         c = self.cur
         M, D = c["M"], self.D
-        self.flat_g[self.head_end:].zero_()
+        if not self.accumulate_grads:
+            self.flat_g[self.head_end:].zero_()
         self.dx[:M].copy_(dxl.reshape(M, D))
         self._side_begin()
         self._backward_trunk()
@@ -586,7 +592,10 @@ class ViTEngine:
                 self.grad_hook(self.depth - i)
         # ---- embedding
         if self.has_pos:
-            self.G("pos_embed").view(T, D).copy_(dx[:M].view(B, T, D).sum(0))
+            if self.accumulate_grads:
+                self.G("pos_embed").view(T, D).add_(dx[:M].view(B, T, D).sum(0))
+            else:
+                self.G("pos_embed").view(T, D).copy_(dx[:M].view(B, T, D).sum(0))
         ops.embed_bwd(dx, c["mask"], B, L, D, self.dYpe, self.G("cls_token"),
                       self.G("mask_token") if "mask_token" in self.segs else self.zero_vec)
         self._on_side(lambda: self._wgrad(self.dYpe, self.patches, B * L, D, self.Kpe, "patch_embed.proj.weight",
