@@ -300,6 +300,19 @@ class ViTEngine:
                               write_grad=True)
         return self.logits[:Mm]
 
+    def _split_point(self, B, num_cu=256):
+        """Sample count of the BIG part of an uneven two-stream split: the largest part whose N = D products (D / 256
+        tile columns, the coarsest launches of a block) fill whole rounds of 256-row tiles on the CUs; the remaining
+        samples run beside it on the second stream and fill what is left.  ViT-B at B = 256: 220 + 36 samples
+        (170 tile rows x {3, 9, 12} tile columns = 510 / 1530 / 2040 tiles = 1.99 / 5.98 / 7.97 rounds)."""
+        ntn = max(1, self.D // 256)
+        tile_rows = -(-B * self.T // 256)
+        rounds = tile_rows * ntn // num_cu
+        if rounds < 1:
+            return 0
+        bs = (rounds * num_cu // ntn) * 256 // self.T
+        return bs if 0 < bs < B and (B - bs) * self.T >= 4096 else 0
+
     def _block_fwd(self, i, b0, b1, dp_masks):
         """Block i on the samples [b0, b1) (mem/modeling_finetune.py:160-189)."""
         D, Hd, T = self.D, self.hidden, self.T
@@ -361,7 +374,8 @@ class ViTEngine:
         # launches interleave on the CUs, so the workgroups of one launch fill the partial last round of the other and
         # the HBM-bound epilogue phase of one half runs beside the MFMA-bound main loop of the other.  Same kernels on
         # the same rows: results are identical to the single-stream order.
-        split = (self.fwd_two_streams and B >= 64 and B % 2 == 0 and ops.GEMM_TIMER is None)
+        bs = self._split_point(B) if (self.fwd_two_streams and ops.GEMM_TIMER is None) else 0
+        split = 0 < bs < B
         if split:
             if self._side is None:
                 self._side = torch.cuda.Stream(device=self.dev)
@@ -369,9 +383,9 @@ class ViTEngine:
             e0.record()
             self._side.wait_event(e0)
             for i in range(self.depth):
-                self._block_fwd(i, 0, B // 2, dp_masks)
+                self._block_fwd(i, 0, bs, dp_masks)
                 with torch.cuda.stream(self._side):
-                    self._block_fwd(i, B // 2, B, dp_masks)
+                    self._block_fwd(i, bs, B, dp_masks)
             e1 = torch.cuda.Event()
             e1.record(self._side)
             torch.cuda.current_stream().wait_event(e1)
