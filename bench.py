@@ -168,8 +168,8 @@ def main():
                     help="skip the secondary figure for BASELINE configs[3] (rasterizer at 1 M events per sample)")
     ap.add_argument("--no-side-stream", action="store_true",
                     help="A/B: keep the weight-gradient GEMMs on the main stream (engine.wgrad_side_stream = False)")
-    ap.add_argument("--fwd-split", action="store_true",
-                    help="A/B: forward with the two halves of the batch on two streams (engine.fwd_two_streams = True)")
+    ap.add_argument("--no-fwd-split", action="store_true",
+                    help="A/B: forward on one stream (engine.fwd_two_streams = False)")
     ap.add_argument("--no-config4-figure", action="store_true",
                     help="skip the secondary figure for BASELINE configs[3] end to end (1 M events per sample feeding ViT-B)")
     ap.add_argument("--rendezvous-only", action="store_true",
@@ -229,7 +229,7 @@ def main():
                    use_abs_pos_emb=False, init_values=0.1).cuda().train()
     eng = model.engine
     eng.wgrad_side_stream = not a.no_side_stream
-    eng.fwd_two_streams = a.fwd_split
+    eng.fwd_two_streams = not a.no_fwd_split
     import contextlib, io
     with contextlib.redirect_stdout(io.StringIO()):
         groups = get_parameter_groups(model, 0.05, model.no_weight_decay())
