@@ -45,6 +45,10 @@
 #ifndef P8_EPI_RESID_LATE
 #define P8_EPI_RESID_LATE 2
 #endif
+#ifndef P8_STAGE_MID
+#define P8_STAGE_MID 0   // 1: a phase's LDS-DMA issue sits between the two halves of its MFMA block instead of in its load
+                         // segment (the counted waits then allow that many fewer pieces in flight)
+#endif
 
 namespace {
 
@@ -206,52 +210,59 @@ __global__ __launch_bounds__(kThreads) void gemm_p8_kernel(GemmArgs p, int ntm, 
 #define P8_READ_B(dst, boff, half)                                                                        \
   _Pragma("unroll") for (int nf = 0; nf < 2; ++nf) _Pragma("unroll") for (int kh = 0; kh < 2; ++kh)       \
       dst[nf][kh] = *reinterpret_cast<const bf16x8*>(rdB[kh] + (boff) + (half) * kHalf + nf * 512)
+#define P8_MFMA_HALF(q, bsrc, kh)                                                                         \
+  _Pragma("unroll") for (int mf = 0; mf < MF; ++mf) _Pragma("unroll") for (int nf = 0; nf < 2; ++nf)      \
+      acc[q][mf][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bsrc[nf][kh], a[mf][kh], acc[q][mf][nf], 0, 0, 0)
 #define P8_MFMA(q, bsrc)                                                                                  \
   do {                                                                                                    \
     __builtin_amdgcn_s_setprio(1);                                                                        \
-    _Pragma("unroll") for (int kh = 0; kh < 2; ++kh) _Pragma("unroll") for (int mf = 0; mf < MF; ++mf)    \
-        _Pragma("unroll") for (int nf = 0; nf < 2; ++nf) acc[q][mf][nf] =                                 \
-            __builtin_amdgcn_mfma_f32_16x16x32_bf16(bsrc[nf][kh], a[mf][kh], acc[q][mf][nf], 0, 0, 0);    \
+    P8_MFMA_HALF(q, bsrc, 0);                                                                             \
+    P8_MFMA_HALF(q, bsrc, 1);                                                                             \
+    __builtin_amdgcn_s_setprio(0);                                                                        \
+  } while (0)
+// compute segment with the phase's LDS-DMA issue in the middle (P8_STAGE_MID)
+#define P8_MFMA_STAGE(q, bsrc, STAGE_CALL)                                                                \
+  do {                                                                                                    \
+    __builtin_amdgcn_s_setprio(1);                                                                        \
+    P8_MFMA_HALF(q, bsrc, 0);                                                                             \
+    __builtin_amdgcn_sched_barrier(0);                                                                    \
+    STAGE_CALL;                                                                                           \
+    __builtin_amdgcn_sched_barrier(0);                                                                    \
+    P8_MFMA_HALF(q, bsrc, 1);                                                                             \
     __builtin_amdgcn_s_setprio(0);                                                                        \
   } while (0)
 // One K-tile = four phases.  B0 of this K-tile is already in `bq0` (read during phase 4 of the
 // previous K-tile); phase 4 reads B0 of the next K-tile into `bq1`, so the two register sets swap
 // roles from one K-tile to the next and the phases read 8 / 4 / 8 / 4 fragments.
+#if P8_STAGE_MID
+#define P8_PHASE(READS, STAGE_CALL, WAITN, PIECES, q, bsrc)                                               \
+    READS;                                                                                                \
+    __builtin_amdgcn_sched_barrier(0);                                                                    \
+    P8_WAIT_VM((WAITN) - (PIECES));                                                                       \
+    P8_BARRIER();                                                                                         \
+    P8_MFMA_STAGE(q, bsrc, STAGE_CALL);                                                                   \
+    P8_BARRIER();
+#else
+#define P8_PHASE(READS, STAGE_CALL, WAITN, PIECES, q, bsrc)                                               \
+    READS;                                                                                                \
+    __builtin_amdgcn_sched_barrier(0);                                                                    \
+    STAGE_CALL;                                                                                           \
+    P8_WAIT_VM(WAITN);                                                                                    \
+    P8_BARRIER();                                                                                         \
+    P8_MFMA(q, bsrc);                                                                                     \
+    P8_BARRIER();
+#endif
 #define P8_KTILE(bq0, bq1)                                                                                  \
   do {                                                                                                    \
     const int bo = bc * kBuf;                                                                             \
     /* phase 1: quadrant (A0, B0) */                                                                      \
-    P8_READ_A(0);                                                                                         \
-    __builtin_amdgcn_sched_barrier(0);                                                                    \
-    stage(HA1, bc ^ 1, tm1, tn1, k1);                                                                     \
-    P8_WAIT_VM(G::kWaitB);                                                                                \
-    P8_BARRIER();                                                                                         \
-    P8_MFMA(0, bq0);                                                                                      \
-    P8_BARRIER();                                                                                         \
+    P8_PHASE(P8_READ_A(0), stage(HA1, bc ^ 1, tm1, tn1, k1), G::kWaitB, AP, 0, bq0)                       \
     /* phase 2: quadrant (A0, B1) */                                                                      \
-    P8_READ_B(bq1, bo, 1);                                                                                \
-    __builtin_amdgcn_sched_barrier(0);                                                                    \
-    stage(HB0, bc, tm2, tn2, k2);                                                                         \
-    P8_WAIT_VM(G::kWaitA);                                                                                \
-    P8_BARRIER();                                                                                         \
-    P8_MFMA(1, bq1);                                                                                      \
-    P8_BARRIER();                                                                                         \
+    P8_PHASE(P8_READ_B(bq1, bo, 1), stage(HB0, bc, tm2, tn2, k2), G::kWaitA, 2, 1, bq1)                   \
     /* phase 3: quadrant (A1, B1) */                                                                      \
-    P8_READ_A(1);                                                                                         \
-    __builtin_amdgcn_sched_barrier(0);                                                                    \
-    stage(HA0, bc, tm2, tn2, k2);                                                                         \
-    P8_WAIT_VM(G::kWaitB);                                                                                \
-    P8_BARRIER();                                                                                         \
-    P8_MFMA(3, bq1);                                                                                      \
-    P8_BARRIER();                                                                                         \
+    P8_PHASE(P8_READ_A(1), stage(HA0, bc, tm2, tn2, k2), G::kWaitB, AP, 3, bq1)                           \
     /* phase 4: quadrant (A1, B0); B0 of the next K-tile comes from the other buffer */                   \
-    P8_READ_B(bq1, (bc ^ 1) * kBuf, 0);                                                                   \
-    __builtin_amdgcn_sched_barrier(0);                                                                    \
-    stage(HB1, bc, tm2, tn2, k2);                                                                         \
-    P8_WAIT_VM(G::kWaitA);                                                                                \
-    P8_BARRIER();                                                                                         \
-    P8_MFMA(2, bq0);                                                                                      \
-    P8_BARRIER();                                                                                         \
+    P8_PHASE(P8_READ_B(bq1, (bc ^ 1) * kBuf, 0), stage(HB1, bc, tm2, tn2, k2), G::kWaitA, 2, 2, bq0)      \
   } while (0)
 #define P8_READ_B0_FIRST() P8_READ_B(bx, 0, 0)
 
