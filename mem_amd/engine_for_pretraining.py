@@ -19,7 +19,18 @@ import torch
 from . import utils
 
 
+_TOK_STREAM = {}
+
+
+def _tokenizer_stream(device):
+    if device not in _TOK_STREAM:
+        _TOK_STREAM[device] = torch.cuda.Stream(device=device)
+    return _TOK_STREAM[device]
+
+
 def _prep_batch(batch, device, model, d_vae, MAE=False):
+    """-> (samples, images, bool_masked_pos, labels, extra) ; extra = dict(rows, mask_u8, labels_event) for raw batches
+    (empty for the reference-style tuple batches)."""
     if isinstance(batch, dict):
         # raw batch (datasets.RawEventDataset.collate): one upload of the events, then the whole transform chain of
         # build_transformNPY + ColorJitter on the GPU (augment.BatchAugPipeline); patches IS visual_tokens for
@@ -27,14 +38,43 @@ def _prep_batch(batch, device, model, d_vae, MAE=False):
         ev = batch["events"].to(device, non_blocking=True)
         samples = batch["pipe"](ev, batch["offsets"], batch["draws"])
         images = samples
-        bool_masked_pos = torch.from_numpy(batch["masks"]).to(device, non_blocking=True)
-    else:
-        samples, images, bool_masked_pos = batch
-        images = images.to(device, non_blocking=True)
-        samples = samples.to(device, non_blocking=True)
-        bool_masked_pos = bool_masked_pos.to(device, non_blocking=True)
+        masks = batch["masks"]
+        if MAE:
+            return samples, images, torch.from_numpy(masks).to(device).flatten(1).to(torch.bool), None, {}
+        # masked rows on the HOST (the masks come from the host): no device nonzero(), no synchronisation
+        import numpy as np
+        B = masks.shape[0]
+        m2 = masks.reshape(B, -1)
+        L = m2.shape[1]
+        bi, pi = np.nonzero(m2)
+        rows = torch.from_numpy((bi * (L + 1) + 1 + pi).astype(np.int32)).to(device, non_blocking=True)
+        flat = torch.from_numpy((bi * L + pi).astype(np.int64)).to(device, non_blocking=True)
+        mask_u8 = torch.from_numpy(m2.astype(np.uint8).reshape(-1)).to(device, non_blocking=True)
+        bool_masked_pos = torch.from_numpy(m2.astype(bool)).to(device, non_blocking=True)
+        # the frozen tokenizer (engine_for_pretraining.py:140-145) runs on its own stream BESIDE the ViT trunk: the labels
+        # are only needed by the loss at the end of the forward pass (ViTEngine.forward waits on labels_event there)
+        main = torch.cuda.current_stream()
+        side = _tokenizer_stream(device)
+        e0 = torch.cuda.Event()
+        e0.record(main)
+        with torch.no_grad(), torch.cuda.stream(side):
+            side.wait_event(e0)
+            input_ids = d_vae.get_codebook_indices(images).flatten(1)       # (B, 14*14)
+            labels = input_ids.reshape(-1).index_select(0, flat)             # == input_ids[bool_masked_pos]
+            ev_done = torch.cuda.Event()
+            ev_done.record(side)
+        images.record_stream(side)
+        labels.record_stream(main)
+        in_chans = model.patch_embed.proj.weight.shape[1]
+        if samples.shape[1] == 3 and in_chans == 2:
+            samples = samples[:, 0::2].contiguous()
+        return samples, images, bool_masked_pos, labels, dict(rows=rows, mask_u8=mask_u8, labels_event=ev_done)
+    samples, images, bool_masked_pos = batch
+    images = images.to(device, non_blocking=True)
+    samples = samples.to(device, non_blocking=True)
+    bool_masked_pos = bool_masked_pos.to(device, non_blocking=True)
     if MAE:                                          # engine_for_pretraining.py:141-142: no tokenizer, 3-channel images
-        return samples, images, bool_masked_pos.flatten(1).to(torch.bool), None
+        return samples, images, bool_masked_pos.flatten(1).to(torch.bool), None, {}
     with torch.no_grad():
         bool_masked_pos = bool_masked_pos.flatten(1).to(torch.bool)
         input_ids = d_vae.get_codebook_indices(images).flatten(1)       # (B, 14*14)
@@ -42,7 +82,7 @@ def _prep_batch(batch, device, model, d_vae, MAE=False):
     in_chans = model.patch_embed.proj.weight.shape[1]
     if samples.shape[1] == 3 and in_chans == 2:
         samples = samples[:, 0::2].contiguous()      # the 2-bin voxel view (engine_for_finetuning.py:228)
-    return samples, images, bool_masked_pos, labels
+    return samples, images, bool_masked_pos, labels, {}
 
 
 def _flush(pending, metric_logger, log_writer, optimizer, run):
@@ -90,11 +130,11 @@ def train_one_epoch(model: torch.nn.Module, d_vae: torch.nn.Module, data_loader:
                     param_group["lr"] = lr_schedule_values[it] * param_group["lr_scale"]
                 if wd_schedule_values is not None and param_group["weight_decay"] > 0:
                     param_group["weight_decay"] = wd_schedule_values[it]
-        samples, images, bool_masked_pos, labels = _prep_batch(batch, device, model, d_vae, MAE)
+        samples, images, bool_masked_pos, labels, extra = _prep_batch(batch, device, model, d_vae, MAE)
         if MAE:
             loss_acc = model.forward_loss(samples)                  # loss, pred, mask = model(samples) (:149); mlm_acc = 0
         else:
-            loss_acc = model.forward_loss(samples, bool_masked_pos, labels)
+            loss_acc = model.forward_loss(samples, bool_masked_pos, labels, **extra)
         model._fused_loss_pending = True
         grad_norm = loss_scaler(loss_acc, optimizer, clip_grad=max_norm, parameters=model.parameters(),
                                 model=model, reducer=reducer)
@@ -125,8 +165,8 @@ def evaluate(data_loader, model, d_vae, device, args, plotting=False, MAE=False)
     header = "Test:"
     model.eval()
     for batch in metric_logger.log_every(data_loader, 10, header):
-        samples, images, bool_masked_pos, labels = _prep_batch(batch[0], device, model, d_vae, MAE)
-        la = (model.forward_loss(samples) if MAE else model.forward_loss(samples, bool_masked_pos, labels)).tolist()
+        samples, images, bool_masked_pos, labels, extra = _prep_batch(batch[0], device, model, d_vae, MAE)
+        la = (model.forward_loss(samples) if MAE else model.forward_loss(samples, bool_masked_pos, labels, **extra)).tolist()
         metric_logger.update(loss=la[0])
         metric_logger.meters["mlm_acc"].update(la[1])
     metric_logger.synchronize_between_processes()

@@ -200,16 +200,17 @@ class VisionTransformerForMaskedImageModeling(nn.Module):
             return out.view(x.shape[0], self.engine.L, -1)
         return out
 
-    def forward_loss(self, x, bool_masked_pos, labels, drop_path_masks=None, rows=None, mask_u8=None):
+    def forward_loss(self, x, bool_masked_pos, labels, drop_path_masks=None, rows=None, mask_u8=None, labels_event=None):
         """Fused forward + mean cross-entropy (+ dlogits).  Returns a device tensor [2] =
-        (loss, mlm_acc) without synchronising.  Call ``backward()`` next for the gradients."""
+        (loss, mlm_acc) without synchronising.  Call ``backward()`` next for the gradients.
+        labels_event: HIP event that marks `labels` ready (tokenizer running on another stream beside the trunk)."""
         if rows is None:
             x, mask_u8, rows = self._prep(x, bool_masked_pos, False)
         if self.training and drop_path_masks is None:
             drop_path_masks = self.draw_drop_path(x.shape[0])
         if not self.training:
             drop_path_masks = None
-        self.engine.forward(x, mask_u8, rows, labels=labels, dp_masks=drop_path_masks)
+        self.engine.forward(x, mask_u8, rows, labels=labels, dp_masks=drop_path_masks, labels_event=labels_event)
         return self.engine.loss_acc
 
     def backward(self):

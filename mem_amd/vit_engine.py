@@ -274,9 +274,10 @@ class ViTEngine:
         return None
 
     # ------------------------------------------------------------------ forward
-    def forward(self, x, mask_u8, rows_idx, labels=None, dp_masks=None, all_tokens=False):
+    def forward(self, x, mask_u8, rows_idx, labels=None, dp_masks=None, all_tokens=False, labels_event=None):
         """x f32 [B,C,H,W]; mask_u8 u8 [B*L]; rows_idx i32 [Mm] (token rows b*T+1+p of the masked
-        patches, or of ALL patches when all_tokens); labels i64 [Mm] or None.
+        patches, or of ALL patches when all_tokens); labels i64 [Mm] or None (labels_event: a HIP event after which
+        `labels` is valid -- the tokenizer may still be running on another stream while the trunk executes).
         dp_masks: f32 [2*depth, B] stochastic-depth keep masks (0/1) or None.
         Leaves logits (bf16 [Mm,V]) in self.logits; with labels also loss/acc in self.loss_acc and
         dlogits (in place of the logits)."""
@@ -296,6 +297,8 @@ class ViTEngine:
         ops.gemm_nt(self.hN, self.W16("lm_head.weight", V, D), Mm, V, D, ops.EPI_BIAS_BF16, out0=self.logits,
                     bias=self.P("lm_head.bias"))
         if labels is not None:
+            if labels_event is not None:
+                torch.cuda.current_stream().wait_event(labels_event)
             ops.cross_entropy(self.logits, labels, Mm, V, 1.0 / Mm, self.row_loss, self.row_ok, self.loss_acc,
                               write_grad=True)
         return self.logits[:Mm]

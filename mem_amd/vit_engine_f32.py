@@ -76,7 +76,7 @@ class ViTEngineF32(ViTEngine):
         self.B, self.Mm_cap = B, Mm_cap
 
     # ------------------------------------------------------------------ forward
-    def forward(self, x, mask_u8, rows_idx, labels=None, dp_masks=None, all_tokens=False):
+    def forward(self, x, mask_u8, rows_idx, labels=None, dp_masks=None, all_tokens=False, labels_event=None):
         assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous()
         B = x.shape[0]
         assert tuple(x.shape[1:]) == (self.C, self.H, self.W), \
@@ -123,6 +123,8 @@ class ViTEngineF32(ViTEngine):
         ops.f32_layernorm_fwd(xl, P("norm.weight"), P("norm.bias"), self.hN, self.meanN, self.rstdN, Mm, D, row_idx=rows_idx)
         G(self.hN, self.W32("lm_head.weight", V, D), Mm, V, D, ops.EPI_BIAS_BF16, out0=self.logits, bias=P("lm_head.bias"))
         if labels is not None:
+            if labels_event is not None:
+                torch.cuda.current_stream().wait_event(labels_event)
             ops.f32_cross_entropy(self.logits, labels, Mm, V, 1.0 / Mm, self.row_loss, self.row_ok, self.loss_acc)
         return self.logits[:Mm]
 
