@@ -63,7 +63,9 @@ def _prep_batch(batch, device, model, d_vae, MAE=False):
             labels = input_ids.reshape(-1).index_select(0, flat)             # == input_ids[bool_masked_pos]
             ev_done = torch.cuda.Event()
             ev_done.record(side)
+        # tensors allocated on one stream and used on the other: keep the caching allocator from recycling them early
         images.record_stream(side)
+        flat.record_stream(side)
         labels.record_stream(main)
         in_chans = model.patch_embed.proj.weight.shape[1]
         if samples.shape[1] == 3 and in_chans == 2:
