@@ -367,6 +367,7 @@ def main():
                     side_t.wait_event(e0)
                     labels = tok.get_codebook_indices(img).reshape(-1).index_select(0, flat)
                     e1 = torch.cuda.Event(); e1.record(side_t)
+                labels.record_stream(torch.cuda.current_stream())     # allocated on the side stream, consumed on the main one
                 model.forward_loss(x, None, labels, rows=rows, mask_u8=mask_u8, labels_event=e1)
                 model.backward()
                 eng.grad_norm()
