@@ -474,6 +474,18 @@ int memhip_nchw_to_padded_nhwc4_f32(const float* x, int B, int C, int H, int W, 
 int memhip_argmax_rows_f32(const float* logits, int64_t ld, int M, int N, int64_t* ids, float* top2_gap,
                            memhip_stream_t stream);
 
+/* "fp16 x 2" mode (opt-in, `--tokenizer_impl hip_fp16x2`): every fp32 value travels as two fp16 planes hi = fp16(v),
+ * lo = fp16((v - hi) * 2048); a product is three fp16 MFMAs (hi*hi + (hi*lo + lo*hi) / 2048, exact products, fp32
+ * accumulation).  Logits within 1.4e-5 of the fp32 module at a spread of 1.77 (between the exact fp32 mode and the bf16
+ * mode), ~2x faster than fp32.  Tensors: base pointer of the hi plane + plane stride in elements to the lo plane; weights
+ * [2][C_out, k*k*C_in]; shapes as memhip_conv2d_nhwc_bf16; out_f32 = 1 writes the dense fp32 logit matrix. */
+int memhip_conv2d_nhwc_f16x2(const void* in, int64_t in_plane, const void* weight, int64_t w_plane, const float* bias,
+                             const void* add, int64_t add_plane, void* out, int64_t out_plane, int B, int H, int W, int Cin,
+                             int Cout, int ksize, int stride, int pad, int relu, int out_padded, int out_f32,
+                             memhip_stream_t stream);
+int memhip_nchw_to_padded_nhwc4_f16x2(const float* x, int B, int C, int H, int W, const float* mean, const float* stdv,
+                                      void* out, int64_t out_plane, memhip_stream_t stream);
+
 /* ------------------------------------------------------------------------
  * Layout / dtype movers
  * ------------------------------------------------------------------------ */

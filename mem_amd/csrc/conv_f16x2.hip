@@ -1,0 +1,273 @@
+// "fp16 x 2" implicit-GEMM convolutions for the frozen dVAE tokenizer forward: fp32-class accuracy at fp16 MFMA speed
+// (reference: eventvae/vae/vae_model.py:29-42,86-101,153-158; fp32 in the reference, mem/engine_for_pretraining.py:140-145).
+//
+// Every fp32 value v is carried as TWO fp16 numbers: hi = fp16(v) and lo = fp16((v - hi) * 2048) -- (v - hi) is exact in
+// fp32 (hi keeps the top 11 bits of a 24-bit significand), so hi + lo / 2048 reproduces v to 2^-22 relative.  A product
+// a * b = a_hi b_hi + (a_hi b_lo + a_lo b_hi) / 2048 + O(2^-22): THREE v_mfma_f32_16x16x32_f16 per tile step instead of one
+// (fp16 x fp16 products are exact in the MFMA's fp32 accumulation), two accumulator sets (the cross terms are scaled once, in
+// the epilogue).  Measured deviation of the 8192 logits from the fp32 module: <= 1.4e-5 at a logit spread of 1.77 (fp32
+// summation-order noise is ~3e-6), ids equal to the reference's on both fixtures -- between the exact fp32 mode
+// (conv_f32.hip, the default) and the bf16 mode (conv.hip, 2e-2) in error, ~2x faster than fp32.
+// Layout: as conv.hip (NHWC with a one-pixel zero border, weights [C_out][ky][kx][c]) with two PLANES per tensor
+// (hi plane, lo plane; plane stride passed in); the structure is conv.hip's 128x128x64 tile with an LDS-DMA-gathered A
+// operand, doubled: {A_hi, A_lo, B_hi, B_lo} x 16 KiB per stage, two stages = 128 KiB (one workgroup per CU).
+#include "common.h"
+
+namespace {
+
+using namespace memhip;
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int kThreads = 256;
+constexpr int kTileBytes = BM * BK * 2;              // one fp16 tile
+constexpr int kStageBytes = 4 * kTileBytes;          // A_hi A_lo B_hi B_lo
+constexpr float kLoScale = 2048.0f, kLoInv = 1.0f / 2048.0f;
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+struct ConvArgsH {
+  const _Float16* in; long long in_plane;      // [2][B, Hp, Wp, Cin]
+  const _Float16* w; long long w_plane;        // [2][Cout, K]
+  const float* bias;
+  const _Float16* add; long long add_plane;    // residual, laid out like `out` (two planes), or null
+  void* out; long long out_plane;              // fp16 two planes, or fp32 dense when out_f32
+  int B, Hp, Wp, Cin, Ho, Wo, Cout, kh, kw, stride, off, K;
+  int out_padded, relu, cin4, out_f32;
+};
+
+__device__ __forceinline__ int swz_slot(int row, int chunk) { return row * 8 + (chunk ^ ((row >> 1) & 7)); }
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                   (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
+}
+__device__ __forceinline__ void split16(float v, _Float16& hi, _Float16& lo) {
+  hi = (_Float16)v;
+  lo = (_Float16)((v - (float)hi) * kLoScale);
+}
+
+__global__ __launch_bounds__(kThreads) void conv_gemm_f16x2_kernel(ConvArgsH p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wr = wave >> 1, wc = wave & 1;
+  const int M = p.B * p.Ho * p.Wo;
+  const int nwg = gridDim.x;
+  int pid = blockIdx.x;
+  {
+    const int q = nwg >> 3, r = nwg & 7, xcd = pid & 7, idx = pid >> 3;
+    pid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int ntn = (p.Cout + BN - 1) / BN;
+  const int m0 = (pid / ntn) * BM, n0 = (pid % ntn) * BN;
+  long long abase[4], bbase[4];
+  int chunkg[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int inst = wave * 4 + j;
+    const int row = inst * 8 + (lane >> 3);
+    chunkg[j] = (lane & 7) ^ ((row >> 1) & 7);
+    int m = m0 + row;
+    m = m < M ? m : M - 1;
+    const int hw = p.Ho * p.Wo;
+    const int b = m / hw, r = m - b * hw;
+    const int oy = r / p.Wo, ox = r - oy * p.Wo;
+    abase[j] = (((long long)b * p.Hp + oy * p.stride + p.off) * p.Wp + ox * p.stride + p.off) * p.Cin;
+    int n = n0 + row;
+    n = n < p.Cout ? n : p.Cout - 1;
+    bbase[j] = (long long)n * p.K;
+  }
+  auto stage = [&](int t, char* dst) {
+    const int k0 = t * BK;
+    long long koff = 0;
+    if (!p.cin4) {
+      const int tap = k0 / p.Cin, c0 = k0 - tap * p.Cin;
+      const int ky = tap / p.kw, kx = tap - ky * p.kw;
+      koff = ((long long)ky * p.Wp + kx) * p.Cin + c0;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int inst = wave * 4 + j;
+      const long long ao = p.cin4 ? ((long long)(chunkg[j] >> 1) * p.Wp + 2 * (chunkg[j] & 1)) * 4 : koff + chunkg[j] * 8;
+      const long long bo = bbase[j] + k0 + chunkg[j] * 8;
+      glds16(p.in + abase[j] + ao, dst + inst * 1024);
+      glds16(p.in + p.in_plane + abase[j] + ao, dst + kTileBytes + inst * 1024);
+      glds16(p.w + bo, dst + 2 * kTileBytes + inst * 1024);
+      glds16(p.w + p.w_plane + bo, dst + 3 * kTileBytes + inst * 1024);
+    }
+  };
+  f32x4 acch[4][4], accx[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { acch[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; accx[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+  const int nk = p.K / BK;
+  stage(0, smem);
+  __syncthreads();
+  int cur = 0;
+  for (int t = 0; t < nk; ++t) {
+    if (t + 1 < nk) stage(t + 1, smem + (cur ^ 1) * kStageBytes);
+    const char* Ah = smem + cur * kStageBytes;
+    const char* Al = Ah + kTileBytes;
+    const char* Bh = Ah + 2 * kTileBytes;
+    const char* Bl = Ah + 3 * kTileBytes;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      half8 ah[4], al[4], bh[4], bl[4];
+      const int chunk = kk * 4 + (lane >> 4);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int s = swz_slot(wr * 64 + i * 16 + (lane & 15), chunk) * 16;
+        ah[i] = *reinterpret_cast<const half8*>(Ah + s);
+        al[i] = *reinterpret_cast<const half8*>(Al + s);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int s = swz_slot(wc * 64 + j * 16 + (lane & 15), chunk) * 16;
+        bh[j] = *reinterpret_cast<const half8*>(Bh + s);
+        bl[j] = *reinterpret_cast<const half8*>(Bl + s);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          acch[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bh[j], acch[i][j], 0, 0, 0);
+          accx[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bl[j], accx[i][j], 0, 0, 0);
+          accx[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i], bh[j], accx[i][j], 0, 0, 0);
+        }
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  // ---- epilogue: the wave's 64x64 sub-tile through LDS, 32 rows at a time (conv.hip's scheme); v = hh + x / 2048
+  const int mw = m0 + wr * 64, nw = n0 + wc * 64;
+  constexpr int LS = 72;
+  float* wreg = reinterpret_cast<float*>(smem + wave * 16384);
+  const int c8 = (lane & 7) * 8;
+  const int n = nw + c8;
+  float bias[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) bias[k] = (p.bias && n + k < p.Cout) ? p.bias[n + k] : 0.f;
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+#pragma unroll
+    for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          wreg[(ii * 16 + (lane >> 4) * 4 + r) * LS + j * 16 + (lane & 15)] =
+              acch[half * 2 + ii][j][r] + accx[half * 2 + ii][j][r] * kLoInv;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int row = it * 8 + (lane >> 3);
+      const int m = mw + half * 32 + row;
+      if (m >= M || n >= p.Cout) continue;
+      long long mo = m;
+      if (p.out_padded) {
+        const int hw = p.Ho * p.Wo;
+        const int b = m / hw, r = m - b * hw;
+        const int oy = r / p.Wo, ox = r - oy * p.Wo;
+        mo = ((long long)b * (p.Ho + 2) + oy + 1) * (p.Wo + 2) + ox + 1;
+      }
+      const float4 v0 = *reinterpret_cast<const float4*>(wreg + row * LS + c8);
+      const float4 v1 = *reinterpret_cast<const float4*>(wreg + row * LS + c8 + 4);
+      float v[8] = {v0.x + bias[0], v0.y + bias[1], v0.z + bias[2], v0.w + bias[3],
+                    v1.x + bias[4], v1.y + bias[5], v1.z + bias[6], v1.w + bias[7]};
+      if (p.relu) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = fmaxf(v[k], 0.f);
+      }
+      if (p.add) {                                      // ResBlock: net(x) + x, x reassembled from its two planes
+        const half8 xh = *reinterpret_cast<const half8*>(p.add + mo * p.Cout + n);
+        const half8 xl = *reinterpret_cast<const half8*>(p.add + p.add_plane + mo * p.Cout + n);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] += (float)xh[k] + (float)xl[k] * kLoInv;
+      }
+      if (p.out_f32) {
+        float* o = reinterpret_cast<float*>(p.out) + mo * p.Cout + n;
+        reinterpret_cast<float4*>(o)[0] = make_float4(v[0], v[1], v[2], v[3]);
+        reinterpret_cast<float4*>(o)[1] = make_float4(v[4], v[5], v[6], v[7]);
+      } else {
+        half8 oh, ol;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { _Float16 h, l; split16(v[k], h, l); oh[k] = h; ol[k] = l; }
+        _Float16* o = reinterpret_cast<_Float16*>(p.out) + mo * p.Cout + n;
+        *reinterpret_cast<half8*>(o) = oh;
+        *reinterpret_cast<half8*>(o + p.out_plane) = ol;
+      }
+    }
+  }
+}
+
+// images f32 NCHW [B, C<=4, H, W] -> two fp16 planes of padded NHWC4, optional (x - mean) / std
+__global__ __launch_bounds__(256) void nchw_to_padded_nhwc4_f16x2_kernel(const float* __restrict__ x, int B, int C, int H,
+                                                                         int W, const float* __restrict__ mean,
+                                                                         const float* __restrict__ stdv,
+                                                                         _Float16* __restrict__ out, long long plane) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long long)B * H * W) return;
+  const int xw = (int)(i % W);
+  const long long t = i / W;
+  const int y = (int)(t % H), b = (int)(t / H);
+  _Float16 h[4] = {0, 0, 0, 0}, l[4] = {0, 0, 0, 0};
+  for (int c = 0; c < C; ++c) {
+    float u = x[(((long long)b * C + c) * H + y) * W + xw];
+    if (mean) u = (u - mean[c]) / stdv[c];
+    split16(u, h[c], l[c]);
+  }
+  const long long o = (((long long)b * (H + 2) + y + 1) * (W + 2) + xw + 1) * 4;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) { out[o + c] = h[c]; out[plane + o + c] = l[c]; }
+}
+
+}  // namespace
+
+extern "C" int memhip_conv2d_nhwc_f16x2(const void* in, int64_t in_plane, const void* weight, int64_t w_plane, const float* bias,
+                                        const void* add, int64_t add_plane, void* out, int64_t out_plane, int B, int H, int W,
+                                        int Cin, int Cout, int ksize, int stride, int pad, int relu, int out_padded,
+                                        int out_f32, memhip_stream_t stream) {
+  MEMHIP_REQUIRE(B >= 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "conv2d_f16x2: bad shape");
+  if (B == 0) return MEMHIP_OK;
+  MEMHIP_REQUIRE(in && weight && out, "conv2d_f16x2: null pointer");
+  MEMHIP_REQUIRE((ksize == 4 && stride == 2 && pad == 1) || (ksize == 3 && stride == 1 && pad == 1) ||
+                     (ksize == 1 && stride == 1 && pad == 0),
+                 "conv2d_f16x2: only the encoder's shapes (4x4/s2/p1, 3x3/s1/p1, 1x1) are provided");
+  const bool cin4 = Cin == 4;
+  MEMHIP_REQUIRE(cin4 ? (ksize == 4) : (Cin % 64 == 0), "conv2d_f16x2: C_in must be 4 (first layer, 4x4) or a multiple of 64");
+  MEMHIP_REQUIRE(Cout % 8 == 0, "conv2d_f16x2: C_out must be a multiple of 8");
+  MEMHIP_REQUIRE(!(out_f32 && out_padded), "conv2d_f16x2: the fp32 output is the dense token-logit matrix");
+  ConvArgsH p;
+  p.in = (const _Float16*)in; p.in_plane = in_plane; p.w = (const _Float16*)weight; p.w_plane = w_plane; p.bias = bias;
+  p.add = (const _Float16*)add; p.add_plane = add_plane; p.out = out; p.out_plane = out_plane;
+  p.B = B; p.Hp = H + 2; p.Wp = W + 2; p.Cin = Cin;
+  p.Ho = (H + 2 * pad - ksize) / stride + 1; p.Wo = (W + 2 * pad - ksize) / stride + 1;
+  p.Cout = Cout; p.kh = ksize; p.kw = ksize; p.stride = stride; p.off = 1 - pad; p.K = ksize * ksize * Cin;
+  p.out_padded = out_padded; p.relu = relu; p.cin4 = cin4 ? 1 : 0; p.out_f32 = out_f32;
+  MEMHIP_REQUIRE(p.K % BK == 0, "conv2d_f16x2: K = %d must be a multiple of 64", p.K);
+  const long long M = (long long)B * p.Ho * p.Wo;
+  MEMHIP_REQUIRE(M < (1LL << 31), "conv2d_f16x2: too many output pixels");
+  const int grid = cdiv(M, BM) * cdiv(Cout, BN);
+  static bool attr_done = false;
+  if (!attr_done) {
+    MEMHIP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_gemm_f16x2_kernel),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kStageBytes));
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(conv_gemm_f16x2_kernel, dim3(grid), dim3(kThreads), 2 * kStageBytes, as_stream(stream), p);
+  return check_launch("conv2d_nhwc_f16x2");
+}
+
+extern "C" int memhip_nchw_to_padded_nhwc4_f16x2(const float* x, int B, int C, int H, int W, const float* mean,
+                                                 const float* stdv, void* out, int64_t out_plane, memhip_stream_t stream) {
+  MEMHIP_REQUIRE(B >= 0 && C >= 1 && C <= 4 && H > 0 && W > 0, "nchw_to_padded_nhwc4_f16x2: bad shape");
+  if (B == 0) return MEMHIP_OK;
+  MEMHIP_REQUIRE(x && out && (!mean == !stdv), "nchw_to_padded_nhwc4_f16x2: null pointer");
+  const long long n = (long long)B * H * W;
+  hipLaunchKernelGGL(nchw_to_padded_nhwc4_f16x2_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream),
+                     x, B, C, H, W, mean, stdv, (_Float16*)out, (long long)out_plane);
+  return check_launch("nchw_to_padded_nhwc4_f16x2");
+}

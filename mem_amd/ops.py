@@ -401,3 +401,27 @@ def mae_dec_assemble_bwd(dxd, ids_restore, B, L, K, D, dy, dmask_token):
 def mae_loss(pred, img, mask, B, Cc, H, W, patch, only_masked, row_loss, dpred, scratch2):
     check(lib.memhip_mae_loss(ptr(pred), ptr(img), ptr(mask), B, Cc, H, W, patch, int(only_masked), ptr(row_loss), ptr(dpred),
                               ptr(scratch2), stream_ptr()), "mae_loss")
+
+
+# ---------------------------------------------------------------- fp16 x 2 tokenizer mode (csrc/conv_f16x2.hip)
+declare({
+    "memhip_conv2d_nhwc_f16x2": (i32, [vp, i64, vp, i64, vp, vp, i64, vp, i64, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32,
+                                       i32, vp]),
+    "memhip_nchw_to_padded_nhwc4_f16x2": (i32, [vp, i32, i32, i32, i32, vp, vp, vp, i64, vp]),
+})
+
+
+def conv2d_nhwc_f16x2(x2, w2, bias, out, B, H, W, Cin, Cout, ksize, stride, pad, relu=False, add2=None, out_padded=True):
+    """x2 fp16 [2,B,H+2,W+2,Cin] (hi / lo planes), w2 fp16 [2,Cout,K] -> out fp16 [2,B,Ho+2,Wo+2,Cout] interior, or a dense
+    fp32 [B*Ho*Wo, Cout] matrix when `out` is float32."""
+    out_f32 = out.dtype == torch.float32
+    check(lib.memhip_conv2d_nhwc_f16x2(ptr(x2), x2.stride(0), ptr(w2), w2.stride(0), ptr(bias), ptr(add2),
+                                       add2.stride(0) if add2 is not None else 0, ptr(out), 0 if out_f32 else out.stride(0),
+                                       B, H, W, Cin, Cout, ksize, stride, pad, int(relu), int(out_padded and not out_f32),
+                                       int(out_f32), stream_ptr()), "conv2d_nhwc_f16x2")
+
+
+def nchw_to_padded_nhwc4_f16x2(x, out2, mean=None, std=None):
+    B, Cc, H, W = x.shape
+    check(lib.memhip_nchw_to_padded_nhwc4_f16x2(ptr(x), B, Cc, H, W, ptr(mean), ptr(std), ptr(out2), out2.stride(0), stream_ptr()),
+          "nchw_to_padded_nhwc4_f16x2")

@@ -57,9 +57,10 @@ def get_args(argv=None):
     p.add_argument("--save_ckpt_freq", "--pt_save_ckpt_freq", default=20, type=int)
     p.add_argument("--discrete_vae_weight_path", type=str)
     p.add_argument("--discrete_vae_type", type=str, default="event")
-    p.add_argument("--tokenizer_impl", type=str, default="hip", choices=["hip", "hip_bf16", "torch"],
+    p.add_argument("--tokenizer_impl", type=str, default="hip", choices=["hip", "hip_fp16x2", "hip_bf16", "torch"],
                    help="hip: hand-written fp32 implicit-GEMM tokenizer forward (csrc/conv_f32.hip; fp32 operands and "
-                        "accumulation like the reference, exact labels); hip_bf16: the bf16-operand kernels of "
+                        "accumulation like the reference, exact labels); hip_fp16x2: two-plane fp16 operands, three fp16 MFMAs per "
+                        "product (logits within ~1e-5 of fp32, ~2x faster than hip); hip_bf16: the bf16-operand kernels of "
                         "csrc/conv.hip (~7x faster, 1-3 %% of the labels differ at near ties); torch: the fp32 module on "
                         "stock PyTorch-ROCm convolutions")
     p.add_argument("--timesurface", type=int, default=0)
@@ -198,11 +199,11 @@ def main(args):
         print("WARNING: no --discrete_vae_weight_path: using a randomly initialised tokenizer (synthetic labels)")
         d_vae = DiscreteVAE(input_H=args.input_H, input_W=args.input_W, num_layers=args.num_layers,
                             num_tokens=args.num_tokens, codebook_dim=32, hidden_dim=64, num_resnet_blocks=0).to(device)
-    if args.tokenizer_impl in ("hip", "hip_bf16") and device.type == "cuda":
+    if args.tokenizer_impl in ("hip", "hip_fp16x2", "hip_bf16") and device.type == "cuda":
         from .vae_model import HipTokenizer
         try:
             d_vae = HipTokenizer(d_vae.eval(), max_batch=args.batch_size,
-                                 precision="bf16" if args.tokenizer_impl == "hip_bf16" else "fp32")
+                                 precision={"hip": "fp32", "hip_fp16x2": "fp16x2", "hip_bf16": "bf16"}[args.tokenizer_impl])
         except AssertionError as e:                     # shapes the HIP convolutions do not provide
             print(f"tokenizer: staying on the torch module ({e})")
     num_tasks, global_rank = utils.get_world_size(), utils.get_rank()

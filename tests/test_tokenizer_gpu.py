@@ -200,3 +200,54 @@ def test_tokenizer_bf16_mode_vs_reference_golden():
     assert diff.mean() <= 0.03, diff.mean()
     spread = float(g["logits_b0"].std())
     assert (gap[diff] <= 0.05 * spread + 1e-3).all(), (gap[diff].max(), spread)
+
+
+def test_tokenizer_fp16x2_mode():
+    """Opt-in `fp16x2` mode (csrc/conv_f16x2.hip: two fp16 planes per value, three fp16 MFMAs per product): ids equal the
+    REFERENCE's fp32 ids on both fixtures; logits within 4e-5 (at a logit spread of 1.77) of the fp32 HIP mode; layer-level:
+    one convolution vs torch in float64 at 3e-6 of the output scale (fp32: 4e-7 sqrt(K))."""
+    import os
+    import numpy as np
+    from mem_amd import ops
+    from oracle.vae_ref import BASE_VAE, TINY_VAE, fill_vae_by_name, vae_inputs
+    from mem_amd.vae_model import DiscreteVAE, HipTokenizer
+    gdir = os.path.join(os.path.dirname(__file__), "golden")
+    for cfg, seed, fix, B in ((TINY_VAE, 0, "vae_tiny.npz", 6), (BASE_VAE, 1, "vae_base.npz", 2)):
+        g = np.load(os.path.join(gdir, fix))
+        m = DiscreteVAE(**cfg).eval()
+        m.load_state_dict(fill_vae_by_name(m.state_dict(), seed=seed))
+        m = m.cuda()
+        img = vae_inputs(cfg, 6, 11) if cfg is TINY_VAE else vae_inputs(cfg, 2, 12) * (vae_inputs(cfg, 2, 13) < 0.3)
+        tok = HipTokenizer(m, max_batch=B, precision="fp16x2")
+        ids = tok.get_codebook_indices(img.cuda()).cpu().numpy()
+        assert np.array_equal(ids, g["ids"]), fix
+        lg2 = tok.logits.clone()
+        tok32 = HipTokenizer(m, max_batch=B)
+        tok32.get_codebook_indices(img.cuda())
+        d = (lg2 - tok32.logits).abs().max().item()
+        print(fix, "max |logit(fp16x2) - logit(fp32)| = %.2e, logit std %.3f" % (d, tok32.logits.std().item()))
+        assert d <= 4e-5 * max(1.0, tok32.logits.std().item())
+    # one layer against float64
+    g = torch.Generator(device="cuda").manual_seed(5)
+    Bn, cin, cout, h, k, s, p = 3, 128, 192, 14, 3, 1, 1
+    x = torch.randn(Bn, cin, h, h, generator=g, device="cuda")
+    w = torch.randn(cout, cin, k, k, generator=g, device="cuda") * 0.05
+    b = torch.randn(cout, generator=g, device="cuda")
+    ref = torch.nn.functional.conv2d(x.double(), w.double(), b.double(), stride=s, padding=p)
+
+    def planes(t):
+        hi = t.half()
+        return torch.stack([hi, ((t - hi.float()) * 2048.0).half()]).contiguous()
+    xp = torch.zeros(Bn, h + 2, h + 2, cin, device="cuda")
+    xp[:, 1:-1, 1:-1] = x.permute(0, 2, 3, 1)
+    x2 = planes(xp)
+    w2 = planes(w.permute(0, 2, 3, 1).reshape(cout, -1).contiguous())
+    dense = torch.zeros(Bn * h * h, cout, device="cuda")
+    ops.conv2d_nhwc_f16x2(x2, w2, b, dense, Bn, h, h, cin, cout, k, s, p, relu=False, out_padded=False)
+    err = (dense.view(Bn, h, h, cout).permute(0, 3, 1, 2).double() - ref).abs().max().item()
+    assert err <= 3e-6 * float(ref.abs().max()), err
+    out2 = torch.zeros(2, Bn, h + 2, h + 2, cout, dtype=torch.float16, device="cuda")
+    ops.conv2d_nhwc_f16x2(x2, w2, b, out2, Bn, h, h, cin, cout, k, s, p, relu=True)
+    got = (out2[0].float() + out2[1].float() / 2048.0)[:, 1:-1, 1:-1].permute(0, 3, 1, 2).double()
+    assert (got - torch.relu(ref)).abs().max().item() <= 3e-6 * float(ref.abs().max())
+    assert out2[:, :, 0].abs().max() == 0 and out2[:, :, :, 0].abs().max() == 0
