@@ -601,6 +601,13 @@ int attn_bwd_stream(const void* qkv, int64_t ldqkv, const void* dout, int64_t ld
                     float* stats, const float* table, int window_h, int window_w, int B, int T, int D, int heads,
                     float scale, void* dqkv, int64_t lddqkv, float* dtable, float* dq_bias, float* dv_bias,
                     hipStream_t s);
+// attn16.hip: the 14 x 14 window (197 tokens) -- key-slot layout, fused backward
+bool attn16_fits(int T, int window_h, int window_w);
+int attn16_fwd(const void* qkv, int64_t ldqkv, int B, int D, int heads, const float* table, void* out, int64_t ldo,
+               float* lse, hipStream_t s);
+int attn16_bwd(const void* qkv, int64_t ldqkv, const void* dout, int64_t ldo, const float* lse, const float* delta,
+               const float* table, int B, int D, int heads, float scale, void* dqkv, int64_t lddqkv, float* dtable,
+               float* dq_bias, hipStream_t s);
 }
 
 #define ATTN_DISPATCH(NKB_EXPR, MACRO)                                    \
@@ -622,6 +629,8 @@ extern "C" int memhip_attn_fwd(const void* qkv, int64_t ldqkv, int B, int T, int
   MEMHIP_REQUIRE(qkv && table && out && lse, "attn_fwd: null pointer");
   MEMHIP_REQUIRE(ldqkv % 8 == 0 && ldo % 8 == 0, "attn_fwd: ld must be a multiple of 8");
   hipStream_t s = as_stream(stream);
+  if (opt(OPT_ATTN16) && memhip::attn16_fits(T, window_h, window_w))
+    return memhip::attn16_fwd(qkv, ldqkv, B, D, heads, table, out, ldo, lse, s);
   const int nkb = (T + 31) / 32;
   const int nrd = (2 * window_h - 1) * (2 * window_w - 1) + 3;
   if (nkb > 8)
@@ -667,6 +676,9 @@ extern "C" int memhip_attn_bwd(const void* qkv, int64_t ldqkv, const void* dout,
   MEMHIP_REQUIRE(qkv && dout && lse && delta && table && dqkv, "attn_bwd: null pointer");
   MEMHIP_REQUIRE(ldqkv % 8 == 0 && ldo % 8 == 0 && lddqkv % 8 == 0, "attn_bwd: ld must be a multiple of 8");
   hipStream_t s = as_stream(stream);
+  // the fused kernel has no v_bias-gradient output (the engine derives it from the proj dgrad: vit_engine.py)
+  if (opt(OPT_ATTN16) && !dv_bias && memhip::attn16_fits(T, window_h, window_w))
+    return memhip::attn16_bwd(qkv, ldqkv, dout, ldo, lse, delta, table, B, D, heads, scale, dqkv, lddqkv, dtable, dq_bias, s);
   const int nkb = (T + 31) / 32;
   const int nrd = (2 * window_h - 1) * (2 * window_w - 1) + 3;
   const int spb = pick_spb(B, heads);

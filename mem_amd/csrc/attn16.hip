@@ -1,0 +1,728 @@
+// Attention for the 14 x 14 token grid (197 tokens: ViT-B/16 and ViT-L/16 at 224 x 224, the BASELINE configuration):
+// forward, and a FUSED backward that computes the probabilities once.  Same contract, rounding points and outputs as the
+// general kernels in attn.hip (reference: Attention.forward, mem/modeling_finetune.py:137-154, bias of RelativePositionBias
+// :213-247); attn.hip dispatches here when the window is 14 x 14.
+//
+// What the general kernels spend their time on (profiles/r02: 9-15 % MFMA-busy, VALU-issue bound): per score element one
+// integer subtract + one LDS gather for the bias bucket, 1.5 instructions to unpack the bf16-rounded score, and -- in
+// backward -- the whole softmax recomputation TWICE (once per operand orientation: dK/dV need dS with queries down the
+// accumulator rows, dQ needs keys down the rows).  Here:
+//
+//   * KEY SLOTS.  The K / V images in LDS hold the keys in "slot" order: grid row ky occupies slots 16 ky .. 16 ky + 13,
+//     slots 16 ky + 14, 15 are padding (zero rows), the cls token sits in slot 14 (the first padding slot of row 0):
+//     224 slots = 7 blocks of 32.  A lane of the S^T = K Q^T accumulator (32x32 MFMA: lane = query column, registers =
+//     key rows 8 g + 4 hh + e of the block) then sees, for register (kb, g, e), the key (ky, kx) = (2 kb + (g >> 1),
+//     8 (g & 1) + 4 hh + e): the bias bucket (qy - ky + 13) * 27 + (qx - kx + 13) is a PER-LANE base minus a
+//     COMPILE-TIME offset.  The head's table is stored reversed in LDS, so the bias of a register is
+//     `ds_read_b32 base_lane offset:const` -- no index arithmetic, no code tables, reads are issued far ahead.
+//     The cls query reads a constant region behind the table, the one cls key element and the padding slots are
+//     selected on hh (wave-uniform positions).
+//   * v_dot2c_f32_bf16 with the selector pair (1, 0) / (0, 1) adds the bias to the low / high half of a packed bf16 pair:
+//     unpack + add in ONE instruction (S is rounded to bf16 as the reference's autocast q k^T output is, the sum is fp32).
+//   * FUSED BACKWARD.  Wave w owns query block w AND key block w.  In step s it computes P^T, dS^T of the tile
+//     (queries w, keys (w + s) mod 7) from its own Q / dO fragments, accumulates dQ^T straight out of the accumulators,
+//     and publishes the two tiles as bf16 (2 x 2 KiB) in LDS; after a barrier it picks up the tile (queries (w - s) mod 7,
+//     keys w) with transposing reads (ds_read_b64_tr_b16: the K dimension of the MFMA becomes the queries) and
+//     accumulates dK^T, dV^T.  Every tile's softmax work is done once; 20 MFMAs per tile instead of 28; Q, K, V, dO are
+//     read from HBM once instead of twice.  Four head images (112 KiB) + the exchange tiles (28 KiB) + tables fill the
+//     160 KiB of LDS, so the images are single-buffered: the LDS-DMA of the next sample is issued as soon as the last
+//     step has passed its barrier and runs under the sample's epilogue (stores, bucket fold).
+//   * the bias-table gradient uses the same constant offsets for its fixed-point LDS atomics (ds_add_u32); the bound of
+//     the fixed-point scale is computed per sample inside the kernel (no per-head statistics pass).
+#include "attn_common.hpp"
+
+namespace {
+
+constexpr int W16 = 14;                                   // window height = width
+constexpr int R16 = 2 * W16 - 1;                          // 27 buckets per relative row
+constexpr int OFF16 = (W16 - 1) * R16 + (W16 - 1);        // 364
+constexpr int M16 = 2 * OFF16;                            // 728: reversed index a = M16 - bucket
+constexpr int KMAX16 = (W16 - 1) * R16 + 15;              // 366: largest key code, padding slots included
+constexpr int CLSQ16 = M16 + 3;                           // 731: first entry of the constant region read by the cls query
+constexpr int TABLEN16 = (CLSQ16 + KMAX16 + 1 + 3) & ~3;  // 1100 entries
+constexpr int T16 = W16 * W16 + 1;                        // 197 tokens
+constexpr int TP16 = 16 * W16;                            // 224 key slots / padded queries
+constexpr int NB16 = TP16 / 32;                           // 7 blocks = 7 waves
+constexpr int IMG16 = TP16 * 128;                         // bytes of a head image
+constexpr int kThreads16 = NB16 * 64;
+constexpr int NRD16 = R16 * R16 + 3;                      // 732 table rows
+
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+
+__device__ __forceinline__ unsigned pk_bf16(float a, float b) {
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{a, b}, bf16x2_t));
+}
+// c + (low / high bf16 of pk): v_dot2c_f32_bf16 with the selector pair (1, 0) / (0, 1).  Measured on gfx950
+// (tools/micro/dot2_bf16.hip): the half selection is exact; the fp32 sum is TRUNCATED, not rounded to nearest (1 ulp of
+// fp32 low in ~6 % of the cases) -- far below the bf16 rounding of the operands this kernel family works with (the fp32
+// parity mode does not use these kernels).  The low selector must live in a REGISTER: written as a constant, hipcc
+// (ROCm 7.2) encodes 0x00003F80 as the inline constant 1.0, which this instruction reads as 0x3F800000 = the HIGH half.
+__device__ __forceinline__ unsigned sel_lo_reg() {
+  unsigned v;
+  asm volatile("s_mov_b32 %0, 0x3f80" : "=s"(v));
+  return v;
+}
+__device__ __forceinline__ float add_lo(unsigned pk, float c, unsigned sel_lo) {
+  return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, pk), __builtin_bit_cast(bf16x2_t, sel_lo), c, false);
+}
+__device__ __forceinline__ float add_hi(unsigned pk, float c) {
+  return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, pk), __builtin_bit_cast(bf16x2_t, 0x3F800000u), c, false);
+}
+
+// ---- coalesced row stores.  An accumulator tile holds a token per LANE and its 64 head-dim values down the registers: a
+// direct store writes 8 bytes per lane, 4.5 KiB apart -- 64 partial cache-line writes per wave-instruction (measured:
+// the stores of one sample took ~13 K cycles, a fifth of the fused backward).  The tile goes through a 4 KiB LDS slot of the
+// wave instead ([32 tokens][128 B], 16-byte chunk c of token r at c ^ ((r >> 1) & 7)) and leaves as 16 bytes per lane,
+// 8 lanes per 128-byte row.  Lanes whose row is padding write to a trash page, so that every wave issues every store
+// (the counted vmcnt waits rely on the number of stores in flight).
+__device__ __attribute__((aligned(256))) unsigned char g_attn16_trash[1024];
+__device__ __forceinline__ void tile_put(char* st, int r, int hh, int db, int g, bf16x4 w) {
+  const int c = db * 4 + g;
+  *reinterpret_cast<bf16x4*>(st + r * 128 + ((c ^ ((r >> 1) & 7)) << 4) + hh * 8) = w;
+}
+__device__ __forceinline__ bf16x8 tile_get(const char* st, int row, int c) {
+  return *reinterpret_cast<const bf16x8*>(st + row * 128 + ((c ^ ((row >> 1) & 7)) << 4));
+}
+
+// s_waitcnt vmcnt(n) through the builtin (gfx9 encoding: vmcnt[3:0] | expcnt 7 << 4 | lgkmcnt 15 << 8 | vmcnt[5:4] << 14): the
+// compiler's waitcnt pass sees it and does not add a vmcnt(0) of its own in front of the first use of a plainly loaded
+// register (which would wait for the stores as well)
+#define ATTN16_WAIT_VM(n)                                                                \
+  do {                                                                                   \
+    __builtin_amdgcn_s_waitcnt(((n) & 15) | (7 << 4) | (15 << 8) | (((n) >> 4) << 14));  \
+    asm volatile("" ::: "memory");                                                       \
+  } while (0)
+
+// token of a key slot (-1: padding)
+__device__ __forceinline__ int slot_tok(int s) {
+  const int kx = s & 15;
+  return kx < W16 ? 1 + (s >> 4) * W16 + kx : (s == W16 ? 0 : -1);
+}
+// Stage a head slice in SLOT order (LDS image layout of attn_common.hpp, the "token" of the swizzle is the slot).
+__device__ __forceinline__ void stage_slots(char* dst, const __bf16* src, long long ld) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int inst = wave; inst < TP16 / 8; inst += NB16) {
+    const int slot = inst * 8 + (lane >> 3), cpos = lane & 7;
+    const int chunk = cpos ^ ((slot >> 1) & 7);
+    const int tok = slot_tok(slot);
+    const void* g = tok >= 0 ? (const void*)(src + (long long)tok * ld + chunk * 8)
+                             : (const void*)(g_attn_zero_page + cpos * 16);
+    glds16(g, dst + inst * 1024);
+  }
+}
+// natural token order, 224 rows (tokens >= 197: zero rows)
+__device__ __forceinline__ void stage_tokens(char* dst, const __bf16* src, long long ld) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int inst = wave; inst < TP16 / 8; inst += NB16) {
+    const int tok = inst * 8 + (lane >> 3), cpos = lane & 7;
+    const int chunk = cpos ^ ((tok >> 1) & 7);
+    const void* g = tok < T16 ? (const void*)(src + (long long)tok * ld + chunk * 8)
+                              : (const void*)(g_attn_zero_page + cpos * 16);
+    glds16(g, dst + inst * 1024);
+  }
+}
+
+// reversed, extended table of head h (natural units):  tabR[a] = table[M16 - a] for a <= M16, 0 for the two entries only
+// padding slots reach, table[cls -> token] from CLSQ16 on
+__device__ __forceinline__ void table16_setup(float* tabR, const float* table, int H, int h) {
+  for (int a = threadIdx.x; a < TABLEN16; a += blockDim.x) {
+    float v = 0.f;
+    if (a <= M16) v = table[(long long)(M16 - a) * H + h];
+    else if (a >= CLSQ16) v = table[(long long)(NRD16 - 3) * H + h];
+    tabR[a] = v;
+  }
+}
+// per-lane index base of query q: a = base + keycode
+__device__ __forceinline__ int q_base16(int q) {
+  if (q == 0) return CLSQ16;
+  if (q >= T16) return 0;
+  const int u = q - 1;
+  return M16 - ((u / W16) * R16 + (u % W16) + OFF16);
+}
+// byte offset of register (g, e) of key block 0 relative to the lane base (the lane base holds 4 hh; block kb adds 216 kb)
+#define KOFF16(g, e) (4 * ((((g) >> 1) * R16) + 8 * ((g) & 1) + (e)))
+constexpr int kBlockStep16 = 4 * 2 * R16;   // 216 bytes per key block
+
+// Samples of one head are dealt to `nwg` workgroups: the first B % nwg take one more.  The workgroups with the smaller
+// share have one sample period of slack: they start `stagger` cycles late (a per-workgroup fraction of it), so that the
+// workgroups of the chip do not all run their memory phases (LDS-DMA of the next sample, stores of the last one) at the
+// same moment -- in lockstep these are HBM bursts of ~45 MB that the whole chip then waits for.
+struct Share16 { int b0, b1; bool slack; };
+__device__ __forceinline__ Share16 share16(int j, int B, int nwg) {
+  const int base = B / nwg, rem = B % nwg;
+  Share16 s;
+  s.b0 = j * base + (j < rem ? j : rem);
+  s.b1 = s.b0 + base + (j < rem ? 1 : 0);
+  s.slack = rem > 0 && j >= rem;
+  return s;
+}
+__device__ __forceinline__ void stagger16(bool slack, int stagger) {
+  if (!slack || stagger <= 0) return;
+  const unsigned frac = ((blockIdx.x * 2654435761u) >> 22) & 1023u;        // 0 .. 1023
+  const unsigned long long wait = ((unsigned long long)stagger * frac) >> 10;
+  const unsigned long long t0 = __builtin_readcyclecounter();
+  while (__builtin_readcyclecounter() - t0 < wait) __builtin_amdgcn_s_sleep(16);
+}
+__device__ __forceinline__ void glds4(const void* gsrc, char* lds_dst) {     // LDS-DMA, 4 bytes per lane
+  const unsigned lds = __builtin_amdgcn_readfirstlane(
+      (unsigned)(unsigned long long)((__attribute__((address_space(3))) char*)lds_dst));
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(gsrc), "s"(lds) : "memory", "m0");
+}
+
+// ------------------------------------------------------------------------------------------------ forward
+__global__ __launch_bounds__(kThreads16) void attn16_fwd_kernel(const __bf16* __restrict__ qkv, long long ldq, int B, int D,
+                                                               int H, const float* __restrict__ table,
+                                                               __bf16* __restrict__ out, long long ldo,
+                                                               float* __restrict__ lse, int nwg, int stagger) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* tabR = reinterpret_cast<float*>(smem);
+  char* imgs = smem + TABLEN16 * 4;
+  char* stg = imgs + 4 * IMG16;                // [7 waves][4 KiB] output staging
+  const int h = blockIdx.x % H;
+  const Share16 sh = share16(blockIdx.x / H, B, nwg);
+  const int b0 = sh.b0, b1 = sh.b1;
+  if (b0 >= b1) return;
+  stagger16(sh.slack, stagger);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 31, hh = lane >> 5;
+  const bool hh1 = hh != 0;
+  const unsigned sel_lo = sel_lo_reg();
+  const LaneOffs lo = lane_offs(lane);
+  table16_setup(tabR, table, H, h);
+  const int q = wave * 32 + r;
+  const int qc = q < T16 ? q : T16 - 1;
+  const unsigned bb = lds_addr_of(reinterpret_cast<const char*>(tabR)) + 4 * (q_base16(q) + 4 * hh);
+  const float clsb = table[(long long)(q == 0 ? NRD16 - 1 : NRD16 - 2) * H + h];
+  {
+    const __bf16* s0 = qkv + (long long)b0 * T16 * ldq + h * HD;
+    stage_slots(imgs, s0 + D, ldq);
+    stage_slots(imgs + IMG16, s0 + 2 * D, ldq);
+  }
+  bf16x8 Qn[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) Qn[t] = ld16(qkv + ((long long)b0 * T16 + qc) * ldq + h * HD + 16 * t + 8 * hh);
+  for (int b = b0; b < b1; ++b) {
+    const int cur = (b - b0) & 1;
+    const char* Ks = imgs + cur * 2 * IMG16;
+    const char* Vs = Ks + IMG16;
+    bf16x8 Qf[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) Qf[t] = Qn[t];
+    // vector-memory operations complete in issue order: everything up to the LDS-DMA of this sample has landed once at
+    // most the 5 stores of the previous sample (1 x lse, 4 x out -- issued after the DMA) are still in flight
+    ATTN16_WAIT_VM(5);
+    __syncthreads();                         // sample b's images (and, the first time, the table) landed; b-1 consumed
+    if (b + 1 < b1) {
+      const __bf16* s1 = qkv + (long long)(b + 1) * T16 * ldq + h * HD;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) Qn[t] = ld16(s1 + (long long)qc * ldq + 16 * t + 8 * hh);
+      stage_slots(imgs + (cur ^ 1) * 2 * IMG16, s1 + D, ldq);
+      stage_slots(imgs + (cur ^ 1) * 2 * IMG16 + IMG16, s1 + 2 * D, ldq);
+    }
+    f32x16 s[NB16];
+#pragma unroll
+    for (int kb = 0; kb < NB16; ++kb) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) s[kb][i] = 0.f;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) s[kb] = MFMA32(row_frag_o(Ks, lo, kb, t), Qf[t], s[kb]);
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kb = 0; kb < NB16; ++kb) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        float bias[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bias[e] = lds_f32_abs((int)bb + kb * kBlockStep16 + KOFF16(g, e));
+        if (g & 1) {                           // slots 14, 15 of a grid row: padding, except the cls key (block 0)
+          bias[2] = hh1 ? (kb == 0 && g == 1 ? clsb : -INFINITY) : bias[2];
+          bias[3] = hh1 ? -INFINITY : bias[3];
+        }
+        const unsigned p0 = pk_bf16(s[kb][4 * g], s[kb][4 * g + 1]), p1 = pk_bf16(s[kb][4 * g + 2], s[kb][4 * g + 3]);
+        s[kb][4 * g] = add_lo(p0, bias[0], sel_lo);
+        s[kb][4 * g + 1] = add_hi(p0, bias[1]);
+        s[kb][4 * g + 2] = add_lo(p1, bias[2], sel_lo);
+        s[kb][4 * g + 3] = add_hi(p1, bias[3]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) mx = fmaxf(mx, s[kb][4 * g + e]);
+      }
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float mneg = -mx * kLog2e;
+    float sum = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < NB16; ++kb)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const float p = fexp2(fmaf(s[kb][i], kLog2e, mneg));
+        s[kb][i] = p;
+        sum += p;
+      }
+    sum += __shfl_xor(sum, 32);
+    const float inv = 1.0f / sum;
+    if (hh == 0 && q < T16) lse[((long long)b * H + h) * TP16 + q] = mx + flog2(sum) * kLn2;
+    f32x16 o[2];
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) o[db][i] = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < NB16; ++kb) {
+      bf16x8 vf[2][2];
+#pragma unroll
+      for (int ss = 0; ss < 2; ++ss)
+#pragma unroll
+        for (int db = 0; db < 2; ++db) vf[ss][db] = col_frag_o(Vs, lo, kb, ss, db);
+      bf16x8 pf[2];
+#pragma unroll
+      for (int ss = 0; ss < 2; ++ss) pf[ss] = acc_frag(s[kb], ss, inv);
+      LDS_TR_WAIT();
+#pragma unroll
+      for (int ss = 0; ss < 2; ++ss)
+#pragma unroll
+        for (int db = 0; db < 2; ++db) o[db] = MFMA32(vf[ss][db], pf[ss], o[db]);
+    }
+    {
+      char* st = stg + wave * 4096;
+#pragma unroll
+      for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          bf16x4 w;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) w[e] = (__bf16)o[db][4 * g + e];
+          tile_put(st, r, hh, db, g, w);
+        }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = (lane >> 3) + 8 * i, qq = wave * 32 + row;
+        const bf16x8 v = tile_get(st, row, lane & 7);
+        __bf16* dst = qq < T16 ? out + ((long long)b * T16 + qq) * ldo + h * HD + (lane & 7) * 8
+                               : reinterpret_cast<__bf16*>(g_attn16_trash) + lane * 8;
+        *reinterpret_cast<bf16x8*>(dst) = v;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ fused backward
+// -DATTN16_TIMING: per-section s_memtime totals of wave 0 / wave 4 of every workgroup (tools/attn16_sections.py)
+#ifdef ATTN16_TIMING
+__device__ unsigned long long g_attn16_prof[2][16];
+#define T16_DECL() unsigned long long t_last_ = __builtin_readcyclecounter(), t_acc_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
+#define T16_TICK(i) do { const unsigned long long t_ = __builtin_readcyclecounter(); t_acc_[i] += t_ - t_last_; t_last_ = t_; } while (0)
+#define T16_FLUSH() do { if (lane == 0 && (wave == 0 || wave == 4)) for (int i_ = 0; i_ < 12; ++i_) atomicAdd(&g_attn16_prof[wave >> 2][i_], t_acc_[i_]); } while (0)
+#else
+#define T16_DECL()
+#define T16_TICK(i)
+#define T16_FLUSH()
+#endif
+// LDS map (bytes)
+constexpr int kTabBytes16 = TABLEN16 * 4;                 // 4400
+constexpr int kBinsI16 = kTabBytes16;                     // int32 fixed-point buckets of the current sample
+constexpr int kBinsF16 = 2 * kTabBytes16;                 // fp32 buckets of the workgroup
+constexpr int kRows16 = 3 * kTabBytes16;                  // [3][256] floats: lse, delta, |dO|^2 of the sample's queries
+constexpr int kRowsLd16 = 256;                            // (four wave-instructions of 64 lanes each)
+constexpr int kRed16 = kRows16 + 3 * kRowsLd16 * 4;                   // [8][4] floats: per-wave maxima of the bound terms
+constexpr int kQsum16 = kRed16 + 128;                     // [64] floats
+constexpr int kImgs16 = (kQsum16 + 256 + 15) & ~15;       // Q dO K V
+constexpr int kExch16 = kImgs16 + 4 * IMG16;              // [7 waves][P^T tile | dS^T tile], 2 KiB each
+constexpr int kLdsBwd16 = kExch16 + NB16 * 4096;
+static_assert(kLdsBwd16 <= 160 * 1024, "fused backward: LDS budget");
+
+// exchange tile [32 queries][32 keys] bf16, 64-byte rows, 8-byte unit u of row r at position u ^ ((r >> 2) & 7)
+__device__ __forceinline__ int exch_off(int row, int unit) { return row * 64 + ((unit ^ ((row >> 2) & 7)) << 3); }
+
+template <bool DT>
+__global__ __launch_bounds__(kThreads16) void attn16_bwd_kernel(const __bf16* __restrict__ qkv, long long ldq,
+                                                               const __bf16* __restrict__ dout, long long ldo,
+                                                               const float* __restrict__ lse,
+                                                               const float* __restrict__ delta,
+                                                               const float* __restrict__ table,
+                                                               __bf16* __restrict__ dqkv, long long lddq,
+                                                               float* __restrict__ dtable, float* __restrict__ dqbias,
+                                                               int B, int D, int H, float scale, int nwg, int stagger) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* tabR = reinterpret_cast<float*>(smem);
+  int* binsi = reinterpret_cast<int*>(smem + kBinsI16);
+  float* rowsL = reinterpret_cast<float*>(smem + kRows16);
+  float* binsf = reinterpret_cast<float*>(smem + kBinsF16);
+  float* red = reinterpret_cast<float*>(smem + kRed16);
+  float* qsum = reinterpret_cast<float*>(smem + kQsum16);
+  char* Qs = smem + kImgs16;
+  char* dOs = Qs + IMG16;
+  char* Ks = dOs + IMG16;
+  char* Vs = Ks + IMG16;
+  char* exch = smem + kExch16;
+  const int h = blockIdx.x % H;
+  const Share16 sh = share16(blockIdx.x / H, B, nwg);
+  const int b0 = sh.b0, b1 = sh.b1;
+  if (b0 >= b1) return;
+  stagger16(sh.slack, stagger);
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int r = lane & 31, hh = lane >> 5;
+  const bool hh1 = hh != 0;
+  const unsigned sel_lo = sel_lo_reg();
+  const LaneOffs lo = lane_offs(lane);
+  table16_setup(tabR, table, H, h);
+  for (int i = threadIdx.x; i < TABLEN16; i += blockDim.x) { binsi[i] = 0; binsf[i] = 0.f; }
+  if (threadIdx.x < HD) qsum[threadIdx.x] = 0.f;
+  const int q = wave * 32 + r;
+  const unsigned bb = lds_addr_of(reinterpret_cast<const char*>(tabR)) + 4 * (q_base16(q) + 4 * hh);
+  const float clsb = table[(long long)(q == 0 ? NRD16 - 1 : NRD16 - 2) * H + h];
+  // exchange tile addressing: writer (row = r, units 2 g + hh), reader (transposing 8-byte reads, see attn_common.hpp)
+  int wr_off[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) wr_off[g] = exch_off(r, 2 * g + hh);
+  int rd_off[2][2];
+  {
+    const int rhalf = (lane >> 4) & 1, q4 = (lane >> 2) & 3, p = lane & 3;
+#pragma unroll
+    for (int ss = 0; ss < 2; ++ss) {
+      rd_off[ss][0] = exch_off(16 * ss + 4 * hh + q4, rhalf * 4 + p);
+      rd_off[ss][1] = exch_off(16 * ss + 8 + 4 * hh + q4, rhalf * 4 + p);
+    }
+  }
+  float bsum[8];                                             // q_bias gradient: columns 8 (lane & 7) .. + 7 of the rows this lane stores
+#pragma unroll
+  for (int i = 0; i < 8; ++i) bsum[i] = 0.f;
+  float dcls = 0.f;                                          // gradient of the (token -> cls) / (cls -> cls) bucket
+  // per-query rows of the sample (lse, delta, |dO|^2) travel by LDS-DMA as well: a plain load into registers would make the
+  // compiler wait for ALL vector-memory operations (the stores of the previous sample included) in front of the first use
+  auto stage_rows = [&](int b) {
+    if (wave < 4) {
+      const int t = wave * 64 + lane;
+      const bool ok = t < T16;
+      const void* z = g_attn_zero_page + (lane & 31) * 4;
+      const long long row = (long long)b * T16 + t;
+      glds4(ok ? (const void*)(lse + ((long long)b * H + h) * TP16 + t) : z, reinterpret_cast<char*>(rowsL) + wave * 256);
+      glds4(ok ? (const void*)(delta + row * H + h) : z, reinterpret_cast<char*>(rowsL + kRowsLd16) + wave * 256);
+      glds4(ok ? (const void*)(delta + ((long long)B * T16 + row) * H + h) : z, reinterpret_cast<char*>(rowsL + 2 * kRowsLd16) + wave * 256);
+    }
+  };
+  auto stage_sample = [&](int b) {
+    const __bf16* s = qkv + (long long)b * T16 * ldq + h * HD;
+    stage_tokens(Qs, s, ldq);
+    stage_tokens(dOs, dout + (long long)b * T16 * ldo + h * HD, ldo);
+    stage_slots(Ks, s + D, ldq);
+    stage_slots(Vs, s + 2 * D, ldq);
+  };
+  stage_rows(b0);
+  stage_sample(b0);
+  T16_DECL();
+  for (int b = b0; b < b1; ++b) {
+    T16_TICK(9);
+    // in issue order: [LDS-DMA of this sample: rows, images] [12 stores of the previous sample]: the stores may stay in
+    // flight under this sample's compute
+    ATTN16_WAIT_VM(12);
+    __syncthreads();                                         // images of sample b (first time: tables) are in LDS
+    const float lq2 = q < T16 ? rowsL[q] * kLog2e : INFINITY;   // padding queries: p = exp2(-inf) = 0
+    const float dq_ = rowsL[kRowsLd16 + q], nqn = rowsL[2 * kRowsLd16 + q];
+    T16_TICK(0);
+    // ---- fixed-point scale of the bucket atomics: |dS| = p |dP - delta| <= max|dO_q| max|V_k| + max|delta_q| =: bound;
+    // 2^21 / bound: fx_round() needs |x| < 2^22 (bf16-rounded dP may pass the bound by 2^-8), 196 terms stay below 2^31
+    float fx = 0.f;
+    if (DT) {
+      float vn = 0.f;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const bf16x8 v = row_frag_o(Vs, lo, wave, t);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) vn = fmaf((float)v[i], (float)v[i], vn);
+      }
+      vn += __shfl_xor(vn, 32);
+      float m0 = nqn, m1 = fabsf(dq_), m2 = vn;
+      for (int o = 16; o > 0; o >>= 1) {
+        m0 = fmaxf(m0, __shfl_xor(m0, o));
+        m1 = fmaxf(m1, __shfl_xor(m1, o));
+        m2 = fmaxf(m2, __shfl_xor(m2, o));
+      }
+      if (lane == 0) { red[wave * 4 + 0] = m0; red[wave * 4 + 1] = m1; red[wave * 4 + 2] = m2; }
+      __syncthreads();
+      float t0 = 0.f, t1 = 0.f, t2 = 0.f;
+#pragma unroll
+      for (int w = 0; w < NB16; ++w) {
+        t0 = fmaxf(t0, red[w * 4 + 0]);
+        t1 = fmaxf(t1, red[w * 4 + 1]);
+        t2 = fmaxf(t2, red[w * 4 + 2]);
+      }
+      const float bound = sqrtf(t0) * sqrtf(t2) + t1;
+      fx = bound > 0.f ? 2097152.0f / bound : 0.f;
+    }
+    f32x16 dQt[2], dKt[2], dVt[2];
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { dQt[db][i] = 0.f; dKt[db][i] = 0.f; dVt[db][i] = 0.f; }
+    T16_TICK(1);
+    int kb = wave, wp = wave;                                // key block produced / producer consumed in this step
+    for (int s = 0; s < NB16; ++s) {
+      // ---------------- produce: tile (queries `wave`, keys kb)
+      f32x16 S, dP;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { S[i] = 0.f; dP[i] = 0.f; }
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        S = MFMA32(row_frag_o(Ks, lo, kb, t), row_frag_o(Qs, lo, wave, t), S);
+        dP = MFMA32(row_frag_o(Vs, lo, kb, t), row_frag_o(dOs, lo, wave, t), dP);
+      }
+      T16_TICK(2);
+      const int ba = (int)bb + kb * kBlockStep16;
+      const int na = ba + kBinsI16;
+      const float padb = kb == 0 ? clsb : -INFINITY;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        float bias[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bias[e] = lds_f32_abs(ba + KOFF16(g, e));
+        if (g & 1) {
+          bias[2] = hh1 ? (g == 1 ? padb : -INFINITY) : bias[2];
+          bias[3] = hh1 ? -INFINITY : bias[3];
+        }
+        const unsigned s0 = pk_bf16(S[4 * g], S[4 * g + 1]), s1 = pk_bf16(S[4 * g + 2], S[4 * g + 3]);
+        const unsigned d0 = pk_bf16(dP[4 * g], dP[4 * g + 1]), d1 = pk_bf16(dP[4 * g + 2], dP[4 * g + 3]);
+        float tt[4], dd[4];
+        tt[0] = add_lo(s0, bias[0], sel_lo); tt[1] = add_hi(s0, bias[1]); tt[2] = add_lo(s1, bias[2], sel_lo); tt[3] = add_hi(s1, bias[3]);
+        dd[0] = add_lo(d0, -dq_, sel_lo); dd[1] = add_hi(d0, -dq_); dd[2] = add_lo(d1, -dq_, sel_lo); dd[3] = add_hi(d1, -dq_);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float p = fexp2(fmaf(tt[e], kLog2e, -lq2));
+          const float ds = p * dd[e];
+          S[4 * g + e] = p;
+          dP[4 * g + e] = ds;
+          if (DT) {
+            float dsb = ds;
+            if (g == 1 && e == 2 && kb == 0) {               // the cls key: its bucket is kept in a register
+              dcls += hh1 ? ds : 0.f;
+              dsb = hh1 ? 0.f : ds;
+            }
+            lds_add_i32_abs(na + KOFF16(g, e), fx_round(dsb, fx));
+          }
+        }
+      }
+      const bf16x8 pf0 = acc_frag(S, 0, 1.0f), pf1 = acc_frag(S, 1, 1.0f);
+      const bf16x8 df0 = acc_frag(dP, 0, 1.0f), df1 = acc_frag(dP, 1, 1.0f);
+      T16_TICK(3);
+      {
+        bf16x8 ckf[2][2];
+#pragma unroll
+        for (int ss = 0; ss < 2; ++ss)
+#pragma unroll
+          for (int db = 0; db < 2; ++db) ckf[ss][db] = col_frag_o(Ks, lo, kb, ss, db);
+        LDS_TR_WAIT();
+#pragma unroll
+        for (int db = 0; db < 2; ++db) {
+          dQt[db] = MFMA32(ckf[0][db], df0, dQt[db]);
+          dQt[db] = MFMA32(ckf[1][db], df1, dQt[db]);
+        }
+      }
+      T16_TICK(4);
+      __syncthreads();                                       // every wave has consumed the tiles of step s - 1
+      T16_TICK(5);
+      {
+        char* mine = exch + wave * 4096;
+        union { bf16x8 v; uint2 h[2]; } u;
+        u.v = pf0; *reinterpret_cast<uint2*>(mine + wr_off[0]) = u.h[0]; *reinterpret_cast<uint2*>(mine + wr_off[1]) = u.h[1];
+        u.v = pf1; *reinterpret_cast<uint2*>(mine + wr_off[2]) = u.h[0]; *reinterpret_cast<uint2*>(mine + wr_off[3]) = u.h[1];
+        u.v = df0; *reinterpret_cast<uint2*>(mine + 2048 + wr_off[0]) = u.h[0]; *reinterpret_cast<uint2*>(mine + 2048 + wr_off[1]) = u.h[1];
+        u.v = df1; *reinterpret_cast<uint2*>(mine + 2048 + wr_off[2]) = u.h[0]; *reinterpret_cast<uint2*>(mine + 2048 + wr_off[3]) = u.h[1];
+      }
+      __syncthreads();                                       // tiles of step s are published
+      T16_TICK(6);
+      // ---------------- consume: tile (queries wp, keys `wave`)
+      {
+        const unsigned tb = lds_addr_of(exch) + wp * 4096;
+#pragma unroll
+        for (int ss = 0; ss < 2; ++ss) {
+          union { struct { s16x4 l, h; } s; bf16x8 v; } pB, dB;
+          pB.s.l = lds_tr16_b64(tb + rd_off[ss][0]);
+          pB.s.h = lds_tr16_b64(tb + rd_off[ss][1]);
+          dB.s.l = lds_tr16_b64(tb + 2048 + rd_off[ss][0]);
+          dB.s.h = lds_tr16_b64(tb + 2048 + rd_off[ss][1]);
+          bf16x8 cdo[2], cq[2];
+#pragma unroll
+          for (int db = 0; db < 2; ++db) {
+            cdo[db] = col_frag_o(dOs, lo, wp, ss, db);
+            cq[db] = col_frag_o(Qs, lo, wp, ss, db);
+          }
+          LDS_TR_WAIT();
+#pragma unroll
+          for (int db = 0; db < 2; ++db) {
+            dVt[db] = MFMA32(cdo[db], pB.v, dVt[db]);
+            dKt[db] = MFMA32(cq[db], dB.v, dKt[db]);
+          }
+        }
+      }
+      kb = kb + 1 == NB16 ? 0 : kb + 1;
+      wp = wp == 0 ? NB16 - 1 : wp - 1;
+      T16_TICK(7);
+    }
+    __syncthreads();                                         // all reads of the images and all bucket atomics are done
+    T16_TICK(8);
+    if (b + 1 < b1) { stage_rows(b + 1); stage_sample(b + 1); }
+    // ---------------- epilogue of sample b (under the LDS-DMA of sample b + 1)
+    if (DT) {
+      const float inv = fx > 0.f ? 1.0f / fx : 0.f;
+      for (int i = threadIdx.x; i < TABLEN16; i += blockDim.x) {
+        const int v = binsi[i];
+        if (v != 0) { binsf[i] += (float)v * inv; binsi[i] = 0; }
+      }
+    }
+    {
+      char* st = exch + wave * 4096;                       // this wave's exchange slot is free until step 0 of the next sample
+      const int c8 = (lane & 7) * 8;
+      // dQ:  d(q_lin) = d(q') * scale
+#pragma unroll
+      for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          bf16x4 w;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) w[e] = (__bf16)(bfr(dQt[db][4 * g + e]) * scale);
+          tile_put(st, r, hh, db, g, w);
+        }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = (lane >> 3) + 8 * i, qq = wave * 32 + row;
+        const bf16x8 v = tile_get(st, row, lane & 7);
+        __bf16* dst = qq < T16 ? dqkv + ((long long)b * T16 + qq) * lddq + h * HD + c8
+                               : reinterpret_cast<__bf16*>(g_attn16_trash) + lane * 8;
+        *reinterpret_cast<bf16x8*>(dst) = v;
+        if (qq < T16) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) bsum[j] += (float)v[j];
+        }
+      }
+      // dK, dV: rows are the tokens of this wave's key slots
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            bf16x4 w;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) w[e] = (__bf16)(m == 0 ? dKt[db][4 * g + e] : dVt[db][4 * g + e]);
+            tile_put(st, r, hh, db, g, w);
+          }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int row = (lane >> 3) + 8 * i, tok = slot_tok(wave * 32 + row);
+          const bf16x8 v = tile_get(st, row, lane & 7);
+          __bf16* dst = tok >= 0 ? dqkv + ((long long)b * T16 + tok) * lddq + (m + 1) * D + h * HD + c8
+                                 : reinterpret_cast<__bf16*>(g_attn16_trash) + lane * 8;
+          *reinterpret_cast<bf16x8*>(dst) = v;
+        }
+      }
+    }
+  }
+  T16_TICK(9);
+  T16_FLUSH();
+  __syncthreads();
+  if (DT) {
+    for (int a = threadIdx.x; a <= M16; a += blockDim.x) {
+      const float v = binsf[a];
+      if (v != 0.f) atomicAdd(dtable + (long long)(M16 - a) * H + h, v);
+    }
+    if (wave == 0) {                                         // the cls query's constant region -> bucket (cls -> token)
+      float v = 0.f;
+      for (int a = CLSQ16 + lane; a < TABLEN16; a += 64) v += binsf[a];
+      for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+      if (lane == 0) atomicAdd(dtable + (long long)(NRD16 - 3) * H + h, v);
+    }
+    // cls key column: (cls, cls) from the cls query's lane, (token -> cls) from everybody else
+    const float own = q == 0 ? dcls : 0.f;
+    float oth = q == 0 ? 0.f : dcls;
+    for (int o = 32; o > 0; o >>= 1) oth += __shfl_xor(oth, o);
+    if (lane == 0) atomicAdd(dtable + (long long)(NRD16 - 2) * H + h, oth);
+    if (q == 0 && hh1) atomicAdd(dtable + (long long)(NRD16 - 1) * H + h, own);
+  }
+  if (dqbias) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float v = bsum[j];
+      v += __shfl_xor(v, 8);
+      v += __shfl_xor(v, 16);
+      v += __shfl_xor(v, 32);
+      if (lane < 8) atomicAdd(qsum + lane * 8 + j, v);
+    }
+    __syncthreads();
+    if (threadIdx.x < HD) atomicAdd(dqbias + h * HD + threadIdx.x, qsum[threadIdx.x]);
+  }
+}
+
+int num_cu16() {
+  static int num_cu = 0;
+  if (!num_cu) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    num_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess &&
+              prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+  }
+  return num_cu;
+}
+// workgroups per head: one workgroup per CU (LDS), as many as fit in one round
+int nwg16(int B, int heads) {
+  const int n = num_cu16() / heads;
+  return n < 1 ? 1 : (n > B ? B : n);
+}
+
+}  // namespace
+
+namespace memhip {
+
+bool attn16_fits(int T, int window_h, int window_w) { return window_h == W16 && window_w == W16 && T == T16; }
+
+int attn16_fwd(const void* qkv, int64_t ldqkv, int B, int D, int heads, const float* table, void* out, int64_t ldo,
+               float* lse, hipStream_t s) {
+  const size_t sm = (size_t)TABLEN16 * 4 + 4 * IMG16 + NB16 * 4096;
+  static bool attr_done = false;
+  if (!attr_done) {
+    MEMHIP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn16_fwd_kernel),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds));
+    attr_done = true;
+  }
+  const int nwg = nwg16(B, heads);
+  hipLaunchKernelGGL(attn16_fwd_kernel, dim3(nwg * heads), dim3(kThreads16), sm, s, (const __bf16*)qkv,
+                     (long long)ldqkv, B, D, heads, table, (__bf16*)out, (long long)ldo, lse, nwg, opt(OPT_ATTN16_STAGGER_FWD));
+  return check_launch("attn_fwd(14x14)");
+}
+
+int attn16_bwd(const void* qkv, int64_t ldqkv, const void* dout, int64_t ldo, const float* lse, const float* delta,
+               const float* table, int B, int D, int heads, float scale, void* dqkv, int64_t lddqkv, float* dtable,
+               float* dq_bias, hipStream_t s) {
+  static bool attr_done = false;
+  if (!attr_done) {
+    MEMHIP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn16_bwd_kernel<true>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds));
+    MEMHIP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn16_bwd_kernel<false>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds));
+    attr_done = true;
+  }
+  const int nwg = nwg16(B, heads), stagger = opt(OPT_ATTN16_STAGGER);
+  const int grid = nwg * heads;
+  if (dtable)
+    hipLaunchKernelGGL(attn16_bwd_kernel<true>, dim3(grid), dim3(kThreads16), kLdsBwd16, s, (const __bf16*)qkv,
+                       (long long)ldqkv, (const __bf16*)dout, (long long)ldo, lse, delta, table, (__bf16*)dqkv,
+                       (long long)lddqkv, dtable, dq_bias, B, D, heads, scale, nwg, stagger);
+  else
+    hipLaunchKernelGGL(attn16_bwd_kernel<false>, dim3(grid), dim3(kThreads16), kLdsBwd16, s, (const __bf16*)qkv,
+                       (long long)ldqkv, (const __bf16*)dout, (long long)ldo, lse, delta, table, (__bf16*)dqkv,
+                       (long long)lddqkv, dtable, dq_bias, B, D, heads, scale, nwg, stagger);
+  return check_launch("attn_bwd(14x14)");
+}
+
+}  // namespace memhip
+
+#ifdef ATTN16_TIMING
+extern "C" int memhip_attn16_prof(unsigned long long* out32, int reset) {
+  if (out32) MEMHIP_HIP(hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_attn16_prof), sizeof(unsigned long long) * 32));
+  if (reset) {
+    unsigned long long z[32] = {0};
+    MEMHIP_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_attn16_prof), z, sizeof(z)));
+  }
+  return MEMHIP_OK;
+}
+#endif

@@ -128,12 +128,26 @@ def _attn_ref(qkv, bias, B, T, D, H, scale):
     return o.transpose(1, 2).reshape(B * T, D), p
 
 
-@pytest.mark.parametrize("B,T,H,win", [(3, 197, 12, (14, 14)), (2, 17, 2, (4, 4)), (5, 65, 4, (8, 8)),
+@pytest.mark.parametrize("B,T,H,win", [(3, 197, 12, (14, 14)), (45, 197, 4, (14, 14)), (2, 17, 2, (4, 4)), (5, 65, 4, (8, 8)),
                                        (1, 256, 2, (15, 17)), (40, 37, 3, (4, 9)),
                                        # > 256 tokens: the streaming kernels (attn_stream.hip); 30x40 = ViT-L @ 480x640
                                        (1, 257, 2, (16, 16)), (3, 324, 3, (17, 19)), (2, 1201, 2, (30, 40)),
                                        (64, 290, 16, (17, 17))])
 def test_attention_fwd_bwd(B, T, H, win):
+    _attention_case(B, T, H, win)
+
+
+def test_attention_general_kernels_at_14x14():
+    """The 14 x 14 window dispatches to attn16.hip; with the switch off the general kernels of attn.hip take it."""
+    from mem_amd import _lib
+    _lib.set_option("attn16", 0)
+    try:
+        _attention_case(29, 197, 3, (14, 14))
+    finally:
+        _lib.set_option("attn16", 1)
+
+
+def _attention_case(B, T, H, win):
     from mem_amd import ops
     from oracle.vit_ref import rel_pos_index
     D = 64 * H
@@ -173,9 +187,14 @@ def test_attention_fwd_bwd(B, T, H, win):
     ops.attn_delta(dout, out, B * T, H, delta)
     torch.testing.assert_close(delta[:B * T], (dout.float() * out.float()).view(B * T, H, 64).sum(-1), rtol=1e-4, atol=1e-3)
     dqb, dvb = torch.zeros(D, device="cuda"), torch.zeros(D, device="cuda")
-    ops.attn_bwd(qkv, dout, lse, delta, table, win, B, T, D, H, scale, dqkv, dtable, dq_bias=dqb, dv_bias=dvb)
+    # 14 x 14 window, B > 3: the engine's call (no v_bias gradient) = the fused backward of attn16.hip; with dv_bias the
+    # general two-kernel backward of attn.hip runs (both forms are covered at 14 x 14)
+    fused = win == (14, 14) and B > 3
+    ops.attn_bwd(qkv, dout, lse, delta, table, win, B, T, D, H, scale, dqkv, dtable, dq_bias=dqb,
+                 dv_bias=None if fused else dvb)
     torch.testing.assert_close(dqb, dqkv[:, :D].float().sum(0), rtol=1e-3, atol=1e-2)
-    torch.testing.assert_close(dvb, dqkv[:, 2 * D:].float().sum(0), rtol=1e-3, atol=1e-2)
+    if not fused:
+        torch.testing.assert_close(dvb, dqkv[:, 2 * D:].float().sum(0), rtol=1e-3, atol=1e-2)
     g = qf.grad.clone()
     g[:, :D] *= scale          # kernel returns d(q_lin) = d(q') * scale
     err = (dqkv.float() - g).abs().max().item()
