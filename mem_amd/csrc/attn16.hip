@@ -30,6 +30,11 @@
 //   * the bias-table gradient uses the same constant offsets for its fixed-point LDS atomics (ds_add_u32); the bound of
 //     the fixed-point scale is computed per sample inside the kernel (no per-head statistics pass).
 #include "attn_common.hpp"
+#include <type_traits>
+
+#ifndef ATTN16_EXP
+#define ATTN16_EXP 0      // timing experiments (tools/build_variant.sh); 0 = the shipped kernel
+#endif
 
 namespace {
 
@@ -104,7 +109,7 @@ __device__ __forceinline__ void stage_slots(char* dst, const __bf16* src, long l
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (int inst = wave; inst < TP16 / 8; inst += NB16) {
     const int slot = inst * 8 + (lane >> 3), cpos = lane & 7;
-    const int chunk = cpos ^ ((slot >> 1) & 7);
+    const int chunk = cpos ^ img_key(slot);
     const int tok = slot_tok(slot);
     const void* g = tok >= 0 ? (const void*)(src + (long long)tok * ld + chunk * 8)
                              : (const void*)(g_attn_zero_page + cpos * 16);
@@ -116,7 +121,7 @@ __device__ __forceinline__ void stage_tokens(char* dst, const __bf16* src, long 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (int inst = wave; inst < TP16 / 8; inst += NB16) {
     const int tok = inst * 8 + (lane >> 3), cpos = lane & 7;
-    const int chunk = cpos ^ ((tok >> 1) & 7);
+    const int chunk = cpos ^ img_key(tok);
     const void* g = tok < T16 ? (const void*)(src + (long long)tok * ld + chunk * 8)
                               : (const void*)(g_attn_zero_page + cpos * 16);
     glds16(g, dst + inst * 1024);
@@ -143,6 +148,48 @@ __device__ __forceinline__ int q_base16(int q) {
 // byte offset of register (g, e) of key block 0 relative to the lane base (the lane base holds 4 hh; block kb adds 216 kb)
 #define KOFF16(g, e) (4 * ((((g) >> 1) * R16) + 8 * ((g) & 1) + (e)))
 constexpr int kBlockStep16 = 4 * 2 * R16;   // 216 bytes per key block
+
+// ---- fragment addressing from TWO lane registers.  In the image layout of attn_common.hpp (128-byte rows, chunk c of token t
+// at c ^ img_key(t)) the chunk and token indices of a lane's fragments differ by whole bits, so every fragment address is
+// (lane base ^ constant) + wave-uniform offset -- one v_xad_u32 -- instead of a register per fragment (12 of them):
+//   row fragment t (token r, chunk 2 t + hh):            (row0 ^ (t << 5)) + block
+//   column fragment (ss, db), low / high half (j):       (col0 ^ (db << 6) ^ (j << 5)) + block + 2048 ss + 1024 j
+//   (tokens + 8 flip bit 2 of (t >> 1), i.e. bit 1 of the key: the 32)
+struct Lane16 { unsigned row0, col0; };
+__device__ __forceinline__ Lane16 lane16(int lane) {
+  const LaneOffs o = lane_offs(lane);
+  return Lane16{(unsigned)o.row[0], (unsigned)o.col[0][0][0]};
+}
+// ... and the wave-uniform / compile-time parts of an address ride in the instruction's 16-bit offset field: a step computes
+// 4 row bases + 2 column bases per image PAIR (V sits IMG16 bytes behind K, dO behind Q) instead of one address per read.
+template <int OFF>
+__device__ __forceinline__ bf16x8 lds_b128(unsigned addr) {
+  return *reinterpret_cast<const __attribute__((address_space(3))) bf16x8*>(addr + OFF);
+}
+template <int OFF>
+__device__ __forceinline__ s16x4 lds_tr16_off(unsigned lds_addr) {
+  s16x4 r;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r) : "v"(lds_addr), "n"(OFF) : "memory");
+  return r;
+}
+struct RowBase16 { unsigned a[4]; };          // (row0 ^ (t << 5)) + block address, t = 0..3
+struct ColBase16 { unsigned a[4]; };          // (col0 ^ (db << 6) ^ (j << 5)) + block address, index db + 2 j
+__device__ __forceinline__ RowBase16 row_base16(const Lane16& l, unsigned blk) {
+  RowBase16 b;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) b.a[t] = (l.row0 ^ (t << 5)) + blk;
+  return b;
+}
+__device__ __forceinline__ ColBase16 col_base16(const Lane16& l, unsigned blk) {
+  return ColBase16{{l.col0 + blk, (l.col0 ^ 64u) + blk, (l.col0 ^ 32u) + blk, (l.col0 ^ 96u) + blk}};
+}
+template <int OFF, int SS, int DB>
+__device__ __forceinline__ bf16x8 col_frag16(const ColBase16& b) {          // OFF: image displacement (0 or IMG16)
+  union { struct { s16x4 l, h; } s; bf16x8 v; } u;
+  u.s.l = lds_tr16_off<OFF + 2048 * SS>(b.a[DB]);
+  u.s.h = lds_tr16_off<OFF + 2048 * SS + 1024>(b.a[DB + 2]);
+  return u.v;
+}
 
 // Samples of one head are dealt to `nwg` workgroups: the first B % nwg take one more.  The workgroups with the smaller
 // share have one sample period of slack: they start `stagger` cycles late (a per-workgroup fraction of it), so that the
@@ -188,7 +235,7 @@ __global__ __launch_bounds__(kThreads16) void attn16_fwd_kernel(const __bf16* __
   const int r = lane & 31, hh = lane >> 5;
   const bool hh1 = hh != 0;
   const unsigned sel_lo = sel_lo_reg();
-  const LaneOffs lo = lane_offs(lane);
+  const Lane16 lo = lane16(lane);
   table16_setup(tabR, table, H, h);
   const int q = wave * 32 + r;
   const int qc = q < T16 ? q : T16 - 1;
@@ -220,13 +267,15 @@ __global__ __launch_bounds__(kThreads16) void attn16_fwd_kernel(const __bf16* __
       stage_slots(imgs + (cur ^ 1) * 2 * IMG16, s1 + D, ldq);
       stage_slots(imgs + (cur ^ 1) * 2 * IMG16 + IMG16, s1 + 2 * D, ldq);
     }
+    const RowBase16 kr = row_base16(lo, lds_addr_of(Ks));
+    const ColBase16 vc = col_base16(lo, lds_addr_of(Vs));
     f32x16 s[NB16];
 #pragma unroll
     for (int kb = 0; kb < NB16; ++kb) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) s[kb][i] = 0.f;
 #pragma unroll
-      for (int t = 0; t < 4; ++t) s[kb] = MFMA32(row_frag_o(Ks, lo, kb, t), Qf[t], s[kb]);
+      for (int t = 0; t < 4; ++t) s[kb] = MFMA32(lds_b128<0>(kr.a[t] + kb * 4096), Qf[t], s[kb]);
     }
     float mx = -INFINITY;
 #pragma unroll
@@ -271,10 +320,11 @@ __global__ __launch_bounds__(kThreads16) void attn16_fwd_kernel(const __bf16* __
 #pragma unroll
     for (int kb = 0; kb < NB16; ++kb) {
       bf16x8 vf[2][2];
-#pragma unroll
-      for (int ss = 0; ss < 2; ++ss)
-#pragma unroll
-        for (int db = 0; db < 2; ++db) vf[ss][db] = col_frag_o(Vs, lo, kb, ss, db);
+      {
+        const ColBase16 vb{{vc.a[0] + kb * 4096, vc.a[1] + kb * 4096, vc.a[2] + kb * 4096, vc.a[3] + kb * 4096}};   // (constants: fold)
+        vf[0][0] = col_frag16<0, 0, 0>(vb); vf[0][1] = col_frag16<0, 0, 1>(vb);
+        vf[1][0] = col_frag16<0, 1, 0>(vb); vf[1][1] = col_frag16<0, 1, 1>(vb);
+      }
       bf16x8 pf[2];
 #pragma unroll
       for (int ss = 0; ss < 2; ++ss) pf[ss] = acc_frag(s[kb], ss, inv);
@@ -332,8 +382,14 @@ constexpr int kExch16 = kImgs16 + 4 * IMG16;              // [7 waves][P^T tile 
 constexpr int kLdsBwd16 = kExch16 + NB16 * 4096;
 static_assert(kLdsBwd16 <= 160 * 1024, "fused backward: LDS budget");
 
-// exchange tile [32 queries][32 keys] bf16, 64-byte rows, 8-byte unit u of row r at position u ^ ((r >> 2) & 7)
-__device__ __forceinline__ int exch_off(int row, int unit) { return row * 64 + ((unit ^ ((row >> 2) & 7)) << 3); }
+// value of lane - 1 within the 16-lane row (0 for the first lane of a row): v_mov_b32_dpp row_shr:1
+__device__ __forceinline__ float dpp_shr1(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x111, 0xf, 0xf, true));
+}
+
+// exchange tile [32 queries][32 keys] bf16, 64-byte rows, 8-byte unit u of row r at position u ^ ((r >> 1) & 7): the
+// ds_write_b64 of 16 consecutive rows and the transposing reads (32 lanes = 4 rows x 8 units) are both conflict-free
+__device__ __forceinline__ int exch_off(int row, int unit) { return row * 64 + ((unit ^ ((row >> 1) & 7)) << 3); }
 
 template <bool DT>
 __global__ __launch_bounds__(kThreads16) void attn16_bwd_kernel(const __bf16* __restrict__ qkv, long long ldq,
@@ -365,7 +421,7 @@ __global__ __launch_bounds__(kThreads16) void attn16_bwd_kernel(const __bf16* __
   const int r = lane & 31, hh = lane >> 5;
   const bool hh1 = hh != 0;
   const unsigned sel_lo = sel_lo_reg();
-  const LaneOffs lo = lane_offs(lane);
+  Lane16 lo = lane16(lane);
   table16_setup(tabR, table, H, h);
   for (int i = threadIdx.x; i < TABLEN16; i += blockDim.x) { binsi[i] = 0; binsf[i] = 0.f; }
   if (threadIdx.x < HD) qsum[threadIdx.x] = 0.f;
@@ -373,21 +429,18 @@ __global__ __launch_bounds__(kThreads16) void attn16_bwd_kernel(const __bf16* __
   const unsigned bb = lds_addr_of(reinterpret_cast<const char*>(tabR)) + 4 * (q_base16(q) + 4 * hh);
   const float clsb = table[(long long)(q == 0 ? NRD16 - 1 : NRD16 - 2) * H + h];
   // exchange tile addressing: writer (row = r, units 2 g + hh), reader (transposing 8-byte reads, see attn_common.hpp)
-  int wr_off[4];
-#pragma unroll
-  for (int g = 0; g < 4; ++g) wr_off[g] = exch_off(r, 2 * g + hh);
-  int rd_off[2][2];
-  {
-    const int rhalf = (lane >> 4) & 1, q4 = (lane >> 2) & 3, p = lane & 3;
-#pragma unroll
-    for (int ss = 0; ss < 2; ++ss) {
-      rd_off[ss][0] = exch_off(16 * ss + 4 * hh + q4, rhalf * 4 + p);
-      rd_off[ss][1] = exch_off(16 * ss + 8 + 4 * hh + q4, rhalf * 4 + p);
-    }
-  }
+  // (the unit and row indices of a lane's accesses differ by whole bits again: one register each, XOR constants)
+  unsigned wr0 = exch_off(r, hh);                      // unit 2 g + hh: wr0 ^ (g << 4)
+  unsigned rd0 = exch_off(4 * hh + ((lane >> 2) & 3), ((lane >> 4) & 1) * 4 + (lane & 3));
+                                                             // rows + 16 ss + 8 j: (rd0 ^ (j << 5)) + 1024 ss + 512 j
   float bsum[8];                                             // q_bias gradient: columns 8 (lane & 7) .. + 7 of the rows this lane stores
 #pragma unroll
   for (int i = 0; i < 8; ++i) bsum[i] = 0.f;
+  // diagonal chains of the bucket sums (see the produce step)
+  const bool has_left = (r & 15) != 0 && q < T16 && q >= 2 && (q - 1) % W16 != 0;          // lane - 1: query q - 1, same grid row
+  const bool has_right = (r & 15) != 15 && q + 1 < T16 && q >= 1 && q % W16 != 0;          // lane + 1 continues this lane's chains
+  const float link = has_left ? 1.f : 0.f;
+  const bool chain_end = !has_right;
   float dcls = 0.f;                                          // gradient of the (token -> cls) / (cls -> cls) bucket
   // per-query rows of the sample (lse, delta, |dO|^2) travel by LDS-DMA as well: a plain load into registers would make the
   // compiler wait for ALL vector-memory operations (the stores of the previous sample included) in front of the first use
@@ -422,13 +475,14 @@ __global__ __launch_bounds__(kThreads16) void attn16_bwd_kernel(const __bf16* __
     const float dq_ = rowsL[kRowsLd16 + q], nqn = rowsL[2 * kRowsLd16 + q];
     T16_TICK(0);
     // ---- fixed-point scale of the bucket atomics: |dS| = p |dP - delta| <= max|dO_q| max|V_k| + max|delta_q| =: bound;
-    // 2^21 / bound: fx_round() needs |x| < 2^22 (bf16-rounded dP may pass the bound by 2^-8), 196 terms stay below 2^31
+    // 2^19 / bound: fx_round() needs |x| < 2^22 and a chain sum has up to four terms (bf16-rounded dP may pass the bound by
+    // 2^-8); a bucket's <= 196 terms stay far below 2^31
     float fx = 0.f;
     if (DT) {
       float vn = 0.f;
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
-        const bf16x8 v = row_frag_o(Vs, lo, wave, t);
+        const bf16x8 v = lds_b128<0>((lo.row0 ^ (t << 5)) + lds_addr_of(Vs) + wave * 4096);   // V rows of this wave's key slots
 #pragma unroll
         for (int i = 0; i < 8; ++i) vn = fmaf((float)v[i], (float)v[i], vn);
       }
@@ -449,7 +503,7 @@ __global__ __launch_bounds__(kThreads16) void attn16_bwd_kernel(const __bf16* __
         t2 = fmaxf(t2, red[w * 4 + 2]);
       }
       const float bound = sqrtf(t0) * sqrtf(t2) + t1;
-      fx = bound > 0.f ? 2097152.0f / bound : 0.f;
+      fx = bound > 0.f ? 524288.0f / bound : 0.f;
     }
     f32x16 dQt[2], dKt[2], dVt[2];
 #pragma unroll
@@ -457,26 +511,66 @@ __global__ __launch_bounds__(kThreads16) void attn16_bwd_kernel(const __bf16* __
 #pragma unroll
       for (int i = 0; i < 16; ++i) { dQt[db][i] = 0.f; dKt[db][i] = 0.f; dVt[db][i] = 0.f; }
     T16_TICK(1);
+    // ---------------- consume: tile (queries wpv, keys `wave`)
+    auto consume = [&](int wpv) {
+      const unsigned tb = lds_addr_of(exch) + wpv * 4096;
+      const ColBase16 qc = col_base16(lo, lds_addr_of(Qs) + wpv * 4096);      // dO image: + IMG16
+      const unsigned rd[2] = {rd0 + tb, (rd0 ^ 32u) + tb};                     // exchange rows + 8 j
+      auto half = [&](auto SS) {
+        constexpr int ss = decltype(SS)::value;
+        union { struct { s16x4 l, h; } s; bf16x8 v; } pB, dB;
+        pB.s.l = lds_tr16_off<1024 * ss>(rd[0]);
+        pB.s.h = lds_tr16_off<1024 * ss + 512>(rd[1]);
+        dB.s.l = lds_tr16_off<2048 + 1024 * ss>(rd[0]);
+        dB.s.h = lds_tr16_off<2048 + 1024 * ss + 512>(rd[1]);
+        bf16x8 cdo[2], cq[2];
+        cdo[0] = col_frag16<IMG16, ss, 0>(qc); cdo[1] = col_frag16<IMG16, ss, 1>(qc);
+        cq[0] = col_frag16<0, ss, 0>(qc); cq[1] = col_frag16<0, ss, 1>(qc);
+        LDS_TR_WAIT();
+#pragma unroll
+        for (int db = 0; db < 2; ++db) {
+          dVt[db] = MFMA32(cdo[db], pB.v, dVt[db]);
+          dKt[db] = MFMA32(cq[db], dB.v, dKt[db]);
+        }
+      };
+      half(std::integral_constant<int, 0>{});
+      half(std::integral_constant<int, 1>{});
+    };
     int kb = wave, wp = wave;                                // key block produced / producer consumed in this step
     for (int s = 0; s < NB16; ++s) {
+      // (keeps the XOR forms of the fragment addresses inside the loop: hoisted, they occupy a register each)
+      asm volatile("" : "+v"(lo.row0), "+v"(lo.col0), "+v"(wr0), "+v"(rd0));
       // ---------------- produce: tile (queries `wave`, keys kb)
+      const unsigned kblk = lds_addr_of(Ks) + kb * 4096;
+      const RowBase16 kr = row_base16(lo, kblk);               // K rows of block kb; V rows: + IMG16
+      const RowBase16 qr = row_base16(lo, lds_addr_of(Qs) + wave * 4096);   // this wave's Q rows; dO rows: + IMG16
       f32x16 S, dP;
 #pragma unroll
       for (int i = 0; i < 16; ++i) { S[i] = 0.f; dP[i] = 0.f; }
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
-        S = MFMA32(row_frag_o(Ks, lo, kb, t), row_frag_o(Qs, lo, wave, t), S);
-        dP = MFMA32(row_frag_o(Vs, lo, kb, t), row_frag_o(dOs, lo, wave, t), dP);
+        S = MFMA32(lds_b128<0>(kr.a[t]), lds_b128<0>(qr.a[t]), S);
+        dP = MFMA32(lds_b128<IMG16>(kr.a[t]), lds_b128<IMG16>(qr.a[t]), dP);
       }
       T16_TICK(2);
       const int ba = (int)bb + kb * kBlockStep16;
       const int na = ba + kBinsI16;
       const float padb = kb == 0 ? clsb : -INFINITY;
+      // the bias reads of register group g + 1 are issued BEFORE the bucket atomics of group g: LDS operations retire in
+      // order, so a read behind an atomic waits for it (measured: the four exposed atomic latencies per tile cost more than
+      // all of the softmax arithmetic)
+      float bnext[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) bnext[e] = lds_f32_abs(ba + KOFF16(0, e));
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         float bias[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) bias[e] = lds_f32_abs(ba + KOFF16(g, e));
+        for (int e = 0; e < 4; ++e) bias[e] = bnext[e];
+        if (g < 3) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) bnext[e] = lds_f32_abs(ba + KOFF16((g + 1) & 3, e));
+        }
         if (g & 1) {
           bias[2] = hh1 ? (g == 1 ? padb : -INFINITY) : bias[2];
           bias[3] = hh1 ? -INFINITY : bias[3];
@@ -486,20 +580,40 @@ __global__ __launch_bounds__(kThreads16) void attn16_bwd_kernel(const __bf16* __
         float tt[4], dd[4];
         tt[0] = add_lo(s0, bias[0], sel_lo); tt[1] = add_hi(s0, bias[1]); tt[2] = add_lo(s1, bias[2], sel_lo); tt[3] = add_hi(s1, bias[3]);
         dd[0] = add_lo(d0, -dq_, sel_lo); dd[1] = add_hi(d0, -dq_); dd[2] = add_lo(d1, -dq_, sel_lo); dd[3] = add_hi(d1, -dq_);
+        float xb[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const float p = fexp2(fmaf(tt[e], kLog2e, -lq2));
           const float ds = p * dd[e];
           S[4 * g + e] = p;
           dP[4 * g + e] = ds;
-          if (DT) {
-            float dsb = ds;
-            if (g == 1 && e == 2 && kb == 0) {               // the cls key: its bucket is kept in a register
-              dcls += hh1 ? ds : 0.f;
-              dsb = hh1 ? 0.f : ds;
-            }
-            lds_add_i32_abs(na + KOFF16(g, e), fx_round(dsb, fx));
+          xb[e] = ds;
+        }
+        if (DT) {
+          if (g == 1 && kb == 0) {                           // the cls key: its bucket is kept in a register
+            dcls += hh1 ? xb[2] : 0.f;
+            xb[2] = hh1 ? 0.f : xb[2];
           }
+          // (query + 1, key + 1) is the bucket of (query, key): the four keys of a register group are summed along the
+          // diagonal over neighbouring lanes first (row_shr:1; `link` = 0 where the left neighbour is in another grid row
+          // or another 16-lane row), so a lane adds ONE chain sum instead of four elements; the lanes at which chains
+          // break off (`chain_end`: about 5 of 32) add their three unfinished chains themselves.
+          const float c1 = fmaf(dpp_shr1(xb[0]), link, xb[1]);
+          const float c2 = fmaf(dpp_shr1(c1), link, xb[2]);
+          const float c3 = fmaf(dpp_shr1(c2), link, xb[3]);
+#if ATTN16_EXP == 1      // timing experiment: arithmetic kept, no atomics
+          dcls += __int_as_float(fx_round(c3, fx) ^ fx_round(xb[0], fx) ^ fx_round(c1, fx) ^ fx_round(c2, fx));
+#elif ATTN16_EXP == 2    // timing experiment: only the full-wave atomic
+          lds_add_i32_abs(na + KOFF16(g, 3), fx_round(c3, fx));
+          dcls += __int_as_float(fx_round(xb[0], fx) ^ fx_round(c1, fx) ^ fx_round(c2, fx));
+#else
+          lds_add_i32_abs(na + KOFF16(g, 3), fx_round(c3, fx));
+          if (chain_end) {
+            lds_add_i32_abs(na + KOFF16(g, 0), fx_round(xb[0], fx));
+            lds_add_i32_abs(na + KOFF16(g, 1), fx_round(c1, fx));
+            lds_add_i32_abs(na + KOFF16(g, 2), fx_round(c2, fx));
+          }
+#endif
         }
       }
       const bf16x8 pf0 = acc_frag(S, 0, 1.0f), pf1 = acc_frag(S, 1, 1.0f);
@@ -507,10 +621,9 @@ __global__ __launch_bounds__(kThreads16) void attn16_bwd_kernel(const __bf16* __
       T16_TICK(3);
       {
         bf16x8 ckf[2][2];
-#pragma unroll
-        for (int ss = 0; ss < 2; ++ss)
-#pragma unroll
-          for (int db = 0; db < 2; ++db) ckf[ss][db] = col_frag_o(Ks, lo, kb, ss, db);
+        const ColBase16 kc = col_base16(lo, kblk);
+        ckf[0][0] = col_frag16<0, 0, 0>(kc); ckf[0][1] = col_frag16<0, 0, 1>(kc);
+        ckf[1][0] = col_frag16<0, 1, 0>(kc); ckf[1][1] = col_frag16<0, 1, 1>(kc);
         LDS_TR_WAIT();
 #pragma unroll
         for (int db = 0; db < 2; ++db) {
@@ -522,39 +635,22 @@ __global__ __launch_bounds__(kThreads16) void attn16_bwd_kernel(const __bf16* __
       __syncthreads();                                       // every wave has consumed the tiles of step s - 1
       T16_TICK(5);
       {
-        char* mine = exch + wave * 4096;
-        union { bf16x8 v; uint2 h[2]; } u;
-        u.v = pf0; *reinterpret_cast<uint2*>(mine + wr_off[0]) = u.h[0]; *reinterpret_cast<uint2*>(mine + wr_off[1]) = u.h[1];
-        u.v = pf1; *reinterpret_cast<uint2*>(mine + wr_off[2]) = u.h[0]; *reinterpret_cast<uint2*>(mine + wr_off[3]) = u.h[1];
-        u.v = df0; *reinterpret_cast<uint2*>(mine + 2048 + wr_off[0]) = u.h[0]; *reinterpret_cast<uint2*>(mine + 2048 + wr_off[1]) = u.h[1];
-        u.v = df1; *reinterpret_cast<uint2*>(mine + 2048 + wr_off[2]) = u.h[0]; *reinterpret_cast<uint2*>(mine + 2048 + wr_off[3]) = u.h[1];
+        const unsigned mine = lds_addr_of(exch) + wave * 4096;
+        unsigned wa[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) wa[g] = (wr0 ^ (g << 4)) + mine;
+        typedef __attribute__((address_space(3))) unsigned long long lds_u64;
+        auto put = [&](int off, const bf16x8& v, int g0) {
+          union { bf16x8 v; unsigned long long h[2]; } u;
+          u.v = v;
+          *reinterpret_cast<lds_u64*>(wa[g0] + off) = u.h[0];
+          *reinterpret_cast<lds_u64*>(wa[g0 + 1] + off) = u.h[1];
+        };
+        put(0, pf0, 0); put(0, pf1, 2); put(2048, df0, 0); put(2048, df1, 2);
       }
       __syncthreads();                                       // tiles of step s are published
       T16_TICK(6);
-      // ---------------- consume: tile (queries wp, keys `wave`)
-      {
-        const unsigned tb = lds_addr_of(exch) + wp * 4096;
-#pragma unroll
-        for (int ss = 0; ss < 2; ++ss) {
-          union { struct { s16x4 l, h; } s; bf16x8 v; } pB, dB;
-          pB.s.l = lds_tr16_b64(tb + rd_off[ss][0]);
-          pB.s.h = lds_tr16_b64(tb + rd_off[ss][1]);
-          dB.s.l = lds_tr16_b64(tb + 2048 + rd_off[ss][0]);
-          dB.s.h = lds_tr16_b64(tb + 2048 + rd_off[ss][1]);
-          bf16x8 cdo[2], cq[2];
-#pragma unroll
-          for (int db = 0; db < 2; ++db) {
-            cdo[db] = col_frag_o(dOs, lo, wp, ss, db);
-            cq[db] = col_frag_o(Qs, lo, wp, ss, db);
-          }
-          LDS_TR_WAIT();
-#pragma unroll
-          for (int db = 0; db < 2; ++db) {
-            dVt[db] = MFMA32(cdo[db], pB.v, dVt[db]);
-            dKt[db] = MFMA32(cq[db], dB.v, dKt[db]);
-          }
-        }
-      }
+      consume(wp);
       kb = kb + 1 == NB16 ? 0 : kb + 1;
       wp = wp == 0 ? NB16 - 1 : wp - 1;
       T16_TICK(7);

@@ -53,16 +53,24 @@ __device__ __forceinline__ void glds16(const void* gsrc, char* lds_dst) {
 }
 #define ATTN_DMA_WAIT() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 
-// LDS image of a [TP tokens][64] bf16 head slice: 128-B rows, 16-B chunk c of token t lives at
-// chunk position c ^ ((t >> 1) & 7) (conflict-free ds_read_b128 row fragments).
-__device__ __forceinline__ int tok_slot(int tok, int chunk) { return tok * 8 + (chunk ^ ((tok >> 1) & 7)); }
+// LDS image of a [TP tokens][64] bf16 head slice: 128-B rows, 16-B chunk c of token t lives at chunk position
+// c ^ img_key(t).  img_key(t) = the three bits of (t >> 1) rotated (bit 0 -> bit 2): any permutation of these bits keeps
+// the ds_read_b128 row fragments conflict-free (16-lane groups, 8 tokens of one parity per group, 8 distinct keys); the
+// rotation also spreads the transposing column reads (ds_read_b64_tr_b16: 32-lane groups = 4 consecutive tokens x 4 chunks
+// x 2 halves) over all 64 banks -- with the plain key (t >> 1) & 7 tokens t and t + 2 of a group met chunks c and c ^ 1 in
+// the same banks (2-way conflict on every column read: tools/attn_pmc.sh, SQ_LDS_BANK_CONFLICT).
+__device__ __forceinline__ int img_key(int tok) {
+  const int k = (tok >> 1) & 7;
+  return ((k & 1) << 2) | (k >> 1);
+}
+__device__ __forceinline__ int tok_slot(int tok, int chunk) { return tok * 8 + (chunk ^ img_key(tok)); }
 
 // Stage src[tok*ld + 0..63] (tok < T, zero beyond) with LDS-DMA: one wave-instruction = 8 tokens.
 __device__ __forceinline__ void stage_head(char* dst, const __bf16* src, long long ld, int T, int TP) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
   for (int inst = wave; inst < TP / 8; inst += nw) {
     const int tok = inst * 8 + (lane >> 3), cpos = lane & 7;
-    const int chunk = cpos ^ ((tok >> 1) & 7);
+    const int chunk = cpos ^ img_key(tok);
     const void* g = tok < T ? (const void*)(src + (long long)tok * ld + chunk * 8)
                             : (const void*)(g_attn_zero_page + cpos * 16);
     glds16(g, dst + inst * 1024);

@@ -20,7 +20,7 @@ __device__ __forceinline__ void stage_chunk(char* dst, const __bf16* src, long l
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
   for (int inst = wave; inst < NT / 8; inst += nw) {
     const int lt = inst * 8 + (lane >> 3), cpos = lane & 7;
-    const int chunk = cpos ^ ((lt >> 1) & 7);
+    const int chunk = cpos ^ img_key(lt);
     const int tok = t0 + lt;
     const void* g = tok < T ? (const void*)(src + (long long)tok * ld + chunk * 8)
                             : (const void*)(g_attn_zero_page + cpos * 16);
