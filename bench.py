@@ -168,13 +168,16 @@ def main():
                     help="skip the secondary figure for BASELINE configs[3] (rasterizer at 1 M events per sample)")
     ap.add_argument("--no-side-stream", action="store_true",
                     help="A/B: keep the weight-gradient GEMMs on the main stream (engine.wgrad_side_stream = False)")
-    ap.add_argument("--no-fwd-split", action="store_true",
-                    help="A/B: forward on one stream (engine.fwd_two_streams = False)")
+    ap.add_argument("--fwd-split", action="store_true",
+                    help="A/B: forward as an uneven two-stream split of the batch (engine.fwd_two_streams = True)")
+    ap.add_argument("--no-fwd-split", action="store_true", help="(default since round 2; kept for old command lines)")
     ap.add_argument("--no-config4-figure", action="store_true",
                     help="skip the secondary figure for BASELINE configs[3] end to end (1 M events per sample feeding ViT-B)")
     ap.add_argument("--rendezvous-only", action="store_true",
                     help="launch plumbing check without a GPU (tests/test_bench_launch.py): start the ranks, form a gloo "
                          "group, all-reduce one number, print a stub JSON line; measures nothing")
+    ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
+                    help="kernel-selection option for A/B runs (memhip_set_option), e.g. --opt gemm_stagger=0")
     a = ap.parse_args()
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(a, sys.argv[1:])                  # never returns
@@ -204,6 +207,11 @@ def main():
                               "rank_sum": float(t.item())}), flush=True)
         return
     torch.cuda.set_device(local_rank)
+    if a.opt:
+        from mem_amd import _lib
+        for kv in a.opt:
+            k, v = kv.split("=")
+            _lib.set_option(k, int(v))
     # MEMHIP_BENCH_FORCE_DIST=1: run the RCCL path (process group, parameter broadcast, per-bucket async all-reduce hooked
     # into backward, join before the optimizer) in a ONE-rank group -- a single-GPU dry run of what N > 1 executes
     force_dist = world == 1 and os.environ.get("MEMHIP_BENCH_FORCE_DIST") == "1"
@@ -229,7 +237,7 @@ def main():
                    use_abs_pos_emb=False, init_values=0.1).cuda().train()
     eng = model.engine
     eng.wgrad_side_stream = not a.no_side_stream
-    eng.fwd_two_streams = not a.no_fwd_split
+    eng.fwd_two_streams = bool(a.fwd_split) and not a.no_fwd_split
     import contextlib, io
     with contextlib.redirect_stdout(io.StringIO()):
         groups = get_parameter_groups(model, 0.05, model.no_weight_decay())

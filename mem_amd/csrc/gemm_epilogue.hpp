@@ -140,7 +140,11 @@ __device__ __forceinline__ void st_stream16(void* base, long long elem_off, unsi
 #ifdef MEMHIP_EXP_NOSTORE
   if ((a ^ b ^ c ^ d) != 0x12345677u) return;
 #endif
+#ifdef MEMHIP_EXP_PLAINSTORE
+  *reinterpret_cast<eu32x4*>(reinterpret_cast<__bf16*>(base) + elem_off) = eu32x4{a, b, c, d};
+#else
   __builtin_nontemporal_store(eu32x4{a, b, c, d}, reinterpret_cast<eu32x4*>(reinterpret_cast<__bf16*>(base) + elem_off));
+#endif
 }
 
 // erf(x / sqrt 2) and exp(-x^2 / 2) for two values (A&S 7.1.26, see erf_fast)
@@ -159,6 +163,9 @@ __device__ __forceinline__ void erf_exp2(ef32x2 x, ef32x2& erf, ef32x2& e) {
   erf = ef32x2{copysignf(y.x, z.x), copysignf(y.y, z.y)};
 }
 __device__ __forceinline__ ef32x2 gelu2(ef32x2 x) {
+#ifdef MEMHIP_EXP_NOGELU
+  return x * splat2(0.5f);
+#endif
   ef32x2 erf, e;
   erf_exp2(x, erf, e);
   const ef32x2 hx = x * splat2(0.5f);
@@ -173,6 +180,9 @@ __device__ __forceinline__ void gelu_and_grad2(ef32x2 x, ef32x2& g, ef32x2& dg) 
   dg = fma2(x * splat2(0.39894228040143267794f), e, cdf);
 }
 __device__ __forceinline__ ef32x2 gelu_grad2(ef32x2 x) {
+#ifdef MEMHIP_EXP_NOGELU
+  return x * splat2(0.5f);
+#endif
   ef32x2 erf, e;
   erf_exp2(x, erf, e);
   const ef32x2 cdf = fma2(splat2(0.5f), erf, splat2(0.5f));
@@ -212,7 +222,13 @@ struct EpiRow<MEMHIP_EPI_DGELU> { uint4 h; };
 template <>
 struct EpiRow<MEMHIP_EPI_MUL_AUX> { uint4 h; };
 template <>
-struct EpiRow<MEMHIP_EPI_RESIDUAL> { float x[8]; };
+struct EpiRow<MEMHIP_EPI_RESIDUAL> { float x[8]; float rm; };
+// No vector-memory instruction of a row epilogue sits behind a branch, not even a wave-uniform one: at the join hipcc's
+// waitcnt pass gives up counting and puts s_waitcnt vmcnt(0) in front of the next use of a loaded row, which then also waits
+// for every store issued so far (one store round trip per row).  Optional operands are therefore handled by POINTER selection:
+// a missing drop-path mask reads the constant 1, a missing bf16 copy of the branch output goes to a scratch line.
+__device__ const float g_epi_one = 1.0f;
+__device__ __attribute__((aligned(256))) unsigned char g_epi_trash[1024];
 template <int EPI>
 __device__ __forceinline__ void epi_row_load(const GemmArgs& p, int m, int n, EpiRow<EPI>& r) {
   if constexpr (EPI == MEMHIP_EPI_DGELU || EPI == MEMHIP_EPI_MUL_AUX) {
@@ -222,8 +238,16 @@ __device__ __forceinline__ void epi_row_load(const GemmArgs& p, int m, int n, Ep
 #endif
     r.h = *reinterpret_cast<const uint4*>(reinterpret_cast<const __bf16*>(p.aux) + (long long)m * p.ldaux + n);
   } else if constexpr (EPI == MEMHIP_EPI_RESIDUAL) {
-    if (p.aux) ld8(reinterpret_cast<const float*>(p.aux) + (long long)m * p.ldaux + n, r.x);
-    else ld8(p.resid + (long long)m * p.ldr + n, r.x);
+    // (base pointer and leading dimension are selected as scalars: one address computation per lane)
+    const float* base = p.aux ? reinterpret_cast<const float*>(p.aux) : p.resid;
+    const long long ld = p.aux ? p.ldaux : p.ldr;
+    ld8(base + (long long)m * ld + n, r.x);
+    // sample of the row for the drop-path mask: (m + 0.5) / rows_per_sample is at least 0.5 / rows_per_sample away from an
+    // integer, far more than the fp32 error of the product for any batch this library sees (quotient < 2^16)
+    const float inv = __frcp_rn((float)p.rows_per_sample);
+    const int smp = p.rowmask ? (int)(((float)(m + p.m_base) + 0.5f) * inv) : 0;
+    const float* rmb = p.rowmask ? p.rowmask : &g_epi_one;
+    r.rm = rmb[smp];
   }
 }
 
@@ -308,7 +332,7 @@ __device__ __forceinline__ void epilogue8(const GemmArgs& p, int m, int n, const
       for (int k = 0; k < 8; ++k) br[k] = __fmul_rn(c.g[k], br[k]);
     }
     if (p.rowmask) {                           // drop path: branch / keep_prob * mask[sample]
-      const float rm = p.rowmask[(m + p.m_base) / p.rows_per_sample];
+      const float rm = row.rm;
       const float rk = __frcp_rn(p.keep_prob);
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
@@ -320,7 +344,11 @@ __device__ __forceinline__ void epilogue8(const GemmArgs& p, int m, int n, const
     }
 #pragma unroll
     for (int k = 0; k < 8; ++k) x[k] = __fadd_rn(x[k], br[k]);
-    if (p.out0) st_stream16(p.out0, (long long)m * p.ldo0 + n, y[0], y[1], y[2], y[3]);
+    {
+      __bf16* ob = p.out0 ? reinterpret_cast<__bf16*>(p.out0) : reinterpret_cast<__bf16*>(g_epi_trash);
+      const long long ldo = p.out0 ? p.ldo0 : 0;
+      *reinterpret_cast<eu32x4*>(ob + (long long)m * ldo + (p.out0 ? n : (n & 255))) = eu32x4{y[0], y[1], y[2], y[3]};
+    }
     st8(p.resid + (long long)m * p.ldr + n, x);
   } else if constexpr (EPI == MEMHIP_EPI_DGELU) {
     const unsigned h[4] = {row.h.x, row.h.y, row.h.z, row.h.w};
@@ -364,6 +392,40 @@ __device__ __forceinline__ void epilogue8(const GemmArgs& p, int m, int n, const
     }
     st8(p.resid + ((long long)b * (L + 1) + 1 + pi) * p.ldr + n, x);
   }
+}
+
+// The residual epilogue from the already rounded and packed branch output y (8 columns = 4 bf16 pairs): see gemm_p8.hip
+__device__ __forceinline__ void epilogue8_residual_packed(const GemmArgs& p, int m, int n, const unsigned* y, const EpiCols& c,
+                                                          const EpiRow<MEMHIP_EPI_RESIDUAL>& row) {
+  float br[8], x[8];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const ef32x2 f = unpack_bf16x2(y[k]);
+    br[2 * k] = f.x;
+    br[2 * k + 1] = f.y;
+  }
+  if (p.vec1) {                                // layer scale: gamma * branch (own rounding, as the reference)
+#pragma unroll
+    for (int k = 0; k < 8; ++k) br[k] = __fmul_rn(c.g[k], br[k]);
+  }
+  if (p.rowmask) {                             // drop path: branch / keep_prob * mask[sample]
+    const float rm = row.rm;
+    const float rk = __frcp_rn(p.keep_prob);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const float q0 = br[k] * rk;
+      const float q = fmaf(fmaf(-q0, p.keep_prob, br[k]), rk, q0);
+      br[k] = __fmul_rn(q, rm);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) x[k] = __fadd_rn(row.x[k], br[k]);
+  {
+    __bf16* ob = p.out0 ? reinterpret_cast<__bf16*>(p.out0) : reinterpret_cast<__bf16*>(g_epi_trash);
+    const long long ldo = p.out0 ? p.ldo0 : 0;
+    *reinterpret_cast<eu32x4*>(ob + (long long)m * ldo + (p.out0 ? n : (n & 255))) = eu32x4{y[0], y[1], y[2], y[3]};
+  }
+  st8(p.resid + (long long)m * p.ldr + n, x);
 }
 
 template <int EPI>

@@ -34,6 +34,7 @@
 // (no LDS transposition, no barrier) while the prefetch stream keeps running under it.
 #include "common.h"
 #include "gemm_epilogue.hpp"
+#include <type_traits>
 
 #ifndef P8_EPI_AHEAD
 #define P8_EPI_AHEAD 2
@@ -100,7 +101,7 @@ __device__ __forceinline__ int key_b(int r) { return ((r >> 1) & 1) | (((r >> 3)
   } while (0)
 
 template <int EPI, int BMT>
-__global__ __launch_bounds__(kThreads) void gemm_p8_kernel(GemmArgs p, int ntm, int ntn) {
+__global__ __launch_bounds__(kThreads) void gemm_p8_kernel(GemmArgs p, int ntm, int ntn, int stagger) {
   using G = P8Geo<BMT>;
   constexpr int kBuf = G::kBuf, MF = G::MF, AP = G::kAPieces, kAHalf = G::kAHalf;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -115,6 +116,20 @@ __global__ __launch_bounds__(kThreads) void gemm_p8_kernel(GemmArgs p, int ntm, 
   const int my_tiles = (ntiles - first + (int)gridDim.x - 1) / (int)gridDim.x;
   const int total = my_tiles * nk;
   if (total <= 0) return;
+  // Phase stagger.  Every workgroup runs the same number of K-tiles per output tile, so all CUs reach their epilogues
+  // together: 256 x (128 KiB store + operand rows) is an HBM burst the whole chip waits for while the main loops leave HBM
+  // idle (tools/epi_probe.py: the fc2-dgrad epilogue costs 118 us of 395).  Workgroups that own one tile less than the
+  // fullest have a tile time of slack: they start late by a per-workgroup fraction of `stagger` cycles per K-tile of a
+  // tile (stagger < 0: every workgroup is delayed, |stagger| cycles per K-tile).
+  if (stagger != 0) {
+    const int max_tiles = (ntiles + (int)gridDim.x - 1) / (int)gridDim.x;
+    if (stagger < 0 || my_tiles < max_tiles) {
+      const unsigned frac = (((unsigned)blockIdx.x * 2654435761u) >> 22) & 1023u;
+      const unsigned long long wait = ((unsigned long long)(stagger < 0 ? -stagger : stagger) * (unsigned)nk * frac) >> 10;
+      const unsigned long long t0 = __builtin_readcyclecounter();
+      while (__builtin_readcyclecounter() - t0 < wait) __builtin_amdgcn_s_sleep(16);
+    }
+  }
 
   // ---- LDS-DMA issue constants: a 128-row half-tile is 16 pieces of 8 rows x 128 B, this wave moves pieces
   // 2*wave and 2*wave+1; a 64-row A half-tile (BMT = 128) is 8 pieces, one per wave
@@ -147,7 +162,7 @@ __global__ __launch_bounds__(kThreads) void gemm_p8_kernel(GemmArgs p, int ntm, 
       char* slot = smem + buf * kBuf + (H == HA1 ? kAHalf : 0) + wave * AP * 1024;
       const int r0 = tm * BMT + (H == HA1 ? BMT / 2 : 0);
       const char* base = reinterpret_cast<const char*>(p.A) + ((long long)r0 * p.lda + kt * BK) * 2;
-      if (tm == ntm - 1 && r0 + BMT / 2 > p.M) {      // last M tile: clamp rows to M-1
+      if (BMT != 256 && tm == ntm - 1 && r0 + BMT / 2 > p.M) {      // last M tile: clamp rows to M-1
 #pragma unroll
         for (int j = 0; j < AP; ++j) {
           int gr = r0 + arow[j];
@@ -302,15 +317,6 @@ __global__ __launch_bounds__(kThreads) void gemm_p8_kernel(GemmArgs p, int ntm, 
 #else
       constexpr int kAhead = (EPI == MEMHIP_EPI_RESIDUAL || EPI == MEMHIP_EPI_PATCH_EMBED) ? 0 : kEpiAhead;
 #endif
-      EpiRow<EPI> rows[4][MF];
-      auto load_batch = [&](int b) {
-        const int jj = b >> 1, ii = b & 1;
-#pragma unroll
-        for (int mf = 0; mf < MF; ++mf) {
-          const int m = mrow + ii * (BMT / 2) + mf * 16;
-          epi_row_load<EPI>(p, m < p.M ? m : p.M - 1, ncol + jj * 128, rows[b][mf]);
-        }
-      };
       // residual epilogue: batch 0 alone; batches 1 and 2 go out together once batch 0 has released its
       // accumulators and row registers (the accumulators are re-zeroed after the loop, not inside it)
 #ifdef P8_RESID_AHEAD
@@ -318,42 +324,94 @@ __global__ __launch_bounds__(kThreads) void gemm_p8_kernel(GemmArgs p, int ntm, 
 #else
       constexpr bool kLate = (EPI == MEMHIP_EPI_RESIDUAL || EPI == MEMHIP_EPI_PATCH_EMBED) && P8_EPI_RESID_LATE;
 #endif
+      // The row guard (m < M) is a per-lane branch: a basic block per row, and at every block entry hipcc's waitcnt pass
+      // falls back to s_waitcnt vmcnt(0) in front of the first use of a loaded row -- which also waits for the STORE of
+      // the previous row (one store round trip per row, 16 per tile: the GELU' epilogue spent 22 us per tile that way).
+      // The 256-row kernel therefore only takes M % 256 == 0 (the launcher hands the remaining rows to the 128-row
+      // kernel, which keeps the guard): its epilogue is one basic block with counted waits -- loads complete under the
+      // arithmetic, stores are never waited for.
+      if constexpr (EPI == MEMHIP_EPI_RESIDUAL && BMT == 256) {
+        // Residual epilogue of the 256-row kernel.  A row carries 8 fp32 registers of residual input next to its 8
+        // accumulators, and about 80 registers are free beside the 128 accumulators, the B fragment of the next tile and the
+        // lane state of the prefetch stream: the generic form (batches of 4 rows) could keep a single batch of row loads in
+        // flight, and spilled.  Here the 16 rows of a lane go one by one with the loads of the next kResidAhead rows in
+        // flight (48 registers), in one basic block (counted waits, no store is ever waited for).
+#ifndef P8_RESID_ROWS_AHEAD
+#define P8_RESID_ROWS_AHEAD 2
+#endif
+        constexpr int kResidAhead = P8_RESID_ROWS_AHEAD;
+        EpiRow<EPI> rows[16];
+        auto row_m = [&](int r) { return mrow + ((r >> 2) & 1) * (BMT / 2) + (r & 3) * 16; };
+        auto row_n = [&](int r) { return ncol + (r >> 3) * 128; };
 #pragma unroll
-      for (int b = 0; b < kAhead && b < 4; ++b) load_batch(b);
-      float cs[8];
-      EpiCols cols;
+        for (int r = 0; r < kResidAhead; ++r) epi_row_load<EPI>(p, row_m(r), row_n(r), rows[r]);
+        float cs[8];
+        EpiCols cols;
 #pragma unroll
-      for (int b = 0; b < 4; ++b) {
-        const int j = b >> 1, i = b & 1;
-        const int n = ncol + j * 128;
-        if (i == 0) {
-#pragma unroll
-          for (int r = 0; r < 8; ++r) cs[r] = 0.f;
-          epi_cols_load<EPI>(p, n, cols);
-        }
-        if constexpr (kLate) {
-          if (b == 0) load_batch(0);
-          if (P8_EPI_RESID_LATE == 1) {
-            if (b == 1) { load_batch(1); load_batch(2); }
-            if (b == 2) load_batch(3);
-          } else {
-            if (b == 1) load_batch(1);
-            if (b == 2) { load_batch(2); load_batch(3); }
-          }
-        } else {
-          if (b + kAhead < 4) load_batch(b + kAhead);
-        }
-#pragma unroll
-        for (int mf = 0; mf < MF; ++mf) {
-          const int m = mrow + i * (BMT / 2) + mf * 16;
+        for (int r = 0; r < 16; ++r) {
+          __builtin_amdgcn_sched_barrier(0);
+          if ((r & 7) == 0) epi_cols_load<EPI>(p, row_n(r), cols);
+          if (r + kResidAhead < 16) epi_row_load<EPI>(p, row_m(r + kResidAhead), row_n(r + kResidAhead), rows[r + kResidAhead]);
+          const int q = ((r >> 2) & 1) * 2 + (r >> 3), mf = r & 3;
           float v[8];
 #pragma unroll
           for (int nf = 0; nf < 2; ++nf)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[nf * 4 + r] = acc[i * 2 + j][mf][nf][r];
-          if (m < p.M) epilogue8<EPI>(p, m, n, v, cs, cols, rows[b][mf]);
+            for (int c = 0; c < 4; ++c) v[nf * 4 + c] = acc[q][mf][nf][c];
+          epilogue8<EPI>(p, row_m(r), row_n(r), v, cs, cols, rows[r]);
         }
-        if (i == 1) colsum_flush16(p, n, cs, lane);
+      } else {
+        constexpr bool kEdge = BMT != 256;
+        EpiRow<EPI> rows[4][MF];
+        auto load_batch = [&](int b) {
+          const int jj = b >> 1, ii = b & 1;
+#pragma unroll
+          for (int mf = 0; mf < MF; ++mf) {
+            const int m = mrow + ii * (BMT / 2) + mf * 16;
+            epi_row_load<EPI>(p, kEdge ? (m < p.M ? m : p.M - 1) : m, ncol + jj * 128, rows[b][mf]);
+          }
+        };
+#pragma unroll
+        for (int b = 0; b < kAhead && b < 4; ++b) load_batch(b);
+        float cs[8];
+        EpiCols cols;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          const int j = b >> 1, i = b & 1;
+          const int n = ncol + j * 128;
+          // (without the row branches the whole epilogue is one scheduling region: keep the loads of later batches from
+          // being hoisted over this batch -- the row registers are budgeted per batch)
+          __builtin_amdgcn_sched_barrier(0);
+          if (i == 0) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) cs[r] = 0.f;
+            epi_cols_load<EPI>(p, n, cols);
+          }
+          if constexpr (kLate) {
+            if (b == 0) load_batch(0);
+            if (P8_EPI_RESID_LATE == 1) {
+              if (b == 1) { load_batch(1); load_batch(2); }
+              if (b == 2) load_batch(3);
+            } else {
+              if (b == 1) load_batch(1);
+              if (b == 2) { load_batch(2); load_batch(3); }
+            }
+          } else {
+            if (b + kAhead < 4) load_batch(b + kAhead);
+          }
+#pragma unroll
+          for (int mf = 0; mf < MF; ++mf) {
+            const int m = mrow + i * (BMT / 2) + mf * 16;
+            float v[8];
+#pragma unroll
+            for (int nf = 0; nf < 2; ++nf)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) v[nf * 4 + r] = acc[i * 2 + j][mf][nf][r];
+            if (!kEdge || m < p.M) epilogue8<EPI>(p, m, n, v, cs, cols, rows[b][mf]);
+            if (!kEdge) __builtin_amdgcn_sched_barrier(0);     // one row at a time (register budget)
+          }
+          if (i == 1) colsum_flush16(p, n, cs, lane);
+        }
       }
 #pragma unroll
       for (int q = 0; q < 4; ++q)
@@ -385,7 +443,8 @@ int launch_p8(const GemmArgs& p, hipStream_t s, int num_cu) {
     attr_done = true;
   }
   const int grid = ntm * ntn < num_cu ? ntm * ntn : num_cu;
-  hipLaunchKernelGGL((gemm_p8_kernel<EPI, BMT>), dim3(grid), dim3(kThreads), P8Geo<BMT>::kLds, s, p, ntm, ntn);
+  hipLaunchKernelGGL((gemm_p8_kernel<EPI, BMT>), dim3(grid), dim3(kThreads), P8Geo<BMT>::kLds, s, p, ntm, ntn,
+                     BMT == 256 ? opt(OPT_GEMM_STAGGER) : 0);
   return check_launch("gemm_bf16_nt(p8)");
 }
 
@@ -421,13 +480,14 @@ int gemm_p8_split_rows(const GemmArgs& p) {
   if (!num_cu) return 0;
   const int ntm = (p.M + BM - 1) / BM, ntn = p.N / BN;
   const int tiles = ntm * ntn, rounds = tiles / num_cu, rem = tiles % num_cu;
-  if (rounds < 1 || rem == 0 || rem * 2 > num_cu) return 0;
+  const int whole = (p.M / BM) * BM;                       // the 256-row kernel takes whole tiles only
+  if (rounds < 1 || rem == 0 || rem * 2 > num_cu) return whole == p.M ? 0 : whole;
   return (rounds * num_cu / ntn) * BM;
 }
 
 // Returns MEMHIP_EUNSUPPORTED when the shape does not fit this structure (caller falls back).
 int gemm_p8_dispatch(const GemmArgs& p, hipStream_t s) {
-  if (!p8_fits(p)) return MEMHIP_EUNSUPPORTED;
+  if (!p8_fits(p) || p.M % BM != 0) return MEMHIP_EUNSUPPORTED;   // whole 256-row tiles only (no row guard in the epilogue)
   const int num_cu = p8_num_cu();
   if (!num_cu) return MEMHIP_EUNSUPPORTED;
   switch (p.epilogue) {

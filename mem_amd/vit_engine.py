@@ -77,8 +77,11 @@ class ViTEngine:
         # linear function of the accumulated weight gradient)
         self.accumulate_grads = False
         self.wgrad_side_stream = True
-        self.fwd_two_streams = True       # forward: uneven two-stream split (see forward_trunk / _split_point);
-                                          # measured -0.24 ms at B = 256 (even halves: -0.08 ms)
+        self.fwd_two_streams = False      # forward: uneven two-stream split (see forward_trunk / _split_point).  It paid
+                                          # -0.24 ms at B = 256 while the GEMM epilogues stalled on their own stores (the
+                                          # second part filled those stalls); with the branch-free epilogues of the 256-row
+                                          # kernel (whole tiles only: a split batch leaves ragged row counts to the slower
+                                          # kernels) one stream is 0.2-0.5 ms faster.  Kept as an option (bench --fwd-split).
         self._side = None
         self._ev_pool, self._ev_i = [], 0
 

@@ -7,7 +7,7 @@ def t(f, n=20):
     for _ in range(n): f()
     torch.cuda.synchronize(); return (time.perf_counter() - t0) / n
 M = 256 * 197
-for N in (2304, 768):
+for N in (3072, 2304):
     for K in (128, 256, 768, 1536, 3072, 6144):
         A = torch.randn(M, K, device="cuda").bfloat16(); B = (torch.randn(N, K, device="cuda") * 0.05).bfloat16()
         o = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")

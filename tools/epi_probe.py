@@ -22,9 +22,14 @@ def run(name, m, n, k):
     r["mulaux"] = t(lambda: ops.gemm_nt(A, B, m, n, k, ops.EPI_MUL_AUX, out0=o, aux=aux, colsum=cs))
     r["resid"] = t(lambda: ops.gemm_nt(A, B, m, n, k, ops.EPI_RESIDUAL, out0=None, bias=bias, vec1=g, resid=x2, aux=x, ldaux=n, rows_per_sample=197))
     print(f"{name:8s} M={m} N={n} K={k} " + " ".join(f"{a} {v*1e6:6.1f}us/{fl/v/1e12:5.0f}TF" for a, v in r.items()), flush=True)
-for a in sys.argv[1:] or ["fc1", "fc2", "proj", "qkv"]:
-    if a == "fc1": run("fc1", M, 3072, 768)
-    if a == "fc2": run("fc2", M, 768, 3072)
-    if a == "proj": run("proj", M, 768, 768)
-    if a == "qkv": run("qkv", M, 2304, 768)
-    if a == "fc1s": run("fc1s", 43520, 3072, 768)
+from mem_amd import _lib
+for kv in os.environ.get('OPTS', '').split(','):
+    if kv: _lib.set_option(kv.split('=')[0], int(kv.split('=')[1]))
+for st in [int(v) for v in os.environ.get('STAGGERS', '0').split(',')]:
+  _lib.set_option("gemm_stagger", st); print("gemm_stagger", st)
+  for a in sys.argv[1:] or ["fc1", "fc2", "proj", "qkv"]:
+      if a == "fc1": run("fc1", M, 3072, 768)
+      if a == "fc2": run("fc2", M, 768, 3072)
+      if a == "proj": run("proj", M, 768, 768)
+      if a == "qkv": run("qkv", M, 2304, 768)
+      if a == "fc1s": run("fc1s", 43520, 3072, 768)
