@@ -100,7 +100,9 @@ __device__ __forceinline__ int key_b(int r) { return ((r >> 1) & 1) | (((r >> 3)
     __builtin_amdgcn_sched_barrier(0);    \
   } while (0)
 
-template <int EPI, int BMT>
+// GUARD: the last tile row may reach past M (rows clamped on load, guarded on store).  The 256-row kernel is only
+// instantiated without it; the 128-row kernel in both forms (the rows it is handed are usually whole tiles too).
+template <int EPI, int BMT, bool GUARD>
 __global__ __launch_bounds__(kThreads) void gemm_p8_kernel(GemmArgs p, int ntm, int ntn, int stagger) {
   using G = P8Geo<BMT>;
   constexpr int kBuf = G::kBuf, MF = G::MF, AP = G::kAPieces, kAHalf = G::kAHalf;
@@ -162,7 +164,7 @@ __global__ __launch_bounds__(kThreads) void gemm_p8_kernel(GemmArgs p, int ntm, 
       char* slot = smem + buf * kBuf + (H == HA1 ? kAHalf : 0) + wave * AP * 1024;
       const int r0 = tm * BMT + (H == HA1 ? BMT / 2 : 0);
       const char* base = reinterpret_cast<const char*>(p.A) + ((long long)r0 * p.lda + kt * BK) * 2;
-      if (BMT != 256 && tm == ntm - 1 && r0 + BMT / 2 > p.M) {      // last M tile: clamp rows to M-1
+      if (GUARD && tm == ntm - 1 && r0 + BMT / 2 > p.M) {      // last M tile: clamp rows to M-1
 #pragma unroll
         for (int j = 0; j < AP; ++j) {
           int gr = r0 + arow[j];
@@ -361,7 +363,7 @@ __global__ __launch_bounds__(kThreads) void gemm_p8_kernel(GemmArgs p, int ntm, 
           epilogue8<EPI>(p, row_m(r), row_n(r), v, cs, cols, rows[r]);
         }
       } else {
-        constexpr bool kEdge = BMT != 256;
+        constexpr bool kEdge = GUARD;
         EpiRow<EPI> rows[4][MF];
         auto load_batch = [&](int b) {
           const int jj = b >> 1, ii = b & 1;
@@ -432,20 +434,26 @@ __global__ __launch_bounds__(kThreads) void gemm_p8_kernel(GemmArgs p, int ntm, 
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // no LDS-DMA may outlive the workgroup
 }
 
-template <int EPI, int BMT>
-int launch_p8(const GemmArgs& p, hipStream_t s, int num_cu) {
+template <int EPI, int BMT, bool GUARD>
+int launch_p8g(const GemmArgs& p, hipStream_t s, int num_cu) {
   const int ntm = (p.M + BMT - 1) / BMT, ntn = p.N / BN;
   static bool attr_done = false;
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_p8_kernel<EPI, BMT>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_p8_kernel<EPI, BMT, GUARD>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, P8Geo<BMT>::kLds);
     if (e != hipSuccess) return fail(MEMHIP_ELAUNCH, "gemm_p8: set smem attr: %s", hipGetErrorString(e));
     attr_done = true;
   }
   const int grid = ntm * ntn < num_cu ? ntm * ntn : num_cu;
-  hipLaunchKernelGGL((gemm_p8_kernel<EPI, BMT>), dim3(grid), dim3(kThreads), P8Geo<BMT>::kLds, s, p, ntm, ntn,
+  hipLaunchKernelGGL((gemm_p8_kernel<EPI, BMT, GUARD>), dim3(grid), dim3(kThreads), P8Geo<BMT>::kLds, s, p, ntm, ntn,
                      BMT == 256 ? opt(OPT_GEMM_STAGGER) : 0);
   return check_launch("gemm_bf16_nt(p8)");
+}
+
+template <int EPI, int BMT>
+int launch_p8(const GemmArgs& p, hipStream_t s, int num_cu) {
+  if constexpr (BMT == 256) return launch_p8g<EPI, 256, false>(p, s, num_cu);
+  else return p.M % 128 == 0 ? launch_p8g<EPI, 128, false>(p, s, num_cu) : launch_p8g<EPI, 128, true>(p, s, num_cu);
 }
 
 }  // namespace
