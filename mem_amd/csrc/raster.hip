@@ -8,6 +8,10 @@
 
 static_assert(sizeof(memhip_event_aug_t) == 56, "memhip_event_aug_t ABI layout");
 
+#ifndef RASTER_EXP
+#define RASTER_EXP 0      // timing experiments (tools/build_variant.sh); 0 = the shipped kernels
+#endif
+
 namespace {
 
 constexpr int kThreads = 256;
@@ -30,12 +34,55 @@ struct Ev { double x, y, t, p; long long pos; bool keep; };
 
 // One event through the reference's augmentation chain (datasets.py:464-549, 598-609), in
 // float64 and in the reference's order.  `i` is the index inside the sample's window of n events.
-__device__ __forceinline__ Ev load_event(const double* __restrict__ ev, long long beg, long long n,
-                                         long long i, const memhip_event_aug_t* __restrict__ a,
+// (the raw 32-byte row and the arithmetic are separate: the kernels issue the loads of ALL the events of a thread before
+// the first event is looked at -- inside the per-event branches (out of range, filtered, bad index) hipcc waits for
+// every load right where it is issued, i.e. one event's 32 bytes in flight per thread)
+struct RawEv { double2 xy, tp; };
+__device__ __forceinline__ RawEv load_raw(const double* __restrict__ ev, long long row) {
+  return RawEv{reinterpret_cast<const double2*>(ev)[2 * row], reinterpret_cast<const double2*>(ev)[2 * row + 1]};
+}
+// The sample's augmentation as wave-uniform float64 constants (neutral when there is none: x * 1.0 and x + 0.0 are exact,
+// the sign of a zero does not survive the truncation to a pixel index): the per-event arithmetic is branch-free and
+// converts nothing -- the reference's order of operations is unchanged.
+struct AugK { double sx, sy, fw1, shx, shy, fw, fh; bool tflip, flipx, filt; };
+__device__ __forceinline__ AugK aug_k(const memhip_event_aug_t* __restrict__ a) {
+  AugK k{1.0, 1.0, 0.0, 0.0, 0.0, 0.0, 0.0, false, false, false};
+  if (a) {
+    k.sx = a->scale_x; k.sy = a->scale_y;
+    k.tflip = a->time_flip != 0; k.flipx = a->flip_x != 0; k.filt = a->do_filter != 0;
+    k.fw1 = (double)(a->flip_w - 1);
+    k.shx = (double)a->shift_x; k.shy = (double)a->shift_y;
+    k.fw = (double)a->filt_w; k.fh = (double)a->filt_h;
+  }
+  return k;
+}
+__device__ __forceinline__ Ev make_event_k(const RawEv& r, long long n, long long i, const AugK& k, double t_last) {
+  Ev e{r.xy.x * k.sx, r.xy.y * k.sy, r.tp.x, r.tp.y, i, true};
+  if (k.tflip) { e.pos = n - 1 - i; e.t = t_last - e.t; e.p = -e.p; }
+  if (k.flipx) e.x = k.fw1 - e.x;
+  e.x += k.shx;
+  e.y += k.shy;
+  if (k.filt) e.keep = (e.x >= 0.0) & (e.x < k.fw) & (e.y >= 0.0) & (e.y < k.fh);
+  return e;
+}
+// unsigned division by a wave-uniform divisor d through its (multiplier, shift) pair (Granlund-Montgomery, n < 2^32):
+//   l = ceil(log2 d), m = floor(2^32 (2^l - d) / d) + 1, n / d = (t + ((n - t) >> 1)) >> (l - 1) with t = mulhi(m, n)
+struct UDiv { unsigned m; int l; };
+__host__ __device__ inline UDiv udiv_prepare(unsigned d) {
+  int l = 0;
+  while ((1ull << l) < d) ++l;
+  const unsigned long long m = ((1ull << 32) * ((1ull << l) - d)) / d + 1;
+  return UDiv{(unsigned)m, l};
+}
+__device__ __forceinline__ unsigned udiv_apply(unsigned n, const UDiv& u) {
+  if (u.l == 0) return n;                                    // d == 1
+  const unsigned t = __umulhi(u.m, n);
+  return (t + ((n - t) >> 1)) >> (u.l - 1);
+}
+
+__device__ __forceinline__ Ev make_event(const RawEv& r, long long n, long long i, const memhip_event_aug_t* __restrict__ a,
                                          double t_last) {
-  const double2 xy = reinterpret_cast<const double2*>(ev)[2 * (beg + i)];
-  const double2 tp = reinterpret_cast<const double2*>(ev)[2 * (beg + i) + 1];
-  Ev e{xy.x, xy.y, tp.x, tp.y, i, true};
+  Ev e{r.xy.x, r.xy.y, r.tp.x, r.tp.y, i, true};
   if (a) {
     e.x *= a->scale_x;
     e.y *= a->scale_y;
@@ -47,6 +94,11 @@ __device__ __forceinline__ Ev load_event(const double* __restrict__ ev, long lon
       e.keep = (e.x >= 0.0) & (e.x < (double)a->filt_w) & (e.y >= 0.0) & (e.y < (double)a->filt_h);
   }
   return e;
+}
+__device__ __forceinline__ Ev load_event(const double* __restrict__ ev, long long beg, long long n,
+                                         long long i, const memhip_event_aug_t* __restrict__ a,
+                                         double t_last) {
+  return make_event(load_raw(ev, beg + i), n, i, a, t_last);
 }
 
 __global__ __launch_bounds__(kThreads) void raster_count(
@@ -70,11 +122,17 @@ __global__ __launch_bounds__(kThreads) void raster_count(
   const long long chunk = (long long)kThreads * kEvPerThread;
   for (long long base = (long long)blockIdx.x * chunk; base < n;
        base += (long long)gridDim.x * chunk) {
+    RawEv raw[kEvPerThread];
+#pragma unroll
+    for (int k = 0; k < kEvPerThread; ++k) {
+      const long long i = base + (long long)k * kThreads + threadIdx.x;
+      raw[k] = load_raw(ev, beg + (i < n ? i : n - 1));          // (n > 0 inside this loop)
+    }
 #pragma unroll
     for (int k = 0; k < kEvPerThread; ++k) {
       const long long i = base + (long long)k * kThreads + threadIdx.x;
       if (i >= n) break;
-      const Ev e = load_event(ev, beg, n, i, a, t_last);
+      const Ev e = make_event(raw[k], n, i, a, t_last);
       if (!e.keep) continue;
       const long long xi = (long long)e.x;   // trunc toward zero == ndarray.astype(int)
       const long long yi = (long long)e.y;
@@ -174,8 +232,19 @@ __global__ __launch_bounds__(kLdsThreads) void raster_lds_kernel(
   const memhip_event_aug_t* a = augs ? augs + b : nullptr;
   const double t_last = (a && a->time_flip && n > 0) ? ev[4 * (beg + n - 1) + 2] : 0.0;
   int bad = 0;
-  for (long long i = threadIdx.x; i < n; i += kLdsThreads) {
-    const Ev e = load_event(ev, beg, n, i, a, t_last);
+  constexpr int kLdsBatch = 4;
+  for (long long i0 = threadIdx.x; i0 < n; i0 += (long long)kLdsBatch * kLdsThreads) {
+    RawEv raw[kLdsBatch];
+#pragma unroll
+    for (int k = 0; k < kLdsBatch; ++k) {
+      const long long i = i0 + (long long)k * kLdsThreads;
+      raw[k] = load_raw(ev, beg + (i < n ? i : n - 1));
+    }
+#pragma unroll
+    for (int k = 0; k < kLdsBatch; ++k) {
+    const long long i = i0 + (long long)k * kLdsThreads;
+    if (i >= n) break;
+    const Ev e = make_event(raw[k], n, i, a, t_last);
     if (!e.keep) continue;
     const long long xi = (long long)e.x;   // trunc toward zero == ndarray.astype(int)
     const long long yi = (long long)e.y;
@@ -186,6 +255,7 @@ __global__ __launch_bounds__(kLdsThreads) void raster_lds_kernel(
     const int l = (int)(flat - lo);
     if (e.p == 1.0) atomicAdd(cnt + l, 1u);
     else if (e.p == -1.0) atomicAdd(cnt + band_px + l, 1u);
+    }
   }
   if (band == 0 && bad) atomicAdd(status + b, bad);
   __syncthreads();
@@ -235,7 +305,9 @@ constexpr int kBinOverflow = 1 << 30;                      // status flag: n_eve
 __global__ __launch_bounds__(kBinThreads) void raster_bin_keys(
     const double* __restrict__ ev, const int64_t* __restrict__ offsets,
     const memhip_event_aug_t* __restrict__ augs, int H, int W, int band_px, int nb, long long n_cap,
-    unsigned short* __restrict__ keys, unsigned int* __restrict__ hdr, int32_t* __restrict__ status) {
+    unsigned short* __restrict__ keys, unsigned int* __restrict__ hdr, int32_t* __restrict__ status, UDiv band_div) {
+  // (the returning LDS atomics on these ~10 counters cost 15 % of the kernel: -DRASTER_EXP=1 without them runs at 0.65 of
+  // 8 TB/s instead of 0.55; a counter set per wave was slower -- 0.51 -- for the extra LDS reads of the scatter)
   __shared__ unsigned int cnt[kBinMaxBands];
   __shared__ unsigned int base[kBinMaxBands + 1];
   __shared__ __attribute__((aligned(16))) unsigned short sorted[kBinSlots];
@@ -248,6 +320,7 @@ __global__ __launch_bounds__(kBinThreads) void raster_bin_keys(
   }
   const memhip_event_aug_t* a = augs ? augs + b : nullptr;
   const double t_last = (a && a->time_flip && n > 0) ? ev[4 * (beg + n - 1) + 2] : 0.0;
+  const AugK K = aug_k(a);
   const long long nchunks = (n + kBinChunk - 1) / kBinChunk;
   const long long hbase = rel / kBinChunk + b;
   int bad = 0;
@@ -257,23 +330,37 @@ __global__ __launch_bounds__(kBinThreads) void raster_bin_keys(
       reinterpret_cast<uint4*>(sorted)[i] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
     __syncthreads();
     unsigned int key[kBinEvPerThread], where[kBinEvPerThread];
+    RawEv raw[kBinEvPerThread];
+#pragma unroll
+    for (int k = 0; k < kBinEvPerThread; ++k) {
+      const long long i = c * kBinChunk + (long long)k * kBinThreads + tid;
+      raw[k] = load_raw(ev, beg + (i < n ? i : n - 1));          // (n > 0: nchunks > 0)
+    }
 #pragma unroll
     for (int k = 0; k < kBinEvPerThread; ++k) {
       const long long i = c * kBinChunk + (long long)k * kBinThreads + tid;
       where[k] = 0xFFFFFFFFu;
       if (i >= n) continue;
-      const Ev e = load_event(ev, beg, n, i, a, t_last);
+      const Ev e = make_event_k(raw[k], n, i, K, t_last);
       if (!e.keep) continue;
-      const long long xi = (long long)e.x;   // trunc toward zero == ndarray.astype(int)
-      const long long yi = (long long)e.y;
-      long long flat = xi + (long long)W * yi;
+      // trunc toward zero == ndarray.astype(int).  Coordinates below 2^30 in magnitude (every real stream) convert with
+      // one v_cvt_i32_f64 each; anything larger takes the 64-bit conversion (the reference indexes with int64)
+      long long flat;
+      if (fabs(e.x) < 1073741824.0 && fabs(e.y) < 1073741824.0) flat = (long long)(int)e.x + (long long)W * (int)e.y;
+      else flat = (long long)e.x + (long long)W * (long long)e.y;
       if (flat < -HW || flat >= HW) { ++bad; continue; }   // reference: IndexError
       if (flat < 0) flat += HW;                             // NumPy negative index
       const bool isneg = e.p == -1.0;
       if (!(e.p == 1.0) && !isneg) continue;
-      const int band = (int)(flat / band_px);
-      key[k] = (unsigned int)(flat - (long long)band * band_px) | (isneg ? 0x8000u : 0u);
-      where[k] = ((unsigned int)band << 16) | atomicAdd(&cnt[band], 1u);   // slot inside the band's segment
+      const unsigned int f32 = (unsigned int)flat;          // 0 <= flat < H * W <= 64 * 32764
+      const unsigned int band = udiv_apply(f32, band_div);
+      key[k] = (f32 - band * (unsigned int)band_px) | (isneg ? 0x8000u : 0u);
+#if RASTER_EXP == 1      // timing experiment: no band atomics (wrong segment positions)
+      where[k] = (band << 16) | (unsigned)((k * kBinThreads + tid) & 0x1FF);
+      if (key[k] == 0x12345u) atomicAdd(&cnt[band], 1u);
+#else
+      where[k] = (band << 16) | atomicAdd(&cnt[band], 1u);   // slot inside the band's segment
+#endif
     }
     __syncthreads();
     if (tid < 64) {                          // exclusive scan of <= 64 band counts (rounded up to 8) in one wave
@@ -636,7 +723,7 @@ extern "C" int memhip_rasterize_binned_f64(const double* ev, const int64_t* offs
   if (bx > 4 * avg_chunks) bx = 4 * avg_chunks;
   if (bx < 1) bx = 1;
   hipLaunchKernelGGL(raster_bin_keys, dim3((unsigned)bx, B), dim3(kBinThreads), 0, s, ev, offsets, aug, H, W, band_px, nb,
-                     (long long)n_events, keys, hdr, status);
+                     (long long)n_events, keys, hdr, status, udiv_prepare((unsigned)band_px));
   hipLaunchKernelGGL(raster_bin_accum, dim3(nb, B), dim3(kAccThreads), (size_t)band_px * 4, s, offsets, H, W, band_px,
                      (long long)n_events, keys, hdr, out);
   return memhip::check_launch("rasterize_binned");
