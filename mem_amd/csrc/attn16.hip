@@ -217,6 +217,17 @@ __device__ __forceinline__ void glds4(const void* gsrc, char* lds_dst) {     // 
   asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(gsrc), "s"(lds) : "memory", "m0");
 }
 
+// -DATTN16_TIMING: per-section s_memtime totals of wave 0 / wave 4 of every workgroup (tools/attn16_sections.py)
+#ifdef ATTN16_TIMING
+__device__ unsigned long long g_attn16_prof[2][16];
+#define T16_DECL() unsigned long long t_last_ = __builtin_readcyclecounter(), t_acc_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
+#define T16_TICK(i) do { const unsigned long long t_ = __builtin_readcyclecounter(); t_acc_[i] += t_ - t_last_; t_last_ = t_; } while (0)
+#define T16_FLUSH() do { if (lane == 0 && (wave == 0 || wave == 4)) for (int i_ = 0; i_ < 12; ++i_) atomicAdd(&g_attn16_prof[wave >> 2][i_], t_acc_[i_]); } while (0)
+#else
+#define T16_DECL()
+#define T16_TICK(i)
+#define T16_FLUSH()
+#endif
 // ------------------------------------------------------------------------------------------------ forward
 __global__ __launch_bounds__(kThreads16) void attn16_fwd_kernel(const __bf16* __restrict__ qkv, long long ldq, int B, int D,
                                                                int H, const float* __restrict__ table,
@@ -249,7 +260,9 @@ __global__ __launch_bounds__(kThreads16) void attn16_fwd_kernel(const __bf16* __
   bf16x8 Qn[4];
 #pragma unroll
   for (int t = 0; t < 4; ++t) Qn[t] = ld16(qkv + ((long long)b0 * T16 + qc) * ldq + h * HD + 16 * t + 8 * hh);
+  T16_DECL();
   for (int b = b0; b < b1; ++b) {
+    T16_TICK(5);
     const int cur = (b - b0) & 1;
     const char* Ks = imgs + cur * 2 * IMG16;
     const char* Vs = Ks + IMG16;
@@ -260,6 +273,7 @@ __global__ __launch_bounds__(kThreads16) void attn16_fwd_kernel(const __bf16* __
     // most the 5 stores of the previous sample (1 x lse, 4 x out -- issued after the DMA) are still in flight
     ATTN16_WAIT_VM(5);
     __syncthreads();                         // sample b's images (and, the first time, the table) landed; b-1 consumed
+    T16_TICK(0);
     if (b + 1 < b1) {
       const __bf16* s1 = qkv + (long long)(b + 1) * T16 * ldq + h * HD;
 #pragma unroll
@@ -277,6 +291,7 @@ __global__ __launch_bounds__(kThreads16) void attn16_fwd_kernel(const __bf16* __
 #pragma unroll
       for (int t = 0; t < 4; ++t) s[kb] = MFMA32(lds_b128<0>(kr.a[t] + kb * 4096), Qf[t], s[kb]);
     }
+    T16_TICK(1);
     float mx = -INFINITY;
 #pragma unroll
     for (int kb = 0; kb < NB16; ++kb) {
@@ -298,6 +313,7 @@ __global__ __launch_bounds__(kThreads16) void attn16_fwd_kernel(const __bf16* __
         for (int e = 0; e < 4; ++e) mx = fmaxf(mx, s[kb][4 * g + e]);
       }
     }
+    T16_TICK(2);
     mx = fmaxf(mx, __shfl_xor(mx, 32));
     const float mneg = -mx * kLog2e;
     float sum = 0.f;
@@ -312,6 +328,7 @@ __global__ __launch_bounds__(kThreads16) void attn16_fwd_kernel(const __bf16* __
     sum += __shfl_xor(sum, 32);
     const float inv = 1.0f / sum;
     if (hh == 0 && q < T16) lse[((long long)b * H + h) * TP16 + q] = mx + flog2(sum) * kLn2;
+    T16_TICK(3);
     f32x16 o[2];
 #pragma unroll
     for (int db = 0; db < 2; ++db)
@@ -334,6 +351,7 @@ __global__ __launch_bounds__(kThreads16) void attn16_fwd_kernel(const __bf16* __
 #pragma unroll
         for (int db = 0; db < 2; ++db) o[db] = MFMA32(vf[ss][db], pf[ss], o[db]);
     }
+    T16_TICK(4);
     {
       char* st = stg + wave * 4096;
 #pragma unroll
@@ -355,20 +373,14 @@ __global__ __launch_bounds__(kThreads16) void attn16_fwd_kernel(const __bf16* __
       }
     }
   }
+  T16_TICK(5);
+#ifdef ATTN16_TIMING
+  if (lane == 0 && (wave == 0 || wave == 4))
+    for (int i_ = 0; i_ < 6; ++i_) atomicAdd(&g_attn16_prof[wave >> 2][6 + i_] , t_acc_[i_]);   // forward: slots 6..11
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------ fused backward
-// -DATTN16_TIMING: per-section s_memtime totals of wave 0 / wave 4 of every workgroup (tools/attn16_sections.py)
-#ifdef ATTN16_TIMING
-__device__ unsigned long long g_attn16_prof[2][16];
-#define T16_DECL() unsigned long long t_last_ = __builtin_readcyclecounter(), t_acc_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
-#define T16_TICK(i) do { const unsigned long long t_ = __builtin_readcyclecounter(); t_acc_[i] += t_ - t_last_; t_last_ = t_; } while (0)
-#define T16_FLUSH() do { if (lane == 0 && (wave == 0 || wave == 4)) for (int i_ = 0; i_ < 12; ++i_) atomicAdd(&g_attn16_prof[wave >> 2][i_], t_acc_[i_]); } while (0)
-#else
-#define T16_DECL()
-#define T16_TICK(i)
-#define T16_FLUSH()
-#endif
 // LDS map (bytes)
 constexpr int kTabBytes16 = TABLEN16 * 4;                 // 4400
 constexpr int kBinsI16 = kTabBytes16;                     // int32 fixed-point buckets of the current sample

@@ -22,6 +22,14 @@ names = ["top wait+barrier", "bound + zero", "S/dP mfma", "softmax+atomics", "dQ
 buf = (ctypes.c_ulonglong * 32)()
 f = _lib.lib.memhip_attn16_prof
 f.argtypes = [ctypes.c_void_p, ctypes.c_int]
+f(None, 1)
+n = 5
+for _ in range(n): ops.attn_fwd(qkv, B, T, D, H, table, (14, 14), out, lse)
+torch.cuda.synchronize(); f(buf, 1)
+fn = ["top wait+barrier", "stage issue + S mfma", "bias + max", "exp + sum", "PV", "stores / next"]
+print("forward (cycles per workgroup-kernel)")
+for w in (0, 1):
+    print(f"  wave {4 * w}: total {sum(buf[w * 16 + 6 + i] for i in range(6)) / (n * 252):9.0f}  " + "  ".join(f"{fn[i]} {buf[w * 16 + 6 + i] / (n * 252):.0f}" for i in range(6)))
 for dt in (dtable, None):
     ops.attn_bwd(qkv, dout, lse, delta, table, (14, 14), B, T, D, H, 0.125, dqkv, dt, dqb, None)
     torch.cuda.synchronize(); f(None, 1)
