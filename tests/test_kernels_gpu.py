@@ -147,6 +147,41 @@ def test_attention_general_kernels_at_14x14():
         _lib.set_option("attn16", 1)
 
 
+def test_attn16_equals_general_kernels():
+    """The 14 x 14 kernels (key-slot layout, fused backward) against the general ones on the same inputs: the same arithmetic
+    up to the order of fp32 sums and the fixed-point step of the table gradient."""
+    from mem_amd import ops, _lib
+    from oracle.vit_ref import rel_pos_index
+    B, T, H, win = 29, 197, 3, (14, 14)
+    D = 64 * H
+    TP = ops.attn_tokens_padded(T)
+    qkv = _rand((B * T, 3 * D), 60, 0.7)
+    qkv[:, :D] *= 0.5
+    qkv = qkv.bfloat16()
+    idx, nrd = rel_pos_index(win)
+    table = _rand((nrd, H), 61, 0.5)
+    dout = _rand((B * T, D), 62, 1.0).bfloat16()
+    res = {}
+    try:
+        for mode in (0, 1):
+            _lib.set_option("attn16", mode)
+            out = torch.zeros((B * T, D), dtype=torch.bfloat16, device="cuda")
+            lse = torch.zeros((B, H, TP), device="cuda")
+            dqkv = torch.full((B * T, 3 * D), 3.0, dtype=torch.bfloat16, device="cuda")
+            dtable = torch.zeros((nrd, H), device="cuda")
+            delta = torch.zeros((2 * B * T + 4, H), device="cuda")
+            dqb = torch.zeros(D, device="cuda")
+            ops.attn_fwd(qkv, B, T, D, H, table, win, out, lse)
+            ops.attn_delta(dout, out, B * T, H, delta)
+            ops.attn_bwd(qkv, dout, lse, delta, table, win, B, T, D, H, 0.125, dqkv, dtable, dq_bias=dqb)
+            res[mode] = (out.float(), lse[:, :, :T].clone(), dqkv.float(), dtable.clone(), dqb.clone())
+    finally:
+        _lib.set_option("attn16", 1)
+    for name, a, b, tol in zip(("out", "lse", "dqkv", "dtable", "dq_bias"), res[0], res[1], (1e-3, 1e-6, 1e-3, 5e-3, 2e-3)):
+        rel = ((a - b).norm() / a.norm()).item()
+        assert rel < tol, (name, rel)
+
+
 def _attention_case(B, T, H, win):
     from mem_amd import ops
     from oracle.vit_ref import rel_pos_index
