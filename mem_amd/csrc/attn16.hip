@@ -270,8 +270,10 @@ __global__ __launch_bounds__(kThreads16) void attn16_fwd_kernel(const __bf16* __
 #pragma unroll
     for (int t = 0; t < 4; ++t) Qf[t] = Qn[t];
     // vector-memory operations complete in issue order: everything up to the LDS-DMA of this sample has landed once at
-    // most the 5 stores of the previous sample (1 x lse, 4 x out -- issued after the DMA) are still in flight
-    ATTN16_WAIT_VM(5);
+    // most the 4 output stores of the previous sample (issued after the DMA, every wave issues all four: padding rows go
+    // to the trash page) are still in flight.  The count must never exceed the stores really issued behind the DMA, so
+    // the lse store (predicated; the oldest of the five) is not counted.
+    ATTN16_WAIT_VM(4);
     __syncthreads();                         // sample b's images (and, the first time, the table) landed; b-1 consumed
     T16_TICK(0);
     if (b + 1 < b1) {
@@ -480,8 +482,9 @@ __global__ __launch_bounds__(kThreads16) void attn16_bwd_kernel(const __bf16* __
   for (int b = b0; b < b1; ++b) {
     T16_TICK(9);
     // in issue order: [LDS-DMA of this sample: rows, images] [12 stores of the previous sample]: the stores may stay in
-    // flight under this sample's compute
-    ATTN16_WAIT_VM(12);
+    // flight under this sample's compute.  Two of the twelve are left out of the count as a margin (the count must never
+    // exceed the stores really issued behind the DMA; waiting for the two oldest costs nothing measurable).
+    ATTN16_WAIT_VM(10);
     __syncthreads();                                         // images of sample b (first time: tables) are in LDS
     const float lq2 = q < T16 ? rowsL[q] * kLog2e : INFINITY;   // padding queries: p = exp2(-inf) = 0
     const float dq_ = rowsL[kRowsLd16 + q], nqn = rowsL[2 * kRowsLd16 + q];

@@ -61,3 +61,36 @@ def test_options_table_and_no_environment_reads():
     syms = subprocess.run(["nm", "-D", "--undefined-only", os.path.join(ROOT, "mem_amd", "libmemhip.so")],
                           capture_output=True, text=True).stdout
     assert "getenv" not in syms
+
+
+def test_attn16_counted_waits_match_the_instruction_stream(tmp_path):
+    """attn16.hip waits for the LDS-DMA of the next sample with a COUNTED s_waitcnt vmcnt(N): the N youngest vector-memory
+    operations (stores of the previous sample) may stay in flight.  That is only sound while a wave issues at least N stores
+    per sample behind the LDS-DMA (in execution order: DMA at the top of the iteration, stores at its end) and nothing else
+    (a register spill would add vector-memory operations the count does not know) -- checked here on the compiler's output."""
+    import re, shutil, subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        import pytest
+        pytest.skip("no hipcc")
+    src = os.path.join(ROOT, "mem_amd", "csrc", "attn16.hip")
+    out = str(tmp_path / "attn16.s")
+    subprocess.run([hipcc, "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-fno-fast-math", "-S", "--cuda-device-only",
+                    "-o", out, src], check=True, capture_output=True)
+    lines = open(out).read().split("\n")
+    checked = 0
+    for kname, n_wait in (("attn16_fwd_kernel", 4), ("attn16_bwd_kernelILb1", 10), ("attn16_bwd_kernelILb0", 10)):
+        i0 = next(i for i, l in enumerate(lines) if l.startswith("_ZN") and kname in l and l.rstrip().endswith(tuple(": ;"))
+                  or (l.startswith("_ZN") and kname in l and ": ;" in l))
+        j = i0
+        while "s_endpgm" not in lines[j]:
+            j += 1
+        body = lines[i0:j]
+        glds = [k for k, l in enumerate(body) if "global_load_lds" in l]
+        stores = [k for k, l in enumerate(body) if re.search(r"\bglobal_store_dwordx4\b", l)]
+        waits = [l for l in body if re.search(r"s_waitcnt vmcnt\(%d\)" % n_wait, l)]
+        assert glds and waits, (kname, len(glds), len(waits))
+        assert len(stores) >= n_wait, (kname, len(stores), n_wait)    # all of them sit in the sample loop, behind its DMA
+        assert not any("scratch_" in l for l in body), kname        # a spill would add uncounted vector-memory operations
+        checked += 1
+    assert checked == 3
