@@ -243,9 +243,12 @@ __device__ __forceinline__ void epi_row_load(const GemmArgs& p, int m, int n, Ep
     const long long ld = p.aux ? p.ldaux : p.ldr;
     ld8(base + (long long)m * ld + n, r.x);
     // sample of the row for the drop-path mask: (m + 0.5) / rows_per_sample is at least 0.5 / rows_per_sample away from an
-    // integer, far more than the fp32 error of the product for any batch this library sees (quotient < 2^16)
+    // integer; the fp32 product is off by at most (m + 0.5) * 2^-23 / rows_per_sample, so it truncates to the right sample
+    // for m < 2^22 (taken up to 2^21; larger row indices use the integer division)
+    const int mm = m + p.m_base;
     const float inv = __frcp_rn((float)p.rows_per_sample);
-    const int smp = p.rowmask ? (int)(((float)(m + p.m_base) + 0.5f) * inv) : 0;
+    int smp = 0;
+    if (p.rowmask) smp = mm < (1 << 21) ? (int)(((float)mm + 0.5f) * inv) : mm / p.rows_per_sample;
     const float* rmb = p.rowmask ? p.rowmask : &g_epi_one;
     r.rm = rmb[smp];
   }
