@@ -396,6 +396,20 @@ constexpr int kExch16 = kImgs16 + 4 * IMG16;              // [7 waves][P^T tile 
 constexpr int kLdsBwd16 = kExch16 + NB16 * 4096;
 static_assert(kLdsBwd16 <= 160 * 1024, "fused backward: LDS budget");
 
+// max over the wave by DPP (row_shr 1 / 2 / 4 / 8, row_bcast 15 / 31: no LDS traffic, 6 VALU), result uniform (lane 63)
+__device__ __forceinline__ float wave_max(float v) {
+#define A16_DPP_MAX(ctrl, rmask)                                                                         \
+  v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), ctrl, rmask, 0xf, false)))
+  A16_DPP_MAX(0x111, 0xf);
+  A16_DPP_MAX(0x112, 0xf);
+  A16_DPP_MAX(0x114, 0xf);
+  A16_DPP_MAX(0x118, 0xf);
+  A16_DPP_MAX(0x142, 0xa);
+  A16_DPP_MAX(0x143, 0xc);
+#undef A16_DPP_MAX
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
 // value of lane - 1 within the 16-lane row (0 for the first lane of a row): v_mov_b32_dpp row_shr:1
 __device__ __forceinline__ float dpp_shr1(float v) {
   return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x111, 0xf, 0xf, true));
@@ -469,15 +483,17 @@ __global__ __launch_bounds__(kThreads16) void attn16_bwd_kernel(const __bf16* __
       glds4(ok ? (const void*)(delta + ((long long)B * T16 + row) * H + h) : z, reinterpret_cast<char*>(rowsL + 2 * kRowsLd16) + wave * 256);
     }
   };
-  auto stage_sample = [&](int b) {
+  auto stage_sample = [&](int b, bool kv) {                 // kv = false: K / V were staged early (last step of the sample before)
     const __bf16* s = qkv + (long long)b * T16 * ldq + h * HD;
     stage_tokens(Qs, s, ldq);
     stage_tokens(dOs, dout + (long long)b * T16 * ldo + h * HD, ldo);
-    stage_slots(Ks, s + D, ldq);
-    stage_slots(Vs, s + 2 * D, ldq);
+    if (kv) {
+      stage_slots(Ks, s + D, ldq);
+      stage_slots(Vs, s + 2 * D, ldq);
+    }
   };
   stage_rows(b0);
-  stage_sample(b0);
+  stage_sample(b0, true);
   T16_DECL();
   for (int b = b0; b < b1; ++b) {
     T16_TICK(9);
@@ -501,13 +517,8 @@ __global__ __launch_bounds__(kThreads16) void attn16_bwd_kernel(const __bf16* __
 #pragma unroll
         for (int i = 0; i < 8; ++i) vn = fmaf((float)v[i], (float)v[i], vn);
       }
-      vn += __shfl_xor(vn, 32);
-      float m0 = nqn, m1 = fabsf(dq_), m2 = vn;
-      for (int o = 16; o > 0; o >>= 1) {
-        m0 = fmaxf(m0, __shfl_xor(m0, o));
-        m1 = fmaxf(m1, __shfl_xor(m1, o));
-        m2 = fmaxf(m2, __shfl_xor(m2, o));
-      }
+      // (padding slots carry a copy of a real key row: only half of a padding lane's |V|^2 can be missing, a bound stays a bound)
+      const float m0 = wave_max(nqn), m1 = wave_max(fabsf(dq_)), m2 = 2.0f * wave_max(vn);   // vn: half a row per lane
       if (lane == 0) { red[wave * 4 + 0] = m0; red[wave * 4 + 1] = m1; red[wave * 4 + 2] = m2; }
       __syncthreads();
       float t0 = 0.f, t1 = 0.f, t2 = 0.f;
@@ -649,6 +660,11 @@ __global__ __launch_bounds__(kThreads16) void attn16_bwd_kernel(const __bf16* __
       T16_TICK(4);
       __syncthreads();                                       // every wave has consumed the tiles of step s - 1
       T16_TICK(5);
+      if (s == NB16 - 1 && b + 1 < b1) {                     // ... and finished its last produce: the K / V images are dead
+        const __bf16* sn = qkv + (long long)(b + 1) * T16 * ldq + h * HD;
+        stage_slots(Ks, sn + D, ldq);
+        stage_slots(Vs, sn + 2 * D, ldq);
+      }
       {
         const unsigned mine = lds_addr_of(exch) + wave * 4096;
         unsigned wa[4];
@@ -672,7 +688,7 @@ __global__ __launch_bounds__(kThreads16) void attn16_bwd_kernel(const __bf16* __
     }
     __syncthreads();                                         // all reads of the images and all bucket atomics are done
     T16_TICK(8);
-    if (b + 1 < b1) { stage_rows(b + 1); stage_sample(b + 1); }
+    if (b + 1 < b1) { stage_rows(b + 1); stage_sample(b + 1, false); }
     // ---------------- epilogue of sample b (under the LDS-DMA of sample b + 1)
     if (DT) {
       const float inv = fx > 0.f ? 1.0f / fx : 0.f;
