@@ -51,6 +51,15 @@
                          // segment (the counted waits then allow that many fewer pieces in flight)
 #endif
 
+#ifndef P8_PRIO_MODE
+#define P8_PRIO_MODE 0   // 0: s_setprio 1 around every MFMA block; 1: none; 2: none + waves 4-7 at priority 1 for the whole kernel
+#endif
+#if P8_PRIO_MODE == 0
+#define P8_PRIO(x) __builtin_amdgcn_s_setprio(x)
+#else
+#define P8_PRIO(x) do { } while (0)
+#endif
+
 namespace {
 
 using namespace memhip;
@@ -201,6 +210,9 @@ __global__ __launch_bounds__(kThreads) void gemm_p8_kernel(GemmArgs p, int ntm, 
   P8_WAIT_VM(G::kWaitA);
   P8_BARRIER();
   if (wr == 1) P8_BARRIER();                            // waves 4-7 run half a phase behind
+#if P8_PRIO_MODE == 2
+  if (wr == 1) __builtin_amdgcn_s_setprio(1);
+#endif
 
   // ---- fragment read addresses: row = 16*x + (lane & 15), chunk = 4*kh + (lane >> 4)
   const int sw = (lane >> 1) & 7;
@@ -232,21 +244,21 @@ __global__ __launch_bounds__(kThreads) void gemm_p8_kernel(GemmArgs p, int ntm, 
       acc[q][mf][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bsrc[nf][kh], a[mf][kh], acc[q][mf][nf], 0, 0, 0)
 #define P8_MFMA(q, bsrc)                                                                                  \
   do {                                                                                                    \
-    __builtin_amdgcn_s_setprio(1);                                                                        \
+    P8_PRIO(1);                                                                        \
     P8_MFMA_HALF(q, bsrc, 0);                                                                             \
     P8_MFMA_HALF(q, bsrc, 1);                                                                             \
-    __builtin_amdgcn_s_setprio(0);                                                                        \
+    P8_PRIO(0);                                                                        \
   } while (0)
 // compute segment with the phase's LDS-DMA issue in the middle (P8_STAGE_MID)
 #define P8_MFMA_STAGE(q, bsrc, STAGE_CALL)                                                                \
   do {                                                                                                    \
-    __builtin_amdgcn_s_setprio(1);                                                                        \
+    P8_PRIO(1);                                                                        \
     P8_MFMA_HALF(q, bsrc, 0);                                                                             \
     __builtin_amdgcn_sched_barrier(0);                                                                    \
     STAGE_CALL;                                                                                           \
     __builtin_amdgcn_sched_barrier(0);                                                                    \
     P8_MFMA_HALF(q, bsrc, 1);                                                                             \
-    __builtin_amdgcn_s_setprio(0);                                                                        \
+    P8_PRIO(0);                                                                        \
   } while (0)
 // One K-tile = four phases.  B0 of this K-tile is already in `bq0` (read during phase 4 of the
 // previous K-tile); phase 4 reads B0 of the next K-tile into `bq1`, so the two register sets swap

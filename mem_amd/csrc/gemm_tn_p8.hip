@@ -16,6 +16,16 @@
 // both are staged through the idle ring.
 #include "common.h"
 
+#ifndef P8_PRIO_MODE
+#define P8_PRIO_MODE 0   // 0: s_setprio 1 around every MFMA block; 1: none; 2: none + waves 4-7 at priority 1 for the whole kernel
+#endif                   // (this kernel alone: 1 and 2 measured +2.5 % (964 -> 990, 1099 -> 1117 TFLOP/s); inside the step, beside the
+                         // dgrad kernels of the other stream, no difference: 38.28 vs 38.35 ms.  gemm_p8.hip: no difference either way)
+#if P8_PRIO_MODE == 0
+#define P8_PRIO(x) __builtin_amdgcn_s_setprio(x)
+#else
+#define P8_PRIO(x) do { } while (0)
+#endif
+
 namespace {
 
 using namespace memhip;
@@ -127,6 +137,9 @@ __global__ __launch_bounds__(kThreads) void gemm_tn_p8_kernel(const __bf16* __re
   TP_WAIT_VM();
   TP_BARRIER();
   if (wr == 1) TP_BARRIER();                                // waves 4-7 run half a phase behind
+#if P8_PRIO_MODE == 2
+  if (wr == 1) __builtin_amdgcn_s_setprio(1);
+#endif
 
   // ---- transposing fragment reads: this lane addresses 4 columns (p) of token row 4g+q (+16)
   const int g4 = lane >> 4, q4 = (lane >> 2) & 3, pp = lane & 3;
@@ -161,11 +174,11 @@ __global__ __launch_bounds__(kThreads) void gemm_tn_p8_kernel(const __bf16* __re
   do {                                                                                                    \
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   /* the asm reads are not tracked by the compiler */ \
     __builtin_amdgcn_sched_barrier(0);                                                                    \
-    __builtin_amdgcn_s_setprio(1);                                                                        \
+    P8_PRIO(1);                                                                        \
     _Pragma("unroll") for (int rh = 0; rh < 2; ++rh) _Pragma("unroll") for (int nf = 0; nf < 4; ++nf)     \
         _Pragma("unroll") for (int kf = 0; kf < 2; ++kf) acc[q][nf][kf] =                                 \
             __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[nf][rh], bsrc[kf][rh], acc[q][nf][kf], 0, 0, 0);    \
-    __builtin_amdgcn_s_setprio(0);                                                                        \
+    P8_PRIO(0);                                                                        \
   } while (0)
 #define TP_KTILE(bq0, bq1)                                                                                \
   do {                                                                                                    \
