@@ -532,7 +532,11 @@ def main():
                         "launches": dom[0], "avg_launch_us": round(dom[1] / dom[0] * 1e3, 2),
                         "algorithmic_flop_per_launch": round(dom[2] / dom[0]),
                         "share_of_step": round(dom[1] / (dt * 1e3 * n_inst / a.steps), 3),
-                        "instrumented_steps": n_inst}
+                        "instrumented_steps": n_inst,
+                        "note": "HIP events around one weight-gradient product = gemm_tn_p8_kernel + its tn_reduce_kernel; the "
+                                "instrumented steps run on ONE stream (the events serialise the side stream), so compare with the "
+                                "sequential rocprofv3 summary (profiles/r02_final_seq_kernel_stats.csv: 141.6 + 13.8 us), not with the "
+                                "two-stream one, where concurrent launches stretch every kernel"}
             else:
                 roof = {"bound": "mfma", "kernel": "bf16 MFMA GEMM family", "achieved": round(ach, 1),
                         "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
