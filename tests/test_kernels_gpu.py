@@ -333,3 +333,15 @@ def test_attention_full_size_properties():
     # softmax-backward rows sum to zero, so each head's bucket gradients sum to (fixed-point / bf16 noise around) zero
     assert (dtable.sum(0).abs() <= 1e-2 * dtable.abs().sum(0) + 1e-3).all(), dtable.sum(0)
     assert torch.isfinite(dqkv.float()).all()
+
+
+def test_attn16_random_shapes_and_repeated_launches():
+    """tools/stress_attn16.py: random batch sizes / head counts / stagger settings against the general kernels, every run
+    repeated for bitwise reproducibility, then the BASELINE-size launch 40 times with bitwise equal results (a stale LDS image
+    behind a counted wait or a barrier race would not be reproducible)."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "stress_attn16.py"), "1", "16", "40"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "bitwise equal every time" in r.stdout
