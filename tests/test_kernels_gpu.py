@@ -1,5 +1,6 @@
 """-m gpu: every non-GEMM ViT kernel against a plain torch fp32 reference of the same op."""
 import math
+import os
 
 import pytest
 import torch
