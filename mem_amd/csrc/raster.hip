@@ -306,8 +306,8 @@ __global__ __launch_bounds__(kBinThreads) void raster_bin_keys(
     const double* __restrict__ ev, const int64_t* __restrict__ offsets,
     const memhip_event_aug_t* __restrict__ augs, int H, int W, int band_px, int nb, long long n_cap,
     unsigned short* __restrict__ keys, unsigned int* __restrict__ hdr, int32_t* __restrict__ status, UDiv band_div) {
-  // (the returning LDS atomics on these ~10 counters cost 15 % of the kernel: -DRASTER_EXP=1 without them runs at 0.65 of
-  // 8 TB/s instead of 0.55; a counter set per wave was slower -- 0.51 -- for the extra LDS reads of the scatter)
+  // (measured: a counter set per wave is slower for its extra LDS reads in the scatter, four sub-counters per band selected by
+  // lane & 3 change nothing -- the returning atomics on these ~10 counters are not what bounds the kernel)
   __shared__ unsigned int cnt[kBinMaxBands];
   __shared__ unsigned int base[kBinMaxBands + 1];
   __shared__ __attribute__((aligned(16))) unsigned short sorted[kBinSlots];
