@@ -336,6 +336,12 @@ __global__ __launch_bounds__(kBinThreads) void raster_bin_keys(
       const long long i = c * kBinChunk + (long long)k * kBinThreads + tid;
       raw[k] = load_raw(ev, beg + (i < n ? i : n - 1));          // (n > 0: nchunks > 0)
     }
+#if RASTER_EXP == 2       // timing experiment: the loads alone
+#pragma unroll
+    for (int k = 0; k < kBinEvPerThread; ++k) bad += (raw[k].xy.x == 12345.5) + (raw[k].tp.y == 12345.5);
+    if (tid <= nb) hdr[(hbase + c) * (kBinMaxBands + 1) + tid] = 0u;      // empty segments for pass 2
+    continue;
+#endif
 #pragma unroll
     for (int k = 0; k < kBinEvPerThread; ++k) {
       const long long i = c * kBinChunk + (long long)k * kBinThreads + tid;
@@ -362,6 +368,13 @@ __global__ __launch_bounds__(kBinThreads) void raster_bin_keys(
       where[k] = (band << 16) | atomicAdd(&cnt[band], 1u);   // slot inside the band's segment
 #endif
     }
+#if RASTER_EXP == 3       // timing experiment: loads + keys + band atomics, no sort / write-out
+#pragma unroll
+    for (int k = 0; k < kBinEvPerThread; ++k) bad += (key[k] == 0x7654321u) + (where[k] == 0x7654321u);
+    if (tid <= nb) hdr[(hbase + c) * (kBinMaxBands + 1) + tid] = 0u;      // empty segments for pass 2
+    __syncthreads();
+    continue;
+#endif
     __syncthreads();
     if (tid < 64) {                          // exclusive scan of <= 64 band counts (rounded up to 8) in one wave
       const unsigned int v = tid < nb ? ((cnt[tid] + 7u) & ~7u) : 0u;
