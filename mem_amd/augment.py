@@ -301,7 +301,9 @@ class BatchAugPipeline:
         status = torch.zeros(B, dtype=torch.int32, device=dev)
         if cfg.canvas is not None:
             H, W = cfg.canvas
-            img = rasterize(ev_w, offs, H, W, cfg.time_surface, aug, strict=False)
+            st_r = []
+            img = rasterize(ev_w, offs, H, W, cfg.time_surface, aug, strict=False, status_out=st_r)
+            st2 = st_r[0]
             dims, slot = None, 3 * H * W
         else:
             Hm, Wm = cfg.canvas_max
@@ -345,5 +347,9 @@ class BatchAugPipeline:
         jit = up(jit_h) if jit_h is not None else None
         out = torch.empty((B, self.out_chans, OH, OW), dtype=torch.float32, device=dev)
         check(lib.memhip_color_jitter(ptr(src), int(src_u8), B, OH, OW, ptr(jit), ptr(out), self.out_chans, st), "color_jitter")
-        stages["status"] = status
+        # bit 29: empty sample after the filter / canvas beyond canvas_max (the reference: ValueError from max() of an
+        # empty array); bit 28: events outside the canvas (the reference: IndexError from np.add.at).  Such a sample is an
+        # all-zero image here; callers check `status` (TransformNPY at once, the training loop at its meter flush).
+        stages["status"] = status | ((st2 != 0).to(torch.int32) << 28)
+        stages["bad_index_events"] = st2
         return (out, stages) if return_stages else out

@@ -25,33 +25,32 @@ constexpr int kT = 1024;
 // torch's separable anti-aliased bilinear resize (aten UpSampleKernel.cpp, _compute_indices_min_size_weights_aa):
 // per output index i: center = scale (i + 0.5), support = max(scale, 1), taps j in [xmin, xmin + xsize) with triangle
 // weights normalised to 1; horizontal pass first (intermediate rounded to f32), then vertical.  fp32 throughout.
-struct Taps { int lo, n; float w[8]; };
+// A tap's weight is recomputed where it is used (tri(j) * norm: the same two float32 operations torch performs when it
+// normalises its weight table), so the support is unbounded: a 440 x 640 canvas resized to 128 x 128 takes 11 taps
+// (2 * ceil(scale) + 1), and there is no table to overflow.
+struct Taps { int lo, n; float center, invscale, norm; };
+
+__device__ __forceinline__ float aa_weight(const Taps& t, int j) {
+  float x = ((float)(j + t.lo) - t.center + 0.5f) * t.invscale;
+  x = fabsf(x);
+  const float w = x < 1.0f ? 1.0f - x : 0.0f;
+  return w * t.norm;
+}
 
 __device__ __forceinline__ Taps aa_taps(int i, int in_size, float scale) {
   Taps t;
   const float support = scale >= 1.0f ? scale : 1.0f;
-  const float invscale = scale >= 1.0f ? 1.0f / scale : 1.0f;
-  const float center = scale * ((float)i + 0.5f);
-  int lo = (int)(center - support + 0.5f);
+  t.invscale = scale >= 1.0f ? 1.0f / scale : 1.0f;
+  t.center = scale * ((float)i + 0.5f);
+  int lo = (int)(t.center - support + 0.5f);
   lo = lo > 0 ? lo : 0;
-  int hi = (int)(center + support + 0.5f);
+  int hi = (int)(t.center + support + 0.5f);
   hi = hi < in_size ? hi : in_size;
-  int n = hi - lo;
-  n = n < 0 ? 0 : (n > 8 ? 8 : n);
+  const int n = hi - lo > 0 ? hi - lo : 0;
+  t.lo = lo; t.n = n; t.norm = 1.0f;
   float total = 0.f;
-  for (int j = 0; j < 8; ++j) {
-    float w = 0.f;
-    if (j < n) {
-      float x = ((float)(j + lo) - center + 0.5f) * invscale;
-      x = fabsf(x);
-      w = x < 1.0f ? 1.0f - x : 0.0f;
-    }
-    t.w[j] = w;
-    total += w;
-  }
-  const float norm = total != 0.f ? 1.0f / total : 0.f;
-  for (int j = 0; j < 8; ++j) t.w[j] *= norm;
-  t.lo = lo; t.n = n;
+  for (int j = 0; j < n; ++j) total += aa_weight(t, j);          // weights in tap order, as torch sums them
+  t.norm = total != 0.f ? 1.0f / total : 0.f;
   return t;
 }
 
@@ -82,10 +81,10 @@ __global__ __launch_bounds__(256) void resample_kernel(const uint8_t* __restrict
   float acc = 0.f;
   for (int jy = 0; jy < ty.n; ++jy) {
     const uint8_t* row = src + (long long)(ty.lo + jy) * w + tx.lo;
-    float hsum = (float)row[0] / 255.0f * tx.w[0];               // horizontal pass of this input row
-    for (int jx = 1; jx < tx.n; ++jx) hsum += (float)row[jx] / 255.0f * tx.w[jx];
-    if (jy == 0) acc = hsum * ty.w[0];
-    else acc += hsum * ty.w[jy];
+    float hsum = (float)row[0] / 255.0f * aa_weight(tx, 0);       // horizontal pass of this input row
+    for (int jx = 1; jx < tx.n; ++jx) hsum += (float)row[jx] / 255.0f * aa_weight(tx, jx);
+    if (jy == 0) acc = hsum * aa_weight(ty, 0);
+    else acc += hsum * aa_weight(ty, jy);
   }
   dst[p] = acc;
 }

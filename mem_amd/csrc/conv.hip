@@ -214,7 +214,14 @@ __global__ __launch_bounds__(256) void nchw_to_padded_nhwc4_kernel(const float* 
   *reinterpret_cast<uint2*>(out + (((long long)b * (H + 2) + y + 1) * (W + 2) + xw + 1) * 4) = o;
 }
 
-// ids[m] = argmax_n logits[m, n] (first maximum), one wave per row, 16-byte loads
+// torch.argmax's order: NaN above every number, ties to the smallest index (all -inf -> 0): always a valid id
+__device__ __forceinline__ bool argmax_better(float a, int ai, float b, int bi) {
+  const bool an = a != a, bn = b != b;
+  if (an || bn) return an && (!bn || ai < bi);
+  return a > b || (a == b && ai < bi);
+}
+
+// ids[m] = argmax_n logits[m, n] (first maximum, NaN wins like torch.argmax), one wave per row, 16-byte loads
 __global__ __launch_bounds__(256) void argmax_rows_kernel(const __bf16* __restrict__ logits, long long ld, int M, int N,
                                                           long long* __restrict__ ids) {
   const int lane = threadIdx.x & 63;
@@ -227,13 +234,13 @@ __global__ __launch_bounds__(256) void argmax_rows_kernel(const __bf16* __restri
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       const float f = (float)v[k];
-      if (f > best) { best = f; bi = n + k; }          // ascending n: keeps the first maximum of this lane
+      if (argmax_better(f, n + k, best, bi)) { best = f; bi = n + k; }
     }
   }
   for (int o = 32; o > 0; o >>= 1) {
     const float ob = __shfl_xor(best, o);
     const int oi = __shfl_xor(bi, o);
-    if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+    if (argmax_better(ob, oi, best, bi)) { best = ob; bi = oi; }
   }
   if (lane == 0) ids[m] = bi;
 }

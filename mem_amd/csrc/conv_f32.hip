@@ -191,7 +191,15 @@ __global__ __launch_bounds__(256) void nchw_to_padded_nhwc4_f32_kernel(const flo
       make_float4(v[0], v[1], v[2], v[3]);
 }
 
-// ids[m] = argmax_n logits[m, n] (first maximum; NaN never wins, like a comparison chain), one wave per row
+// torch.argmax's order: a NaN is greater than every number, ties (and several NaNs) go to the smallest index; so a row of
+// all -inf gives 0 and a row with a NaN gives the first NaN's index -- always a valid id (it is used as a label next).
+__device__ __forceinline__ bool argmax_better(float a, int ai, float b, int bi) {
+  const bool an = a != a, bn = b != b;
+  if (an || bn) return an && (!bn || ai < bi);
+  return a > b || (a == b && ai < bi);
+}
+
+// ids[m] = argmax_n logits[m, n] (first maximum, NaN wins like torch.argmax), one wave per row
 __global__ __launch_bounds__(256) void argmax_rows_f32_kernel(const float* __restrict__ logits, long long ld, int M, int N,
                                                               long long* __restrict__ ids, float* __restrict__ gap) {
   const int lane = threadIdx.x & 63;
@@ -204,14 +212,14 @@ __global__ __launch_bounds__(256) void argmax_rows_f32_kernel(const float* __res
     const float f[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      if (f[k] > best) { second = best; best = f[k]; bi = n + k; }
+      if (argmax_better(f[k], n + k, best, bi)) { second = best; best = f[k]; bi = n + k; }
       else if (f[k] > second) second = f[k];
     }
   }
   for (int o = 32; o > 0; o >>= 1) {
     const float ob = __shfl_xor(best, o), os = __shfl_xor(second, o);
     const int oi = __shfl_xor(bi, o);
-    if (ob > best || (ob == best && oi < bi)) {
+    if (argmax_better(ob, oi, best, bi)) {
       second = fmaxf(best, os);                       // the displaced maximum may be the runner-up (ties: gap 0)
       best = ob; bi = oi;
     } else {

@@ -507,7 +507,10 @@ __global__ __launch_bounds__(256) void ce_kernel(__bf16* __restrict__ logits, lo
   const float sum = bc[1];
   const long long lab = labels[r];
   if (tid == 0) {
-    const float zl = (float)logits[(long long)r * ld + lab];
+    // a label outside [0, V) (torch: "Target out of bounds") must not become an out-of-bounds read: the row's loss is
+    // NaN, which the training loop's non-finite-loss abort reports (engine_for_pretraining.py:154-156)
+    const bool lab_ok = lab >= 0 && lab < V;
+    const float zl = lab_ok ? (float)logits[(long long)r * ld + lab] : __builtin_nanf("");
     row_loss[r] = (mx + __logf(sum)) - zl;        // -log_softmax[label]
     row_correct[r] = (amax == (int)lab) ? 1 : 0;
   }

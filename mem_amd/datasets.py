@@ -62,11 +62,12 @@ def _new_aug_array(n):
     return a
 
 
-def rasterize(ev, offsets, H, W, time_surface=False, aug=None, strict=True, binned=None):
+def rasterize(ev, offsets, H, W, time_surface=False, aug=None, strict=True, binned=None, status_out=None):
     """ev f64 [n,4] (cuda), offsets i64 [B+1] (cuda), aug = uint8 cuda view of B aug records or
     None -> u8 [B,3,H,W] (cuda).  strict: raise IndexError like the reference when an event lands
-    outside the canvas (costs one host sync).  binned: None = choose by size, True/False = force the
-    two-pass long-stream kernels / the single-pass kernels."""
+    outside the canvas (costs one host sync); with strict=False pass a list as status_out to receive the
+    per-sample i32 count of such events (device tensor) and check it later.  binned: None = choose by size,
+    True/False = force the two-pass long-stream kernels / the single-pass kernels."""
     require_gpu()
     B = offsets.numel() - 1
     out = torch.empty((B, 3, H, W), dtype=torch.uint8, device=ev.device)
@@ -87,6 +88,8 @@ def rasterize(ev, offsets, H, W, time_surface=False, aug=None, strict=True, binn
         ws = torch.empty((wsb,), dtype=torch.uint8, device=ev.device)
         check(lib.memhip_rasterize_aug_f64(ptr(ev), ptr(offsets), ptr(aug), B, H, W, int(bool(time_surface)),
                                            ptr(out), ptr(status), ptr(ws), wsb, stream_ptr()), "rasterize")
+    if status_out is not None:
+        status_out.append(status)
     if strict and int(status.sum().item()) != 0:
         raise IndexError("event outside the H x W canvas (reference: np.add.at IndexError)")
     return out
@@ -300,7 +303,10 @@ class TransformNPY:
         ev = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float64)).cuda() if isinstance(x, np.ndarray) else x.cuda()
         d = self.draw(ev.shape[0])
         out, st = self.pipe(ev, [0, ev.shape[0]], [d], return_stages=True)
-        if int(st["status"].sum().item()) != 0:
+        code = int(st["status"][0].item())
+        if code & (1 << 28):
+            raise IndexError("event outside the canvas (reference: np.add.at IndexError)")
+        if code != 0:
             raise ValueError("empty sample or canvas beyond the sensor bound (reference: max() of an empty array)")
         return out[0].cpu()
 
@@ -458,8 +464,9 @@ def _host_loader(args):
 
 def build_pretraining_dataset(args, is_train=True):
     """datasets.py:146-174.  A data_path that exists is read like the reference reads it (root/train|val/<class>/*.npy);
-    otherwise -- there are no datasets in this environment -- seeded synthetic streams of the geometry the data_path
-    names (N-Caltech101: per-sample extents inside 240 x 180) stand in, loudly."""
+    a path that does not exist raises like the reference's assert, unless it is the literal ``synthetic`` or the caller
+    opted in with ``--synthetic_if_missing 1``: then seeded synthetic streams of the geometry the data_path names
+    (N-Caltech101: per-sample extents inside 240 x 180) stand in, with a WARNING in every case."""
     import os
     transform = DataAugmentationForPT(args, is_train)
     print("Data Aug = %s" % str(transform))
@@ -472,20 +479,24 @@ def build_pretraining_dataset(args, is_train=True):
     if root is not None:
         src = NpyFolderSource(root, _host_loader(args))
         return RawEventDataset(len(src), src, transform)
-    if args.data_path != "synthetic" and not getattr(args, "synthetic_if_missing", 1):
-        raise AssertionError(f"{args.data_path} not found")
+    if args.data_path != "synthetic":
+        # the reference asserts that the root exists (datasets.py:149-154): a missing path fails unless the caller opted in
+        if not getattr(args, "synthetic_if_missing", 0):
+            raise AssertionError(f"{args.data_path} not found (pass --data_path synthetic, or --synthetic_if_missing 1 "
+                                 f"to train on seeded synthetic event streams instead)")
     n = getattr(args, "synthetic_samples", 64)
     n = n if is_train else max(2, n // 8)
     cfg = transform.common_transform.cfg
     key = next((k for k in _SENSOR if k in args.data_path), None)
-    if key is None:                                   # "synthetic": streams on the model's own canvas
+    if key is None:                                   # "synthetic" (or an unrecognised name): streams on the model's own canvas
         W, H, vary = args.input_W, args.input_H, False
         cfg.canvas = cfg.canvas or (args.input_H, args.input_W)
     else:
         (W, H), vary = _SENSOR[key], cfg.canvas is None
-        print(f"WARNING: {args.data_path} does not exist here -- using seeded synthetic event streams with the "
-              f"{key} sensor geometry ({W}x{H})")
         cfg.canvas_max = (max(cfg.canvas_max[0], H), max(cfg.canvas_max[1], W))
+    if args.data_path != "synthetic":
+        print(f"WARNING: {args.data_path} does not exist here -- --synthetic_if_missing 1: training on SEEDED SYNTHETIC event "
+              f"streams ({key or 'model canvas'} geometry, {W}x{H}), not on data", flush=True)
     src = SyntheticEventSource(args.slice_max_evs, W, H, seed=1234 if is_train else 4321, vary_extent=vary)
     return RawEventDataset(n, src, transform)
 

@@ -4,8 +4,9 @@ train_one_epoch :41-212, evaluate :215-244), SURVEY section 8 row f3.
 Same signatures and returned meter dicts.  Differences, all forced by the fused engine and stated here:
 bf16 needs no loss scaling (``loss_scaler`` is utils.NativeScalerWithGradNormCount: backward -> fused clip ->
 grouped AdamW); the deepspeed branch (``loss_scaler is None``) and the wandb image logging are not carried;
-gradient accumulation is not supported by the flat gradient buffer (``update_freq`` must be 1); ``model_ema``
-is updated through its own ``update(model)`` if one is passed."""
+``update_freq`` > 1 accumulates the micro-batch gradients in the flat gradient buffer (``engine.accumulate_grads``;
+``optimizer.zero_grad()`` clears it after the update); ``model_ema`` is updated through its own ``update(model)`` if
+one is passed."""
 import math
 import sys
 from typing import Iterable, Optional

@@ -20,6 +20,30 @@ from . import utils
 
 
 _TOK_STREAM = {}
+_BAD_SAMPLES = {}          # device -> i64 [1]: samples the augmentation chain flagged since the last check
+
+
+def _note_status(device, status):
+    """Per-sample status words of augment.BatchAugPipeline (empty after the filter / canvas beyond the bound / events
+    outside the canvas -- the reference raises ValueError or IndexError in the DataLoader worker for those; here the
+    sample became an all-zero image).  Accumulated on the device, read with the meters' deferred transfer."""
+    key = str(device)
+    if key not in _BAD_SAMPLES:
+        _BAD_SAMPLES[key] = torch.zeros(1, dtype=torch.int64, device=device)
+    _BAD_SAMPLES[key] += (status != 0).sum()
+
+
+def check_bad_samples(device=None):
+    """Raise if the augmentation chain flagged a sample since the last call (one host read-back)."""
+    for key, t in _BAD_SAMPLES.items():
+        if device is not None and key != str(device):
+            continue
+        n = int(t.item())
+        if n:
+            t.zero_()
+            raise ValueError(f"{n} sample(s) were empty after the event filter, needed a canvas beyond the sensor bound, or had "
+                             f"events outside their canvas (the reference raises ValueError / IndexError in its transform "
+                             f"chain for these; here they would train as all-zero images)")
 
 
 def _tokenizer_stream(device):
@@ -36,7 +60,8 @@ def _prep_batch(batch, device, model, d_vae, MAE=False):
         # build_transformNPY + ColorJitter on the GPU (augment.BatchAugPipeline); patches IS visual_tokens for
         # discrete_vae_type == "event" (datasets.py:49-51)
         ev = batch["events"].to(device, non_blocking=True)
-        samples = batch["pipe"](ev, batch["offsets"], batch["draws"])
+        samples, stages = batch["pipe"](ev, batch["offsets"], batch["draws"], return_stages=True)
+        _note_status(ev.device, stages["status"])
         images = samples
         masks = batch["masks"]
         if MAE:
@@ -91,6 +116,7 @@ def _flush(pending, metric_logger, log_writer, optimizer, run):
     """One device->host transfer for all steps since the last flush."""
     if not pending:
         return
+    check_bad_samples()
     vals = torch.stack([torch.cat([la, gn]) for la, gn, _ in pending]).tolist()     # [[loss, acc, gnorm], ...]
     for (loss_value, mlm_acc, grad_norm), (_, _, meta) in zip(vals, pending):
         if not math.isfinite(loss_value):
@@ -171,6 +197,7 @@ def evaluate(data_loader, model, d_vae, device, args, plotting=False, MAE=False)
         la = (model.forward_loss(samples) if MAE else model.forward_loss(samples, bool_masked_pos, labels, **extra)).tolist()
         metric_logger.update(loss=la[0])
         metric_logger.meters["mlm_acc"].update(la[1])
+    check_bad_samples()
     metric_logger.synchronize_between_processes()
     print("* mlm_acc {mlm_acc.global_avg:.3f} loss {losses.global_avg:.3f}".format(
         mlm_acc=metric_logger.mlm_acc, losses=metric_logger.loss))

@@ -126,15 +126,16 @@ def get_args(argv=None):
                    help="bf16: the reference's autocast placement (bf16 GEMM operands, fp32 accumulate / residual / softmax); "
                         "fp32: parity mode, fp32 operands everywhere like the reference without autocast (slow; for loss-curve "
                         "parity against the reference's fp32 run)")
-    p.add_argument("--num_workers", default=0, type=int)
-    p.add_argument("--synthetic_if_missing", default=1, type=int,
-                   help="1: a --data_path that does not exist is replaced (loudly) by seeded synthetic event streams of the "
-                        "sensor geometry its name implies; 0: fail like the reference's assert")
+    p.add_argument("--num_workers", default=10, type=int)        # run_mem_pretraining.py:152
+    p.add_argument("--synthetic_if_missing", default=0, type=int,
+                   help="0 (default): a --data_path that does not exist fails like the reference's assert (only the literal "
+                        "'synthetic' selects synthetic streams); 1: opt in to replacing a missing path (loudly) by seeded "
+                        "synthetic event streams of the sensor geometry its name implies")
     p.add_argument("--canvas_max_H", default=0, type=int, help="bound of data-dependent canvases (0: 480)")
     p.add_argument("--canvas_max_W", default=0, type=int, help="bound of data-dependent canvases (0: 640)")
     p.add_argument("--pin_mem", action="store_true")
     p.add_argument("--no_pin_mem", action="store_false", dest="pin_mem")
-    p.set_defaults(pin_mem=False)
+    p.set_defaults(pin_mem=True)                                      # run_mem_pretraining.py:155-157
     p.add_argument("--world_size", default=1, type=int)
     p.add_argument("--local_rank", default=-1, type=int)
     p.add_argument("--dist_on_itp", action="store_true")

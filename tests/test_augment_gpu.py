@@ -79,17 +79,21 @@ def test_each_op_vs_oracle(name, mag):
     _u8_close(got, A.apply_op(small, name, mag).numpy(), (name, "37x53"))
 
 
-@pytest.mark.parametrize("h,w", [(180, 240), (173, 201), (100, 120), (224, 224), (440, 640), (120, 100), (300, 224)])
-def test_resize_antialias_vs_oracle(h, w):
+@pytest.mark.parametrize("h,w,oh,ow", [(180, 240, 224, 224), (173, 201, 224, 224), (100, 120, 224, 224), (224, 224, 224, 224),
+                                       (440, 640, 224, 224), (120, 100, 224, 224), (300, 224, 224, 224),
+                                       # downscales beyond 3.5x (more than 8 taps per axis): the CLI default --input_H/W 128
+                                       # on a DSEC canvas (5x: 11 taps), 480 x 640 -> 64 x 64 (10x: 21 taps), 6.9x / 1.1x mixed
+                                       (440, 640, 128, 128), (480, 640, 64, 64), (440, 141, 64, 128)])
+def test_resize_antialias_vs_oracle(h, w, oh, ow):
     from mem_amd._lib import check, lib, ptr, stream_ptr
     g = torch.Generator().manual_seed(h * 1000 + w)
     B = 3
     img = torch.randint(0, 256, (B, 3, h, w), dtype=torch.uint8, generator=g)
     img[:, :, :, ::3] = 0
-    out = torch.empty((B, 3, 224, 224), device="cuda")
+    out = torch.empty((B, 3, oh, ow), device="cuda")
     d = img.cuda()
-    check(lib.memhip_resample_to_f32(ptr(d), None, 3 * h * w, h, w, 0, None, B, 224, 224, ptr(out), stream_ptr()), "resize")
-    want = torch.stack([A.resize_bilinear_aa(img[b].float().div(255), (224, 224)) for b in range(B)])
+    check(lib.memhip_resample_to_f32(ptr(d), None, 3 * h * w, h, w, 0, None, B, oh, ow, ptr(out), stream_ptr()), "resize")
+    want = torch.stack([A.resize_bilinear_aa(img[b].float().div(255), (oh, ow)) for b in range(B)])
     assert (out.cpu() - want).abs().max().item() <= 2e-6
 
 
@@ -194,8 +198,8 @@ def test_full_chain_vs_oracle(data_path, is_train, W, H, vary, kw):
 
 def test_ncaltech_conf_runs_unmodified(tmp_path):
     """configs/ncaltech.conf of the reference (rand_aug = 1, pt_color_jitter = 0.2, data-dependent canvases) through
-    run_mem_pretraining unmodified: the data_path of the config does not exist here, so seeded synthetic streams of the
-    N-Caltech101 sensor geometry stand in (loud warning); two short epochs, finite losses, checkpoint written."""
+    run_mem_pretraining unmodified: the data_path of the config does not exist here, so (explicit --synthetic_if_missing 1)
+    seeded synthetic streams of the N-Caltech101 sensor geometry stand in (loud warning); two short epochs, finite losses, checkpoint written."""
     import json
     from mem_amd.run_mem_pretraining import get_args, main
     conf = tmp_path / "ncaltech.conf"
@@ -222,9 +226,39 @@ def test_ncaltech_conf_runs_unmodified(tmp_path):
     args = get_args(["--config", str(conf), "--batch_size", "8", "--epochs", "2", "--warmup_epochs", "0",
                      "--synthetic_samples", "16", "--output_dir", str(out), "--transformer_depth", "2",
                      "--transformer_emb", "128", "--transformer_heads", "2", "--num_workers", "2", "--num_tokens", "512",
-                     "--warmup_steps", "-1"])
+                     "--warmup_steps", "-1", "--synthetic_if_missing", "1"])
     assert args.rand_aug == 1 and abs(args.color_jitter - 0.2) < 1e-12 and "ncaltech101" in args.data_path
     assert args.clip_grad == 30.0 and args.num_mask_patches == 98 and args.masking == "block"
     main(args)
     log = [json.loads(l) for l in open(out / "log.txt")]
     assert len(log) == 2 and all(np.isfinite(e["train_loss"]) for e in log)
+
+
+def test_bad_samples_are_reported_at_the_deferred_check():
+    """The reference raises in the transform chain (ValueError: max() of an empty array; IndexError from np.add.at) for a
+    sample that is empty after the event filter or has events outside its canvas.  The batched GPU chain turns such a
+    sample into a zero image and a status word; the training loop accumulates the words on the device and raises at its
+    next meter flush (engine_for_pretraining.check_bad_samples) instead of training on it silently."""
+    from mem_amd import engine_for_pretraining as E
+    from mem_amd.augment import BatchAugPipeline, ChainConfig, draw_sample
+    a = _args(data_path="x/nimagenet_npy/", rand_aug=0, color_jitter=0.0)
+    cfg = ChainConfig(a, False)                                # evaluation chain: fixed 224 x 224 canvas after the rescale
+    evs = _streams(4, 640, 480, False)
+    random.seed(1); np.random.seed(2); torch.manual_seed(3)
+    draws = [draw_sample(cfg, len(e)) for e in evs]
+    offs = np.concatenate([[0], np.cumsum([len(e) for e in evs])])
+    pipe = BatchAugPipeline(cfg, 3)
+    E.check_bad_samples()                                      # clean start
+    ev = torch.from_numpy(np.concatenate(evs, 0)).cuda()
+    _, st = pipe(ev, offs, draws, return_stages=True)
+    E._note_status(ev.device, st["status"])
+    E.check_bad_samples()                                      # nothing flagged
+    bad = [e.copy() for e in evs]
+    bad[2][:7, 0] = 5000.0                                     # seven events far outside the sensor
+    ev = torch.from_numpy(np.concatenate(bad, 0)).cuda()
+    _, st = pipe(ev, offs, draws, return_stages=True)
+    assert st["status"].tolist() == [0, 0, 1 << 28, 0] and st["bad_index_events"].tolist() == [0, 0, 7, 0]
+    E._note_status(ev.device, st["status"])
+    with pytest.raises(ValueError, match="1 sample"):
+        E.check_bad_samples()
+    E.check_bad_samples()                                      # the counter was reset

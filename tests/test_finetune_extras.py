@@ -106,6 +106,17 @@ def test_update_freq_accumulates_like_one_large_batch():
     m1, o1 = make()
     m2, o2 = make()
     p0 = m1.engine.flat_p.clone()
+    grads = {}
+
+    def snapshot_before_step(tag, m, o):                      # the gradient the optimizer actually consumes
+        step = o.step
+
+        def wrapped(*a, **k):
+            grads[tag] = m.engine.flat_g.clone()
+            return step(*a, **k)
+        o.step = wrapped
+    snapshot_before_step("one", m1, o1)
+    snapshot_before_step("acc", m2, o2)
     with contextlib.redirect_stdout(io.StringIO()):
         EF.train_one_epoch(None, m1, crit, [(x, y)], o1, torch.device("cuda"), 0, NativeScalerWithGradNormCount(), 0,
                            lr_schedule_values=[1e-3], update_freq=1)
@@ -116,3 +127,16 @@ def test_update_freq_accumulates_like_one_large_batch():
     rel = float((d1 - d2).norm() / d1.norm())
     print("relative difference of the parameter update, update_freq 2 vs one batch: %.3e" % rel)
     assert o2.steps == 1 and rel <= 3e-2
+    # the first AdamW step is ~ lr * sign(g): it cannot see a mis-scaled accumulated gradient (a missing 1 / update_freq,
+    # a double-counted layer-scale gradient ...).  So compare the gradient buffers themselves, magnitude included.
+    g1, g2 = grads["one"], grads["acc"]
+    rel_g = float((g1 - g2).norm() / g1.norm())
+    cos = float(torch.dot(g1, g2) / (g1.norm() * g2.norm()))
+    ratio = float(g2.norm() / g1.norm())
+    print("accumulated vs one-batch gradient: rel-L2 %.3e, cosine %.6f, norm ratio %.4f" % (rel_g, cos, ratio))
+    assert rel_g <= 3e-2 and cos >= 0.9995 and abs(ratio - 1) <= 1e-2
+    # per tensor (a wrong factor on ONE small tensor -- e.g. the layer-scale gammas -- hides in the global norm)
+    for name, (o, k) in m1.engine.segs.items():
+        a, b = g1[o:o + k], g2[o:o + k]
+        if float(a.norm()) > 1e-6:
+            assert float((a - b).norm() / a.norm()) <= 6e-2, name

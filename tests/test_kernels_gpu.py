@@ -120,6 +120,24 @@ def test_cross_entropy(M, V):
     torch.testing.assert_close(lg.float(), lr_.grad.bfloat16().float(), rtol=2e-2, atol=1e-7)
 
 
+def test_cross_entropy_label_out_of_range_is_nan_not_a_fault():
+    """torch raises "Target out of bounds"; the device kernel must not read logits[label] then: the loss becomes NaN,
+    which the training loop's non-finite-loss abort reports at its next meter flush."""
+    from mem_amd import ops
+    M, V = 64, 512
+    logits = _rand((M, V), 17, 2.0).bfloat16()
+    labels = torch.randint(0, V, (M,), device="cuda")
+    labels[7] = 2147483647
+    labels[9] = -5
+    row_loss, row_ok = torch.zeros(M, device="cuda"), torch.zeros(M, dtype=torch.int32, device="cuda")
+    out2 = torch.zeros(2, device="cuda")
+    ops.cross_entropy(logits, labels, M, V, 1.0 / M, row_loss, row_ok, out2)
+    torch.cuda.synchronize()
+    assert torch.isnan(row_loss[7]) and torch.isnan(row_loss[9]) and torch.isnan(out2[0])
+    good = torch.ones(M, dtype=torch.bool, device="cuda"); good[7] = good[9] = False
+    assert torch.isfinite(row_loss[good]).all() and torch.isfinite(logits.float()).all()
+
+
 def _attn_ref(qkv, bias, B, T, D, H, scale):
     """reference attention in fp32 with the autocast rounding points (bf16 matmul outputs)."""
     q, k, v = qkv.float().view(B, T, 3, H, 64).permute(2, 0, 3, 1, 4)

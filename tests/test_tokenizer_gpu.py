@@ -109,6 +109,26 @@ def test_argmax_rows_f32_first_maximum_and_gap():
     assert torch.equal(gap, top2[:, 0] - top2[:, 1])
 
 
+def test_argmax_rows_nan_and_all_inf_rows_give_valid_ids():
+    """torch.argmax: NaN beats every number (first NaN), a row of all -inf gives 0.  The ids are used unchecked as
+    labels, so they must always be in range (a non-finite input image used to yield id 0x7fffffff)."""
+    from mem_amd import ops
+    x = torch.randn(64, 8192, device="cuda")
+    x[3] = float("nan")
+    x[4] = float("-inf")
+    x[5, 4000] = float("nan"); x[5, 77] = 1e30
+    x[6, 8000] = float("nan"); x[6, 300] = float("nan")
+    x[7, :5000] = float("-inf")
+    ids = torch.empty(64, dtype=torch.int64, device="cuda")
+    ops.argmax_rows(x, 64, 8192, ids)
+    assert torch.equal(ids, x.argmax(1)) and ids[3].item() == 0 and ids[4].item() == 0 and ids[5].item() == 4000
+    assert ids[6].item() == 300
+    xb = x.bfloat16()
+    ops.argmax_rows(xb, 64, 8192, ids)
+    assert int(ids.min()) >= 0 and int(ids.max()) < 8192
+    assert ids[3].item() == 0 and ids[4].item() == 0 and ids[5].item() == 4000 and ids[6].item() == 300
+
+
 def test_tokenizer_fp32_equals_reference_golden():
     """ids written by the REFERENCE DiscreteVAE in fp32 (oracle/gen_golden_vae.py): the default HIP mode must reproduce
     every one of them -- tiny config and the ViT-B tokenizer shape (hidden 384, 3 ResBlocks, 8192 tokens, 224^2)."""
