@@ -219,6 +219,15 @@ int memhip_color_jitter(const void* in, int in_is_u8, int B, int H, int W, const
 int memhip_event_norm(const void* in, int in_is_u8, int B, int H, int W, int flags,
                       float num_stds, float gamma, float* out, int out_chans,
                       memhip_stream_t stream);
+/* RemoveHotPixels(num_hot_pixels = k) form of the same chain     mem/transforms.py:257-263
+ * (the k largest entries of x[0::2].flatten() are hot; k is clamped to sum / 4 like the
+ * reference; both polarities of a hot pixel are zeroed).  Equal values at the selection
+ * boundary: the reference leaves their order to torch.argsort(stable=False); here the
+ * larger flat index is taken.  hot_keys: u64 [B] scratch (the per-sample selection key).
+ * MEMHIP_EV_HOTPIX is implied. */
+int memhip_event_norm_topk(const void* in, int in_is_u8, int B, int H, int W, int flags,
+                           int num_hot_pixels, float gamma, float* out, int out_chans,
+                           uint64_t* hot_keys, memhip_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * Mask generators (HOST code: bit-exact CPython `random` semantics need

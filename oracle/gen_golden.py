@@ -179,6 +179,45 @@ def gen_transforms():
         u8 = RT.ToUnit8()(r3.clone()); assert torch.equal(u8, T.to_uint8(r3)); out[name + "__u8"] = u8.numpy().copy()
         f32 = RT.ToFloat32()(u8.clone()); assert torch.equal(f32, T.to_float32(u8)); out[name + "__f32"] = f32.numpy().copy()
     np.savez_compressed(os.path.join(OUT, "transforms.npz"), **out)
+    gen_transforms_topk()
+
+
+def gen_transforms_topk():
+    """RemoveHotPixels(num_hot_pixels = k) (transforms.py:257-263): the REFERENCE class on inputs whose selection
+    boundary is tie-free (distinct hot values above the background), incl. the sum / 4 clamp and a pixel that is hot in
+    both polarities -> tests/golden/transforms_topk.npz.  (With ties at the boundary the reference's result depends on
+    the order torch.argsort(stable=False) gives equal values: not a property of the algorithm, not in the fixture.)"""
+    import contextlib
+    import io
+    import transforms as RT
+    out = {}
+    for name, (H, W), seed in (("t32", (32, 32), 1), ("t224", (224, 224), 2), ("t40x56", (40, 56), 3)):
+        g = torch.Generator().manual_seed(seed)
+        x = torch.zeros(3, H, W)
+        x[0] = torch.randint(0, 4, (H, W), generator=g).float() / 255          # background: counts 0..3
+        x[2] = torch.randint(0, 4, (H, W), generator=g).float() / 255
+        x[1] = torch.rand(H, W, generator=g)                                   # the time surface stays untouched
+        perm = torch.randperm(2 * H * W, generator=g)[:40]
+        for j, f in enumerate(perm.tolist()):                                  # 40 distinct hot values 60..99 (/255)
+            c, r = (0, f) if f < H * W else (2, f - H * W)
+            x[c, r // W, r % W] = (60 + j) / 255
+        y0, x0 = 3, 5
+        x[0, y0, x0], x[2, y0, x0] = 200 / 255, 201 / 255                      # one pixel hot in both polarities
+        out[name + "__in"] = x.numpy().copy()
+        ks = [0, 1, 2, 7, 25, 42] + ([10 ** 6] if name == "t32" else [])        # 10^6: clamped to sum / 4
+        out[name + "__ks"] = np.array(ks)
+        for k in ks:
+            assert T.topk_is_tie_free(x, k) or k == 10 ** 6, (name, k)
+            with contextlib.redirect_stdout(io.StringIO()):
+                r = RT.RemoveHotPixels(num_hot_pixels=k)(x.clone())
+            o = T.remove_hot_pixels_topk(x, k)
+            if T.topk_is_tie_free(x, k):
+                assert torch.equal(r, o), (name, k)
+                out[name + f"__top{k}"] = r.numpy().copy()
+            else:   # clamped k lands among the tied background values: keep the count and the value bound only
+                kk = T.topk_clamped(x, k)
+                out[name + f"__clamped_k{k}"] = np.array([kk])
+    np.savez_compressed(os.path.join(OUT, "transforms_topk.npz"), **out)
 
 
 def gen_masks():

@@ -32,6 +32,40 @@ def remove_hot_pixels(x, num_stds=10.0):
     return x
 
 
+def remove_hot_pixels_topk(x, num_hot_pixels):
+    """transforms.py:257-263,270-274 (num_hot_pixels branch), restated with the reference's own operations: the clamp
+    to sum / 4, torch.argsort of the flattened [pos, neg] planes, the last int(k) indices, unravelled to (y, x), both
+    polarities zeroed.  torch.argsort(stable=False) orders EQUAL values as the sort implementation pleases, so the
+    result is defined by the reference only when the k-th and (k+1)-th largest values differ (``topk_is_tie_free``)."""
+    x = x.clone()
+    pol = x[0::2]
+    flat = pol.flatten()
+    k = num_hot_pixels
+    if k >= pol.sum() / 4:
+        k = pol.sum() / 4
+    idx = torch.atleast_1d(torch.argsort(flat)[len(flat) - int(k):])
+    hw = x.shape[1] * x.shape[2]
+    yy, xx = (idx % hw) // x.shape[2], idx % x.shape[2]
+    x[0, yy, xx] = 0
+    x[2, yy, xx] = 0
+    return x
+
+
+def topk_clamped(x, num_hot_pixels):
+    pol = x[0::2]
+    k = num_hot_pixels
+    if k >= pol.sum() / 4:
+        k = pol.sum() / 4
+    return int(k)
+
+
+def topk_is_tie_free(x, num_hot_pixels):
+    k = topk_clamped(x, num_hot_pixels)
+    v = torch.sort(x[0::2].flatten()).values
+    n = len(v)
+    return k <= 0 or k >= n or bool(v[n - k] > v[n - k - 1])
+
+
 def normalize_event(x):
     """transforms.py:225-237: divide channels {0,2} by their joint max when it
     is non-zero (multiplication by the fp32 reciprocal, as the reference does)."""

@@ -133,6 +133,54 @@ def test_event_norm_reference_goldens():
         assert torch.equal(T.ToFloat32()(torch.from_numpy(g[name + "__u8"])), torch.from_numpy(g[name + "__f32"]))
 
 
+def test_hot_pixel_topk_vs_reference_goldens_and_tie_properties():
+    """a4, RemoveHotPixels(num_hot_pixels=k) (transforms.py:257-263): equal to the REFERENCE's outputs wherever the
+    reference defines them (tie-free selection boundary; incl. k = 0, the sum / 4 clamp, a pixel hot in both
+    polarities, a non-square canvas); with ties at the boundary the result must still be A valid top-k selection:
+    exactly k flat entries chosen, none of the others larger than the smallest chosen one."""
+    from mem_amd import transforms as T
+    from oracle import transforms_t as OT
+    g = np.load(os.path.join(GOLDEN, "transforms_topk.npz"))
+    for name in ("t32", "t224", "t40x56"):
+        x = torch.from_numpy(g[name + "__in"])
+        for k in g[name + "__ks"].tolist():
+            got = T.RemoveHotPixels(num_hot_pixels=k)(x.clone())
+            assert torch.equal(got, torch.from_numpy(g[name + f"__top{k}"])), (name, k)
+    # batched u8 input + the rest of the chain (normalise, 2-bin view) vs the oracle chain with the top-k filter
+    rng = np.random.default_rng(5)
+    B, H, W = 3, 224, 224
+    img = torch.from_numpy(rng.integers(0, 3, (B, 3, H, W)).astype(np.uint8))
+    for b in range(B):
+        pos = rng.choice(H * W, 30, replace=False)
+        img[b, 0].view(-1)[torch.from_numpy(pos[:15])] = torch.arange(100, 115, dtype=torch.uint8)
+        img[b, 2].view(-1)[torch.from_numpy(pos[15:])] = torch.arange(120, 135, dtype=torch.uint8)
+    out = T.event_norm(img.cuda(), T.EV_RM_TS | T.EV_NORMALIZE, out_chans=2, num_hot_pixels=12).cpu()
+    for b in range(B):
+        xf = img[b].float() / 255
+        assert OT.topk_is_tie_free(xf, 12)
+        want = OT.normalize_event(OT.remove_hot_pixels_topk(OT.remove_timesurface(xf), 12))
+        assert torch.equal(out[b], want[0::2]), b
+    # ties at the boundary (many equal counts): a valid selection, deterministic
+    x = torch.zeros(3, 64, 64)
+    gen = torch.Generator().manual_seed(9)
+    x[0] = torch.randint(0, 6, (64, 64), generator=gen).float() / 255
+    x[2] = torch.randint(0, 6, (64, 64), generator=gen).float() / 255
+    for k in (1, 9, 200):
+        kk = OT.topk_clamped(x, k)
+        y = T.RemoveHotPixels(num_hot_pixels=k)(x.clone())
+        assert torch.equal(y, T.RemoveHotPixels(num_hot_pixels=k)(x.clone()))
+        flat, zeroed = x[0::2].flatten(), (y[0::2].flatten() == 0) & (x[0::2].flatten() != 0)
+        vals = torch.sort(flat).values
+        kth = vals[len(vals) - kk]
+        # every entry strictly above the k-th value is zeroed; nothing below it is zeroed except as the other polarity
+        # of a chosen pixel; the number of chosen pixels is between k / 2 and k
+        assert bool((y[0::2].flatten()[flat > kth] == 0).all())
+        changed_px = ((y[0] != x[0]) | (y[2] != x[2])).sum().item()
+        assert changed_px <= kk
+        pol_max = torch.maximum(x[0], x[2])[(y[0] != x[0]) | (y[2] != x[2])]
+        assert bool((pol_max >= kth).all())
+
+
 def test_event_norm_u8_batched_2chan_vs_oracle():
     from mem_amd import datasets as D, transforms as T
     from oracle import events_np as E, transforms_t as OT

@@ -99,6 +99,19 @@ def test_mask_goldens():
     assert np.array_equal(np.array([random.random() for _ in range(16)]), g["mt__random_s12345"])
 
 
+def test_hot_pixel_topk_oracle_vs_reference_golden():
+    """RemoveHotPixels(num_hot_pixels=k): the oracle restatement against the reference's outputs (tie-free boundaries)."""
+    from oracle import transforms_t as OT
+    g = np.load(os.path.join(GOLDEN, "transforms_topk.npz"))
+    for name in ("t32", "t224", "t40x56"):
+        x = torch.from_numpy(g[name + "__in"])
+        for k in g[name + "__ks"].tolist():
+            assert OT.topk_is_tie_free(x, k)
+            assert np.array_equal(OT.remove_hot_pixels_topk(x, k).numpy(), g[name + f"__top{k}"]), (name, k)
+    x = torch.from_numpy(g["t32__in"])
+    assert OT.topk_clamped(x, 10 ** 6) == int(x[0::2].sum() / 4) < 100         # the sum / 4 clamp was exercised
+
+
 def test_schedule_goldens():
     g = np.load(os.path.join(GOLDEN, "schedules.npz"))
     s = V.cosine_scheduler(5e-4, 1e-5, 3000, 8, warmup_epochs=5, warmup_steps=1000)
