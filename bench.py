@@ -29,6 +29,43 @@ TIMER_EVERY = 8                                    # every 8th timed step carrie
 PEAK_BF16_TFLOPS = 2500.0                          # MI355X dense bf16 (MI355X_MICROARCH.md)
 
 
+# ---- readers of the committed PMC summaries (profiles/*.json).  Each returns None when the file or a key is missing:
+# a changed layout must show up as a failing CPU test (tests/test_bench_profiles.py), not as a lost figure at run time.
+def _load_profile(name):
+    path = os.path.join(ROOT, "profiles", name)
+    if not os.path.exists(path):
+        return None
+    with open(path) as f:
+        return json.load(f)
+
+
+def raster_traffic_per_sample(tj=None):
+    """HBM bytes per sample of the long-stream rasterizer (raster_bin_keys + raster_bin_accum) from
+    profiles/raster_traffic.json = tools/prof_pmc_raster.sh: per-kernel {hbm_bytes_per_launch}, one launch =
+    `_meta.samples_per_launch` samples of 1 M events (64 when the file carries no _meta: tools/raster_bench.py)."""
+    tj = _load_profile("raster_traffic.json") if tj is None else tj
+    if not tj:
+        return None
+    per_launch = 0
+    for k in ("raster_bin_keys", "raster_bin_accum"):
+        if k not in tj or "hbm_bytes_per_launch" not in tj[k]:
+            return None
+        per_launch += tj[k]["hbm_bytes_per_launch"]
+    return per_launch / float(tj.get("_meta", {}).get("samples_per_launch", 64))
+
+
+def gemm_traffic_per_launch(kernel, tj=None):
+    tj = _load_profile("gemm_traffic.json") if tj is None else tj
+    return (tj or {}).get(kernel, {}).get("hbm_bytes_per_launch")
+
+
+def mfma_util_by_kernel(uj=None):
+    uj = _load_profile("mfma_util.json") if uj is None else uj
+    if not uj:
+        return None
+    return {k.lstrip("_"): v["mfma_util"] for k, v in uj.items() if isinstance(v, dict) and "mfma_util" in v}
+
+
 def _cpu_model():
     try:
         for line in open("/proc/cpuinfo"):
@@ -432,12 +469,14 @@ def main():
                                        "frac": round(byts / rdt / 8e12, 4), "algorithmic_bytes_per_sample": 32 * rn + 3 * rh * rw,
                                        "traffic": None}}
             # HBM bytes per launch from the PMC passes (tools/prof_pmc_raster.sh -> profiles/raster_traffic.json)
-            rpath = os.path.join(ROOT, "profiles", "raster_traffic.json")
-            if os.path.exists(rpath):
-                raster_fig["roofline"]["traffic"] = json.load(open(rpath))["hbm_bytes_per_sample"] * rb
-            del ev
+            per_sample = raster_traffic_per_sample()
+            if per_sample is not None:
+                raster_fig["roofline"]["traffic"] = round(per_sample * rb)
         except Exception as e:                                        # the figure is optional
             print(f"[bench] rasterizer figure skipped: {e}", file=sys.stderr)
+        finally:
+            ev = off = None                                          # 1 GB of events: released on every path
+            torch.cuda.empty_cache()
     # ---- secondary figure: BASELINE configs[3] END TO END -- N-ImageNet-scale streams (1 M events per sample on the
     # 640 x 480 sensor) feeding the same ViT-B step.  Policy (stated): the reference's N-ImageNet evaluation chain,
     # ReshapeScaleXandY(newH = newW = 224, oldH = 480, oldW = 640, is_train = False) (mem/datasets.py:464-485,615-621:
@@ -517,8 +556,7 @@ def main():
             ach = tot_fl / (tot_ms * 1e-3) / 1e12
             # HBM bytes per launch from the PMC passes (tools/prof_pmc.sh -> profiles/gemm_traffic.json;
             # FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950), None until collected
-            tpath = os.path.join(ROOT, "profiles", "gemm_traffic.json")
-            tj = json.load(open(tpath)) if os.path.exists(tpath) else {}
+            tj = _load_profile("gemm_traffic.json") or {}
             fam = {str(k): {"launches": v[0], "avg_us": round(v[1] / v[0] * 1e3, 2),
                             "tflops": round(v[2] / (v[1] * 1e-3) / 1e12, 1)} for k, v in sorted(per.items())}
             # the dominant kernel of the step is the weight-gradient GEMM (gemm_tn_p8_kernel, logged as 100)
@@ -528,7 +566,7 @@ def main():
                 roof = {"bound": "mfma", "kernel": "gemm_tn_p8_kernel (bf16 weight-gradient GEMM, split over token rows)",
                         "achieved": round(d_ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                         "frac": round(d_ach / PEAK_BF16_TFLOPS, 4),
-                        "traffic": tj.get("gemm_tn_p8_kernel", {}).get("hbm_bytes_per_launch"),
+                        "traffic": gemm_traffic_per_launch("gemm_tn_p8_kernel", tj),
                         "launches": dom[0], "avg_launch_us": round(dom[1] / dom[0] * 1e3, 2),
                         "algorithmic_flop_per_launch": round(dom[2] / dom[0]),
                         "share_of_step": round(dom[1] / (dt * 1e3 * n_inst / a.steps), 3),
@@ -543,10 +581,9 @@ def main():
                         "traffic": None}
             # MFMA-pipe utilisation from the SQ counters (tools/prof_mfma.sh -> profiles/mfma_util.json, own PMC passes):
             # SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x 1024 SIMDs), per kernel family and over the whole step
-            upath = os.path.join(ROOT, "profiles", "mfma_util.json")
-            if os.path.exists(upath):
-                uj = json.load(open(upath))
-                roof["mfma_util_pmc"] = {k.lstrip("_"): v["mfma_util"] for k, v in uj.items() if "mfma_util" in v}
+            util = mfma_util_by_kernel()
+            if util is not None:
+                roof["mfma_util_pmc"] = util
             # the honest headline next to the dominant kernel: the model-level rate of the WHOLE step (all kernels, all
             # gaps) against the dense bf16 peak, and the GEMM family as a whole (below)
             ws = value / world * FLOP_PER_SAMPLE[C] / 1e12
