@@ -196,19 +196,37 @@ struct EpiCols {
   ef32x2 bias[4];
   float g[8];
 };
+// Absent per-column operands are read from constant lines (bias 0, layer scale 1) through a POINTER selection, and the
+// arithmetic that uses them is unconditional: a branch around the load -- even a wave-uniform one -- ends the basic block,
+// and at the join hipcc's waitcnt pass waits with s_waitcnt vmcnt(0) for the operand, i.e. also for every store issued so
+// far and for the LDS-DMA stream that is prefetching the next tile (two to three such drains per output tile).
+// (The selected pointer must stay a GLOBAL pointer: a select between a kernel-argument pointer and the address of a
+// __device__ constant is a generic pointer to hipcc, the load becomes flat_load, and a flat load is preceded by
+// s_waitcnt vmcnt(0) while LDS-DMA is in flight -- it might read LDS -- and followed by vmcnt(0) lgkmcnt(0).)
+static __device__ __attribute__((aligned(32))) const float g_epi_zero8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+static __device__ __attribute__((aligned(32))) const float g_epi_one8[8] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
+static __device__ __attribute__((aligned(128))) const float g_epi_zero256[256] = {};   // a whole tile's worth (gemm_p8.hip)
+struct EpiOnes256 { float v[256]; constexpr EpiOnes256() : v() { for (int i = 0; i < 256; ++i) v[i] = 1.0f; } };
+static __device__ __attribute__((aligned(128))) const EpiOnes256 g_epi_one256_s{};
+#define g_epi_one256 (g_epi_one256_s.v)
+typedef const float __attribute__((address_space(1)))* gcf32_ptr;
+typedef float __attribute__((ext_vector_type(4))) ef32x4;
+typedef const ef32x4 __attribute__((address_space(1)))* gcf32x4_ptr;
+__device__ __forceinline__ gcf32_ptr as_global(const float* q) { return (gcf32_ptr)q; }
+__device__ __forceinline__ void ld8g(gcf32_ptr q, float* o) {
+  const ef32x4 a = reinterpret_cast<gcf32x4_ptr>(q)[0], b = reinterpret_cast<gcf32x4_ptr>(q)[1];
+  o[0] = a[0]; o[1] = a[1]; o[2] = a[2]; o[3] = a[3]; o[4] = b[0]; o[5] = b[1]; o[6] = b[2]; o[7] = b[3];
+}
 template <int EPI>
 __device__ __forceinline__ void epi_cols_load(const GemmArgs& p, int n, EpiCols& c) {
   if constexpr (EPI != MEMHIP_EPI_DGELU && EPI != MEMHIP_EPI_F32 && EPI != MEMHIP_EPI_MUL_AUX) {
-    if (p.bias) {
-      const float4 b0 = reinterpret_cast<const float4*>(p.bias + n)[0], b1 = reinterpret_cast<const float4*>(p.bias + n)[1];
-      c.bias[0] = ef32x2{b0.x, b0.y}; c.bias[1] = ef32x2{b0.z, b0.w}; c.bias[2] = ef32x2{b1.x, b1.y}; c.bias[3] = ef32x2{b1.z, b1.w};
-    } else {
+    float b[8];
+    ld8g(p.bias ? as_global(p.bias + n) : as_global(g_epi_zero8), b);
 #pragma unroll
-      for (int k = 0; k < 4; ++k) c.bias[k] = ef32x2{0.f, 0.f};
-    }
+    for (int k = 0; k < 4; ++k) c.bias[k] = ef32x2{b[2 * k], b[2 * k + 1]};
   }
   if constexpr (EPI == MEMHIP_EPI_RESIDUAL) {
-    if (p.vec1) ld8(p.vec1 + n, c.g);
+    ld8g(p.vec1 ? as_global(p.vec1 + n) : as_global(g_epi_one8), c.g);
   }
 }
 
@@ -229,7 +247,9 @@ struct EpiRow<MEMHIP_EPI_RESIDUAL> { float x[8]; float rm; };
 // a missing drop-path mask reads the constant 1, a missing bf16 copy of the branch output goes to a scratch line.
 __device__ const float g_epi_one = 1.0f;
 __device__ __attribute__((aligned(256))) unsigned char g_epi_trash[1024];
-template <int EPI>
+// BIGROWS = false: the caller guarantees m + m_base < 2^21 whenever a drop-path mask is given (no integer division, no
+// branch: the row epilogue stays one basic block)
+template <int EPI, bool BIGROWS = true>
 __device__ __forceinline__ void epi_row_load(const GemmArgs& p, int m, int n, EpiRow<EPI>& r) {
   if constexpr (EPI == MEMHIP_EPI_DGELU || EPI == MEMHIP_EPI_MUL_AUX) {
 #ifdef MEMHIP_EXP_NOLOAD
@@ -246,25 +266,36 @@ __device__ __forceinline__ void epi_row_load(const GemmArgs& p, int m, int n, Ep
     // integer; the fp32 product is off by at most (m + 0.5) * 2^-23 / rows_per_sample, so it truncates to the right sample
     // for m < 2^22 (taken up to 2^21; larger row indices use the integer division)
     const int mm = m + p.m_base;
-    const float inv = __frcp_rn((float)p.rows_per_sample);
-    int smp = 0;
-    if (p.rowmask) smp = mm < (1 << 21) ? (int)(((float)mm + 0.5f) * inv) : mm / p.rows_per_sample;
-    const float* rmb = p.rowmask ? p.rowmask : &g_epi_one;
+    const float inv = p.rowmask ? __frcp_rn((float)p.rows_per_sample) : 0.f;      // no mask: sample 0 of the constant 1
+    int smp = (int)(((float)mm + 0.5f) * inv);
+    if constexpr (BIGROWS) {
+      if (p.rowmask && mm >= (1 << 21)) smp = mm / p.rows_per_sample;
+    }
+    const gcf32_ptr rmb = p.rowmask ? as_global(p.rowmask) : as_global(&g_epi_one);
     r.rm = rmb[smp];
   }
 }
 
-template <int EPI>
+// the optional bf16 copy of the branch output (out0 of the residual epilogue): a global store either way (see as_global)
+typedef eu32x4 __attribute__((address_space(1)))* gu32x4_ptr;
+__device__ __forceinline__ void st_branch_copy(const GemmArgs& p, int m, int n, const unsigned* y) {
+  const gu32x4_ptr dst = p.out0 ? (gu32x4_ptr)(reinterpret_cast<__bf16*>(p.out0) + (long long)m * p.ldo0 + n)
+                                : (gu32x4_ptr)(g_epi_trash + 2 * (n & 255));
+  *dst = eu32x4{y[0], y[1], y[2], y[3]};
+}
+
+// COPY (residual epilogue): 1 = the bf16 copy of the branch output goes to out0, or to a scratch line when out0 is NULL
+// (a select, which hipcc may turn into a branch); 0 = no copy is written (p.out0 is not looked at); 2 = out0 is known
+// to be non-NULL (no select: the row epilogue stays one basic block)
+template <int EPI, int COPY = 1>
 __device__ __forceinline__ void epilogue8(const GemmArgs& p, int m, int n, const float* acc, float* cs, const EpiCols& c,
                                           const EpiRow<EPI>& row) {
   ef32x2 t[4];
 #pragma unroll
   for (int k = 0; k < 4; ++k) t[k] = ef32x2{acc[2 * k], acc[2 * k + 1]};
   if constexpr (EPI != MEMHIP_EPI_DGELU && EPI != MEMHIP_EPI_F32 && EPI != MEMHIP_EPI_MUL_AUX) {
-    if (p.bias) {
 #pragma unroll
-      for (int k = 0; k < 4; ++k) t[k] += c.bias[k];
-    }
+    for (int k = 0; k < 4; ++k) t[k] += c.bias[k];                 // zeros when there is no bias (epi_cols_load)
   }
   if constexpr (EPI == MEMHIP_EPI_BIAS_BF16) {
     unsigned y[4];
@@ -330,28 +361,26 @@ __device__ __forceinline__ void epilogue8(const GemmArgs& p, int m, int n, const
       br[2 * k] = f.x;
       br[2 * k + 1] = f.y;
     }
-    if (p.vec1) {                              // layer scale: gamma * branch (own rounding, as the reference)
+    // layer scale: gamma * branch (own rounding, as the reference); gamma = 1 (exact) when there is none
 #pragma unroll
-      for (int k = 0; k < 8; ++k) br[k] = __fmul_rn(c.g[k], br[k]);
-    }
-    if (p.rowmask) {                           // drop path: branch / keep_prob * mask[sample]
-      const float rm = row.rm;
-      const float rk = __frcp_rn(p.keep_prob);
+    for (int k = 0; k < 8; ++k) br[k] = __fmul_rn(c.g[k], br[k]);
+    {                                          // drop path: branch / keep_prob * mask[sample]; without a mask both are the
+      const float rm = row.rm;                 // constant 1 and every step below is exact (q0 = br, residual 0, q = br)
+      const float kp = p.rowmask ? p.keep_prob : 1.0f;
+      const float rk = __frcp_rn(kp);
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
         // correctly rounded quotient from one Newton step on the reciprocal (no denormal inputs here)
         const float q0 = br[k] * rk;
-        const float q = fmaf(fmaf(-q0, p.keep_prob, br[k]), rk, q0);
+        const float q = fmaf(fmaf(-q0, kp, br[k]), rk, q0);
         br[k] = __fmul_rn(q, rm);
       }
     }
 #pragma unroll
     for (int k = 0; k < 8; ++k) x[k] = __fadd_rn(x[k], br[k]);
-    {
-      __bf16* ob = p.out0 ? reinterpret_cast<__bf16*>(p.out0) : reinterpret_cast<__bf16*>(g_epi_trash);
-      const long long ldo = p.out0 ? p.ldo0 : 0;
-      *reinterpret_cast<eu32x4*>(ob + (long long)m * ldo + (p.out0 ? n : (n & 255))) = eu32x4{y[0], y[1], y[2], y[3]};
-    }
+    if constexpr (COPY == 1) st_branch_copy(p, m, n, y);
+    if constexpr (COPY == 2)
+      *(gu32x4_ptr)(reinterpret_cast<__bf16*>(p.out0) + (long long)m * p.ldo0 + n) = eu32x4{y[0], y[1], y[2], y[3]};
     st8(p.resid + (long long)m * p.ldr + n, x);
   } else if constexpr (EPI == MEMHIP_EPI_DGELU) {
     const unsigned h[4] = {row.h.x, row.h.y, row.h.z, row.h.w};
@@ -423,11 +452,7 @@ __device__ __forceinline__ void epilogue8_residual_packed(const GemmArgs& p, int
   }
 #pragma unroll
   for (int k = 0; k < 8; ++k) x[k] = __fadd_rn(row.x[k], br[k]);
-  {
-    __bf16* ob = p.out0 ? reinterpret_cast<__bf16*>(p.out0) : reinterpret_cast<__bf16*>(g_epi_trash);
-    const long long ldo = p.out0 ? p.ldo0 : 0;
-    *reinterpret_cast<eu32x4*>(ob + (long long)m * ldo + (p.out0 ? n : (n & 255))) = eu32x4{y[0], y[1], y[2], y[3]};
-  }
+  st_branch_copy(p, m, n, y);
   st8(p.resid + (long long)m * p.ldr + n, x);
 }
 

@@ -76,6 +76,10 @@ template <int BMT> struct P8Geo {
   static constexpr int kBOff = 2 * kAHalf;                  // B0 behind A0, A1
   static constexpr int kBuf = 2 * kAHalf + 2 * kHalf;       // A0 A1 B0 B1
   static constexpr int kLds = 2 * kBuf;
+  // behind the operand buffers: per tile parity the tile's bias and layer-scale columns (2 x [256 f32 | 256 f32]), then a
+  // 1 KiB landing slot per wave for the epilogue-operand prefetch (never read)
+  static constexpr int kColsOff = kLds, kTrashOff = kLds + 4096;
+  static constexpr int kLdsAll = kLds + 4096 + 8 * 1024;
   static constexpr int MF = BMT / 64;                       // 16-row fragments per wave and A half
   static constexpr int kAPieces = BMT / 128;                // LDS-DMA instructions per wave for an A half-tile
   // glds in flight that a phase's wait must leave alone (= the five half-tiles issued after the one needed)
@@ -111,8 +115,10 @@ __device__ __forceinline__ int key_b(int r) { return ((r >> 1) & 1) | (((r >> 3)
 
 // GUARD: the last tile row may reach past M (rows clamped on load, guarded on store).  The 256-row kernel is only
 // instantiated without it; the 128-row kernel in both forms (the rows it is handed are usually whole tiles too).
-template <int EPI, int BMT, bool GUARD>
-__global__ __launch_bounds__(kThreads) void gemm_p8_kernel(GemmArgs p, int ntm, int ntn, int stagger) {
+// COPY (residual epilogue only): the bf16 copy of the branch output (out0) is wanted.  Without it the epilogue has no
+// such store at all (it used to go to a 1 KiB scratch line shared by the whole chip: 77 MB of stores per launch).
+template <int EPI, int BMT, bool GUARD, bool COPY>
+__global__ __launch_bounds__(kThreads) void gemm_p8_kernel(GemmArgs p, int ntm, int ntn, int stagger, int prefetch) {
   using G = P8Geo<BMT>;
   constexpr int kBuf = G::kBuf, MF = G::MF, AP = G::kAPieces, kAHalf = G::kAHalf;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -281,32 +287,123 @@ __global__ __launch_bounds__(kThreads) void gemm_p8_kernel(GemmArgs p, int ntm, 
     P8_MFMA(q, bsrc);                                                                                     \
     P8_BARRIER();
 #endif
-#define P8_KTILE(bq0, bq1)                                                                                  \
+// X1..X4: vector-memory instructions besides the half-tile stream that the phase's wait must leave in flight as well
+// (the epilogue-operand prefetch, one LDS-DMA per wave and loop iteration: see `prefetch_aux`)
+#define P8_KTILE(bq0, bq1, X1, X2, X3, X4)                                                                \
   do {                                                                                                    \
     const int bo = bc * kBuf;                                                                             \
     /* phase 1: quadrant (A0, B0) */                                                                      \
-    P8_PHASE(P8_READ_A(0), stage(HA1, bc ^ 1, tm1, tn1, k1), G::kWaitB, AP, 0, bq0)                       \
+    P8_PHASE(P8_READ_A(0), stage(HA1, bc ^ 1, tm1, tn1, k1), G::kWaitB + (X1), AP, 0, bq0)                \
     /* phase 2: quadrant (A0, B1) */                                                                      \
-    P8_PHASE(P8_READ_B(bq1, bo, 1), stage(HB0, bc, tm2, tn2, k2), G::kWaitA, 2, 1, bq1)                   \
+    P8_PHASE(P8_READ_B(bq1, bo, 1), stage(HB0, bc, tm2, tn2, k2), G::kWaitA + (X2), 2, 1, bq1)            \
     /* phase 3: quadrant (A1, B1) */                                                                      \
-    P8_PHASE(P8_READ_A(1), stage(HA0, bc, tm2, tn2, k2), G::kWaitB, AP, 3, bq1)                           \
+    P8_PHASE(P8_READ_A(1), stage(HA0, bc, tm2, tn2, k2), G::kWaitB + (X3), AP, 3, bq1)                    \
     /* phase 4: quadrant (A1, B0); B0 of the next K-tile comes from the other buffer */                   \
-    P8_PHASE(P8_READ_B(bq1, (bc ^ 1) * kBuf, 0), stage(HB1, bc, tm2, tn2, k2), G::kWaitA, 2, 2, bq0)      \
+    P8_PHASE(P8_READ_B(bq1, (bc ^ 1) * kBuf, 0), stage(HB1, bc, tm2, tn2, k2), G::kWaitA + (X4), 2, 2, bq0) \
   } while (0)
 #define P8_READ_B0_FIRST() P8_READ_B(bx, 0, 0)
+
+  // ---- one extra LDS-DMA per wave and loop iteration (two K-tiles), always issued, so that the counted waits stay
+  // compile-time constants (+1 for the five phases behind it: X1..X4 of P8_KTILE):
+  //  * iteration 0 of a tile: wave 0 brings the tile's 256 bias values (1 KiB = one 16-byte-per-lane instruction), wave 1
+  //    its 256 layer-scale values into LDS (double-buffered by tile parity: a slow wave may still be reading the previous
+  //    tile's copy in its epilogue).  The epilogue then takes its per-column operands from LDS: it used to load them from
+  //    global memory at its start, and waiting for the YOUNGEST vector-memory operation is s_waitcnt vmcnt(0) -- every
+  //    store issued so far and the whole prefetch stream of the next tile, two to three times per output tile.  Absent
+  //    operands come from constant lines (bias 0, scale 1): no branch, no special case in the epilogue.
+  //  * later iterations: EPILOGUE-OPERAND PREFETCH.  The GELU' / residual epilogues read a 256 x 256 tile of a second
+  //    operand (the GELU input, bf16, 128 KB; the fp32 residual stream, 256 KB) straight from HBM, all workgroups at about
+  //    the same time, while the main loops leave HBM idle.  Every wave touches 64 of that tile's 128-byte lines per
+  //    iteration (per-lane source addresses; the data lands in a scratch slot and is never read): 512 lines per iteration
+  //    and workgroup, the whole operand tile within 2 (bf16) or 4 (fp32) of a K = 768 tile's 6 iterations; the epilogue's
+  //    own loads then hit L2.
+  constexpr bool kHasAux = EPI == MEMHIP_EPI_DGELU || EPI == MEMHIP_EPI_MUL_AUX || EPI == MEMHIP_EPI_RESIDUAL;
+  constexpr bool kHasBias = EPI == MEMHIP_EPI_BIAS_BF16 || EPI == MEMHIP_EPI_BIAS_GELU || EPI == MEMHIP_EPI_RESIDUAL ||
+                            EPI == MEMHIP_EPI_BIAS_GELU_DG;
+  constexpr int PX = 1;
+  const char* pf_base = reinterpret_cast<const char*>(p.A);
+  long long pf_ld = 0;                                     // bytes per row
+  int pf_lpr = 1;                                          // 128-byte lines per tile row
+  if constexpr (kHasAux) {
+    if constexpr (EPI == MEMHIP_EPI_RESIDUAL) {
+      pf_base = p.aux ? reinterpret_cast<const char*>(p.aux) : reinterpret_cast<const char*>(p.resid);
+      pf_ld = (p.aux ? p.ldaux : p.ldr) * 4;
+      pf_lpr = BN * 4 / 128;
+    } else {
+      pf_base = reinterpret_cast<const char*>(p.aux);
+      pf_ld = p.ldaux * 2;
+      pf_lpr = BN * 2 / 128;
+    }
+  }
+  int tile_par = 0;                                        // parity of the current output tile of this workgroup
+  int ctm, ctn;                                            // coordinates of the current output tile
+  decode(c_tile, ctm, ctn);
+  auto iter_dma = [&]() {
+    const int it = c_k >> 1;
+    const int tm = ctm, tn = ctn;
+    const char* src = pf_base;
+    char* dst = smem + G::kTrashOff + wave * 1024;
+    // (lane id from a fresh mbcnt: no lane constant of this block may stay live across the main loop -- the loop uses
+    // every register, the constant is spilled, and its reload waits with vmcnt(0) in every iteration)
+    int dlane;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(dlane));
+    if constexpr (kHasAux) {
+      int line = (it - 1) * 512 + wave * 64 + dlane;
+      if (!prefetch || it < 1 || line >= BMT * pf_lpr) line = 0;
+      int row = tm * BMT + line / pf_lpr;
+      if (GUARD) row = row < p.M ? row : p.M - 1;
+      src = pf_base + (long long)row * pf_ld + (long long)tn * (pf_lpr * 128) + (line % pf_lpr) * 128;
+    }
+    if (it == 0) {
+      if constexpr (kHasBias) {
+        if (wave == 0) {
+          src = (p.bias ? reinterpret_cast<const char*>(p.bias + tn * BN) : reinterpret_cast<const char*>(g_epi_zero256)) + dlane * 16;
+          dst = smem + G::kColsOff + tile_par * 2048;
+        }
+      }
+      if constexpr (EPI == MEMHIP_EPI_RESIDUAL) {
+        if (wave == 1) {
+          src = (p.vec1 ? reinterpret_cast<const char*>(p.vec1 + tn * BN) : reinterpret_cast<const char*>(g_epi_one256)) + dlane * 16;
+          dst = smem + G::kColsOff + tile_par * 2048 + 1024;
+        }
+      }
+    }
+    glds16(src, dst);
+  };
+  // the tile's per-column operands of a lane's 8 columns (ncl = first column inside the tile), from LDS
+  // (read with inline asm: a C++ LDS read here makes hipcc drain the LDS-DMA stream -- s_waitcnt vmcnt(0) -- first, since
+  // it cannot tell that the prefetch stream writes other LDS bytes; the slot itself was filled a whole tile ago, behind
+  // the main loop's counted waits and barriers)
+  auto lds_read8 = [&](unsigned addr, float* o) {
+    f32x4 q0, q1;
+    asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:16\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(q0), "=&v"(q1) : "v"(addr) : "memory");
+    o[0] = q0[0]; o[1] = q0[1]; o[2] = q0[2]; o[3] = q0[3]; o[4] = q1[0]; o[5] = q1[1]; o[6] = q1[2]; o[7] = q1[3];
+  };
+  auto cols_from_lds = [&](int ncl, EpiCols& c) {
+    const unsigned addr = (unsigned)(unsigned long long)((__attribute__((address_space(3))) char*)smem) + (unsigned)(G::kColsOff + tile_par * 2048 + ncl * 4);
+    if constexpr (kHasBias) {
+      float b[8];
+      lds_read8(addr, b);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) c.bias[k] = ef32x2{b[2 * k], b[2 * k + 1]};
+    }
+    if constexpr (EPI == MEMHIP_EPI_RESIDUAL) lds_read8(addr + 1024, c.g);
+  };
 
   P8_READ_B0_FIRST();
   // K-tiles go in pairs (K % 128 == 0), so that buffer parity and the B register roles are static
   for (int c = 0; c < total; c += 2) {
+    iter_dma();
     {
       constexpr int bc = 0;
-      P8_KTILE(bx, by);
+      P8_KTILE(bx, by, PX, PX, PX, PX);
       tm1 = tm2; tn1 = tn2; k1 = k2;
       advance2();
     }
     {
       constexpr int bc = 1;
-      P8_KTILE(by, bx);
+      P8_KTILE(by, bx, PX, 0, 0, 0);
       tm1 = tm2; tn1 = tn2; k1 = k2;
       advance2();
     }
@@ -317,10 +414,15 @@ __global__ __launch_bounds__(kThreads) void gemm_p8_kernel(GemmArgs p, int ntm, 
       if (P8_REALIGN && wr == 0) P8_BARRIER();
       // ---- epilogue of tile c_tile straight out of the accumulators: the MFMAs ran with swapped
       // operands, so a lane holds 4 consecutive columns (registers) of one row (lane & 15)
-      int tm, tn;
-      decode(c_tile, tm, tn);
-      const int mrow = tm * BMT + wr * (MF * 16) + (lane & 15);
-      const int ncol = tn * BN + wc * 32 + (lane >> 4) * 8;
+      const int tm = ctm, tn = ctn;
+      // the lane's row / column inside the tile is recomputed here from a fresh lane id: taken from the kernel's entry
+      // block these two lane constants are live across the whole main loop, hipcc spills them (the loop uses every
+      // register), and the reload at the top of the epilogue comes with s_waitcnt vmcnt(0) -- the prefetch stream drained
+      // (asm: hipcc knows that mbcnt is the lane id, folds it into the value it already has and spills that one)
+      int elane;
+      asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(elane));
+      const int mrow = tm * BMT + wr * (MF * 16) + (elane & 15);
+      const int ncol = tn * BN + wc * 32 + (elane >> 4) * 8;
       // four batches (j = column half, i = row half) of MF rows each.  The per-row operand loads (GELU input /
       // residual) of batch b + kAhead are issued before batch b is computed: with one batch in flight
       // a CU has 32 KB outstanding, i.e. ~20 GB/s per CU at ~1.5 us latency -- the epilogue was latency
@@ -353,27 +455,61 @@ __global__ __launch_bounds__(kThreads) void gemm_p8_kernel(GemmArgs p, int ntm, 
 #ifndef P8_RESID_ROWS_AHEAD
 #define P8_RESID_ROWS_AHEAD 2
 #endif
-        constexpr int kResidAhead = P8_RESID_ROWS_AHEAD;
-        EpiRow<EPI> rows[16];
+        // The row loads are inline asm with HAND-COUNTED waits: left to hipcc this block's schedule is a matter of luck
+        // (with the loads visible to it, one build ran the load-independent arithmetic of all rows first and consumed
+        // each row's loads right after issuing them; another spilled and waited with vmcnt(0) per row).  hipcc never
+        // waits for its own stores here (nothing depends on them) and does not see the asm loads, so it inserts no wait
+        // at all; the only waits are the vmcnt(N) below, N = the vector-memory operations issued behind the row's loads:
+        // per row section [3 loads of row r+2][arithmetic of row r][kStores stores of row r].
+        constexpr int kResidAhead = 2;
+        constexpr int kStores = 2 + (COPY ? 1 : 0);
         auto row_m = [&](int r) { return mrow + ((r >> 2) & 1) * (BMT / 2) + (r & 3) * 16; };
         auto row_n = [&](int r) { return ncol + (r >> 3) * 128; };
-#pragma unroll
-        for (int r = 0; r < kResidAhead; ++r) epi_row_load<EPI>(p, row_m(r), row_n(r), rows[r]);
+        const float* xbase = p.aux ? reinterpret_cast<const float*>(p.aux) : p.resid;
+        const long long xld = p.aux ? p.ldaux : p.ldr;
+        const float inv_rps = p.rowmask ? __frcp_rn((float)p.rows_per_sample) : 0.f;
+        const float* rmb = p.rowmask ? p.rowmask : &g_epi_one;
+        f32x4 xa[3], xb[3];
+        float rmv[3];
+        auto issue_row = [&](int r, int slot) {
+          const int m = row_m(r);
+          const float* src = xbase + (long long)m * xld + row_n(r);
+          const int smp = (int)(((float)(m + p.m_base) + 0.5f) * inv_rps);        // rows < 2^21 (p8_fits)
+          const float* rsrc = rmb + smp;
+          asm volatile("global_load_dwordx4 %0, %3, off\n\tglobal_load_dwordx4 %1, %3, off offset:16\n\tglobal_load_dword %2, %4, off"
+                       : "=&v"(xa[slot]), "=&v"(xb[slot]), "=&v"(rmv[slot]) : "v"(src), "v"(rsrc) : "memory");
+        };
+        issue_row(0, 0);
+        issue_row(1, 1);
         float cs[8];
         EpiCols cols;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
+        auto do_row = [&](int r, int slot, auto waitc) {
           __builtin_amdgcn_sched_barrier(0);
-          if ((r & 7) == 0) epi_cols_load<EPI>(p, row_n(r), cols);
-          if (r + kResidAhead < 16) epi_row_load<EPI>(p, row_m(r + kResidAhead), row_n(r + kResidAhead), rows[r + kResidAhead]);
+          if ((r & 7) == 0) cols_from_lds(wc * 32 + (elane >> 4) * 8 + (r >> 3) * 128, cols);
+          if (r + kResidAhead < 16) issue_row(r + kResidAhead, (slot + kResidAhead) % 3);
           const int q = ((r >> 2) & 1) * 2 + (r >> 3), mf = r & 3;
           float v[8];
 #pragma unroll
           for (int nf = 0; nf < 2; ++nf)
 #pragma unroll
             for (int c = 0; c < 4; ++c) v[nf * 4 + c] = acc[q][mf][nf][c];
-          epilogue8<EPI>(p, row_m(r), row_n(r), v, cs, cols, rows[r]);
-        }
+          // the row's loads have landed (and its registers are named here, so nothing reads or reuses them earlier)
+          asm volatile("s_waitcnt vmcnt(%3)" : "+v"(xa[slot]), "+v"(xb[slot]), "+v"(rmv[slot]) : "n"(decltype(waitc)::value) : "memory");
+          EpiRow<EPI> row;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) { row.x[c] = xa[slot][c]; row.x[4 + c] = xb[slot][c]; }
+          row.rm = rmv[slot];
+          epilogue8<EPI, COPY ? 2 : 0>(p, row_m(r), row_n(r), v, cs, cols, row);
+        };
+        using W2 = std::integral_constant<int, 2 * kStores + 6>;     // S(r-2) L(r+1) S(r-1) L(r+2) behind L(r)
+        using W1 = std::integral_constant<int, 2 * kStores + 3>;     // row 14: no L(16)
+        using W0 = std::integral_constant<int, 2 * kStores>;         // row 15
+        do_row(0, 0, std::integral_constant<int, 6>{});              // behind L(0): L(1) L(2)
+        do_row(1, 1, std::integral_constant<int, kStores + 6>{});    // behind L(1): L(2) S(0) L(3)
+#pragma unroll
+        for (int r = 2; r < 14; ++r) do_row(r, r % 3, W2{});
+        do_row(14, 14 % 3, W1{});
+        do_row(15, 15 % 3, W0{});
       } else {
         constexpr bool kEdge = GUARD;
         EpiRow<EPI> rows[4][MF];
@@ -399,7 +535,7 @@ __global__ __launch_bounds__(kThreads) void gemm_p8_kernel(GemmArgs p, int ntm, 
           if (i == 0) {
 #pragma unroll
             for (int r = 0; r < 8; ++r) cs[r] = 0.f;
-            epi_cols_load<EPI>(p, n, cols);
+            cols_from_lds(wc * 32 + (elane >> 4) * 8 + j * 128, cols);
           }
           if constexpr (kLate) {
             if (b == 0) load_batch(0);
@@ -421,10 +557,10 @@ __global__ __launch_bounds__(kThreads) void gemm_p8_kernel(GemmArgs p, int ntm, 
             for (int nf = 0; nf < 2; ++nf)
 #pragma unroll
               for (int r = 0; r < 4; ++r) v[nf * 4 + r] = acc[i * 2 + j][mf][nf][r];
-            if (!kEdge || m < p.M) epilogue8<EPI>(p, m, n, v, cs, cols, rows[b][mf]);
+            if (!kEdge || m < p.M) epilogue8<EPI, COPY ? 2 : 0>(p, m, n, v, cs, cols, rows[b][mf]);
             if (!kEdge) __builtin_amdgcn_sched_barrier(0);     // one row at a time (register budget)
           }
-          if (i == 1) colsum_flush16(p, n, cs, lane);
+          if (i == 1) colsum_flush16(p, n, cs, elane);
         }
       }
 #pragma unroll
@@ -437,6 +573,8 @@ __global__ __launch_bounds__(kThreads) void gemm_p8_kernel(GemmArgs p, int ntm, 
             for (int r = 0; r < 4; ++r) acc[q][mf][nf][r] = 0.f;
       c_k = 0;
       c_tile += gridDim.x;
+      if (c_tile < ntiles) decode(c_tile, ctm, ctn);
+      tile_par ^= 1;
       if (P8_REALIGN && wr == 1) P8_BARRIER();
     } else {
       c_k += 2;
@@ -446,20 +584,28 @@ __global__ __launch_bounds__(kThreads) void gemm_p8_kernel(GemmArgs p, int ntm, 
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // no LDS-DMA may outlive the workgroup
 }
 
-template <int EPI, int BMT, bool GUARD>
-int launch_p8g(const GemmArgs& p, hipStream_t s, int num_cu) {
+template <int EPI, int BMT, bool GUARD, bool COPY>
+int launch_p8gc(const GemmArgs& p, hipStream_t s, int num_cu) {
   const int ntm = (p.M + BMT - 1) / BMT, ntn = p.N / BN;
   static bool attr_done = false;
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_p8_kernel<EPI, BMT, GUARD>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, P8Geo<BMT>::kLds);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_p8_kernel<EPI, BMT, GUARD, COPY>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, P8Geo<BMT>::kLdsAll);
     if (e != hipSuccess) return fail(MEMHIP_ELAUNCH, "gemm_p8: set smem attr: %s", hipGetErrorString(e));
     attr_done = true;
   }
   const int grid = ntm * ntn < num_cu ? ntm * ntn : num_cu;
-  hipLaunchKernelGGL((gemm_p8_kernel<EPI, BMT, GUARD>), dim3(grid), dim3(kThreads), P8Geo<BMT>::kLds, s, p, ntm, ntn,
-                     BMT == 256 ? opt(OPT_GEMM_STAGGER) : 0);
+  hipLaunchKernelGGL((gemm_p8_kernel<EPI, BMT, GUARD, COPY>), dim3(grid), dim3(kThreads), P8Geo<BMT>::kLdsAll, s, p, ntm, ntn,
+                     BMT == 256 ? opt(OPT_GEMM_STAGGER) : 0, opt(OPT_GEMM_PREFETCH));
   return check_launch("gemm_bf16_nt(p8)");
+}
+
+template <int EPI, int BMT, bool GUARD>
+int launch_p8g(const GemmArgs& p, hipStream_t s, int num_cu) {
+  if constexpr (EPI == MEMHIP_EPI_RESIDUAL) {
+    if (!p.out0) return launch_p8gc<EPI, BMT, GUARD, false>(p, s, num_cu);
+  }
+  return launch_p8gc<EPI, BMT, GUARD, true>(p, s, num_cu);
 }
 
 template <int EPI, int BMT>
@@ -489,7 +635,9 @@ static bool p8_fits(const GemmArgs& p) {
   // poorly filled last round to the 128x128 kernel (gemm_p8_split_rows).  MEMHIP_GEMM_P8_MIN_N overrides.
   const int min_n = opt(OPT_GEMM_P8_MIN_N);
   const bool wide = p.N >= min_n;
-  return p.M >= 4096 && wide && p.N % BN == 0 && p.K % (2 * BK) == 0 && vec;
+  // (the residual epilogue of the 256-row kernel finds a row's sample without an integer division: rows below 2^21)
+  const bool rows_ok = !p.rowmask || (long long)p.M + p.m_base < (1 << 21);
+  return p.M >= 4096 && wide && p.N % BN == 0 && p.K % (2 * BK) == 0 && vec && rows_ok;
 }
 
 // Rows the persistent launch should take when its last round of tiles would be less than half full

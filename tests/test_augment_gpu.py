@@ -254,7 +254,8 @@ def test_bad_samples_are_reported_at_the_deferred_check():
     E._note_status(ev.device, st["status"])
     E.check_bad_samples()                                      # nothing flagged
     bad = [e.copy() for e in evs]
-    bad[2][:7, 0] = 1e6                                        # seven events whose FLAT index x + W * y leaves the canvas
+    bad[2][15000:15007, 0] = 1e6  # (inside every slice window of SliceRandomMaxEvs)
+    #                                        # seven events whose FLAT index x + W * y leaves the canvas
     ev = torch.from_numpy(np.concatenate(bad, 0)).cuda()
     _, st = pipe(ev, offs, draws, return_stages=True)
     assert st["status"].tolist() == [0, 0, 1 << 28, 0] and st["bad_index_events"].tolist() == [0, 0, 7, 0]
