@@ -66,6 +66,98 @@ def mfma_util_by_kernel(uj=None):
     return {k.lstrip("_"): v["mfma_util"] for k, v in uj.items() if isinstance(v, dict) and "mfma_util" in v}
 
 
+class _CachedEvents:
+    """Event streams held in host memory (what a page-cached .npy folder is to the reference's loaders): built once in the
+    parent, shared with the forked DataLoader workers.  source(i) -> (N,4) float64 ndarray."""
+
+    def __init__(self, source, n):
+        self.items = [source(i) for i in range(n)]
+
+    def __call__(self, i):
+        return self.items[i % len(self.items)]
+
+
+def entrypoint_figure(model, opt, B, steps, warmup, workers, lr_sched):
+    """The drop-in entrypoint as a user runs it (run_mem_pretraining.py:330-347,392-412): engine_for_pretraining.
+    train_one_epoch over torch DataLoader(num_workers, pin_memory) of RawEventDataset -- N-Caltech101 geometry (240 x 180
+    sensor, per-sample extents, data-dependent canvases), SliceRandomMaxEvs 30 000, the ncaltech.conf augmentation chain
+    (random shift / flips, Resize(antialias), EventRandAugment, ColorJitter) batched on the GPU, the exact fp32 tokenizer
+    producing the labels, block-wise masks drawn per sample in the workers -- with the 246 MB of events of every batch
+    crossing PCIe inside the timed region.  Returns samples/s over `steps` steps after `warmup`, and the stages timed alone."""
+    import contextlib
+    import io
+    import numpy as np
+    import torch
+    from mem_amd import datasets as D, engine_for_pretraining as E
+    from mem_amd.run_mem_pretraining import get_args
+    from mem_amd.utils import NativeScalerWithGradNormCount
+    from mem_amd.vae_model import DiscreteVAE, HipTokenizer
+    dev = torch.device("cuda")
+    with contextlib.redirect_stdout(io.StringIO()):
+        args = get_args(["--expweek", "bench", "--data_path", "x/ncaltech101/", "--synthetic_if_missing", "1",
+                         "--input_H", "224", "--input_W", "224", "--batch_size", str(B), "--num_mask_patches", "98",
+                         "--normalize_events", "1", "--rand_aug", "1", "--color_jitter", "0.2", "--max_random_shift_evs", "8",
+                         "--num_workers", str(workers), "--clip_grad", "30.0", "--synthetic_samples", str(B * (steps + warmup))])
+        args.window_size = (14, 14)
+        ds = D.build_pretraining_dataset(args)
+        ds.source = _CachedEvents(ds.source, 512)
+    vae = DiscreteVAE(input_H=224, input_W=224, num_tokens=8192, codebook_dim=512, num_layers=4, num_resnet_blocks=3,
+                      hidden_dim=384, channels=3).cuda().eval()
+    tok = HipTokenizer(vae, max_batch=B)
+    loader = torch.utils.data.DataLoader(ds, batch_size=B, shuffle=False, num_workers=workers, pin_memory=bool(args.pin_mem),
+                                         drop_last=True, collate_fn=ds.collate, prefetch_factor=2 if workers else None)
+    marks = {}
+
+    class Timed:
+        def __len__(self):
+            return len(loader)
+
+        def __iter__(self):
+            for i, b in enumerate(loader):
+                if i == warmup:
+                    torch.cuda.synchronize()
+                    marks["t0"] = time.perf_counter()
+                yield b
+    scaler = NativeScalerWithGradNormCount()
+    with contextlib.redirect_stdout(io.StringIO()):
+        stats = E.train_one_epoch(model, tok, Timed(), opt, dev, 0, scaler, 30.0, lr_schedule_values=lr_sched,
+                                  wd_schedule_values=None, args=args)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - marks["t0"]
+    # the stages alone, on one batch (device time by events; H2D from the pinned batch the loader hands over)
+    batch, _ = next(iter(torch.utils.data.DataLoader(ds, batch_size=B, shuffle=False, num_workers=0, pin_memory=True,
+                                                     collate_fn=ds.collate)))
+
+    def dev_ms(fn, n=3):
+        fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / n
+    ev_dev = batch["events"].to(dev, non_blocking=True)
+    h2d = dev_ms(lambda: batch["events"].to(dev, non_blocking=True))
+    aug = dev_ms(lambda: batch["pipe"](ev_dev, batch["offsets"], batch["draws"]))
+    img = batch["pipe"](ev_dev, batch["offsets"], batch["draws"])
+    tok_ms = dev_ms(lambda: tok.get_codebook_indices(img))
+    t_host0 = time.perf_counter()
+    for _ in range(3):
+        batch["pipe"].pack(batch["draws"], batch["offsets"])
+    pack_ms = (time.perf_counter() - t_host0) / 3 * 1e3
+    del loader
+    return {"value": round(B * steps / dt, 1), "unit": "samples/sec", "ms_per_step": round(dt / steps * 1e3, 2), "steps": steps,
+            "warmup": warmup, "workers": workers, "pin_memory": bool(args.pin_mem), "batch": B,
+            "events_bytes_per_step": int(batch["events"].numel() * 8), "last_loss": round(float(stats["loss"]), 4),
+            "stages_alone_ms": {"h2d_events": round(h2d, 2), "augment_chain": round(aug, 2), "tokenizer_fp32": round(tok_ms, 2),
+                                "host_pack_draws": round(pack_ms, 2)},
+            "workload": "mem_amd.engine_for_pretraining.train_one_epoch over DataLoader(RawEventDataset): N-Caltech101 geometry "
+                        "(data-dependent canvases), ncaltech.conf augmentations, fp32 tokenizer labels, ViT-B/16 bf16, "
+                        "events cross PCIe inside the timed region; event streams served from host memory"}
+
+
 def _cpu_model():
     try:
         for line in open("/proc/cpuinfo"):
@@ -208,6 +300,9 @@ def main():
     ap.add_argument("--fwd-split", action="store_true",
                     help="A/B: forward as an uneven two-stream split of the batch (engine.fwd_two_streams = True)")
     ap.add_argument("--no-fwd-split", action="store_true", help="(default since round 2; kept for old command lines)")
+    ap.add_argument("--no-entrypoint-figure", action="store_true",
+                    help="skip the measurement of the real entrypoint loop (train_one_epoch over a DataLoader)")
+    ap.add_argument("--entrypoint-workers", type=int, default=10, help="DataLoader workers of the entrypoint figure")
     ap.add_argument("--no-config4-figure", action="store_true",
                     help="skip the secondary figure for BASELINE configs[3] end to end (1 M events per sample feeding ViT-B)")
     ap.add_argument("--rendezvous-only", action="store_true",
@@ -438,6 +533,15 @@ def main():
             del vae, img, tok
         except Exception as e:                                        # the figure is optional
             print(f"[bench] tokenizer figure skipped: {e}", file=sys.stderr)
+    # ---- secondary figure: the REAL entrypoint loop (DataLoader workers, H2D, augmentation chain, tokenizer, ViT)
+    entry_fig = None
+    if world == 1 and not a.no_entrypoint_figure:
+        try:
+            entry_fig = entrypoint_figure(model, opt, B, 20, 4, a.entrypoint_workers, lr_sched)
+        except Exception as e:                                        # the figure is optional
+            import traceback
+            traceback.print_exc()
+            print(f"[bench] entrypoint figure skipped: {e}", file=sys.stderr)
     # ---- secondary figure: BASELINE configs[3], the rasterizer alone at N-ImageNet scale (1 M events per
     # sample, 480 x 640 canvas): HBM-bound, algorithmic bytes = 32 B per event + 3*H*W output bytes
     raster_fig = None
@@ -630,6 +734,10 @@ def main():
                                              "v_mfma_f32_16x16x4_f32: fp32 operands like the reference, exact labels); the "
                                              "opt-in bf16-operand mode (csrc/conv.hip, 1-3 % of labels differ) and the fp32 "
                                              "torch module on stock PyTorch-ROCm are timed beside it"}
+        if entry_fig is not None:
+            out["entrypoint"] = entry_fig
+            if tok_ms is not None:
+                out["entrypoint"]["vs_with_tokenizer"] = round(entry_fig["value"] / (world * B / (tok_step_ms * 1e-3)), 3)
         if raster_fig is not None:
             out["rasterizer_1m_events"] = raster_fig
         if cfg4 is not None:

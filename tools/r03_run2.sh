@@ -1,4 +1,4 @@
-common="--no-cpu-baseline --no-tokenizer-figure --no-raster-figure --no-config4-figure --no-gemm-timer --steps 20 --warmup 5"
+common="--no-cpu-baseline --no-tokenizer-figure --no-raster-figure --no-config4-figure --no-entrypoint-figure --no-gemm-timer --steps 20 --warmup 5"
 run() { MEMHIP_LIB="$1" python bench.py $common $2 2>/dev/null | python -c "
 import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$3', d['ms_per_step'], d['ms_per_step_p50'])"; }
 for i in 1 2 3; do
