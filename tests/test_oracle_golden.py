@@ -166,6 +166,24 @@ def test_vit_long_nonsquare_golden():
         assert np.array_equal(m(x, mask).numpy(), g["fp32__logits"])
 
 
+def test_config5_geometry_golden_oracle_fp32():
+    """tests/golden/vit_c5.npz (reference, BASELINE configs[4] geometry at depth 2): the oracle's fp32 forward reproduces the
+    reference's loss and logits (to 1e-5: the fixture was written with 8 CPU threads; the generator asserts bit-equality
+    in-process, gradients included, in fp32 and under bf16 autocast)."""
+    from oracle.gen_golden import vit_inputs
+    from oracle.gen_golden_c5 import C5, C5_INPUTS
+    g = np.load(os.path.join(GOLDEN, "vit_c5.npz"))
+    m = V.RefViT(**C5)
+    m.load_state_dict(V.fill_by_name(m.state_dict(), seed=9))
+    assert tuple(m.state_dict()["rel_pos_bias.relative_position_bias_table"].shape) == (4664, 16)
+    x, mask, labels = vit_inputs(C5, *C5_INPUTS)
+    with torch.no_grad():
+        lo = m(x, mask)
+        loss = torch.nn.CrossEntropyLoss()(lo, labels)
+    assert abs(float(loss) - float(g["fp32__loss"])) <= 1e-5
+    assert np.abs(lo[:96].numpy() - g["fp32__logits_head"]).max() <= 1e-4
+
+
 def test_finetune_model_golden_and_layer_decay_groups():
     """f3: the oracle's finetuning model (RefFtViT) against the reference outputs of oracle/gen_golden_ft.py, bit for
     bit under bf16 autocast, in both head configurations; the layer-decay parameter groups of the oracle AND of the
