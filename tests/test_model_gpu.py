@@ -339,9 +339,9 @@ def test_vit_base_vs_reference_golden(C):
     order = np.argsort(-dev)[:3]
     print("ViT-B C=%d per-tensor gradient-norm deviation from the reference (bf16): worst " % C
           + ", ".join("%s %.4f" % (names[i], dev[i]) for i in order))
-    assert np.abs(gn[big] / ref[big] - 1).max() <= 0.08, np.abs(gn[big] / ref[big] - 1).max()
+    assert np.abs(gn[big] / ref[big] - 1).max() <= 0.015, np.abs(gn[big] / ref[big] - 1).max()     # measured: 0.0047 (C=2), 0.0018 (C=3)
     tot = np.sqrt((gn ** 2).sum()) / np.sqrt((ref ** 2).sum())
-    assert abs(tot - 1) <= 0.02, tot
+    assert abs(tot - 1) <= 0.01, tot
     # direction at ViT-B size: full gradient tensors of a cross-section of parameters (whole small tensors, strided
     # rows of the big matrices) against the reference's bf16-autocast gradients: rel-L2 <= 3e-2 each, cosine >= 0.999
     from oracle.gen_golden import BASE_GRAD_SAMPLES
