@@ -300,6 +300,10 @@ def main():
     ap.add_argument("--fwd-split", action="store_true",
                     help="A/B: forward as an uneven two-stream split of the batch (engine.fwd_two_streams = True)")
     ap.add_argument("--no-fwd-split", action="store_true", help="(default since round 2; kept for old command lines)")
+    ap.add_argument("--bucket-dtype", choices=["fp32", "bf16"], default="fp32",
+                    help="N > 1: wire format of the gradient buckets (fp32 = the reference's DDP exchange; bf16: half the bytes)")
+    ap.add_argument("--reserve-cus", type=int, default=0,
+                    help="N > 1: CUs the persistent GEMM / attention grids leave to RCCL while gradient buckets are in flight")
     ap.add_argument("--no-entrypoint-figure", action="store_true",
                     help="skip the measurement of the real entrypoint loop (train_one_epoch over a DataLoader)")
     ap.add_argument("--entrypoint-workers", type=int, default=10, help="DataLoader workers of the entrypoint figure")
@@ -378,7 +382,8 @@ def main():
     opt.max_norm = 30.0
     reducer = None
     if world > 1 or force_dist:
-        reducer = GradReducer(eng.flat_g, eng.buckets, flat_p=eng.flat_p, force=force_dist)
+        reducer = GradReducer(eng.flat_g, eng.buckets, flat_p=eng.flat_p, force=force_dist,
+                              bucket_dtype=torch.bfloat16 if a.bucket_dtype == "bf16" else None, reserve_cus=a.reserve_cus)
         eng.grad_hook = reducer
         eng.weights_dirty = True
 
@@ -466,6 +471,39 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    # ---- N > 1 (and the one-rank RCCL dry run): what RCCL saw, and how much of the gradient exchange is EXPOSED -- the
+    # same ranks run the same steps once more with the exchange switched off (no collective is issued; backward, norm and
+    # AdamW unchanged); per-step times by HIP events, median per rank, MAX over ranks
+    rccl_info = None
+    if reducer is not None:
+        ranks = [None] * dist.get_world_size()
+        prop = torch.cuda.get_device_properties(torch.cuda.current_device())
+        dist.all_gather_object(ranks, {"rank": dist.get_rank(), "local_rank": local_rank, "device_index": torch.cuda.current_device(),
+                                       "device": prop.name, "gcn_arch": getattr(prop, "gcnArchName", None),
+                                       "pci_bus_id": getattr(prop, "pci_bus_id", None), "host": os.uname().nodename})
+        n_ref = min(10, a.steps)
+        reducer.active = False
+        fence()
+        ref_ev = [torch.cuda.Event(enable_timing=True) for _ in range(n_ref + 1)]
+        ref_ev[0].record()
+        for it in range(n_ref):
+            step(a.warmup + a.steps + it)
+            ref_ev[it + 1].record()
+        fence()
+        reducer.active = True
+        ref_ms = sorted(ref_ev[i].elapsed_time(ref_ev[i + 1]) for i in range(n_ref))
+        med = torch.tensor([plain[len(plain) // 2] if plain else step_ms[len(step_ms) // 2], ref_ms[len(ref_ms) // 2]],
+                           dtype=torch.float64, device="cuda")
+        dist.all_reduce(med, op=dist.ReduceOp.MAX)
+        with_x, without_x = float(med[0].item()), float(med[1].item())
+        rccl_info = {"world_size": dist.get_world_size(), "backend": dist.get_backend(), "ranks": ranks,
+                     "buckets_per_step": len(eng.buckets), "bytes_per_step": reducer.bytes_per_step,
+                     "bucket_dtype": a.bucket_dtype, "reserve_cus": a.reserve_cus,
+                     "ms_per_step_p50_with_exchange": round(with_x, 3), "ms_per_step_p50_without_exchange": round(without_x, 3),
+                     "allreduce_exposed_ms": round(with_x - without_x, 3),
+                     "note": "exchange = one asynchronous all-reduce per gradient bucket, issued from backward's bucket hook, "
+                             "joined before the gradient norm; `without` = the same steps on the same ranks with no collective "
+                             "issued (medians of per-step HIP-event times, MAX over ranks)"}
 
     # ---- secondary figure: the frozen tokenizer forward that the reference runs every step to make the
     # labels (engine_for_pretraining.py:144); not part of `value` (BASELINE: tokenizer outside the timed set)
@@ -734,6 +772,8 @@ def main():
                                              "v_mfma_f32_16x16x4_f32: fp32 operands like the reference, exact labels); the "
                                              "opt-in bf16-operand mode (csrc/conv.hip, 1-3 % of labels differ) and the fp32 "
                                              "torch module on stock PyTorch-ROCm are timed beside it"}
+        if rccl_info is not None:
+            out["rccl"] = rccl_info
         if entry_fig is not None:
             out["entrypoint"] = entry_fig
             if tok_ms is not None:

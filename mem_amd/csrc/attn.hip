@@ -580,13 +580,8 @@ __global__ void attn_stats_zero_kernel(float* stats, int n) {
 // the crossing workgroups pay the per-head setup twice.  Smallest count for which the grid fits one
 // round, capped at 16 (the table-gradient buckets are sized for that).
 int pick_spb(int B, int heads) {
-  static int num_cu = 0;
-  if (!num_cu) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    num_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess &&
-              prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
-  }
+  int num_cu = memhip::usable_cus();
+  if (num_cu <= 0) num_cu = 256;
   for (int spb = 1; spb <= 16; ++spb)
     if ((long long)((B + spb - 1) / spb) * heads <= num_cu) return spb;
   return 16;

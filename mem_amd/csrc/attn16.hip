@@ -780,16 +780,7 @@ __global__ __launch_bounds__(kThreads16) void attn16_bwd_kernel(const __bf16* __
   }
 }
 
-int num_cu16() {
-  static int num_cu = 0;
-  if (!num_cu) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    num_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess &&
-              prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
-  }
-  return num_cu;
-}
+int num_cu16() { const int n = memhip::usable_cus(); return n > 0 ? n : 256; }
 // workgroups per head: one workgroup per CU (LDS), as many as fit in one round
 int nwg16(int B, int heads) {
   const int n = num_cu16() / heads;

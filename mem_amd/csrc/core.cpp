@@ -10,10 +10,26 @@ thread_local char g_err[512] = "";
 // reads no environment variable.  Defaults = the shipped dispatch.
 static std::atomic<int> g_opt[OPT_COUNT_] = {
     /*gemm_p8*/ {1}, /*gemm256*/ {1}, /*gemm_split*/ {1}, /*gemm_p8_half*/ {1}, /*gemm_p8_min_n*/ {768},
-    /*gemm256_min_n*/ {1024}, /*tn_p8*/ {1}, /*tn256*/ {1}, /*raster_lds*/ {1}, /*attn16*/ {1}, /*attn16_stagger (cycles)*/ {40000}, /*attn16_stagger_fwd*/ {0}, /*gemm_stagger (cycles per K-tile)*/ {0}, /*gemm_prefetch (epilogue-operand L2 prefetch; measured slower: the touches share the in-order vmcnt queue with the operand stream)*/ {0}};
+    /*gemm256_min_n*/ {1024}, /*tn_p8*/ {1}, /*tn256*/ {1}, /*raster_lds*/ {1}, /*attn16*/ {1}, /*attn16_stagger (cycles)*/ {40000}, /*attn16_stagger_fwd*/ {0}, /*gemm_stagger (cycles per K-tile)*/ {0}, /*gemm_prefetch (epilogue-operand L2 prefetch; measured slower: the touches share the in-order vmcnt queue with the operand stream)*/ {0},
+    /*reserve_cus*/ {0}};
 static const char* const g_opt_name[OPT_COUNT_] = {"gemm_p8", "gemm256", "gemm_split", "gemm_p8_half", "gemm_p8_min_n",
-                                                   "gemm256_min_n", "tn_p8", "tn256", "raster_lds", "attn16", "attn16_stagger", "attn16_stagger_fwd", "gemm_stagger", "gemm_prefetch"};
+                                                   "gemm256_min_n", "tn_p8", "tn256", "raster_lds", "attn16", "attn16_stagger", "attn16_stagger_fwd", "gemm_stagger", "gemm_prefetch", "reserve_cus"};
 int opt(int id) { return g_opt[id].load(std::memory_order_relaxed); }
+
+int usable_cus() {
+  static std::atomic<int> device_cus{0};
+  int n = device_cus.load(std::memory_order_relaxed);
+  if (!n) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
+    n = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    device_cus.store(n, std::memory_order_relaxed);
+  }
+  int r = opt(OPT_RESERVE_CUS);
+  r = r < 0 ? 0 : (r + 7) / 8 * 8;
+  return n - r >= 8 ? n - r : (n >= 8 ? 8 : n);
+}
 }  // namespace memhip
 
 extern "C" {

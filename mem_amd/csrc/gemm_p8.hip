@@ -618,16 +618,7 @@ int launch_p8(const GemmArgs& p, hipStream_t s, int num_cu) {
 
 namespace memhip {
 
-static int p8_num_cu() {
-  static int num_cu = 0;
-  if (!num_cu) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
-    num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-  }
-  return num_cu;
-}
+static int p8_num_cu() { return usable_cus(); }
 
 static bool p8_fits(const GemmArgs& p) {
   const bool vec = ((p.ldo0 | p.ldo1 | p.ldr | p.ldaux | p.colscale_n) & 7) == 0;      // host twin of vec_ok()

@@ -303,16 +303,7 @@ static void tn_p8_plan(int R, int N, int K, int num_cu, int& tiles, int& splits,
   rows_per_split = cdiv(pairs, splits) * 2 * BR;
   splits = cdiv(R, rows_per_split);
 }
-static int tn_p8_num_cu() {
-  static int num_cu = 0;
-  if (!num_cu) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
-    num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-  }
-  return num_cu;
-}
+static int tn_p8_num_cu() { return usable_cus(); }
 
 // bytes of workspace with which the partial tiles go through plain stores + a reduction pass
 size_t gemm_tn_p8_workspace(int R, int N, int K) {

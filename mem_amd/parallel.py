@@ -9,14 +9,28 @@ its own stream behind an event on the compute stream, i.e. overlapped with the r
 ``finish()`` joins them before the gradient norm / AdamW.  ~30 MB fp32 per ViT-B block: large
 enough for xGMI link bandwidth, small enough to pipeline 14 messages per step.
 Mean semantics (SUM / world) == DDP.  Works on CPU tensors with gloo for the CPU tests.
+
+Options (both off by default = the reference's fp32 DDP exchange):
+  * ``bucket_dtype=torch.bfloat16``: a bucket is rounded to bf16, pre-divided by the world size, summed over the ranks in
+    bf16 and widened back (torch's bf16_compress_hook arithmetic): 184 MB instead of 367 MB per ViT-B step on the wire;
+  * ``reserve_cus=k``: while buckets are in flight the library sizes its persistent one-workgroup-per-CU grids (GEMMs,
+    attention) for k CUs fewer (memhip option ``reserve_cus``), so that RCCL's channel kernels find CUs of their own
+    instead of displacing workgroups of a grid that covers the whole chip (whose stragglers then run a second round).
 """
 import torch
 import torch.distributed as dist
 
 
 class GradReducer:
-    def __init__(self, flat_g, buckets, flat_p=None, group=None, coalesce_small=0, force=False):
+    def __init__(self, flat_g, buckets, flat_p=None, group=None, coalesce_small=0, force=False, bucket_dtype=None,
+                 reserve_cus=0):
         self.flat_g, self.buckets, self.group = flat_g, buckets, group
+        self.bucket_dtype = bucket_dtype if bucket_dtype not in (None, torch.float32) else None
+        self.reserve_cus = int(reserve_cus)
+        self._reserved = False
+        self.wire = torch.empty_like(flat_g, dtype=self.bucket_dtype) if self.bucket_dtype is not None else None
+        esz = 2 if self.bucket_dtype is not None else 4
+        self.bytes_per_step = sum(b1 - b0 for _, b0, b1 in buckets) * esz
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         # force: issue the collectives even in a one-rank group (single-GPU dry run of the RCCL path: bench.py
         # with MEMHIP_BENCH_FORCE_DIST=1)
@@ -28,11 +42,24 @@ class GradReducer:
         if flat_p is not None and self.active:
             dist.broadcast(flat_p, src=0, group=group)          # rank-0 weights everywhere (DDP ctor)
 
+    def _reserve(self, on):
+        if self.reserve_cus > 0 and self._reserved != on and self.flat_g.is_cuda:
+            from ._lib import set_option
+            set_option("reserve_cus", self.reserve_cus if on else 0)
+            self._reserved = on
+
     def __call__(self, bucket_index):
         if not self.active:
             return
+        self._reserve(True)                       # from the first bucket of a step until finish()
         _, b0, b1 = self.buckets[bucket_index]
         view = self.flat_g[b0:b1]
+        if self.wire is not None:
+            w = self.wire[b0:b1]
+            w.copy_(view / self.world)             # pre-divide in fp32, ONE rounding to bf16, then a bf16 SUM over the ranks
+            h = dist.all_reduce(w, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            self.handles.append((h, (view, w)))
+            return
         if self.use_avg:
             h = dist.all_reduce(view, op=dist.ReduceOp.AVG, group=self.group, async_op=True)
             self.handles.append((h, None))
@@ -43,6 +70,9 @@ class GradReducer:
     def finish(self):
         for h, view in self.handles:
             h.wait()
-            if view is not None:
+            if isinstance(view, tuple):            # bf16 wire buffer -> the fp32 gradient
+                view[0].copy_(view[1])
+            elif view is not None:
                 view.div_(self.world)
         self.handles = []
+        self._reserve(False)

@@ -52,6 +52,46 @@ def test_grad_reducer_world2_gloo():
     assert sorted(res) == [(0, True), (1, True)]
 
 
+def _worker_bf16(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from mem_amd.parallel import GradReducer
+    n = 4 * 1024
+    buckets = [("head", 0, 1024), ("block0", 1024, 3072), ("embed", 3072, n)]
+    g = torch.Generator().manual_seed(100 + rank)
+    flat_g = torch.randn(n, generator=g) * 0.01
+    mine = flat_g.clone()
+    others = [torch.randn(n, generator=torch.Generator().manual_seed(100 + r)) * 0.01 for r in range(world)]
+    red = GradReducer(flat_g, buckets, bucket_dtype=torch.bfloat16)
+    assert red.bytes_per_step == 2 * n
+    for b in range(len(buckets)):
+        red(b)
+    red.finish()
+    want32 = sum(others) / world                                  # the fp32 exchange
+    # bf16_compress_hook arithmetic: every rank's bucket / world rounded to bf16, summed in bf16
+    want16 = sum((o / world).bfloat16() for o in others).float()
+    ok = torch.equal(flat_g, want16) and flat_g.dtype == torch.float32
+    rel = float((flat_g - want32).norm() / want32.norm())
+    ok = ok and rel < 8e-3 and torch.equal(mine, others[rank])
+    q.put((rank, bool(ok), rel))
+    dist.destroy_process_group()
+
+
+def test_grad_reducer_bf16_buckets_world2_gloo():
+    """The bf16-bucket option (184 MB instead of 367 MB per ViT-B step): two ranks end with IDENTICAL gradients, equal to
+    the bf16 compress-hook arithmetic and within bf16 rounding (< 1 %) of the fp32 mean."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_bf16, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(60)
+    assert sorted(r[:2] for r in res) == [(0, True), (1, True)], res
+
+
 def test_reducer_single_process_noop():
     from mem_amd.parallel import GradReducer
     g = torch.ones(2048)

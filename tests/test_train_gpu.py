@@ -183,7 +183,8 @@ def test_bench_contract_and_rccl_dry_run():
     from conftest import ROOT
     env = dict(os.environ, MEMHIP_BENCH_FORCE_DIST="1", MASTER_PORT="29577")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--batch", "16", "--steps", "3", "--warmup", "1",
-                        "--no-tokenizer-figure", "--no-raster-figure", "--no-cpu-baseline"], env=env, capture_output=True,
+                        "--no-tokenizer-figure", "--no-raster-figure", "--no-cpu-baseline", "--no-entrypoint-figure",
+                        "--no-config4-figure", "--bucket-dtype", "bf16", "--reserve-cus", "16"], env=env, capture_output=True,
                        text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
@@ -194,3 +195,11 @@ def test_bench_contract_and_rccl_dry_run():
     assert out["n_gpus"] == 1 and out["steps"] == 3 and out["scaling"] == "weak" and out["dtype"] == "bf16"
     assert out["roofline"]["bound"] == "mfma" and 0 < out["roofline"]["frac"] < 1
     assert sum(ln.lstrip().startswith("{") for ln in lines) == 1
+    # the N > 1 evidence block: what RCCL reports, who took part, bytes on the wire, exposed exchange time
+    rc = out["rccl"]
+    assert rc["world_size"] == 1 and rc["backend"] == "nccl" and len(rc["ranks"]) == 1 and rc["ranks"][0]["rank"] == 0
+    assert rc["bucket_dtype"] == "bf16" and rc["reserve_cus"] == 16 and rc["buckets_per_step"] == 14
+    assert 180e6 < rc["bytes_per_step"] < 190e6                      # 91.8 M parameters (padded) x 2 bytes
+    assert isinstance(rc["allreduce_exposed_ms"], float)
+    from mem_amd import _lib
+    assert _lib.get_option("reserve_cus") == 0                      # (this process: the option is per process, default off)
