@@ -302,8 +302,10 @@ def main():
     ap.add_argument("--no-fwd-split", action="store_true", help="(default since round 2; kept for old command lines)")
     ap.add_argument("--bucket-dtype", choices=["fp32", "bf16"], default="fp32",
                     help="N > 1: wire format of the gradient buckets (fp32 = the reference's DDP exchange; bf16: half the bytes)")
-    ap.add_argument("--reserve-cus", type=int, default=0,
-                    help="N > 1: CUs the persistent GEMM / attention grids leave to RCCL while gradient buckets are in flight")
+    ap.add_argument("--reserve-cus", type=int, default=-1,
+                    help="N > 1: CUs the persistent GEMM / attention grids leave to RCCL while gradient buckets are in flight "
+                         "(-1 = 16 when more than one rank runs, 0 in a one-rank run; one-rank dry-run A/B: "
+                         "profiles/r03_rccl_dryrun.json -- reserving 16 CUs costs <= 0.3 ms of a 39 ms step)")
     ap.add_argument("--no-entrypoint-figure", action="store_true",
                     help="skip the measurement of the real entrypoint loop (train_one_epoch over a DataLoader)")
     ap.add_argument("--entrypoint-workers", type=int, default=10, help="DataLoader workers of the entrypoint figure")
@@ -382,6 +384,8 @@ def main():
     opt.max_norm = 30.0
     reducer = None
     if world > 1 or force_dist:
+        if a.reserve_cus < 0:
+            a.reserve_cus = 16 if world > 1 else 0
         reducer = GradReducer(eng.flat_g, eng.buckets, flat_p=eng.flat_p, force=force_dist,
                               bucket_dtype=torch.bfloat16 if a.bucket_dtype == "bf16" else None, reserve_cus=a.reserve_cus)
         eng.grad_hook = reducer

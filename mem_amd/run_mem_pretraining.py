@@ -234,7 +234,8 @@ def main(args):
     print("Number of training steps = %d" % num_training_steps_per_epoch)
     eng = model.engine                                   # packs parameters into the flat buffers
     if args.distributed:
-        model._reducer = GradReducer(eng.flat_g, eng.buckets, flat_p=eng.flat_p)
+        # (16 CUs left to RCCL's channel kernels while buckets are in flight: parallel.py)
+        model._reducer = GradReducer(eng.flat_g, eng.buckets, flat_p=eng.flat_p, reserve_cus=16)
         eng.grad_hook = model._reducer
         eng.weights_dirty = True
     optimizer = create_optimizer(args, model_without_ddp)
