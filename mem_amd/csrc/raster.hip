@@ -38,8 +38,18 @@ struct Ev { double x, y, t, p; long long pos; bool keep; };
 // the first event is looked at -- inside the per-event branches (out of range, filtered, bad index) hipcc waits for
 // every load right where it is issued, i.e. one event's 32 bytes in flight per thread)
 struct RawEv { double2 xy, tp; };
+#ifndef RASTER_NT
+#define RASTER_NT 0
+#endif
 __device__ __forceinline__ RawEv load_raw(const double* __restrict__ ev, long long row) {
+#if RASTER_NT   // read-once stream: nontemporal loads (A/B: tools/build_variant.sh raster_nt -DRASTER_NT=1)
+  typedef double __attribute__((ext_vector_type(2))) d2;
+  const d2 a = __builtin_nontemporal_load(reinterpret_cast<const d2*>(ev) + 2 * row);
+  const d2 b = __builtin_nontemporal_load(reinterpret_cast<const d2*>(ev) + 2 * row + 1);
+  return RawEv{double2{a[0], a[1]}, double2{b[0], b[1]}};
+#else
   return RawEv{reinterpret_cast<const double2*>(ev)[2 * row], reinterpret_cast<const double2*>(ev)[2 * row + 1]};
+#endif
 }
 // The sample's augmentation as wave-uniform float64 constants (neutral when there is none: x * 1.0 and x + 0.0 are exact,
 // the sign of a zero does not survive the truncation to a pixel index): the per-event arithmetic is branch-free and
