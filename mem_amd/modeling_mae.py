@@ -6,10 +6,15 @@ Same constructor, parameter names / shapes (timm 0.4.12 PatchEmbed / Block / Att
 reference checkpoints load), the same initialisation order (same torch seed -> same weights), fixed 2-D sin-cos position
 embeddings, per-sample random masking by argsort of uniform noise, decoder with mask tokens, per-patch MSE loss.
 
-Execution: `MaeEngineF32` (below) on the fp32 kernels of csrc/fp32_path.hip -- fp32 MFMA GEMMs with fused bias / GELU /
-residual epilogues, the generic attention kernel (head_dim 64 in the encoder, 32 in the decoder), LayerNorm, the token
-gather / un-shuffle and loss kernels.  This round the MAE variant runs in fp32 only (the reference runs it under fp16
-autocast: fp32 is the stricter arithmetic; a bf16 fast path for 32-wide heads is not built).  No CPU / eager fallback.
+Execution (``precision``):
+  * "bf16" (default, what `--mae 1` trains with): `MaeEngineBF16` -- the reference's autocast placement on the bf16 MFMA
+    kernels of the pretraining model (gemm_p8 / gemm_tn_p8 with fused bias / GELU / GELU' / residual epilogues, the
+    LDS-resident attention kernels, LayerNorm, AdamW): bf16 GEMM / attention operands, fp32 accumulate, fp32 residual
+    stream, LayerNorm statistics, softmax and loss.  The decoder's 32-wide heads run on the 64-wide attention kernels
+    through zero-padded head slots (padded shadow weights: the padding columns are exact zeros end to end).
+  * "fp32": `MaeEngineF32` on csrc/fp32_path.hip (fp32 MFMA GEMMs, generic attention with 64- and 32-wide heads) -- the
+    parity mode (loss 2e-6 from the reference's fp32 run).
+No CPU / eager fallback.
 """
 import math
 from functools import partial
@@ -178,7 +183,7 @@ class MaskedAutoencoderViT(nn.Module):
     def engine(self):
         if self._engine is None:
             require_gpu()
-            self._engine = MaeEngineF32(self)
+            self._engine = MaeEngineF32(self) if getattr(self, "precision", "bf16") == "fp32" else MaeEngineBF16(self)
         return self._engine
 
     def load_state_dict(self, *a, **k):
@@ -207,15 +212,18 @@ class MaskedAutoencoderViT(nn.Module):
         la = self.forward_loss(imgs, mask_ratio, noise)
         eng = self.engine
         B = imgs.shape[0]
-        pred = eng.pred[: B * eng.T].view(B, eng.T, -1)[:, 1:, :]
+        pred = eng.pred[: B * eng.T].view(B, eng.T, -1)[:, 1:, :].float()
         return la[0].clone(), self.unpatchify(pred.clone()), self._last_mask
 
 
-def mae_vit_base_patch16_dec512d8b(norm_pix_loss=False, LOSS_ONLY_MASKED_MAE=False, **kwargs):
-    return MaskedAutoencoderViT(patch_size=16, embed_dim=768, depth=12, num_heads=12, decoder_embed_dim=512,
-                                decoder_depth=8, decoder_num_heads=16, mlp_ratio=4,
-                                norm_layer=partial(nn.LayerNorm, eps=1e-6), norm_pix_loss=norm_pix_loss,
-                                LOSS_ONLY_MASKED_MAE=LOSS_ONLY_MASKED_MAE, **kwargs)
+def mae_vit_base_patch16_dec512d8b(norm_pix_loss=False, LOSS_ONLY_MASKED_MAE=False, precision="bf16", **kwargs):
+    m = MaskedAutoencoderViT(patch_size=16, embed_dim=768, depth=12, num_heads=12, decoder_embed_dim=512,
+                             decoder_depth=8, decoder_num_heads=16, mlp_ratio=4,
+                             norm_layer=partial(nn.LayerNorm, eps=1e-6), norm_pix_loss=norm_pix_loss,
+                             LOSS_ONLY_MASKED_MAE=LOSS_ONLY_MASKED_MAE, **kwargs)
+    assert precision in ("bf16", "fp32")
+    m.precision = precision
+    return m
 
 
 class MaeEngineF32:
@@ -470,3 +478,255 @@ class MaeEngineF32:
         ops.adamw(self.flat_p, self.flat_g, m, v, self.nflat, self.wd_flags, lr, betas[0], betas[1], eps, wd, step,
                   gnorm=self.gnorm, max_norm=max_norm or 0.0)
         self.weights_dirty = True
+
+
+
+class MaeEngineBF16(MaeEngineF32):
+    """The MAE model on the bf16 MFMA kernels (same flat fp32 master buffers, optimizer and reducer contract as
+    MaeEngineF32).  Rounding points = the reference under autocast (mem/engine_for_pretraining.py:141-149): every Linear /
+    Conv output is bf16 (fp32 accumulate + fp32 bias), the residual stream, LayerNorm, softmax and the loss are fp32.
+
+    32-wide heads (the decoder: 512 / 16): the attention kernels are built for 64-wide heads, so q / k / v of head h live
+    in columns [64 h, 64 h + 32) of a padded [*, 3 * 64 * heads] qkv matrix and the other 32 columns are zero.  The qkv
+    and proj weights have padded bf16 shadows (zero rows / columns), so the GEMMs produce and consume the padded layout
+    directly; q k^T, the softmax and the real output columns are unchanged, the padded columns of every activation and
+    gradient are exact zeros, and the weight gradients of the padded rows / columns (zero) are dropped when the real rows
+    are copied back."""
+    precision = "bf16"
+
+    def __init__(self, model):
+        super().__init__(model)
+        dev = self.dev
+        for spec in (self.enc, self.dec):
+            hd = spec["D"] // spec["heads"]
+            assert hd in (32, 64) and spec["D"] % 64 == 0 and spec["hidden"] % 64 == 0, \
+                "bf16 MAE engine: head_dim 32 or 64, widths multiples of 64 (use precision='fp32' otherwise)"
+            spec["hd"], spec["Dp"] = hd, spec["heads"] * 64
+        assert self.Kpe % 64 == 0 and self.Pp % 8 == 0
+        self.w16, self.wT16, self.bpad = {}, {}, {}
+        self.tn_ws = None
+
+    # ---- bf16 shadows of the Linear weights ([out,in] for forward, [in,out] for dgrad), padded where heads are 32 wide
+    def _padded(self, spec, kind, W):
+        """fp32 [out, in] -> the padded fp32 matrix the shadows are cast from (None: no padding for this spec)."""
+        if spec["hd"] == 64:
+            return None
+        H, D, Dp = spec["heads"], spec["D"], spec["Dp"]
+        if kind == "qkv":
+            Wp = torch.zeros((3 * Dp, D), dtype=torch.float32, device=self.dev)
+            Wp.view(3, H, 64, D)[:, :, :32, :] = W.view(3, H, 32, D)
+        else:                                                       # proj: padded INPUT columns
+            Wp = torch.zeros((D, Dp), dtype=torch.float32, device=self.dev)
+            Wp.view(D, H, 64)[:, :, :32] = W.view(D, H, 32)
+        return Wp
+
+    def sync_weights(self):
+        def shadow(name, W):
+            W = W.contiguous()
+            o, i = W.shape
+            if name not in self.w16 or self.w16[name].shape != (o, i):
+                self.w16[name] = torch.empty((o, i), dtype=torch.bfloat16, device=self.dev)
+                self.wT16[name] = torch.empty((i, o), dtype=torch.bfloat16, device=self.dev)
+            ops.cast_f32_bf16(W, self.w16[name], o * i)
+            ops.transpose_cast(W, o, i, self.wT16[name])
+        shadow("patch_embed.proj.weight", self.Wm("patch_embed.proj.weight"))
+        shadow("decoder_embed.weight", self.Wm("decoder_embed.weight"))
+        shadow("decoder_pred.weight", self.Wm("decoder_pred.weight"))
+        for spec in (self.enc, self.dec):
+            for i in range(spec["depth"]):
+                pre = f"{spec['pre']}{i}."
+                for kind in ("qkv", "proj"):
+                    n = pre + f"attn.{kind}.weight"
+                    Wp = self._padded(spec, kind, self.Wm(n))
+                    shadow(n, self.Wm(n) if Wp is None else Wp)
+                shadow(pre + "mlp.fc1.weight", self.Wm(pre + "mlp.fc1.weight"))
+                shadow(pre + "mlp.fc2.weight", self.Wm(pre + "mlp.fc2.weight"))
+                if spec["hd"] == 32:
+                    b = torch.zeros(3 * spec["Dp"], dtype=torch.float32, device=self.dev)
+                    b.view(3, spec["heads"], 64)[:, :, :32] = self.P(pre + "attn.qkv.bias").view(3, spec["heads"], 32)
+                    self.bpad[pre] = b
+        self.weights_dirty = False
+
+    def ensure_batch(self, B, K):
+        if B <= self.B and K == getattr(self, "K", None):
+            return
+        dev, f, h = self.dev, torch.float32, torch.bfloat16
+        e = lambda *s: torch.empty(s, dtype=f, device=dev)      # noqa: E731
+        e16 = lambda *s: torch.empty(s, dtype=h, device=dev)    # noqa: E731
+        L, T, D, Dd = self.L, self.T, self.D, self.Dd
+        Me, Md = B * (K + 1), B * T
+        self.patches, self.xe16, self.xe = e16(B * L, self.Kpe), e16(B * L, D), e(B * L, D)
+
+        def acts(spec, M, Tt):
+            Dm, Hd, Dp, heads = spec["D"], spec["hidden"], spec["Dp"], spec["heads"]
+            TP = ops.attn_tokens_padded(Tt)
+            window = (14, 14) if Tt == 197 else (1, Tt - 1)      # no position bias: any window with Tt - 1 cells (zero table)
+            nrd = (2 * window[0] - 1) * (2 * window[1] - 1) + 3
+            return dict(x=[torch.zeros((M, Dm), dtype=f, device=dev) for _ in range(2 * spec["depth"] + 1)],
+                        a=[dict(h1=e16(M, Dm), qkv=torch.zeros((M, 3 * Dp), dtype=h, device=dev), ao=e16(M, Dp), h2=e16(M, Dm),
+                                hpre=e16(M, Hd), a=e16(M, Hd), mean1=e(M), rstd1=e(M), mean2=e(M), rstd2=e(M),
+                                lse=e(B, heads, TP)) for _ in range(spec["depth"])],
+                        dx=torch.zeros((M, Dm), dtype=f, device=dev), dy16=e16(M, Dm), dh16=e16(M, Dm), dbig16=e16(M, Hd),
+                        dqkv16=e16(M, 3 * Dp), dao16=e16(M, Dp), delta=e(2 * M + 4, heads),
+                        window=window, table=torch.zeros((nrd, heads), dtype=f, device=dev),
+                        gq=torch.zeros((3 * Dp, Dm), dtype=f, device=dev) if spec["hd"] == 32 else None,
+                        gp=torch.zeros((Dm, Dp), dtype=f, device=dev) if spec["hd"] == 32 else None,
+                        gb=torch.zeros(3 * Dp, dtype=f, device=dev) if spec["hd"] == 32 else None)
+        self.ea, self.da = acts(self.enc, Me, K + 1), acts(self.dec, Md, T)
+        self.latent16, self.meanE, self.rstdE = e16(Me, D), e(Me), e(Me)
+        self.yd16, self.yd, self.dyd, self.dyd16 = e16(Me, Dd), e(Me, Dd), e(Me, Dd), e16(Me, Dd)
+        self.hdn16, self.meanD, self.rstdD = e16(Md, Dd), e(Md), e(Md)
+        self.pred16, self.pred, self.dpred, self.dpred16 = e16(Md, self.Pp), e(Md, self.Pp), e(Md, self.Pp), e16(Md, self.Pp)
+        self.row_loss = e(B * L)
+        self.dlat16, self.dxe, self.dxe16 = e16(Me, D), e(B * L, D), e16(B * L, D)
+        need = 0
+        for spec, M in ((self.enc, Me), (self.dec, Md)):
+            for n_out, n_in in ((3 * spec["Dp"], spec["D"]), (spec["D"], spec["Dp"]), (spec["hidden"], spec["D"]),
+                                (spec["D"], spec["hidden"])):
+                need = max(need, ops.gemm_tn_workspace(M, n_out, n_in))
+        need = max(need, ops.gemm_tn_workspace(Md, self.Pp, Dd), ops.gemm_tn_workspace(Me, Dd, D),
+                   ops.gemm_tn_workspace(B * L, D, self.Kpe))
+        self.tn_ws = torch.empty(max(need, 16), dtype=torch.uint8, device=dev)
+        self.B, self.K = B, K
+
+    # ---- timm Block on the bf16 kernels
+    def _blk_fwd(self, spec, acts, i, B, T):
+        P = self.P
+        D, Hd, heads, Dp = spec["D"], spec["hidden"], spec["heads"], spec["Dp"]
+        M = B * T
+        pre = f"{spec['pre']}{i}."
+        a = acts["a"][i]
+        xin, xmid, xout = acts["x"][2 * i], acts["x"][2 * i + 1], acts["x"][2 * i + 2]
+        scale = spec["hd"] ** -0.5
+        qb = self.bpad[pre] if spec["hd"] == 32 else P(pre + "attn.qkv.bias")
+        ops.layernorm_fwd(xin, P(pre + "norm1.weight"), P(pre + "norm1.bias"), a["h1"], a["mean1"], a["rstd1"], M, D, eps=self.eps)
+        ops.gemm_nt(a["h1"], self.w16[pre + "attn.qkv.weight"], M, 3 * Dp, D, ops.EPI_BIAS_BF16, out0=a["qkv"], bias=qb,
+                    colscale=scale, colscale_n=Dp)
+        ops.attn_fwd(a["qkv"], B, T, Dp, heads, acts["table"], acts["window"], a["ao"], a["lse"])
+        ops.gemm_nt(a["ao"], self.w16[pre + "attn.proj.weight"], M, D, Dp, ops.EPI_RESIDUAL, bias=P(pre + "attn.proj.bias"),
+                    resid=xmid, aux=xin, ldaux=D, rows_per_sample=T)
+        ops.layernorm_fwd(xmid, P(pre + "norm2.weight"), P(pre + "norm2.bias"), a["h2"], a["mean2"], a["rstd2"], M, D, eps=self.eps)
+        ops.gemm_nt(a["h2"], self.w16[pre + "mlp.fc1.weight"], M, Hd, D, ops.EPI_BIAS_GELU, out0=a["hpre"], out1=a["a"],
+                    bias=P(pre + "mlp.fc1.bias"))
+        ops.gemm_nt(a["a"], self.w16[pre + "mlp.fc2.weight"], M, D, Hd, ops.EPI_RESIDUAL, bias=P(pre + "mlp.fc2.bias"),
+                    resid=xout, aux=xmid, ldaux=D, rows_per_sample=T)
+
+    def _wgrad16(self, dY, X, R, n_out, n_in, out):
+        ops.gemm_tn(dY, X, R, n_out, n_in, out, accumulate=True, workspace=self.tn_ws)
+
+    def _blk_bwd(self, spec, acts, i, B, T):
+        P, Gr = self.P, self.G
+        D, Hd, heads, Dp = spec["D"], spec["hidden"], spec["heads"], spec["Dp"]
+        M = B * T
+        pre = f"{spec['pre']}{i}."
+        a = acts["a"][i]
+        xin, xmid = acts["x"][2 * i], acts["x"][2 * i + 1]
+        dx, dy, dh, dbig, dqkv, dao = acts["dx"], acts["dy16"], acts["dh16"], acts["dbig16"], acts["dqkv16"], acts["dao16"]
+        scale = spec["hd"] ** -0.5
+        pad = spec["hd"] == 32
+        Gw = lambda n: Gr(n).view(self.named[n].shape[0], -1)       # noqa: E731
+        # MLP branch: the branch output gradient IS dx (no layer scale, no drop path); Linear grad_outputs are bf16
+        ops.cast_f32_bf16(dx, dy, M * D)
+        ops.colsum_bf16(dy, M, D, Gr(pre + "mlp.fc2.bias"))
+        ops.gemm_nt(dy, self.wT16[pre + "mlp.fc2.weight"], M, Hd, D, ops.EPI_DGELU, out0=dbig, aux=a["hpre"],
+                    colsum=Gr(pre + "mlp.fc1.bias"))
+        self._wgrad16(dy, a["a"], M, D, Hd, Gw(pre + "mlp.fc2.weight"))
+        self._wgrad16(dbig, a["h2"], M, Hd, D, Gw(pre + "mlp.fc1.weight"))
+        ops.gemm_nt(dbig, self.wT16[pre + "mlp.fc1.weight"], M, D, Hd, ops.EPI_BIAS_BF16, out0=dh)
+        ops.layernorm_bwd(dh, xmid, P(pre + "norm2.weight"), a["mean2"], a["rstd2"], dx, Gr(pre + "norm2.weight"),
+                          Gr(pre + "norm2.bias"), M, D, accumulate=True)
+        # attention branch
+        ops.cast_f32_bf16(dx, dy, M * D)
+        ops.colsum_bf16(dy, M, D, Gr(pre + "attn.proj.bias"))
+        ops.gemm_nt(dy, self.wT16[pre + "attn.proj.weight"], M, Dp, D, ops.EPI_BIAS_BF16, out0=dao)
+        if pad:
+            acts["gp"].zero_()
+            self._wgrad16(dy, a["ao"], M, D, Dp, acts["gp"])
+            Gw(pre + "attn.proj.weight").view(D, heads, 32).add_(acts["gp"].view(D, heads, 64)[:, :, :32])
+        else:
+            self._wgrad16(dy, a["ao"], M, D, Dp, Gw(pre + "attn.proj.weight"))
+        ops.attn_delta(dao, a["ao"], M, heads, acts["delta"])
+        ops.attn_bwd(a["qkv"], dao, a["lse"], acts["delta"], acts["table"], acts["window"], B, T, Dp, heads, scale, dqkv, None)
+        if pad:
+            acts["gb"].zero_(); acts["gq"].zero_()
+            ops.colsum_bf16(dqkv, M, 3 * Dp, acts["gb"])
+            self._wgrad16(dqkv, a["h1"], M, 3 * Dp, D, acts["gq"])
+            Gr(pre + "attn.qkv.bias").view(3, heads, 32).add_(acts["gb"].view(3, heads, 64)[:, :, :32])
+            Gw(pre + "attn.qkv.weight").view(3, heads, 32, D).add_(acts["gq"].view(3, heads, 64, D)[:, :, :32, :])
+        else:
+            ops.colsum_bf16(dqkv, M, 3 * D, Gr(pre + "attn.qkv.bias"))
+            self._wgrad16(dqkv, a["h1"], M, 3 * D, D, Gw(pre + "attn.qkv.weight"))
+        ops.gemm_nt(dqkv, self.wT16[pre + "attn.qkv.weight"], M, D, 3 * Dp, ops.EPI_BIAS_BF16, out0=dh)
+        ops.layernorm_bwd(dh, xin, P(pre + "norm1.weight"), a["mean1"], a["rstd1"], dx, Gr(pre + "norm1.weight"),
+                          Gr(pre + "norm1.bias"), M, D, accumulate=True)
+
+    def forward(self, imgs, ids_keep, ids_restore, mask):
+        assert imgs.is_cuda and imgs.dtype == torch.float32 and imgs.is_contiguous()
+        B = imgs.shape[0]
+        assert tuple(imgs.shape[1:]) == (self.C, self.H, self.W), f"Input image size {tuple(imgs.shape)} doesn't match the model"
+        K = ids_keep.shape[1]
+        self.ensure_batch(B, K)
+        if self.weights_dirty:
+            self.sync_weights()
+        P, m = self.P, self.model
+        L, T, D, Dd = self.L, self.T, self.D, self.Dd
+        Me, Md = B * (K + 1), B * T
+        self.cur = dict(B=B, K=K, ids_keep=ids_keep, ids_restore=ids_restore, mask=mask, imgs=imgs)
+        ops.im2col(imgs, B, self.C, self.H, self.W, self.ph, self.pw, self.patches)
+        ops.gemm_nt(self.patches, self.w16["patch_embed.proj.weight"], B * L, D, self.Kpe, ops.EPI_BIAS_BF16, out0=self.xe16,
+                    bias=P("patch_embed.proj.bias"))
+        self.xe[: B * L].copy_(self.xe16[: B * L])                   # bf16 conv output + fp32 pos_embed -> fp32 (type promotion)
+        ops.mae_enc_assemble(self.xe, m.pos_embed.data.view(T, D), P("cls_token"), ids_keep, B, L, K, D, self.ea["x"][0])
+        for i in range(self.enc["depth"]):
+            self._blk_fwd(self.enc, self.ea, i, B, K + 1)
+        ops.layernorm_fwd(self.ea["x"][-1], P("norm.weight"), P("norm.bias"), self.latent16, self.meanE, self.rstdE, Me, D, eps=self.eps)
+        ops.gemm_nt(self.latent16, self.w16["decoder_embed.weight"], Me, Dd, D, ops.EPI_BIAS_BF16, out0=self.yd16,
+                    bias=P("decoder_embed.bias"))
+        self.yd[:Me].copy_(self.yd16[:Me])
+        ops.mae_dec_assemble(self.yd, P("mask_token"), m.decoder_pos_embed.data.view(T, Dd), ids_restore, B, L, K, Dd, self.da["x"][0])
+        for i in range(self.dec["depth"]):
+            self._blk_fwd(self.dec, self.da, i, B, T)
+        ops.layernorm_fwd(self.da["x"][-1], P("decoder_norm.weight"), P("decoder_norm.bias"), self.hdn16, self.meanD, self.rstdD,
+                          Md, Dd, eps=self.eps)
+        ops.gemm_nt(self.hdn16, self.w16["decoder_pred.weight"], Md, self.Pp, Dd, ops.EPI_BIAS_BF16, out0=self.pred16,
+                    bias=P("decoder_pred.bias"))
+        self.pred[:Md].copy_(self.pred16[:Md])                       # (pred - target) ** 2 runs in fp32 on the bf16 prediction
+        ops.mae_loss(self.pred, imgs, mask, B, self.C, self.H, self.W, self.ph, m.LOSS_ONLY_MASKED_MAE, self.row_loss, self.dpred,
+                     self.scratch2)
+        self.loss_acc[0:1].copy_(self.scratch2[1:2])
+        return self.loss_acc
+
+    def backward(self):
+        c = self.cur
+        B, K = c["B"], c["K"]
+        P, Gr = self.P, self.G
+        L, T, D, Dd = self.L, self.T, self.D, self.Dd
+        Me, Md = B * (K + 1), B * T
+        Gw = lambda n: Gr(n).view(self.named[n].shape[0], -1)       # noqa: E731
+        self.attach_grads()
+        self.flat_g.zero_()
+        ops.cast_f32_bf16(self.dpred, self.dpred16, Md * self.Pp)
+        self._wgrad16(self.dpred16, self.hdn16, Md, self.Pp, Dd, Gw("decoder_pred.weight"))
+        ops.colsum_bf16(self.dpred16, Md, self.Pp, Gr("decoder_pred.bias"))
+        ops.gemm_nt(self.dpred16, self.wT16["decoder_pred.weight"], Md, Dd, self.Pp, ops.EPI_BIAS_BF16, out0=self.da["dh16"])
+        ops.layernorm_bwd(self.da["dh16"], self.da["x"][-1], P("decoder_norm.weight"), self.meanD, self.rstdD, self.da["dx"],
+                          Gr("decoder_norm.weight"), Gr("decoder_norm.bias"), Md, Dd, accumulate=False)
+        for i in reversed(range(self.dec["depth"])):
+            self._blk_bwd(self.dec, self.da, i, B, T)
+        ops.mae_dec_assemble_bwd(self.da["dx"], c["ids_restore"], B, L, K, Dd, self.dyd, Gr("mask_token"))
+        ops.cast_f32_bf16(self.dyd, self.dyd16, Me * Dd)
+        self._wgrad16(self.dyd16, self.latent16, Me, Dd, D, Gw("decoder_embed.weight"))
+        ops.colsum_bf16(self.dyd16, Me, Dd, Gr("decoder_embed.bias"))
+        if self.grad_hook:
+            self.grad_hook(0)
+        ops.gemm_nt(self.dyd16, self.wT16["decoder_embed.weight"], Me, D, Dd, ops.EPI_BIAS_BF16, out0=self.dlat16)
+        ops.layernorm_bwd(self.dlat16, self.ea["x"][-1], P("norm.weight"), self.meanE, self.rstdE, self.ea["dx"],
+                          Gr("norm.weight"), Gr("norm.bias"), Me, D, accumulate=False)
+        for i in reversed(range(self.enc["depth"])):
+            self._blk_bwd(self.enc, self.ea, i, B, K + 1)
+        ops.mae_enc_assemble_bwd(self.ea["dx"], c["ids_keep"], B, L, K, D, self.dxe, Gr("cls_token"))
+        ops.cast_f32_bf16(self.dxe, self.dxe16, B * L * D)
+        self._wgrad16(self.dxe16, self.patches, B * L, D, self.Kpe, Gw("patch_embed.proj.weight"))
+        ops.colsum_bf16(self.dxe16, B * L, D, Gr("patch_embed.proj.bias"))
+        if self.grad_hook:
+            self.grad_hook(1)

@@ -183,8 +183,9 @@ def main(args):
     if args.MAE:                                         # run_mem_pretraining.py:231-232,275-276
         from .modeling_mae import mae_vit_base_patch16_dec512d8b
         assert args.input_H == args.input_W, "the MAE variant patchifies square images (modeling_mae.py:169)"
-        model = mae_vit_base_patch16_dec512d8b(norm_pix_loss=0, LOSS_ONLY_MASKED_MAE=True, img_size=args.input_H)
-        print("Using MAE loss (fp32 kernels: mem_amd/modeling_mae.py)")
+        model = mae_vit_base_patch16_dec512d8b(norm_pix_loss=0, LOSS_ONLY_MASKED_MAE=True, img_size=args.input_H,
+                                               precision=args.precision)
+        print(f"Using MAE loss ({args.precision} engine: mem_amd/modeling_mae.py)")
     patch_size = model.patch_embed.patch_size
     print("Patch size = %s" % str(patch_size))
     args.window_size = (input_size[0] // patch_size[0], input_size[1] // patch_size[1])

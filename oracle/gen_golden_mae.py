@@ -55,6 +55,60 @@ def main():
     out = os.path.join(ROOT, "tests", "golden", "mae_tiny.npz")
     np.savez_compressed(out, **res)
     print("wrote", out, os.path.getsize(out) // 1024, "KiB; loss masked/all:", float(res["masked__loss"]), float(res["all__loss"]))
+    gen_bf16(RM)
+
+
+SMALL = 1 << 16
+
+
+def sample(t):
+    """What the bf16 fixture keeps of a gradient tensor: small tensors whole, big matrices every 32nd row."""
+    return t if t.numel() <= SMALL else t[::32]
+
+
+BASE_MAE_B = 2
+
+
+def gen_bf16(RM):
+    """The reference under bf16 autocast (mem/engine_for_pretraining.py:141-149 runs the MAE model under autocast like
+    pt_vit): tiny config (every gradient whole) and the ViT-B factory at B = 2 (loss, a block of the prediction, every
+    gradient's norm, small gradients whole, big ones on every 32nd row) -> tests/golden/mae_bf16.npz.  The oracle
+    restatement is asserted bit-equal to the reference in the same process first."""
+    import contextlib, io
+    from functools import partial
+    import torch.nn as nn
+    res = {}
+    base = dict(img_size=224, patch_size=16, in_chans=3, embed_dim=768, depth=12, num_heads=12, decoder_embed_dim=512,
+                decoder_depth=8, decoder_num_heads=16, mlp_ratio=4, norm_layer=partial(nn.LayerNorm, eps=1e-6))
+    for tag, cfg0, B, seed, threads in (("tiny", M.TINY_MAE, 4, 21, 1), ("base", base, BASE_MAE_B, 33, 8)):
+        torch.set_num_threads(threads)
+        cfg = dict(cfg0, LOSS_ONLY_MASKED_MAE=True)
+        with contextlib.redirect_stdout(io.StringIO()):
+            torch.manual_seed(3); ref = RM.MaskedAutoencoderViT(**cfg)
+        torch.manual_seed(3); ora = M.RefMAE(**cfg)
+        imgs, noise = M.mae_inputs(cfg, B, seed)
+        real_rand = torch.rand
+        torch.rand = lambda *a, **k: noise.clone()
+        try:
+            with torch.autocast("cpu", dtype=torch.bfloat16):
+                loss_r, img_r, mask_r = ref(imgs)
+        finally:
+            torch.rand = real_rand
+        with torch.autocast("cpu", dtype=torch.bfloat16):
+            loss_o, pred_o, mask_o = ora(imgs, noise)
+        assert torch.equal(loss_r, loss_o) and torch.equal(mask_r, mask_o) and torch.equal(ref.patchify(img_r).float(), pred_o.float())
+        loss_r.backward(); loss_o.backward()
+        for (k, p), (_, q) in zip(ref.named_parameters(), ora.named_parameters()):
+            if p.requires_grad:
+                assert torch.equal(p.grad, q.grad), k
+                res[f"{tag}__gnorm__{k}"] = np.float64(p.grad.double().norm().item())
+                res[f"{tag}__grad__{k}"] = sample(p.grad).numpy()
+        res[f"{tag}__loss"] = loss_r.detach().float().numpy()
+        res[f"{tag}__pred_head"] = pred_o.detach().float()[:, :24].numpy()
+        res[f"{tag}__mask"] = mask_r.numpy()
+    out = os.path.join(ROOT, "tests", "golden", "mae_bf16.npz")
+    np.savez_compressed(out, **res)
+    print("wrote", out, os.path.getsize(out) // 1024, "KiB; bf16 loss tiny/base:", float(res["tiny__loss"]), float(res["base__loss"]))
 
 
 if __name__ == "__main__":
