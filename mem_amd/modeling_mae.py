@@ -520,31 +520,63 @@ class MaeEngineBF16(MaeEngineF32):
             Wp.view(D, H, 64)[:, :, :32] = W.view(D, H, 32)
         return Wp
 
-    def sync_weights(self):
-        def shadow(name, W):
-            W = W.contiguous()
+    def _build_shadows(self):
+        """Once: the bf16 twin of the whole flat master buffer ([out,in] shadows of unpadded weights are views of it), the
+        padded fp32 staging matrices (zero outside the real rows / columns, which every sync overwrites), their bf16
+        shadows, and the descriptors of ONE batched transpose launch for all [in,out]-major copies."""
+        import numpy as np
+        dev = self.dev
+        self.flat_w16 = torch.zeros(self.nflat, dtype=torch.bfloat16, device=dev)
+        self.pad_src, self.pad_cast, items = [], [], []   # pad_src: (staging fp32, view of its real part, fp32 master view)
+
+        def add(name, src32, o, i, w16):
+            self.w16[name] = w16
+            self.wT16[name] = torch.empty((i, o), dtype=torch.bfloat16, device=dev)
+            items.append((src32, o, i, self.wT16[name]))
+
+        def plain(name):
+            W = self.Wm(name)
             o, i = W.shape
-            if name not in self.w16 or self.w16[name].shape != (o, i):
-                self.w16[name] = torch.empty((o, i), dtype=torch.bfloat16, device=self.dev)
-                self.wT16[name] = torch.empty((i, o), dtype=torch.bfloat16, device=self.dev)
-            ops.cast_f32_bf16(W, self.w16[name], o * i)
-            ops.transpose_cast(W, o, i, self.wT16[name])
-        shadow("patch_embed.proj.weight", self.Wm("patch_embed.proj.weight"))
-        shadow("decoder_embed.weight", self.Wm("decoder_embed.weight"))
-        shadow("decoder_pred.weight", self.Wm("decoder_pred.weight"))
+            off, k = self.segs[name]
+            add(name, W, o, i, self.flat_w16[off:off + k].view(o, i))
+        plain("patch_embed.proj.weight"); plain("decoder_embed.weight"); plain("decoder_pred.weight")
         for spec in (self.enc, self.dec):
+            H, D, Dp = spec["heads"], spec["D"], spec["Dp"]
             for i in range(spec["depth"]):
                 pre = f"{spec['pre']}{i}."
-                for kind in ("qkv", "proj"):
-                    n = pre + f"attn.{kind}.weight"
-                    Wp = self._padded(spec, kind, self.Wm(n))
-                    shadow(n, self.Wm(n) if Wp is None else Wp)
-                shadow(pre + "mlp.fc1.weight", self.Wm(pre + "mlp.fc1.weight"))
-                shadow(pre + "mlp.fc2.weight", self.Wm(pre + "mlp.fc2.weight"))
-                if spec["hd"] == 32:
-                    b = torch.zeros(3 * spec["Dp"], dtype=torch.float32, device=self.dev)
-                    b.view(3, spec["heads"], 64)[:, :, :32] = self.P(pre + "attn.qkv.bias").view(3, spec["heads"], 32)
-                    self.bpad[pre] = b
+                plain(pre + "mlp.fc1.weight"); plain(pre + "mlp.fc2.weight")
+                if spec["hd"] == 64:
+                    plain(pre + "attn.qkv.weight"); plain(pre + "attn.proj.weight")
+                    continue
+                Wq = torch.zeros((3 * Dp, D), dtype=torch.float32, device=dev)
+                Wp = torch.zeros((D, Dp), dtype=torch.float32, device=dev)
+                b = torch.zeros(3 * Dp, dtype=torch.float32, device=dev)
+                self.pad_src += [(Wq, Wq.view(3, H, 64, D)[:, :, :32, :], self.Wm(pre + "attn.qkv.weight").view(3, H, 32, D)),
+                                 (Wp, Wp.view(D, H, 64)[:, :, :32], self.Wm(pre + "attn.proj.weight").view(D, H, 32)),
+                                 (None, b.view(3, H, 64)[:, :, :32], self.P(pre + "attn.qkv.bias").view(3, H, 32))]
+                self.bpad[pre] = b
+                add(pre + "attn.qkv.weight", Wq, 3 * Dp, D, torch.empty((3 * Dp, D), dtype=torch.bfloat16, device=dev))
+                add(pre + "attn.proj.weight", Wp, D, Dp, torch.empty((D, Dp), dtype=torch.bfloat16, device=dev))
+                self.pad_cast += [(Wq, self.w16[pre + "attn.qkv.weight"]), (Wp, self.w16[pre + "attn.proj.weight"])]
+        desc = np.zeros((len(items), 6), dtype=np.int64)
+        prefix = np.zeros(len(items) + 1, dtype=np.int32)
+        for k, (src, R, Cc, dst) in enumerate(items):
+            desc[k] = (src.data_ptr(), src.stride(0), R, Cc, dst.data_ptr(), dst.stride(0))
+            prefix[k + 1] = prefix[k] + ((R + 63) // 64) * ((Cc + 63) // 64)
+        self._tdesc, self._tprefix = torch.from_numpy(desc).to(dev), torch.from_numpy(prefix).to(dev)
+        self._tn, self._ttiles = len(items), int(prefix[-1])
+
+    def sync_weights(self):
+        """fp32 masters -> bf16 shadows: one flat cast, the padded matrices refreshed (copy of the real part + cast), one
+        batched transpose launch for the [in,out]-major copies."""
+        if not hasattr(self, "flat_w16"):
+            self._build_shadows()
+        ops.cast_f32_bf16(self.flat_p, self.flat_w16, self.nflat)
+        for stage, real, master in self.pad_src:
+            real.copy_(master)
+        for stage, w in self.pad_cast:
+            ops.cast_f32_bf16(stage, w, stage.numel())
+        ops.transpose_cast_batched(self._tdesc, self._tprefix, self._tn, self._ttiles)
         self.weights_dirty = False
 
     def ensure_batch(self, B, K):
@@ -626,8 +658,7 @@ class MaeEngineBF16(MaeEngineF32):
         pad = spec["hd"] == 32
         Gw = lambda n: Gr(n).view(self.named[n].shape[0], -1)       # noqa: E731
         # MLP branch: the branch output gradient IS dx (no layer scale, no drop path); Linear grad_outputs are bf16
-        ops.cast_f32_bf16(dx, dy, M * D)
-        ops.colsum_bf16(dy, M, D, Gr(pre + "mlp.fc2.bias"))
+        ops.branch_bwd(dx, None, None, dy, None, Gr(pre + "mlp.fc2.bias"), M, D)      # dy = bf16(dx) + its column sums, one pass
         ops.gemm_nt(dy, self.wT16[pre + "mlp.fc2.weight"], M, Hd, D, ops.EPI_DGELU, out0=dbig, aux=a["hpre"],
                     colsum=Gr(pre + "mlp.fc1.bias"))
         self._wgrad16(dy, a["a"], M, D, Hd, Gw(pre + "mlp.fc2.weight"))
@@ -636,9 +667,14 @@ class MaeEngineBF16(MaeEngineF32):
         ops.layernorm_bwd(dh, xmid, P(pre + "norm2.weight"), a["mean2"], a["rstd2"], dx, Gr(pre + "norm2.weight"),
                           Gr(pre + "norm2.bias"), M, D, accumulate=True)
         # attention branch
-        ops.cast_f32_bf16(dx, dy, M * D)
-        ops.colsum_bf16(dy, M, D, Gr(pre + "attn.proj.bias"))
-        ops.gemm_nt(dy, self.wT16[pre + "attn.proj.weight"], M, Dp, D, ops.EPI_BIAS_BF16, out0=dao)
+        ops.branch_bwd(dx, None, None, dy, None, Gr(pre + "attn.proj.bias"), M, D)
+        # qkv.bias gradient without a pass over dqkv: the v part is colsum(dao) (sum_k dV_k = sum_q dO_q: softmax rows sum to
+        # one), fused into the GEMM that produces dao; the q part comes out of the attention backward kernel; the k part is
+        # zero in real arithmetic (sum_k dS_qk = 0 for every query row) and is left at zero
+        gb = acts["gb"] if pad else Gr(pre + "attn.qkv.bias")
+        if pad:
+            gb.zero_()
+        ops.gemm_nt(dy, self.wT16[pre + "attn.proj.weight"], M, Dp, D, ops.EPI_BIAS_BF16, out0=dao, colsum=gb[2 * Dp:3 * Dp])
         if pad:
             acts["gp"].zero_()
             self._wgrad16(dy, a["ao"], M, D, Dp, acts["gp"])
@@ -646,15 +682,14 @@ class MaeEngineBF16(MaeEngineF32):
         else:
             self._wgrad16(dy, a["ao"], M, D, Dp, Gw(pre + "attn.proj.weight"))
         ops.attn_delta(dao, a["ao"], M, heads, acts["delta"])
-        ops.attn_bwd(a["qkv"], dao, a["lse"], acts["delta"], acts["table"], acts["window"], B, T, Dp, heads, scale, dqkv, None)
+        ops.attn_bwd(a["qkv"], dao, a["lse"], acts["delta"], acts["table"], acts["window"], B, T, Dp, heads, scale, dqkv, None,
+                     dq_bias=gb[0:Dp])
         if pad:
-            acts["gb"].zero_(); acts["gq"].zero_()
-            ops.colsum_bf16(dqkv, M, 3 * Dp, acts["gb"])
+            acts["gq"].zero_()
             self._wgrad16(dqkv, a["h1"], M, 3 * Dp, D, acts["gq"])
             Gr(pre + "attn.qkv.bias").view(3, heads, 32).add_(acts["gb"].view(3, heads, 64)[:, :, :32])
             Gw(pre + "attn.qkv.weight").view(3, heads, 32, D).add_(acts["gq"].view(3, heads, 64, D)[:, :, :32, :])
         else:
-            ops.colsum_bf16(dqkv, M, 3 * D, Gr(pre + "attn.qkv.bias"))
             self._wgrad16(dqkv, a["h1"], M, 3 * D, D, Gw(pre + "attn.qkv.weight"))
         ops.gemm_nt(dqkv, self.wT16[pre + "attn.qkv.weight"], M, D, 3 * Dp, ops.EPI_BIAS_BF16, out0=dh)
         ops.layernorm_bwd(dh, xin, P(pre + "norm1.weight"), a["mean1"], a["rstd1"], dx, Gr(pre + "norm1.weight"),
@@ -705,18 +740,16 @@ class MaeEngineBF16(MaeEngineF32):
         Gw = lambda n: Gr(n).view(self.named[n].shape[0], -1)       # noqa: E731
         self.attach_grads()
         self.flat_g.zero_()
-        ops.cast_f32_bf16(self.dpred, self.dpred16, Md * self.Pp)
+        ops.branch_bwd(self.dpred, None, None, self.dpred16, None, Gr("decoder_pred.bias"), Md, self.Pp)
         self._wgrad16(self.dpred16, self.hdn16, Md, self.Pp, Dd, Gw("decoder_pred.weight"))
-        ops.colsum_bf16(self.dpred16, Md, self.Pp, Gr("decoder_pred.bias"))
         ops.gemm_nt(self.dpred16, self.wT16["decoder_pred.weight"], Md, Dd, self.Pp, ops.EPI_BIAS_BF16, out0=self.da["dh16"])
         ops.layernorm_bwd(self.da["dh16"], self.da["x"][-1], P("decoder_norm.weight"), self.meanD, self.rstdD, self.da["dx"],
                           Gr("decoder_norm.weight"), Gr("decoder_norm.bias"), Md, Dd, accumulate=False)
         for i in reversed(range(self.dec["depth"])):
             self._blk_bwd(self.dec, self.da, i, B, T)
         ops.mae_dec_assemble_bwd(self.da["dx"], c["ids_restore"], B, L, K, Dd, self.dyd, Gr("mask_token"))
-        ops.cast_f32_bf16(self.dyd, self.dyd16, Me * Dd)
+        ops.branch_bwd(self.dyd, None, None, self.dyd16, None, Gr("decoder_embed.bias"), Me, Dd)
         self._wgrad16(self.dyd16, self.latent16, Me, Dd, D, Gw("decoder_embed.weight"))
-        ops.colsum_bf16(self.dyd16, Me, Dd, Gr("decoder_embed.bias"))
         if self.grad_hook:
             self.grad_hook(0)
         ops.gemm_nt(self.dyd16, self.wT16["decoder_embed.weight"], Me, D, Dd, ops.EPI_BIAS_BF16, out0=self.dlat16)
@@ -725,8 +758,7 @@ class MaeEngineBF16(MaeEngineF32):
         for i in reversed(range(self.enc["depth"])):
             self._blk_bwd(self.enc, self.ea, i, B, K + 1)
         ops.mae_enc_assemble_bwd(self.ea["dx"], c["ids_keep"], B, L, K, D, self.dxe, Gr("cls_token"))
-        ops.cast_f32_bf16(self.dxe, self.dxe16, B * L * D)
+        ops.branch_bwd(self.dxe, None, None, self.dxe16, None, Gr("patch_embed.proj.bias"), B * L, D)
         self._wgrad16(self.dxe16, self.patches, B * L, D, self.Kpe, Gw("patch_embed.proj.weight"))
-        ops.colsum_bf16(self.dxe16, B * L, D, Gr("patch_embed.proj.bias"))
         if self.grad_hook:
             self.grad_hook(1)

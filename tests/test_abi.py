@@ -49,7 +49,7 @@ def test_options_table_and_no_environment_reads():
     """Kernel-selection switches exist only behind memhip_set_option; the shared object imports no getenv."""
     import subprocess
     from mem_amd import _lib
-    assert _lib.get_option("gemm_p8") == 1 and _lib.get_option("gemm_p8_min_n") == 768
+    assert _lib.get_option("gemm_p8") == 1 and _lib.get_option("gemm_p8_min_n") == 512
     _lib.set_option("gemm_p8", 0)
     assert _lib.get_option("gemm_p8") == 0
     _lib.set_option("gemm_p8", 1)
