@@ -306,6 +306,9 @@ def main():
                     help="N > 1: CUs the persistent GEMM / attention grids leave to RCCL while gradient buckets are in flight "
                          "(-1 = 16 when more than one rank runs, 0 in a one-rank run; one-rank dry-run A/B: "
                          "profiles/r03_rccl_dryrun.json -- reserving 16 CUs costs <= 0.3 ms of a 39 ms step)")
+    ap.add_argument("--no-dp-skip", action="store_true",
+                    help="stochastic depth by masking (every sample computed, dropped ones multiplied by zero) instead of "
+                         "work skipping: A/B switch")
     ap.add_argument("--no-entrypoint-figure", action="store_true",
                     help="skip the measurement of the real entrypoint loop (train_one_epoch over a DataLoader)")
     ap.add_argument("--entrypoint-workers", type=int, default=10, help="DataLoader workers of the entrypoint figure")
@@ -375,6 +378,7 @@ def main():
                    use_abs_pos_emb=False, init_values=0.1).cuda().train()
     eng = model.engine
     eng.wgrad_side_stream = not a.no_side_stream
+    eng.dp_skip = not a.no_dp_skip
     eng.fwd_two_streams = bool(a.fwd_split) and not a.no_fwd_split
     import contextlib, io
     with contextlib.redirect_stdout(io.StringIO()):

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define MEMHIP_ABI_VERSION 1
+#define MEMHIP_ABI_VERSION 2
 
 #define MEMHIP_OK 0
 #define MEMHIP_EINVAL (-1)   /* bad argument (shape / alignment / null) */
@@ -285,6 +285,11 @@ typedef struct memhip_gemm_args {
   int32_t accumulate;     /* F32: 1 = out0 += acc */
   float* colsum;          /* BIAS_BF16 / DGELU: f32 [N] += column sums of the bf16 output rows < M (the
                              bias gradient of the Linear whose grad_output this GEMM produces); NULL = off */
+  const int32_t* sample_map; /* RESIDUAL, stochastic depth as WORK SKIPPING (the GEMM runs on the rows of the kept samples
+                             only): output row m belongs to compact sample c = m / rows_per_sample, and its residual row in
+                             `resid` / `aux` is sample_map[c] * rows_per_sample + m % rows_per_sample.  The kept branch is
+                             scaled by 1 / keep_prob; rowmask must be NULL.  The array must be readable for 256 entries
+                             past the last compact sample.  NULL = rows map to themselves. */
 } memhip_gemm_args_t;
 int memhip_gemm_bf16_nt(const memhip_gemm_args_t* args, memhip_stream_t stream);
 
@@ -352,6 +357,24 @@ int memhip_layernorm_bwd_branch(const void* dy_bf16, int64_t lddy, const float* 
 int memhip_branch_bwd(const float* dx, int64_t lddx, const void* y_bf16, int64_t ldy, const float* gamma,
                       const float* rowmask, float keep_prob, int rows_per_sample, int M, int D,
                       void* dy_bf16, int64_t lddy, float* dgamma, float* dbias, memhip_stream_t stream);
+/* Stochastic depth as WORK SKIPPING (timm drop_path, mem/modeling_finetune.py:42-53,187-188: a dropped sample's branch
+ * contributes nothing, so nothing of it is computed).  Sample maps, i32 [samples]: sample -> its index among the samples the
+ * branch KEPT this step, or -1.  memhip_branch_bwd_map: out_map places the kept samples' rows of dy compactly (row
+ * out_map[s] * rows_per_sample + t) scaled by 1 / keep_prob; dropped samples are neither read nor written.
+ * memhip_layernorm_bwd_branch_map: in_map says which samples the LayerNorm'ed branch kept (dy / mean / rstd hold those
+ * samples only; the others get no LayerNorm gradient), out_map the same for the branch whose output gradient is produced.
+ * M / R count the rows of the residual stream (all samples).  rowmask and y must be NULL; NULL maps = identity. */
+int memhip_branch_bwd_map(const float* dx, int64_t lddx, const void* y_bf16, int64_t ldy, const float* gamma,
+                          const float* rowmask, float keep_prob, int rows_per_sample, int M, int D,
+                          void* dy_bf16, int64_t lddy, float* dgamma, float* dbias, const int32_t* out_map,
+                          memhip_stream_t stream);
+int memhip_layernorm_bwd_branch_map(const void* dy_bf16, int64_t lddy, const float* x, int64_t ldx, int R, int D,
+                                    const float* gamma, const float* mean, const float* rstd, float* dres,
+                                    int64_t lddres, float* dgamma, float* dbeta, const void* y_branch_bf16, int64_t ldyb,
+                                    const float* gamma_branch, const float* rowmask, float keep_prob,
+                                    int rows_per_sample, void* dy_branch_bf16, int64_t lddyb, float* dgamma_branch,
+                                    float* dbias_branch, const int32_t* in_map, const int32_t* out_map,
+                                    memhip_stream_t stream);
 
 /* Backward of the token assembly (mem/modeling_pretrain.py:101-108): dcls += dx[cls rows],
  * dmask_token += sum dx*w, dy bf16 [B*L, D] = bf16(dx*(1-w)); mask u8 [B*L]. */

@@ -210,7 +210,10 @@ extern "C" int memhip_gemm_bf16_nt(const memhip_gemm_args_t* a, memhip_stream_t 
   switch (p.epilogue) {
     case MEMHIP_EPI_BIAS_BF16: MEMHIP_REQUIRE(p.out0, "gemm: out0"); break;
     case MEMHIP_EPI_BIAS_GELU: MEMHIP_REQUIRE(p.out0 && p.out1, "gemm: out0/out1"); break;
-    case MEMHIP_EPI_RESIDUAL: MEMHIP_REQUIRE(p.resid, "gemm: residual args"); break;
+    case MEMHIP_EPI_RESIDUAL:
+      MEMHIP_REQUIRE(p.resid, "gemm: residual args");
+      MEMHIP_REQUIRE(!p.sample_map || (!p.rowmask && p.rows_per_sample > 0), "gemm: sample_map excludes rowmask");
+      break;
     case MEMHIP_EPI_DGELU: MEMHIP_REQUIRE(p.out0 && p.aux, "gemm: dgelu args"); break;
     case MEMHIP_EPI_BIAS_GELU_DG: MEMHIP_REQUIRE(p.out0 && p.out1, "gemm: out0/out1"); break;
     case MEMHIP_EPI_MUL_AUX: MEMHIP_REQUIRE(p.out0 && p.aux, "gemm: mul_aux args"); break;
@@ -238,8 +241,10 @@ extern "C" int memhip_gemm_bf16_nt(const memhip_gemm_args_t* a, memhip_stream_t 
         p.A += r * p.lda;
         if (p.out0) p.out0 = (char*)p.out0 + r * p.ldo0 * (p.epilogue == MEMHIP_EPI_F32 ? 4 : 2);
         if (p.out1) p.out1 = (char*)p.out1 + r * p.ldo1 * 2;
-        if (p.resid) p.resid += r * p.ldr;
-        if (p.aux) p.aux = (const char*)p.aux + r * p.ldaux * (p.epilogue == MEMHIP_EPI_RESIDUAL ? 4 : 2);
+        // (with a sample map the residual rows are addressed through the map: resid / aux stay where they are)
+        if (p.resid && !p.sample_map) p.resid += r * p.ldr;
+        if (p.aux && !(p.sample_map && p.epilogue == MEMHIP_EPI_RESIDUAL))
+          p.aux = (const char*)p.aux + r * p.ldaux * (p.epilogue == MEMHIP_EPI_RESIDUAL ? 4 : 2);
         p.M -= split;
         p.m_base = split;
         // the left-over rows: the same phase structure on 128-row tiles (MEMHIP_GEMM_P8_HALF=0: 128x128 kernel)

@@ -22,6 +22,7 @@ struct GemmArgs {   // memhip_gemm_args_t, followed by launcher-internal fields
   int rows_per_sample;
   int accumulate;
   float* colsum;   // optional: += column sums of the (rounded) primary output
+  const int* sample_map;   // RESIDUAL: compact sample -> sample whose residual rows this output row updates (NULL: identity)
   // ---- internal (not part of the C ABI; zero when the struct is copied from memhip_gemm_args_t)
   int m_base;      // row offset of this launch inside the caller's problem (a GEMM may be launched in two
                    // row ranges): only the per-sample row mask index needs the absolute row
@@ -81,10 +82,15 @@ __device__ __forceinline__ void epilogue(const GemmArgs& p, int m, int n, float 
     if (p.out0) reinterpret_cast<__bf16*>(p.out0)[(long long)m * p.ldo0 + n] = y;
     float t = p.vec1 ? __fmul_rn(vec_n, (float)y) : (float)y;            // gamma * branch
     if (p.rowmask) t = __fmul_rn(__fdiv_rn(t, p.keep_prob), p.rowmask[(m + p.m_base) / p.rows_per_sample]);
+    long long rr = m;                                                    // residual row (relative to resid / aux)
+    if (p.sample_map) {                                                  // work-skipping stochastic depth: kept samples only
+      const int mm = m + p.m_base, c = mm / p.rows_per_sample;
+      rr = (long long)p.sample_map[c] * p.rows_per_sample + (mm - c * p.rows_per_sample);
+      t = __fdiv_rn(t, p.keep_prob);
+    }
     // residual input: aux (fp32, ldaux) when given, else in place
-    const float xin = p.aux ? reinterpret_cast<const float*>(p.aux)[(long long)m * p.ldaux + n]
-                            : p.resid[(long long)m * p.ldr + n];
-    p.resid[(long long)m * p.ldr + n] = __fadd_rn(xin, t);
+    const float xin = p.aux ? reinterpret_cast<const float*>(p.aux)[rr * p.ldaux + n] : p.resid[rr * p.ldr + n];
+    p.resid[rr * p.ldr + n] = __fadd_rn(xin, t);
   } else if constexpr (EPI == MEMHIP_EPI_DGELU) {
     const float da = bf16_round(acc);
     const float h = (float)reinterpret_cast<const __bf16*>(p.aux)[(long long)m * p.ldaux + n];
@@ -240,12 +246,14 @@ struct EpiRow<MEMHIP_EPI_DGELU> { uint4 h; };
 template <>
 struct EpiRow<MEMHIP_EPI_MUL_AUX> { uint4 h; };
 template <>
-struct EpiRow<MEMHIP_EPI_RESIDUAL> { float x[8]; float rm; };
+struct EpiRow<MEMHIP_EPI_RESIDUAL> { float x[8]; float rm; long long row; };   // row: the residual row (sample_map resolved)
 // No vector-memory instruction of a row epilogue sits behind a branch, not even a wave-uniform one: at the join hipcc's
 // waitcnt pass gives up counting and puts s_waitcnt vmcnt(0) in front of the next use of a loaded row, which then also waits
 // for every store issued so far (one store round trip per row).  Optional operands are therefore handled by POINTER selection:
 // a missing drop-path mask reads the constant 1, a missing bf16 copy of the branch output goes to a scratch line.
 __device__ const float g_epi_one = 1.0f;
+__device__ const int g_epi_izero = 0;
+typedef const int __attribute__((address_space(1)))* gci32_ptr;
 __device__ __attribute__((aligned(256))) unsigned char g_epi_trash[1024];
 // BIGROWS = false: the caller guarantees m + m_base < 2^21 whenever a drop-path mask is given (no integer division, no
 // branch: the row epilogue stays one basic block)
@@ -261,18 +269,23 @@ __device__ __forceinline__ void epi_row_load(const GemmArgs& p, int m, int n, Ep
     // (base pointer and leading dimension are selected as scalars: one address computation per lane)
     const float* base = p.aux ? reinterpret_cast<const float*>(p.aux) : p.resid;
     const long long ld = p.aux ? p.ldaux : p.ldr;
-    ld8(base + (long long)m * ld + n, r.x);
     // sample of the row for the drop-path mask: (m + 0.5) / rows_per_sample is at least 0.5 / rows_per_sample away from an
     // integer; the fp32 product is off by at most (m + 0.5) * 2^-23 / rows_per_sample, so it truncates to the right sample
     // for m < 2^22 (taken up to 2^21; larger row indices use the integer division)
     const int mm = m + p.m_base;
-    const float inv = p.rowmask ? __frcp_rn((float)p.rows_per_sample) : 0.f;      // no mask: sample 0 of the constant 1
+    const bool per_sample = p.rowmask || p.sample_map;
+    const float inv = per_sample ? __frcp_rn((float)p.rows_per_sample) : 0.f;     // neither: sample 0 of the constants
     int smp = (int)(((float)mm + 0.5f) * inv);
     if constexpr (BIGROWS) {
-      if (p.rowmask && mm >= (1 << 21)) smp = mm / p.rows_per_sample;
+      if (per_sample && mm >= (1 << 21)) smp = mm / p.rows_per_sample;
     }
     const gcf32_ptr rmb = p.rowmask ? as_global(p.rowmask) : as_global(&g_epi_one);
-    r.rm = rmb[smp];
+    r.rm = rmb[p.rowmask ? smp : 0];
+    // work-skipping stochastic depth: the row of the KEPT sample in the residual stream (identity without a map)
+    const gci32_ptr smb = p.sample_map ? (gci32_ptr)p.sample_map : (gci32_ptr)&g_epi_izero;
+    const int kid = smb[p.sample_map ? smp : 0];
+    r.row = p.sample_map ? (long long)kid * p.rows_per_sample + (mm - smp * p.rows_per_sample) : (long long)m;
+    ld8(base + r.row * ld + n, r.x);
   }
 }
 
@@ -366,7 +379,7 @@ __device__ __forceinline__ void epilogue8(const GemmArgs& p, int m, int n, const
     for (int k = 0; k < 8; ++k) br[k] = __fmul_rn(c.g[k], br[k]);
     {                                          // drop path: branch / keep_prob * mask[sample]; without a mask both are the
       const float rm = row.rm;                 // constant 1 and every step below is exact (q0 = br, residual 0, q = br)
-      const float kp = p.rowmask ? p.keep_prob : 1.0f;
+      const float kp = (p.rowmask || p.sample_map) ? p.keep_prob : 1.0f;
       const float rk = __frcp_rn(kp);
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
@@ -381,7 +394,7 @@ __device__ __forceinline__ void epilogue8(const GemmArgs& p, int m, int n, const
     if constexpr (COPY == 1) st_branch_copy(p, m, n, y);
     if constexpr (COPY == 2)
       *(gu32x4_ptr)(reinterpret_cast<__bf16*>(p.out0) + (long long)m * p.ldo0 + n) = eu32x4{y[0], y[1], y[2], y[3]};
-    st8(p.resid + (long long)m * p.ldr + n, x);
+    st8(p.resid + row.row * p.ldr + n, x);
   } else if constexpr (EPI == MEMHIP_EPI_DGELU) {
     const unsigned h[4] = {row.h.x, row.h.y, row.h.z, row.h.w};
     unsigned o[4];
@@ -440,7 +453,7 @@ __device__ __forceinline__ void epilogue8_residual_packed(const GemmArgs& p, int
 #pragma unroll
     for (int k = 0; k < 8; ++k) br[k] = __fmul_rn(c.g[k], br[k]);
   }
-  if (p.rowmask) {                             // drop path: branch / keep_prob * mask[sample]
+  if (p.rowmask || p.sample_map) {             // drop path: branch / keep_prob * mask[sample]
     const float rm = row.rm;
     const float rk = __frcp_rn(p.keep_prob);
 #pragma unroll
@@ -453,7 +466,7 @@ __device__ __forceinline__ void epilogue8_residual_packed(const GemmArgs& p, int
 #pragma unroll
   for (int k = 0; k < 8; ++k) x[k] = __fadd_rn(row.x[k], br[k]);
   st_branch_copy(p, m, n, y);
-  st8(p.resid + (long long)m * p.ldr + n, x);
+  st8(p.resid + row.row * p.ldr + n, x);
 }
 
 template <int EPI>

@@ -60,6 +60,23 @@
 #define P8_PRIO(x) do { } while (0)
 #endif
 
+#ifdef P8_STAMP
+// diagnostic build (tools/build_variant.sh stamp -DP8_STAMP): wave 0 of every workgroup records s_memtime at the main-loop
+// start, epilogue start and epilogue end of its first 10 tiles; memhip_debug_p8_stamps copies the table out.  Never part of
+// the shipped library (its fences forbid overlaps the real kernel has: read the SHARES, not the lengths).
+__device__ unsigned long long g_p8_stamps[256 * 32];
+#define P8_STAMP_AT(slot)                                                                                   \
+  do {                                                                                                      \
+    if (wave == 0 && stamp_tile < 10) {                                                                     \
+      unsigned long long t_;                                                                                \
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                           \
+      if (lane == 0) g_p8_stamps[(blockIdx.x & 255) * 32 + stamp_tile * 3 + (slot)] = t_;                   \
+    }                                                                                                       \
+  } while (0)
+#else
+#define P8_STAMP_AT(slot) do { } while (0)
+#endif
+
 namespace {
 
 using namespace memhip;
@@ -76,10 +93,11 @@ template <int BMT> struct P8Geo {
   static constexpr int kBOff = 2 * kAHalf;                  // B0 behind A0, A1
   static constexpr int kBuf = 2 * kAHalf + 2 * kHalf;       // A0 A1 B0 B1
   static constexpr int kLds = 2 * kBuf;
-  // behind the operand buffers: per tile parity the tile's bias and layer-scale columns (2 x [256 f32 | 256 f32]), then a
-  // 1 KiB landing slot per wave for the epilogue-operand prefetch (never read)
-  static constexpr int kColsOff = kLds, kTrashOff = kLds + 4096;
-  static constexpr int kLdsAll = kLds + 4096 + 8 * 1024;
+  // behind the operand buffers: per tile parity the tile's bias and layer-scale columns and the sample-map entries of its
+  // rows (work-skipping stochastic depth), then a 1 KiB landing slot per wave for the epilogue-operand prefetch (never read)
+  static constexpr int kColsSlot = 3072;                    // [256 f32 bias | 256 f32 layer scale | 256 i32 sample map]
+  static constexpr int kColsOff = kLds, kTrashOff = kLds + 2 * kColsSlot;
+  static constexpr int kLdsAll = kLds + 2 * kColsSlot + 8 * 1024;
   static constexpr int MF = BMT / 64;                       // 16-row fragments per wave and A half
   static constexpr int kAPieces = BMT / 128;                // LDS-DMA instructions per wave for an A half-tile
   // glds in flight that a phase's wait must leave alone (= the five half-tiles issued after the one needed)
@@ -358,13 +376,19 @@ __global__ __launch_bounds__(kThreads) void gemm_p8_kernel(GemmArgs p, int ntm, 
       if constexpr (kHasBias) {
         if (wave == 0) {
           src = (p.bias ? reinterpret_cast<const char*>(p.bias + tn * BN) : reinterpret_cast<const char*>(g_epi_zero256)) + dlane * 16;
-          dst = smem + G::kColsOff + tile_par * 2048;
+          dst = smem + G::kColsOff + tile_par * G::kColsSlot;
         }
       }
       if constexpr (EPI == MEMHIP_EPI_RESIDUAL) {
         if (wave == 1) {
           src = (p.vec1 ? reinterpret_cast<const char*>(p.vec1 + tn * BN) : reinterpret_cast<const char*>(g_epi_one256)) + dlane * 16;
-          dst = smem + G::kColsOff + tile_par * 2048 + 1024;
+          dst = smem + G::kColsOff + tile_par * G::kColsSlot + 1024;
+        }
+        if (wave == 2) {     // sample-map entries from the tile's first compact sample on (the tile's rows span at most 4)
+          const int s0 = (tm * BMT + p.m_base) / p.rows_per_sample;
+          src = (p.sample_map ? reinterpret_cast<const char*>(p.sample_map + s0) : reinterpret_cast<const char*>(g_epi_zero256)) +
+                dlane * 16;
+          dst = smem + G::kColsOff + tile_par * G::kColsSlot + 2048;
         }
       }
     }
@@ -381,7 +405,7 @@ __global__ __launch_bounds__(kThreads) void gemm_p8_kernel(GemmArgs p, int ntm, 
     o[0] = q0[0]; o[1] = q0[1]; o[2] = q0[2]; o[3] = q0[3]; o[4] = q1[0]; o[5] = q1[1]; o[6] = q1[2]; o[7] = q1[3];
   };
   auto cols_from_lds = [&](int ncl, EpiCols& c) {
-    const unsigned addr = (unsigned)(unsigned long long)((__attribute__((address_space(3))) char*)smem) + (unsigned)(G::kColsOff + tile_par * 2048 + ncl * 4);
+    const unsigned addr = (unsigned)(unsigned long long)((__attribute__((address_space(3))) char*)smem) + (unsigned)(G::kColsOff + tile_par * G::kColsSlot + ncl * 4);
     if constexpr (kHasBias) {
       float b[8];
       lds_read8(addr, b);
@@ -393,7 +417,11 @@ __global__ __launch_bounds__(kThreads) void gemm_p8_kernel(GemmArgs p, int ntm, 
 
   P8_READ_B0_FIRST();
   // K-tiles go in pairs (K % 128 == 0), so that buffer parity and the B register roles are static
+#ifdef P8_STAMP
+  int stamp_tile = 0;
+#endif
   for (int c = 0; c < total; c += 2) {
+    if (c_k == 0) P8_STAMP_AT(0);
     iter_dma();
     {
       constexpr int bc = 0;
@@ -412,6 +440,7 @@ __global__ __launch_bounds__(kThreads) void gemm_p8_kernel(GemmArgs p, int ntm, 
       // waves 0-3 wait for the last compute segment of waves 4-7, so that all eight waves run the
       // (VALU-bound, barrier-free) epilogue together; waves 4-7 fall half a phase behind again after it
       if (P8_REALIGN && wr == 0) P8_BARRIER();
+      P8_STAMP_AT(1);
       // ---- epilogue of tile c_tile straight out of the accumulators: the MFMAs ran with swapped
       // operands, so a lane holds 4 consecutive columns (registers) of one row (lane & 15)
       const int tm = ctm, tn = ctn;
@@ -467,15 +496,27 @@ __global__ __launch_bounds__(kThreads) void gemm_p8_kernel(GemmArgs p, int ntm, 
         auto row_n = [&](int r) { return ncol + (r >> 3) * 128; };
         const float* xbase = p.aux ? reinterpret_cast<const float*>(p.aux) : p.resid;
         const long long xld = p.aux ? p.ldaux : p.ldr;
-        const float inv_rps = p.rowmask ? __frcp_rn((float)p.rows_per_sample) : 0.f;
+        const bool per_sample = p.rowmask || p.sample_map;
+        const float inv_rps = per_sample ? __frcp_rn((float)p.rows_per_sample) : 0.f;
         const float* rmb = p.rowmask ? p.rowmask : &g_epi_one;
+        // work-skipping stochastic depth: the residual rows of the tile's compact samples come from the LDS copy of the
+        // sample map that iteration 0 of this tile brought in (entries s0, s0 + 1, ...: zeros without a map)
+        const int s0 = (tm * BMT + p.m_base) / p.rows_per_sample;
+        const unsigned kid_lds = (unsigned)(unsigned long long)((__attribute__((address_space(3))) char*)smem) +
+                                 (unsigned)(G::kColsOff + tile_par * G::kColsSlot + 2048);
         f32x4 xa[3], xb[3];
         float rmv[3];
+        int rrow[3];                                            // residual row of the slot's row (32 bits: rows < 2^21)
         auto issue_row = [&](int r, int slot) {
           const int m = row_m(r);
-          const float* src = xbase + (long long)m * xld + row_n(r);
-          const int smp = (int)(((float)(m + p.m_base) + 0.5f) * inv_rps);        // rows < 2^21 (p8_fits)
-          const float* rsrc = rmb + smp;
+          const int mm = m + p.m_base;
+          const int smp = (int)(((float)mm + 0.5f) * inv_rps);                    // rows < 2^21 (p8_fits)
+          // (one LDS word per row issue, read on the spot: four more live values do not fit this epilogue's registers)
+          int kd;
+          asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(kd) : "v"(kid_lds + (unsigned)((smp - s0) << 2)) : "memory");
+          rrow[slot] = p.sample_map ? kd * p.rows_per_sample + (mm - smp * p.rows_per_sample) : m;
+          const float* src = xbase + (long long)rrow[slot] * xld + row_n(r);
+          const float* rsrc = rmb + (p.rowmask ? smp : 0);
           asm volatile("global_load_dwordx4 %0, %3, off\n\tglobal_load_dwordx4 %1, %3, off offset:16\n\tglobal_load_dword %2, %4, off"
                        : "=&v"(xa[slot]), "=&v"(xb[slot]), "=&v"(rmv[slot]) : "v"(src), "v"(rsrc) : "memory");
         };
@@ -499,6 +540,7 @@ __global__ __launch_bounds__(kThreads) void gemm_p8_kernel(GemmArgs p, int ntm, 
 #pragma unroll
           for (int c = 0; c < 4; ++c) { row.x[c] = xa[slot][c]; row.x[4 + c] = xb[slot][c]; }
           row.rm = rmv[slot];
+          row.row = rrow[slot];
           epilogue8<EPI, COPY ? 2 : 0>(p, row_m(r), row_n(r), v, cs, cols, row);
         };
         using W2 = std::integral_constant<int, 2 * kStores + 6>;     // S(r-2) L(r+1) S(r-1) L(r+2) behind L(r)
@@ -571,6 +613,10 @@ __global__ __launch_bounds__(kThreads) void gemm_p8_kernel(GemmArgs p, int ntm, 
           for (int nf = 0; nf < 2; ++nf)
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc[q][mf][nf][r] = 0.f;
+      P8_STAMP_AT(2);
+#ifdef P8_STAMP
+      ++stamp_tile;
+#endif
       c_k = 0;
       c_tile += gridDim.x;
       if (c_tile < ntiles) decode(c_tile, ctm, ctn);
@@ -616,6 +662,12 @@ int launch_p8(const GemmArgs& p, hipStream_t s, int num_cu) {
 
 }  // namespace
 
+#ifdef P8_STAMP
+extern "C" int memhip_debug_p8_stamps(unsigned long long* host_out) {
+  return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_p8_stamps), sizeof(unsigned long long) * 256 * 32) == hipSuccess ? 0 : -1;
+}
+#endif
+
 namespace memhip {
 
 static int p8_num_cu() { return usable_cus(); }
@@ -627,7 +679,9 @@ static bool p8_fits(const GemmArgs& p) {
   const int min_n = opt(OPT_GEMM_P8_MIN_N);
   const bool wide = p.N >= min_n;
   // (the residual epilogue of the 256-row kernel finds a row's sample without an integer division: rows below 2^21)
-  const bool rows_ok = !p.rowmask || (long long)p.M + p.m_base < (1 << 21);
+  // (a 256-row tile touches at most four samples of a sample map: rows_per_sample >= 86)
+  const bool rows_ok = (!(p.rowmask || p.sample_map) || (long long)p.M + p.m_base < (1 << 21)) &&
+                       (!p.sample_map || p.rows_per_sample >= 86);
   return p.M >= 4096 && wide && p.N % BN == 0 && p.K % (2 * BK) == 0 && vec && rows_ok;
 }
 
@@ -645,8 +699,12 @@ int gemm_p8_split_rows(const GemmArgs& p) {
 }
 
 // Returns MEMHIP_EUNSUPPORTED when the shape does not fit this structure (caller falls back).
+int gemm_p8_half_dispatch(const GemmArgs& p, hipStream_t s);
 int gemm_p8_dispatch(const GemmArgs& p, hipStream_t s) {
   if (!p8_fits(p) || p.M % BM != 0) return MEMHIP_EUNSUPPORTED;   // whole 256-row tiles only (no row guard in the epilogue)
+#ifdef P8_FORCE_HALF      // measurement build: every row on the 128-row form of the kernel
+  { const int rc = gemm_p8_half_dispatch(p, s); if (rc != MEMHIP_EUNSUPPORTED) return rc; }
+#endif
   const int num_cu = p8_num_cu();
   if (!num_cu) return MEMHIP_EUNSUPPORTED;
   switch (p.epilogue) {

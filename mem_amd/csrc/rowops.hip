@@ -185,7 +185,9 @@ __global__ __launch_bounds__(256) void branch_bwd_kernel(const float* __restrict
                                                          const float* __restrict__ rowmask, float keep,
                                                          int rps, int M, int D, __bf16* __restrict__ dyo,
                                                          long long lddy, float* __restrict__ dgamma,
-                                                         float* __restrict__ dbias) {
+                                                         float* __restrict__ dbias, const int* __restrict__ out_map) {
+  // out_map (work-skipping stochastic depth): sample -> index of the sample among the KEPT ones, or -1.  The rows of a
+  // dropped sample are neither read nor written; kept rows land at their compact position and are scaled by 1 / keep.
   extern __shared__ float red[];   // [4][2][D]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nch = D >> 2;
@@ -204,12 +206,19 @@ __global__ __launch_bounds__(256) void branch_bwd_kernel(const float* __restrict
     float4 dv[2][NCH];
     bf16x4 yv[2][NCH];
     float kk[2];
+    long long mo[2];                                       // output row (-1: nothing to do for this row)
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       const int m = m0 + u * stride;
       const int mc = m < M ? m : M - 1;
       const float4* dr = reinterpret_cast<const float4*>(dx + (long long)mc * lddx);
       kk[u] = rowmask ? rowmask[mc / rps] : 1.f;
+      mo[u] = m < M ? m : -1;
+      if (out_map && m < M) {
+        const int smp = mc / rps, co = out_map[smp];
+        mo[u] = co < 0 ? -1 : (long long)co * rps + (mc - smp * rps);
+      }
+      if (mo[u] < 0) continue;
 #pragma unroll
       for (int c = 0; c < NCH; ++c) {
         const int i = lane + c * 64;
@@ -221,16 +230,15 @@ __global__ __launch_bounds__(256) void branch_bwd_kernel(const float* __restrict
     }
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-      const int m = m0 + u * stride;
-      if (m >= M) break;
-      bf16x4* orow = reinterpret_cast<bf16x4*>(dyo + (long long)m * lddy);
+      if (mo[u] < 0) continue;
+      bf16x4* orow = reinterpret_cast<bf16x4*>(dyo + mo[u] * lddy);
       const float k = kk[u];
 #pragma unroll
       for (int c = 0; c < NCH; ++c) {
         const int i = lane + c * 64;
         if (i < nch) {
           float4 d = dv[u][c];
-          if (rowmask) {                       // (dx * mask) / keep: reciprocal + one Newton step = the IEEE quotient
+          if (rowmask || out_map) {            // (dx * mask) / keep: reciprocal + one Newton step = the IEEE quotient
             d.x = div_newton(d.x * k, keep, rk); d.y = div_newton(d.y * k, keep, rk);
             d.z = div_newton(d.z * k, keep, rk); d.w = div_newton(d.w * k, keep, rk);
           }
@@ -281,7 +289,12 @@ __global__ __launch_bounds__(256) void ln_bwd_branch_kernel(const __bf16* __rest
                                                             const __bf16* __restrict__ yb, long long ldyb,
                                                             const float* __restrict__ gb, const float* __restrict__ rowmask,
                                                             float keep, int rps, __bf16* __restrict__ dyo, long long lddyo,
-                                                            float* __restrict__ dgb, float* __restrict__ dbiasb) {
+                                                            float* __restrict__ dgb, float* __restrict__ dbiasb,
+                                                            const int* __restrict__ in_map, const int* __restrict__ out_map) {
+  // Work-skipping stochastic depth: r runs over the rows of the residual stream (x, dres).  in_map: sample -> its index
+  // among the samples the LayerNorm'ed branch KEPT (dy, mean, rstd hold those samples only), -1: that branch skipped the
+  // sample, its rows get no LayerNorm gradient.  out_map: the same for the branch whose output gradient is produced
+  // (dyo holds the kept samples only, scaled by 1 / keep), -1: no output row.  NULL = identity.
   extern __shared__ float red[];   // [4][4][D]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nch = D >> 2;
@@ -298,17 +311,27 @@ __global__ __launch_bounds__(256) void ln_bwd_branch_kernel(const __bf16* __rest
   const int rstride = gridDim.x * 4;
   float4 xn[NCH], pn[NCH];
   bf16x4 dn[NCH], yn[HAS_Y ? NCH : 1];
+  long long rin_n = 0, rout_n = 0;                 // compact rows of the row whose loads are in flight (-1: not taking part)
   auto load_row = [&](int r) {
+    rin_n = r; rout_n = r;
+    if (in_map || out_map) {
+      const int smp = r / rps, off = r - smp * rps;
+      if (in_map) { const int ci = in_map[smp]; rin_n = ci < 0 ? -1 : (long long)ci * rps + off; }
+      if (out_map) { const int co = out_map[smp]; rout_n = co < 0 ? -1 : (long long)co * rps + off; }
+    }
+    if (rin_n < 0 && rout_n < 0) return;
     const float4* xr = reinterpret_cast<const float4*>(x + (long long)r * ldx);
-    const bf16x4* dyr = reinterpret_cast<const bf16x4*>(dy + (long long)r * lddy);
+    const bf16x4* dyr = reinterpret_cast<const bf16x4*>(dy + (rin_n < 0 ? 0 : rin_n) * lddy);
     const float4* o = reinterpret_cast<const float4*>(dres + (long long)r * lddres);
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
       const int i = lane + c * 64;
       if (i < nch) {
         pn[c] = o[i];
-        xn[c] = xr[i];
-        dn[c] = dyr[i];
+        if (rin_n >= 0) {
+          xn[c] = xr[i];
+          dn[c] = dyr[i];
+        }
         if constexpr (HAS_Y) yn[c] = reinterpret_cast<const bf16x4*>(yb + (long long)r * ldyb)[i];
       }
     }
@@ -316,8 +339,13 @@ __global__ __launch_bounds__(256) void ln_bwd_branch_kernel(const __bf16* __rest
   int r = blockIdx.x * 4 + wave;
   if (r < R) load_row(r);
   for (; r < R; r += rstride) {
+    const long long rin = rin_n, rout = rout_n;
+    if (rin < 0 && rout < 0) {                     // dropped by both branches: the row of dres stays as it is
+      if (r + rstride < R) load_row(r + rstride);
+      continue;
+    }
     float4* o = reinterpret_cast<float4*>(dres + (long long)r * lddres);
-    const float mu = mean[r], rs = rstd[r];
+    const float mu = rin >= 0 ? mean[rin] : 0.f, rs = rin >= 0 ? rstd[rin] : 0.f;
     const float km = rowmask ? rowmask[r / rps] : 1.f;
     float4 xh[NCH], gg[NCH], prev[NCH];
     bf16x4 yv[HAS_Y ? NCH : 1];
@@ -328,6 +356,10 @@ __global__ __launch_bounds__(256) void ln_bwd_branch_kernel(const __bf16* __rest
       if (i < nch) {
         prev[c] = pn[c];
         if constexpr (HAS_Y) yv[c] = yn[c];
+        if (rin < 0) {                             // no LayerNorm gradient for this row (rs = 0 below: d = prev)
+          xh[c] = gg[c] = float4{0.f, 0.f, 0.f, 0.f};
+          continue;
+        }
         const float4 xv = xn[c];
         const bf16x4 d4 = dn[c];
         const float d0 = (float)d4[0], d1 = (float)d4[1], d2 = (float)d4[2], d3 = (float)d4[3];
@@ -342,15 +374,16 @@ __global__ __launch_bounds__(256) void ln_bwd_branch_kernel(const __bf16* __rest
     }
     if (r + rstride < R) load_row(r + rstride);
     const float m1 = wsum(s1) / (float)D, m2 = wsum(s2) / (float)D;
-    bf16x4* orow = reinterpret_cast<bf16x4*>(dyo + (long long)r * lddyo);
+    bf16x4* orow = reinterpret_cast<bf16x4*>(dyo + (rout < 0 ? 0 : rout) * lddyo);
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
       const int i = lane + c * 64;
       if (i < nch) {
         float4 d{prev[c].x + rs * (gg[c].x - m1 - xh[c].x * m2), prev[c].y + rs * (gg[c].y - m1 - xh[c].y * m2),
                  prev[c].z + rs * (gg[c].z - m1 - xh[c].z * m2), prev[c].w + rs * (gg[c].w - m1 - xh[c].w * m2)};
-        o[i] = d;
-        if (rowmask) {
+        if (rin >= 0) o[i] = d;
+        if (rout < 0) continue;
+        if (rowmask || out_map) {
           d.x = div_newton(d.x * km, keep, rk); d.y = div_newton(d.y * km, keep, rk);
           d.z = div_newton(d.z * km, keep, rk); d.w = div_newton(d.w * km, keep, rk);
         }
@@ -591,11 +624,12 @@ extern "C" int memhip_layernorm_bwd(const void* dy, int64_t lddy, const float* x
   return check_launch("layernorm_bwd");
 }
 
-extern "C" int memhip_branch_bwd(const float* dx, int64_t lddx, const void* y, int64_t ldy,
-                                 const float* gamma, const float* rowmask, float keep_prob,
-                                 int rows_per_sample, int M, int D, void* dy, int64_t lddy,
-                                 float* dgamma, float* dbias, memhip_stream_t stream) {
+extern "C" int memhip_branch_bwd_map(const float* dx, int64_t lddx, const void* y, int64_t ldy,
+                                     const float* gamma, const float* rowmask, float keep_prob,
+                                     int rows_per_sample, int M, int D, void* dy, int64_t lddy,
+                                     float* dgamma, float* dbias, const int32_t* out_map, memhip_stream_t stream) {
   MEMHIP_REQUIRE(M >= 0 && D > 0 && D % 4 == 0, "branch_bwd: bad M=%d D=%d", M, D);
+  MEMHIP_REQUIRE(!out_map || (!rowmask && !y && rows_per_sample > 0), "branch_bwd: out_map excludes rowmask / y");
   if (M == 0) return MEMHIP_OK;
   MEMHIP_REQUIRE(dx && dy, "branch_bwd: null pointer");
   MEMHIP_REQUIRE(y || !dgamma, "branch_bwd: dgamma needs y (or use memhip_layerscale_grad)");
@@ -606,7 +640,8 @@ extern "C" int memhip_branch_bwd(const float* dx, int64_t lddx, const void* y, i
 #define BRB_LAUNCH(N)                                                                                    \
   hipLaunchKernelGGL(branch_bwd_kernel<N>, dim3(grid), dim3(256), (size_t)8 * D * sizeof(float), as_stream(stream), \
                      dx, (long long)lddx, (const __bf16*)y, (long long)ldy, gamma, rowmask, keep_prob,    \
-                     rows_per_sample > 0 ? rows_per_sample : 1, M, D, (__bf16*)dy, (long long)lddy, dgamma, dbias)
+                     rows_per_sample > 0 ? rows_per_sample : 1, M, D, (__bf16*)dy, (long long)lddy, dgamma, dbias, \
+                     (const int*)out_map)
   const int nchl = cdiv(D / 4, 64);
   if (nchl <= 1) BRB_LAUNCH(1);
   else if (nchl <= 2) BRB_LAUNCH(2);
@@ -615,6 +650,14 @@ extern "C" int memhip_branch_bwd(const float* dx, int64_t lddx, const void* y, i
   else BRB_LAUNCH(8);
 #undef BRB_LAUNCH
   return check_launch("branch_bwd");
+}
+
+extern "C" int memhip_branch_bwd(const float* dx, int64_t lddx, const void* y, int64_t ldy,
+                                 const float* gamma, const float* rowmask, float keep_prob,
+                                 int rows_per_sample, int M, int D, void* dy, int64_t lddy,
+                                 float* dgamma, float* dbias, memhip_stream_t stream) {
+  return memhip_branch_bwd_map(dx, lddx, y, ldy, gamma, rowmask, keep_prob, rows_per_sample, M, D, dy, lddy, dgamma, dbias,
+                               nullptr, stream);
 }
 
 extern "C" int memhip_embed_bwd(const float* dx, int64_t lddx, const uint8_t* mask, int B, int L, int D,
@@ -650,13 +693,16 @@ extern "C" int memhip_cross_entropy(void* logits, int64_t ld, const int64_t* lab
   return check_launch("cross_entropy");
 }
 
-extern "C" int memhip_layernorm_bwd_branch(const void* dy, int64_t lddy, const float* x, int64_t ldx, int R, int D,
-                                           const float* gamma, const float* mean, const float* rstd, float* dres,
-                                           int64_t lddres, float* dgamma, float* dbeta, const void* y_branch,
-                                           int64_t ldyb, const float* gamma_branch, const float* rowmask,
-                                           float keep_prob, int rows_per_sample, void* dy_branch, int64_t lddyb,
-                                           float* dgamma_branch, float* dbias_branch, memhip_stream_t stream) {
+extern "C" int memhip_layernorm_bwd_branch_map(const void* dy, int64_t lddy, const float* x, int64_t ldx, int R, int D,
+                                               const float* gamma, const float* mean, const float* rstd, float* dres,
+                                               int64_t lddres, float* dgamma, float* dbeta, const void* y_branch,
+                                               int64_t ldyb, const float* gamma_branch, const float* rowmask,
+                                               float keep_prob, int rows_per_sample, void* dy_branch, int64_t lddyb,
+                                               float* dgamma_branch, float* dbias_branch, const int32_t* in_map,
+                                               const int32_t* out_map, memhip_stream_t stream) {
   MEMHIP_REQUIRE(R >= 0 && D > 0 && D % 4 == 0 && D <= 64 * 4 * 4, "layernorm_bwd_branch: D=%d unsupported (<= 1024)", D);
+  MEMHIP_REQUIRE(!(in_map || out_map) || (!rowmask && !y_branch && rows_per_sample > 0),
+                 "layernorm_bwd_branch: sample maps exclude rowmask / y_branch");
   if (R == 0) return MEMHIP_OK;
   MEMHIP_REQUIRE(dy && x && gamma && mean && rstd && dres && dgamma && dbeta && dy_branch,
                  "layernorm_bwd_branch: null pointer");
@@ -672,7 +718,8 @@ extern "C" int memhip_layernorm_bwd_branch(const void* dy, int64_t lddy, const f
                      as_stream(stream), (const __bf16*)dy, (long long)lddy, x, (long long)ldx, R, D, gamma, mean, \
                      rstd, dres, (long long)lddres, dgamma, dbeta, (const __bf16*)y_branch, (long long)ldyb, \
                      gamma_branch, rowmask, keep_prob, rows_per_sample > 0 ? rows_per_sample : 1,         \
-                     (__bf16*)dy_branch, (long long)lddyb, dgamma_branch, dbias_branch)
+                     (__bf16*)dy_branch, (long long)lddyb, dgamma_branch, dbias_branch, (const int*)in_map, \
+                     (const int*)out_map)
   const int nchl = cdiv(D / 4, 64);
   if (nchl <= 1) LBB_LAUNCH(1);
   else if (nchl <= 2) LBB_LAUNCH(2);
@@ -681,6 +728,17 @@ extern "C" int memhip_layernorm_bwd_branch(const void* dy, int64_t lddy, const f
 #undef LBB_LAUNCH
 #undef LBB_LAUNCH2
   return check_launch("layernorm_bwd_branch");
+}
+
+extern "C" int memhip_layernorm_bwd_branch(const void* dy, int64_t lddy, const float* x, int64_t ldx, int R, int D,
+                                           const float* gamma, const float* mean, const float* rstd, float* dres,
+                                           int64_t lddres, float* dgamma, float* dbeta, const void* y_branch,
+                                           int64_t ldyb, const float* gamma_branch, const float* rowmask,
+                                           float keep_prob, int rows_per_sample, void* dy_branch, int64_t lddyb,
+                                           float* dgamma_branch, float* dbias_branch, memhip_stream_t stream) {
+  return memhip_layernorm_bwd_branch_map(dy, lddy, x, ldx, R, D, gamma, mean, rstd, dres, lddres, dgamma, dbeta, y_branch,
+                                         ldyb, gamma_branch, rowmask, keep_prob, rows_per_sample, dy_branch, lddyb,
+                                         dgamma_branch, dbias_branch, nullptr, nullptr, stream);
 }
 
 extern "C" int memhip_layerscale_grad(const void* W_bf16, int64_t ldw, const float* dW, int64_t lddw, const float* bias,

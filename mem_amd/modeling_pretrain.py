@@ -181,6 +181,10 @@ class VisionTransformerForMaskedImageModeling(nn.Module):
         keep = getattr(self, "_dp_keep", None)
         if keep is None or keep[0] != probs:          # the static (1 - p) column lives on the device once
             keep = self._dp_keep = (probs, (1.0 - torch.tensor(probs, device=eng.dev)).view(-1, 1))
+        if getattr(eng, "dp_skip", False):
+            # work-skipping stochastic depth (ViTEngine.dp_skip): the engine sizes its launches by the number of kept samples,
+            # so the masks are drawn on the HOST (torch's CPU generator; timm draws on the device: another stream, same law)
+            return torch.floor((1.0 - torch.tensor(probs)).view(-1, 1) + torch.rand((2 * eng.depth, B)))
         u = torch.rand((2 * eng.depth, B), device=eng.dev)
         return torch.floor(keep[1] + u).contiguous()
 

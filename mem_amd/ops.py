@@ -20,7 +20,7 @@ class GemmArgs(C.Structure):
                 ("bias", vp), ("vec1", vp), ("resid", vp), ("ldr", i64),
                 ("aux", vp), ("ldaux", i64), ("rowmask", vp), ("keep_prob", f32),
                 ("colscale", f32), ("colscale_n", i32), ("rows_per_sample", i32), ("accumulate", i32),
-                ("colsum", vp)]
+                ("colsum", vp), ("sample_map", vp)]
 
 
 declare({"memhip_gemm_bf16_nt": (i32, [C.POINTER(GemmArgs), vp])})
@@ -44,7 +44,7 @@ def _timer_event():
 
 def gemm_nt(A, B, M, N, K, epi, out0=None, out1=None, bias=None, vec1=None, resid=None, aux=None,
             rowmask=None, keep_prob=1.0, colscale=1.0, colscale_n=0, rows_per_sample=1, accumulate=False, colsum=None,
-            lda=None, ldb=None, ldo0=None, ldo1=None, ldr=None, ldaux=None):
+            lda=None, ldb=None, ldo0=None, ldo1=None, ldr=None, ldaux=None, sample_map=None):
     """C[M,N] = A[M,K] @ B[N,K]^T with a fused epilogue.  A/B bf16, row-major, K contiguous."""
     a = GemmArgs()
     a.A, a.B = _p(A), _p(B)
@@ -63,6 +63,7 @@ def gemm_nt(A, B, M, N, K, epi, out0=None, out1=None, bias=None, vec1=None, resi
     a.keep_prob, a.colscale, a.colscale_n = keep_prob, colscale, colscale_n
     a.rows_per_sample, a.accumulate = rows_per_sample, int(accumulate)
     a.colsum = _p(colsum)
+    a.sample_map = _p(sample_map)
     if GEMM_TIMER is None:
         check(lib.memhip_gemm_bf16_nt(C.byref(a), stream_ptr()), "gemm_bf16_nt")
     else:
@@ -81,6 +82,9 @@ declare({
                                           i32, vp, i64, vp, vp, vp]),
     "memhip_layerscale_grad": (i32, [vp, i64, vp, i64, vp, vp, vp, i32, i32, vp, vp]),
     "memhip_branch_bwd": (i32, [vp, i64, vp, i64, vp, vp, f32, i32, i32, i32, vp, i64, vp, vp, vp]),
+    "memhip_branch_bwd_map": (i32, [vp, i64, vp, i64, vp, vp, f32, i32, i32, i32, vp, i64, vp, vp, vp, vp]),
+    "memhip_layernorm_bwd_branch_map": (i32, [vp, i64, vp, i64, i32, i32, vp, vp, vp, vp, i64, vp, vp, vp, i64, vp, vp, f32,
+                                              i32, vp, i64, vp, vp, vp, vp, vp]),
     "memhip_embed_bwd": (i32, [vp, i64, vp, i32, i32, i32, vp, i64, vp, vp, vp]),
     "memhip_cross_entropy": (i32, [vp, i64, vp, i32, i32, f32, vp, vp, i32, vp, vp]),
     "memhip_attn_tokens_padded": (i32, [i32]),
@@ -120,13 +124,14 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dres, dgamma, dbeta, R, D, accumulat
 
 
 def layernorm_bwd_branch(dy, x, gamma, mean, rstd, dres, dgamma, dbeta, R, D, y_b, gamma_b, dy_b, dgamma_b, dbias_b,
-                         rowmask=None, keep_prob=1.0, rows_per_sample=1):
-    """layernorm_bwd(accumulate=True) + the branch_bwd that reads the updated dres, in one pass."""
-    check(lib.memhip_layernorm_bwd_branch(ptr(dy), dy.stride(0), ptr(x), x.stride(0), R, D, ptr(gamma), ptr(mean),
-                                          ptr(rstd), ptr(dres), dres.stride(0), ptr(dgamma), ptr(dbeta), ptr(y_b),
-                                          y_b.stride(0) if y_b is not None else 0, ptr(gamma_b), ptr(rowmask), keep_prob, rows_per_sample,
-                                          ptr(dy_b), dy_b.stride(0), ptr(dgamma_b), ptr(dbias_b), stream_ptr()),
-          "layernorm_bwd_branch")
+                         rowmask=None, keep_prob=1.0, rows_per_sample=1, in_map=None, out_map=None):
+    """layernorm_bwd(accumulate=True) + the branch_bwd that reads the updated dres, in one pass.  in_map / out_map (i32
+    [samples], -1 = dropped): work-skipping stochastic depth, dy / mean / rstd and dy_b then hold kept samples only."""
+    check(lib.memhip_layernorm_bwd_branch_map(ptr(dy), dy.stride(0), ptr(x), x.stride(0), R, D, ptr(gamma), ptr(mean),
+                                              ptr(rstd), ptr(dres), dres.stride(0), ptr(dgamma), ptr(dbeta), ptr(y_b),
+                                              y_b.stride(0) if y_b is not None else 0, ptr(gamma_b), ptr(rowmask), keep_prob,
+                                              rows_per_sample, ptr(dy_b), dy_b.stride(0), ptr(dgamma_b), ptr(dbias_b),
+                                              ptr(in_map), ptr(out_map), stream_ptr()), "layernorm_bwd_branch")
 
 
 def layerscale_grad(W16, dW, bias, dbias, gamma, N, K, dgamma):
@@ -135,10 +140,10 @@ def layerscale_grad(W16, dW, bias, dbias, gamma, N, K, dgamma):
                                      N, K, ptr(dgamma), stream_ptr()), "layerscale_grad")
 
 
-def branch_bwd(dx, y, gamma, dy, dgamma, dbias, M, D, rowmask=None, keep_prob=1.0, rows_per_sample=1):
-    check(lib.memhip_branch_bwd(ptr(dx), dx.stride(0), ptr(y), y.stride(0) if y is not None else 0, ptr(gamma), ptr(rowmask), keep_prob,
-                                rows_per_sample, M, D, ptr(dy), dy.stride(0), ptr(dgamma), ptr(dbias),
-                                stream_ptr()), "branch_bwd")
+def branch_bwd(dx, y, gamma, dy, dgamma, dbias, M, D, rowmask=None, keep_prob=1.0, rows_per_sample=1, out_map=None):
+    check(lib.memhip_branch_bwd_map(ptr(dx), dx.stride(0), ptr(y), y.stride(0) if y is not None else 0, ptr(gamma), ptr(rowmask),
+                                    keep_prob, rows_per_sample, M, D, ptr(dy), dy.stride(0), ptr(dgamma), ptr(dbias),
+                                    ptr(out_map), stream_ptr()), "branch_bwd")
 
 
 def gemv_acc(W, N, K, x, y, x_acc=None, zero=None):

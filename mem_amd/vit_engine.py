@@ -84,6 +84,12 @@ class ViTEngine:
                                           # kernels) one stream is 0.2-0.5 ms faster.  Kept as an option (bench --fwd-split).
         self._side = None
         self._ev_pool, self._ev_i = [], 0
+        # Stochastic depth as WORK SKIPPING (timm drop_path zeroes a dropped sample's branch output: nothing of that branch
+        # has to be computed, forward or backward).  Per block and branch the kept samples are processed as a compact batch:
+        # LayerNorm gathers their rows, the GEMMs / attention run on kept * T rows, the residual epilogue and the backward
+        # row kernels address the residual stream through a sample map.  ~5 % of all block work at drop_path 0.1.
+        self.dp_skip = True
+        self._dp_stage = None
 
     # ------------------------------------------------------------------ parameter packing
     def _pack_parameters(self):
@@ -276,6 +282,52 @@ class ViTEngine:
             return self.G(f"blocks.{i}.attn.relative_position_bias_table")
         return None
 
+    # ------------------------------------------------------------------ stochastic depth: per-step work plan
+    def _dp_plan(self, dp_masks, B):
+        """dp_masks [2*depth, B] (0/1; host tensor / ndarray preferred, a device tensor costs one sync) -> plan dict or
+        None.  Per row j of the mask with a drop probability: the kept samples (count on the host: it sizes the launches),
+        on the device kidx[j] (compact -> sample, padded with zeros for the GEMM epilogue's read-ahead), cmap[j]
+        (sample -> compact or -1), the dropped samples, and ridx[j] (compact row -> row of the residual stream)."""
+        import numpy as np
+        if dp_masks is None or not self.dp_skip:
+            return None
+        probs = [float(b.drop_prob) for b in self.model.blocks for _ in range(2)]
+        if max(probs) == 0.0:
+            return None
+        mk = dp_masks.detach().cpu().numpy() if isinstance(dp_masks, torch.Tensor) else np.asarray(dp_masks)
+        mk = mk.reshape(2 * self.depth, B) != 0
+        J, T = 2 * self.depth, self.T
+        W = 3 * B + 256                                      # per row: kidx [B + 256] | cmap [B] | dropped [B]
+        host = np.zeros((J, W), dtype=np.int32)
+        host[:, B + 256:2 * B + 256] = -1
+        kept_n = []
+        for j in range(J):
+            if probs[j] == 0.0:
+                kept_n.append(None)                          # branch never drops: plain path
+                continue
+            k = np.flatnonzero(mk[j]).astype(np.int32)
+            d = np.flatnonzero(~mk[j]).astype(np.int32)
+            host[j, :len(k)] = k
+            host[j, B + 256 + k] = np.arange(len(k), dtype=np.int32)
+            host[j, 2 * B + 256:2 * B + 256 + len(d)] = d
+            kept_n.append(len(k))
+        if self._dp_stage is None or self._dp_stage_w != J * W:
+            from .utils import HostStager
+            self._dp_stage, self._dp_stage_w = HostStager(J * W * 4, self.dev), J * W
+            self._dp_ar = torch.arange(T, dtype=torch.int32, device=self.dev)
+        dev = self._dp_stage.put(host).view(torch.int32).view(J, W)
+        # compact row -> residual-stream row, all branches in one launch (rows past kept * T are never read)
+        ridx = (dev[:, :B, None] * T + self._dp_ar[None, None, :]).view(J, B * T)
+        return dict(n=kept_n, kidx=dev[:, :B + 256], cmap=dev[:, B + 256:2 * B + 256], drop=dev[:, 2 * B + 256:], ridx=ridx, B=B)
+
+    @staticmethod
+    def _copy_dropped(plan, j, src, dst, B):
+        """Rows of the samples branch j dropped pass through unchanged: dst[sample] = src[sample]."""
+        nd = B - plan["n"][j]
+        if nd > 0:
+            d = plan["drop"][j, :nd].long()
+            dst.view(B, -1).index_copy_(0, d, src.view(B, -1).index_select(0, d))
+
     # ------------------------------------------------------------------ forward
     def forward(self, x, mask_u8, rows_idx, labels=None, dp_masks=None, all_tokens=False, labels_event=None):
         """x f32 [B,C,H,W]; mask_u8 u8 [B*L]; rows_idx i32 [Mm] (token rows b*T+1+p of the masked
@@ -334,6 +386,11 @@ class ViTEngine:
         g1 = self.P(pre + "gamma_1") if (pre + "gamma_1") in self.segs else None
         g2 = self.P(pre + "gamma_2") if (pre + "gamma_2") in self.segs else None
         h1, qkv, ao, h2, hpre, aa = (a[k][r0:r1] for k in ("h1", "qkv", "ao", "h2", "hpre", "a"))
+        plan = self.cur.get("plan")
+        if plan is not None and (plan["n"][2 * i] is not None or plan["n"][2 * i + 1] is not None):
+            assert b0 == 0 and b1 == plan["B"], "stochastic-depth work skipping runs the whole batch on one stream"
+            self._block_fwd_skip(i, plan, a, xin, xmid, xout, g1, g2, table, keep)
+            return
         ops.layernorm_fwd(xin, self.P(pre + "norm1.weight"), self.P(pre + "norm1.bias"), h1, a["mean1"][r0:r1],
                           a["rstd1"][r0:r1], M, D)
         ops.gemm_nt(h1, self.W16(pre + "attn.qkv.weight", 3 * D, D), M, 3 * D, D, ops.EPI_BIAS_BF16,
@@ -350,6 +407,43 @@ class ViTEngine:
                     bias=self.P(pre + "mlp.fc2.bias"), vec1=g2, resid=xout, aux=xmid, ldaux=D,
                     rowmask=dp_masks[2 * i + 1][b0:b1] if use_dp else None, keep_prob=keep, rows_per_sample=T)
 
+    def _block_fwd_skip(self, i, plan, a, xin, xmid, xout, g1, g2, table, keep):
+        """Block i with the dropped samples of each branch skipped (see dp_skip): compact activations."""
+        D, Hd, T, B = self.D, self.hidden, self.T, plan["B"]
+        pre = f"blocks.{i}."
+        ja, jm = 2 * i, 2 * i + 1
+        na = B if plan["n"][ja] is None else plan["n"][ja]
+        nm = B if plan["n"][jm] is None else plan["n"][jm]
+        # -- attention branch on the na kept samples
+        if plan["n"][ja] is not None:
+            self._copy_dropped(plan, ja, xin, xmid, B)
+        if na > 0:
+            M1 = na * T
+            ridx = plan["ridx"][ja] if plan["n"][ja] is not None else None
+            smap = plan["kidx"][ja] if plan["n"][ja] is not None else None
+            ops.layernorm_fwd(xin, self.P(pre + "norm1.weight"), self.P(pre + "norm1.bias"), a["h1"], a["mean1"], a["rstd1"],
+                              M1, D, row_idx=ridx)
+            ops.gemm_nt(a["h1"], self.W16(pre + "attn.qkv.weight", 3 * D, D), M1, 3 * D, D, ops.EPI_BIAS_BF16,
+                        out0=a["qkv"], bias=self.P(pre + "attn.qkvbias3"), colscale=self.scale, colscale_n=D)
+            ops.attn_fwd(a["qkv"], na, T, D, self.heads, table, self.window, a["ao"], a["lse"])
+            ops.gemm_nt(a["ao"], self.W16(pre + "attn.proj.weight", D, D), M1, D, D, ops.EPI_RESIDUAL, out0=None,
+                        bias=self.P(pre + "attn.proj.bias"), vec1=g1, resid=xmid, aux=xin, ldaux=D,
+                        keep_prob=keep if smap is not None else 1.0, rows_per_sample=T, sample_map=smap)
+        # -- MLP branch on the nm kept samples
+        if plan["n"][jm] is not None:
+            self._copy_dropped(plan, jm, xmid, xout, B)
+        if nm > 0:
+            M2 = nm * T
+            ridx = plan["ridx"][jm] if plan["n"][jm] is not None else None
+            smap = plan["kidx"][jm] if plan["n"][jm] is not None else None
+            ops.layernorm_fwd(xmid, self.P(pre + "norm2.weight"), self.P(pre + "norm2.bias"), a["h2"], a["mean2"], a["rstd2"],
+                              M2, D, row_idx=ridx)
+            ops.gemm_nt(a["h2"], self.W16(pre + "mlp.fc1.weight", Hd, D), M2, Hd, D, self.epi_gelu, out0=a["hpre"],
+                        out1=a["a"], bias=self.P(pre + "mlp.fc1.bias"))
+            ops.gemm_nt(a["a"], self.W16(pre + "mlp.fc2.weight", D, Hd), M2, D, Hd, ops.EPI_RESIDUAL, out0=None,
+                        bias=self.P(pre + "mlp.fc2.bias"), vec1=g2, resid=xout, aux=xmid, ldaux=D,
+                        keep_prob=keep if smap is not None else 1.0, rows_per_sample=T, sample_map=smap)
+
     def forward_trunk(self, x, mask_u8=None, dp_masks=None):
         """Patch embedding (+ mask-token blend, + abs. position embedding) and the blocks: x f32 [B,C,H,W] ->
         the fp32 residual stream after the last block, [B*T, D] (engine-owned, valid until the next forward)."""
@@ -364,7 +458,10 @@ class ViTEngine:
             mask_u8 = self.zero_mask[: B * self.L]
         D, Hd, T, L = self.D, self.hidden, self.T, self.L
         M = B * T
-        self.cur = dict(B=B, M=M, Mm=0, mask=mask_u8, rows=None, dp=dp_masks, labels=None)
+        plan = self._dp_plan(dp_masks, B)
+        if plan is not None:
+            dp_masks = None                                  # the plan replaces the keep masks everywhere below
+        self.cur = dict(B=B, M=M, Mm=0, mask=mask_u8, rows=None, dp=dp_masks, labels=None, plan=plan)
         if self.head_kind == "cls" and not self.accumulate_grads:
             self.flat_g[: self.head_end].zero_()        # the torch tail accumulates its gradients here before backward_trunk
         ops.im2col(x, B, self.C, self.H, self.W, self.ph, self.pw, self.patches)
@@ -380,7 +477,7 @@ class ViTEngine:
         # launches interleave on the CUs, so the workgroups of one launch fill the partial last round of the other and
         # the HBM-bound epilogue phase of one half runs beside the MFMA-bound main loop of the other.  Same kernels on
         # the same rows: results are identical to the single-stream order.
-        bs = self._split_point(B) if (self.fwd_two_streams and ops.GEMM_TIMER is None) else 0
+        bs = self._split_point(B) if (self.fwd_two_streams and ops.GEMM_TIMER is None and plan is None) else 0
         split = 0 < bs < B
         if split:
             if self._side is None:
@@ -504,8 +601,119 @@ class ViTEngine:
         self._side_begin()
         self._backward_trunk()
 
+    def _backward_trunk_skip(self, plan):
+        """_backward_trunk with the dropped samples of every branch skipped (dp_skip): the branch gradients dY / dY2, the
+        dgrad chain and the weight gradients run on the kept samples' rows only; the row kernels move between the compact
+        row sets and the residual-stream gradient dx through sample maps (in_map: who the LayerNorm'ed branch kept,
+        out_map: who the branch whose output gradient is produced kept)."""
+        c = self.cur
+        B, M = c["B"], c["M"]
+        D, Hd, T, L = self.D, self.hidden, self.T, self.L
+        dx = self.dx
+        if self.grad_hook:
+            self._side_join()
+            self.grad_hook(0)
+        self.bias_scr.zero_()
+        fuse = D <= 1024 and self.fuse_ln_branch
+        nk = lambda j: B if plan["n"][j] is None else plan["n"][j]               # noqa: E731  kept samples of branch j
+        cmap = lambda j: None if plan["n"][j] is None else plan["cmap"][j]       # noqa: E731
+        ridx = lambda j: None if plan["n"][j] is None else plan["ridx"][j]       # noqa: E731
+        kp = lambda j, i: (1.0 - self.model.blocks[i].drop_prob) if plan["n"][j] is not None else 1.0   # noqa: E731
+        for i in reversed(range(self.depth)):
+            pre = f"blocks.{i}."
+            a = self.act[i]
+            ja, jm = 2 * i, 2 * i + 1
+            na, nm = nk(ja), nk(jm)
+            M1, M2 = na * T, nm * T
+            xin, xmid = self.x[2 * i], self.x[2 * i + 1]
+            has_g = (pre + "gamma_1") in self.segs
+            table, dtable = self.table(i), self.dtable(i)
+            dY, dY2 = self.dY, self.dY2
+            # -- MLP branch (for every block but the last dY already came out of the fused norm1 backward of block i + 1)
+            if i == self.depth - 1 or not fuse:
+                self._before_overwrite("dY")
+                ops.branch_bwd(dx, None, self.P(pre + "gamma_2") if has_g else None, dY, None, self.G(pre + "mlp.fc2.bias"),
+                               M, D, keep_prob=kp(jm, i), rows_per_sample=T, out_map=cmap(jm))
+            if nm > 0:
+                self._before_overwrite("dbig")
+                ops.gemm_nt(dY, self.wT[i]["fc2"], M2, Hd, D, self.epi_dgelu, out0=self.dbig, aux=a["hpre"],
+                            colsum=self.G(pre + "mlp.fc1.bias"))
+
+                def wg_mlp(i=i, pre=pre, a=a, has_g=has_g, M2=M2):
+                    self._wgrad(dY, a["a"], M2, D, Hd, pre + "mlp.fc2.weight")
+                    self._side_read_done("dY")
+                    if has_g:
+                        ops.layerscale_grad(self.W16(pre + "mlp.fc2.weight", D, Hd), self.G(pre + "mlp.fc2.weight").view(D, Hd),
+                                            self.P(pre + "mlp.fc2.bias"), self.G(pre + "mlp.fc2.bias"),
+                                            self.P(pre + "gamma_2"), D, Hd, self.G(pre + "gamma_2"))
+                    self._wgrad(self.dbig, a["h2"], M2, Hd, D, pre + "mlp.fc1.weight")
+                    self._side_read_done("dbig")
+                self._on_side(wg_mlp)
+                ops.gemm_nt(self.dbig, self.wT[i]["fc1"], M2, D, Hd, ops.EPI_BIAS_BF16, out0=self.dh_small)
+            scr = self.bias_scr[i & 1]
+            if fuse:
+                # norm2 backward (rows the MLP branch kept) + attention-branch backward (rows it kept) in one pass over dx
+                self._before_overwrite("dY2")
+                ops.layernorm_bwd_branch(self.dh_small, xmid, self.P(pre + "norm2.weight"), a["mean2"], a["rstd2"], dx,
+                                         self.G(pre + "norm2.weight"), self.G(pre + "norm2.bias"), M, D, None,
+                                         self.P(pre + "gamma_1") if has_g else None, dY2, None, scr,
+                                         keep_prob=kp(ja, i), rows_per_sample=T,
+                                         in_map=cmap(jm) if cmap(jm) is not None else None, out_map=cmap(ja))
+            else:
+                if nm > 0:
+                    ops.layernorm_bwd(self.dh_small, xmid, self.P(pre + "norm2.weight"), a["mean2"], a["rstd2"], dx,
+                                      self.G(pre + "norm2.weight"), self.G(pre + "norm2.bias"), M2, D, accumulate=True,
+                                      row_idx=ridx(jm))
+                self._before_overwrite("dY2")
+                ops.branch_bwd(dx, None, self.P(pre + "gamma_1") if has_g else None, dY2, None, scr, M, D,
+                               keep_prob=kp(ja, i), rows_per_sample=T, out_map=cmap(ja))
+            # -- attention branch
+            if na > 0:
+                ops.gemm_nt(dY2, self.wT[i]["proj"], M1, D, D, ops.EPI_BIAS_BF16, out0=self.dao)
+            ops.gemv_acc(self.wT[i]["proj"], D, D, scr, self.G(pre + "attn.v_bias"),
+                         x_acc=self.G(pre + "attn.proj.bias"), zero=self.bias_scr[(i & 1) ^ 1])
+            if na > 0:
+                def wg_proj(pre=pre, a=a, has_g=has_g, M1=M1):
+                    self._wgrad(dY2, a["ao"], M1, D, D, pre + "attn.proj.weight")
+                    self._side_read_done("dY2")
+                    if has_g:
+                        ops.layerscale_grad(self.W16(pre + "attn.proj.weight", D, D), self.G(pre + "attn.proj.weight").view(D, D),
+                                            self.P(pre + "attn.proj.bias"), self.G(pre + "attn.proj.bias"),
+                                            self.P(pre + "gamma_1"), D, D, self.G(pre + "gamma_1"))
+                self._on_side(wg_proj)
+                ops.attn_delta(self.dao, a["ao"], M1, self.heads, self.delta_ws)
+                self._before_overwrite("dqkv")
+                ops.attn_bwd(a["qkv"], self.dao, a["lse"], self.delta_ws, table, self.window, na, T, D, self.heads,
+                             self.scale, self.dqkv, dtable, dq_bias=self.G(pre + "attn.q_bias"))
+
+                def wg_qkv(pre=pre, a=a, M1=M1):
+                    self._wgrad(self.dqkv, a["h1"], M1, 3 * D, D, pre + "attn.qkv.weight")
+                    self._side_read_done("dqkv")
+                self._on_side(wg_qkv)
+                ops.gemm_nt(self.dqkv, self.wT[i]["qkv"], M1, D, 3 * D, ops.EPI_BIAS_BF16, out0=self.dh_small)
+            if fuse and i > 0:
+                # norm1 backward of block i (rows its attention branch kept) + MLP-branch backward of block i - 1
+                pb = f"blocks.{i - 1}."
+                has_gb = (pb + "gamma_1") in self.segs
+                jb = 2 * (i - 1) + 1
+                self._before_overwrite("dY")
+                ops.layernorm_bwd_branch(self.dh_small, xin, self.P(pre + "norm1.weight"), a["mean1"], a["rstd1"], dx,
+                                         self.G(pre + "norm1.weight"), self.G(pre + "norm1.bias"), M, D, None,
+                                         self.P(pb + "gamma_2") if has_gb else None, dY, None, self.G(pb + "mlp.fc2.bias"),
+                                         keep_prob=kp(jb, i - 1), rows_per_sample=T, in_map=cmap(ja), out_map=cmap(jb))
+            elif na > 0:
+                ops.layernorm_bwd(self.dh_small, xin, self.P(pre + "norm1.weight"), a["mean1"], a["rstd1"], dx,
+                                  self.G(pre + "norm1.weight"), self.G(pre + "norm1.bias"), M1, D, accumulate=True,
+                                  row_idx=ridx(ja))
+            if self.grad_hook:
+                self._side_join()
+                self.grad_hook(self.depth - i)
+        self._backward_embed(c, B, M)
+
     def _backward_trunk(self):
         c = self.cur
+        if c.get("plan") is not None:
+            return self._backward_trunk_skip(c["plan"])
         B, M = c["B"], c["M"]
         D, Hd, T, L = self.D, self.hidden, self.T, self.L
         dp_masks = c["dp"]
@@ -610,6 +818,11 @@ class ViTEngine:
             if self.grad_hook:
                 self._side_join()
                 self.grad_hook(self.depth - i)
+        self._backward_embed(c, B, M)
+
+    def _backward_embed(self, c, B, M):
+        D, T, L = self.D, self.T, self.L
+        dx = self.dx
         # ---- embedding
         if self.has_pos:
             if self.accumulate_grads:

@@ -306,6 +306,48 @@ def test_drop_path_masks_vs_oracle():
         assert rel <= 4e-2, (k, rel.item())
 
 
+@pytest.mark.parametrize("fuse", [True, False])
+def test_drop_path_work_skipping_equals_masked_execution(fuse):
+    """Stochastic depth as work skipping (ViTEngine.dp_skip: every branch runs on its kept samples only, through compact
+    batches and sample maps) against the masked execution of the same step (all samples computed, dropped ones multiplied
+    by zero), at ViT-B width on the persistent 256-row GEMM kernels: same loss, same gradients (sums over fewer rows in
+    another split order: fp32 round-off only), same residual stream.  Includes a branch that keeps everything, one that
+    drops most, and a block without stochastic depth."""
+    from mem_amd.modeling_pretrain import pt_vit
+    from oracle.gen_golden import BASE, vit_inputs
+    from oracle.vit_ref import fill_by_name
+    cfg = dict(BASE, in_chans=2, depth=4, drop_path_rate=0.3)
+    B = 48
+    x, mask, labels = vit_inputs(cfg, B, 21, 98)
+    g = torch.Generator().manual_seed(5)
+    masks = (torch.rand(8, B, generator=g) > 0.25).float()
+    masks[2] = 1.0                                             # block 1, attention branch: nothing dropped this step
+    masks[5] = (torch.rand(B, generator=g) > 0.8).float()      # block 2, MLP branch: most samples dropped
+    res = {}
+    for skip in (False, True):
+        m = pt_vit(**cfg)
+        m.load_state_dict(fill_by_name(m.state_dict(), seed=1))
+        m = m.cuda().train()
+        m.engine.dp_skip = skip
+        m.engine.fuse_ln_branch = fuse
+        la = m.forward_loss(x.cuda(), mask.cuda(), labels.cuda(), drop_path_masks=masks.cuda())
+        m.backward()
+        torch.cuda.synchronize()
+        assert (m.engine.cur["plan"] is not None) == skip
+        res[skip] = (la.clone(), m.engine.flat_g.clone(), m.engine.x[2 * 4].clone(), dict(m.engine.segs))
+        del m
+    (l0, g0, x0, segs), (l1, g1, x1, _) = res[False], res[True]
+    assert torch.equal(x0, x1)                                 # forward: identical arithmetic per kept row
+    assert abs(l0[0].item() - l1[0].item()) <= 1e-6 and l0[1].item() == l1[1].item()
+    cos = torch.dot(g0, g1) / (g0.norm() * g1.norm())
+    assert cos.item() >= 0.99999, cos.item()
+    for name, (o, k) in segs.items():
+        a, b = g0[o:o + k], g1[o:o + k]
+        if float(a.norm()) > 0:
+            rel = float((a - b).norm() / a.norm())
+            assert rel <= 2e-3, (name, rel)                    # bf16 column-sum / split-order noise
+
+
 @pytest.mark.parametrize("C", [3, 2])
 def test_vit_base_vs_reference_golden(C):
     """ViT-B/16 224^2 (BASELINE shapes), B=2: loss, sampled logits and per-parameter gradient norms."""
