@@ -205,7 +205,8 @@ def cpu_baseline(batch=8, budget_s=10.0, max_threads=32):
     import torch
     from oracle import vit_ref as V
     from oracle.gen_golden import BASE, vit_inputs
-    ncpu = os.cpu_count() or 1
+    from mem_amd.utils import host_cpu_budget
+    ncpu = host_cpu_budget()                          # the container's CPU quota, not the machine's core count
     threads = max(1, min(ncpu, max_threads))
     torch.set_num_threads(threads)
     cfg = dict(BASE, in_chans=2, drop_path_rate=0.0)
@@ -225,9 +226,9 @@ def cpu_baseline(batch=8, budget_s=10.0, max_threads=32):
     v8, steps, dt = leg(batch, budget_s)
     v2, steps2, dt2 = leg(2, 3.0)
     out = {"value": round(v8, 3), "unit": "samples/sec", "cores": threads, "kind": "port", "cpu_model": _cpu_model(),
-           "cores_on_box": ncpu,
+           "cores_on_box": ncpu, "cores_of_machine": os.cpu_count(),
            "sample": f"ViT-B/16 C=2 fp32 eager CPU (oracle/vit_ref.py), batch {batch}, {steps} steps "
-                     f"after 1 warm-up in {dt:.1f} s, {threads} threads of {ncpu} cores",
+                     f"after 1 warm-up in {dt:.1f} s, {threads} threads of the {ncpu} CPUs the container may use",
            "batch2": {"value": round(v2, 3), "unit": "samples/sec", "steps": steps2,
                       "sample": "BASELINE configs[0] shape: the same model at batch 2"}}
     try:
@@ -369,8 +370,11 @@ def main():
     from mem_amd.modeling_pretrain import pt_vit
     from mem_amd.optim_factory import FlatAdamW, get_parameter_groups
     from mem_amd.parallel import GradReducer
-    from mem_amd.utils import cosine_scheduler
+    from mem_amd.utils import cap_host_threads, cosine_scheduler
 
+    # the launch thread must not be throttled: torch's default intra-op pool (one spinning thread per core of the machine)
+    # exhausts the container's CPU quota (mem_amd/utils.py: cap_host_threads)
+    host_threads = cap_host_threads(4)
     B, NE, H, W, C = a.batch, a.events, 224, 224, 2
     torch.manual_seed(1234 + rank)
     model = pt_vit(img_size=(H, W), patch_size=(16, 16), in_chans=C, vocab_size=8192, embed_dim=768, depth=12,
@@ -756,7 +760,8 @@ def main():
                                       "+ ViT fwd/CE/bwd + clip + AdamW",
                           "global_batch": world * B, "events_per_sample": NE, "parallelism": f"dp{world}",
                           "model_flops_frac_of_peak": round(value / world * FLOP_PER_SAMPLE[C] / (PEAK_BF16_TFLOPS * 1e12), 4),
-                          "last_loss": round(loss_last, 4)},
+                          "last_loss": round(loss_last, 4), "host_threads": host_threads,
+                          "stochastic_depth": "work skipping" if eng.dp_skip else "masked"},
                "roofline": roof}
         if tok_ms is not None:
             out["with_tokenizer"] = {"value": round(world * B / (tok_step_ms * 1e-3), 1), "unit": "samples/sec",

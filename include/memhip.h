@@ -524,6 +524,10 @@ int memhip_nchw_to_padded_nhwc4_f16x2(const float* x, int B, int C, int H, int W
  * Layout / dtype movers
  * ------------------------------------------------------------------------ */
 int memhip_cast_f32_bf16(const float* in, void* out_bf16, int64_t n, memhip_stream_t stream);
+/* dst[s] = src[s] for the n listed samples s = ids[k] (n_per_sample fp32 values each, a multiple of 4): the residual rows of
+ * the samples a stochastic-depth branch dropped (mem/modeling_finetune.py:187-188 with a zero keep mask) */
+int memhip_copy_samples_f32(const float* src, float* dst, const int32_t* ids, int n, int64_t n_per_sample,
+                            memhip_stream_t stream);
 /* out bf16 [Cc, ldout] = in f32 [R, Cc]^T (the [in,out]-major copy of a Linear weight used by dgrad) */
 int memhip_transpose_cast_f32_bf16(const float* in, int64_t ldin, int R, int Cc, void* out_bf16,
                                    int64_t ldout, memhip_stream_t stream);

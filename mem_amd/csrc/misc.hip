@@ -244,6 +244,28 @@ extern "C" int memhip_im2col_bf16(const float* x, int B, int C, int H, int W, in
   return check_launch("im2col");
 }
 
+// dst[sample] = src[sample] for the listed samples (n_per_sample fp32 values each, a multiple of 4): the rows of the
+// samples a stochastic-depth branch dropped pass through the residual stream unchanged (work-skipping mode)
+__global__ __launch_bounds__(256) void copy_samples_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                                           const int* __restrict__ ids, long long n_per_sample) {
+  const long long base = (long long)ids[blockIdx.y] * n_per_sample;
+  const float4* s4 = reinterpret_cast<const float4*>(src + base);
+  float4* d4 = reinterpret_cast<float4*>(dst + base);
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n_per_sample / 4; i += (long long)gridDim.x * 256) d4[i] = s4[i];
+}
+
+extern "C" int memhip_copy_samples_f32(const float* src, float* dst, const int32_t* ids, int n, int64_t n_per_sample,
+                                       memhip_stream_t stream) {
+  MEMHIP_REQUIRE(n >= 0 && n_per_sample > 0 && n_per_sample % 4 == 0, "copy_samples: bad shape");
+  if (n == 0) return MEMHIP_OK;
+  MEMHIP_REQUIRE(src && dst && ids, "copy_samples: null pointer");
+  int gx = (int)((n_per_sample / 4 + 255) / 256);
+  if (gx > 64) gx = 64;
+  hipLaunchKernelGGL(copy_samples_kernel, dim3(gx, n), dim3(256), 0, as_stream(stream), src, dst, (const int*)ids,
+                     (long long)n_per_sample);
+  return check_launch("copy_samples");
+}
+
 extern "C" int memhip_fill_cls(float* x, int64_t ldx, int B, int T, int D, const float* cls,
                                memhip_stream_t stream) {
   MEMHIP_REQUIRE(B >= 0 && T > 0 && D > 0, "fill_cls: bad shape");

@@ -93,6 +93,7 @@ declare({
     "memhip_attn_delta": (i32, [vp, vp, i64, i64, i32, vp, vp]),
     "memhip_attn_bwd": (i32, [vp, i64, vp, i64, vp, vp, vp, i32, i32, i32, i32, i32, i32, f32, vp, i64, vp, vp, vp, vp]),
     "memhip_cast_f32_bf16": (i32, [vp, vp, i64, vp]),
+    "memhip_copy_samples_f32": (i32, [vp, vp, vp, i32, i64, vp]),
     "memhip_transpose_cast_f32_bf16": (i32, [vp, i64, i32, i32, vp, i64, vp]),
     "memhip_transpose_bf16": (i32, [vp, i64, i32, i32, vp, i64, i32, vp, i32, i32, vp, i32, i32, vp]),
     "memhip_im2col_bf16": (i32, [vp, i32, i32, i32, i32, i32, i32, vp, vp]),
@@ -214,6 +215,10 @@ def attn_bwd(qkv, dout, lse, delta, table, window, B, T, D, heads, scale, dqkv, 
     check(lib.memhip_attn_bwd(ptr(qkv), qkv.stride(0), ptr(dout), dout.stride(0), ptr(lse), ptr(delta), ptr(table),
                               window[0], window[1], B, T, D, heads, scale, ptr(dqkv), dqkv.stride(0), ptr(dtable),
                               ptr(dq_bias), ptr(dv_bias), stream_ptr()), "attn_bwd")
+
+
+def copy_samples(src, dst, ids_i32, n, n_per_sample):
+    check(lib.memhip_copy_samples_f32(ptr(src), ptr(dst), ptr(ids_i32), n, n_per_sample, stream_ptr()), "copy_samples")
 
 
 def cast_f32_bf16(src, dst, n):

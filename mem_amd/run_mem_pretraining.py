@@ -169,6 +169,8 @@ def get_model(args):
 
 def main(args):
     utils.init_distributed_mode(args)
+    # the launch thread shares the container's CPU quota with num_workers loader processes: keep torch's intra-op pool small
+    utils.cap_host_threads(4)
     print("Running", f"{args.expweek}_{args.expname}")
     print(args)
     if bool(args.pretrained):

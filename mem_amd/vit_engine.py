@@ -206,13 +206,19 @@ class ViTEngine:
         D, Hd, T, V = self.D, self.hidden, self.T, self.V
         M = B * T
         Mp = _pad(M, 64)
+        # Work-skipping stochastic depth runs the GEMMs of a branch on its kept samples' rows ROUNDED UP to whole 256-row
+        # tiles (a ragged row count costs every product an extra launch on the 128-row kernel): the token-major buffers
+        # carry 256 rows of slack (zero-initialised, only ever finite), and the residual snapshots one dummy sample that the
+        # padded rows' residual updates go to (sample index B in the sample map)
+        Ma = M + 256
         e = lambda *s, dt=bf: torch.empty(s, dtype=dt, device=dev)   # noqa: E731
+        z = lambda *s, dt=bf: torch.zeros(s, dtype=dt, device=dev)   # noqa: E731
         self.patches = e(B * self.L, self.Kpe)
-        self.x = [torch.zeros((M, D), dtype=f32, device=dev) for _ in range(2 * self.depth + 1)]
+        self.x = [torch.zeros((M + T, D), dtype=f32, device=dev) for _ in range(2 * self.depth + 1)]
         self.act = []
         for _ in range(self.depth):
-            self.act.append(dict(h1=e(M, D), qkv=e(M, 3 * D), ao=e(M, D), h2=e(M, D), hpre=e(M, Hd),
-                                 a=e(M, Hd), lse=e(B, self.heads, self.TP, dt=f32),
+            self.act.append(dict(h1=z(Ma, D), qkv=z(Ma, 3 * D), ao=z(Ma, D), h2=z(Ma, D), hpre=z(Ma, Hd),
+                                 a=z(Ma, Hd), lse=e(B, self.heads, self.TP, dt=f32),
                                  mean1=e(M, dt=f32), rstd1=e(M, dt=f32), mean2=e(M, dt=f32), rstd2=e(M, dt=f32)))
         # head
         if self.head_kind == "mlm":
@@ -225,11 +231,11 @@ class ViTEngine:
             self.zero_mask = torch.zeros(B * self.L, dtype=torch.uint8, device=dev)
         # backward temporaries (shared by all blocks)
         self.dx = torch.zeros((M, D), dtype=f32, device=dev)
-        self.dY, self.dh_small = e(M, D), e(M, D)
-        self.dY2 = e(M, D)                                    # attention-branch twin of dY (the side stream reads both)
-        self.dbig = e(M, Hd)
-        self.dqkv = e(M, 3 * D)
-        self.dao = e(M, D)
+        self.dY, self.dh_small = z(Ma, D), z(Ma, D)
+        self.dY2 = z(Ma, D)                                   # attention-branch twin of dY (the side stream reads both)
+        self.dbig = z(Ma, Hd)
+        self.dqkv = z(Ma, 3 * D)
+        self.dao = z(Ma, D)
         self.delta_ws = e(2 * M + 4, self.heads, dt=f32)   # rowsum(dO*O), |dO|^2, 4 rows of per-head bounds
         self._tn_ws = torch.empty(0, dtype=torch.uint8, device=dev)     # partial tiles of the weight-gradient GEMMs
         self.bias_scr = torch.zeros(2, D, dtype=f32, device=dev)   # ping-pong colsum(dY) of the proj branch
@@ -308,6 +314,7 @@ class ViTEngine:
             k = np.flatnonzero(mk[j]).astype(np.int32)
             d = np.flatnonzero(~mk[j]).astype(np.int32)
             host[j, :len(k)] = k
+            host[j, len(k):B + 256] = B                       # rows of the padded tile rows: the dummy sample
             host[j, B + 256 + k] = np.arange(len(k), dtype=np.int32)
             host[j, 2 * B + 256:2 * B + 256 + len(d)] = d
             kept_n.append(len(k))
@@ -320,13 +327,11 @@ class ViTEngine:
         ridx = (dev[:, :B, None] * T + self._dp_ar[None, None, :]).view(J, B * T)
         return dict(n=kept_n, kidx=dev[:, :B + 256], cmap=dev[:, B + 256:2 * B + 256], drop=dev[:, 2 * B + 256:], ridx=ridx, B=B)
 
-    @staticmethod
-    def _copy_dropped(plan, j, src, dst, B):
+    def _copy_dropped(self, plan, j, src, dst, B):
         """Rows of the samples branch j dropped pass through unchanged: dst[sample] = src[sample]."""
         nd = B - plan["n"][j]
         if nd > 0:
-            d = plan["drop"][j, :nd].long()
-            dst.view(B, -1).index_copy_(0, d, src.view(B, -1).index_select(0, d))
+            ops.copy_samples(src, dst, plan["drop"][j], nd, self.T * self.D)
 
     # ------------------------------------------------------------------ forward
     def forward(self, x, mask_u8, rows_idx, labels=None, dp_masks=None, all_tokens=False, labels_event=None):
@@ -421,12 +426,13 @@ class ViTEngine:
             M1 = na * T
             ridx = plan["ridx"][ja] if plan["n"][ja] is not None else None
             smap = plan["kidx"][ja] if plan["n"][ja] is not None else None
+            M1p = _pad(M1, 256) if smap is not None else M1       # GEMM rows: whole 256-row tiles (see ensure_batch)
             ops.layernorm_fwd(xin, self.P(pre + "norm1.weight"), self.P(pre + "norm1.bias"), a["h1"], a["mean1"], a["rstd1"],
                               M1, D, row_idx=ridx)
-            ops.gemm_nt(a["h1"], self.W16(pre + "attn.qkv.weight", 3 * D, D), M1, 3 * D, D, ops.EPI_BIAS_BF16,
+            ops.gemm_nt(a["h1"], self.W16(pre + "attn.qkv.weight", 3 * D, D), M1p, 3 * D, D, ops.EPI_BIAS_BF16,
                         out0=a["qkv"], bias=self.P(pre + "attn.qkvbias3"), colscale=self.scale, colscale_n=D)
             ops.attn_fwd(a["qkv"], na, T, D, self.heads, table, self.window, a["ao"], a["lse"])
-            ops.gemm_nt(a["ao"], self.W16(pre + "attn.proj.weight", D, D), M1, D, D, ops.EPI_RESIDUAL, out0=None,
+            ops.gemm_nt(a["ao"], self.W16(pre + "attn.proj.weight", D, D), M1p, D, D, ops.EPI_RESIDUAL, out0=None,
                         bias=self.P(pre + "attn.proj.bias"), vec1=g1, resid=xmid, aux=xin, ldaux=D,
                         keep_prob=keep if smap is not None else 1.0, rows_per_sample=T, sample_map=smap)
         # -- MLP branch on the nm kept samples
@@ -436,11 +442,12 @@ class ViTEngine:
             M2 = nm * T
             ridx = plan["ridx"][jm] if plan["n"][jm] is not None else None
             smap = plan["kidx"][jm] if plan["n"][jm] is not None else None
+            M2p = _pad(M2, 256) if smap is not None else M2
             ops.layernorm_fwd(xmid, self.P(pre + "norm2.weight"), self.P(pre + "norm2.bias"), a["h2"], a["mean2"], a["rstd2"],
                               M2, D, row_idx=ridx)
-            ops.gemm_nt(a["h2"], self.W16(pre + "mlp.fc1.weight", Hd, D), M2, Hd, D, self.epi_gelu, out0=a["hpre"],
+            ops.gemm_nt(a["h2"], self.W16(pre + "mlp.fc1.weight", Hd, D), M2p, Hd, D, self.epi_gelu, out0=a["hpre"],
                         out1=a["a"], bias=self.P(pre + "mlp.fc1.bias"))
-            ops.gemm_nt(a["a"], self.W16(pre + "mlp.fc2.weight", D, Hd), M2, D, Hd, ops.EPI_RESIDUAL, out0=None,
+            ops.gemm_nt(a["a"], self.W16(pre + "mlp.fc2.weight", D, Hd), M2p, D, Hd, ops.EPI_RESIDUAL, out0=None,
                         bias=self.P(pre + "mlp.fc2.bias"), vec1=g2, resid=xout, aux=xmid, ldaux=D,
                         keep_prob=keep if smap is not None else 1.0, rows_per_sample=T, sample_map=smap)
 
@@ -495,7 +502,7 @@ class ViTEngine:
         else:
             for i in range(self.depth):
                 self._block_fwd(i, 0, B, dp_masks)
-        return self.x[2 * self.depth]
+        return self.x[2 * self.depth][:M]
 
     # ------------------------------------------------------------------ backward
     def _wgrad(self, dY, X, R, n_out, n_in, gname, bias_grads=()):
@@ -625,6 +632,9 @@ class ViTEngine:
             ja, jm = 2 * i, 2 * i + 1
             na, nm = nk(ja), nk(jm)
             M1, M2 = na * T, nm * T
+            # dgrad GEMM rows: whole 256-row tiles (ensure_batch); the weight gradients take the exact row counts
+            M1p = _pad(M1, 256) if plan["n"][ja] is not None else M1
+            M2p = _pad(M2, 256) if plan["n"][jm] is not None else M2
             xin, xmid = self.x[2 * i], self.x[2 * i + 1]
             has_g = (pre + "gamma_1") in self.segs
             table, dtable = self.table(i), self.dtable(i)
@@ -636,7 +646,9 @@ class ViTEngine:
                                M, D, keep_prob=kp(jm, i), rows_per_sample=T, out_map=cmap(jm))
             if nm > 0:
                 self._before_overwrite("dbig")
-                ops.gemm_nt(dY, self.wT[i]["fc2"], M2, Hd, D, self.epi_dgelu, out0=self.dbig, aux=a["hpre"],
+                if M2p > M2:
+                    dY[M2:M2p].zero_()      # rows of the padding: zero in, zero out (the epilogue's column sums see them)
+                ops.gemm_nt(dY, self.wT[i]["fc2"], M2p, Hd, D, self.epi_dgelu, out0=self.dbig, aux=a["hpre"],
                             colsum=self.G(pre + "mlp.fc1.bias"))
 
                 def wg_mlp(i=i, pre=pre, a=a, has_g=has_g, M2=M2):
@@ -649,7 +661,7 @@ class ViTEngine:
                     self._wgrad(self.dbig, a["h2"], M2, Hd, D, pre + "mlp.fc1.weight")
                     self._side_read_done("dbig")
                 self._on_side(wg_mlp)
-                ops.gemm_nt(self.dbig, self.wT[i]["fc1"], M2, D, Hd, ops.EPI_BIAS_BF16, out0=self.dh_small)
+                ops.gemm_nt(self.dbig, self.wT[i]["fc1"], M2p, D, Hd, ops.EPI_BIAS_BF16, out0=self.dh_small)
             scr = self.bias_scr[i & 1]
             if fuse:
                 # norm2 backward (rows the MLP branch kept) + attention-branch backward (rows it kept) in one pass over dx
@@ -669,7 +681,7 @@ class ViTEngine:
                                keep_prob=kp(ja, i), rows_per_sample=T, out_map=cmap(ja))
             # -- attention branch
             if na > 0:
-                ops.gemm_nt(dY2, self.wT[i]["proj"], M1, D, D, ops.EPI_BIAS_BF16, out0=self.dao)
+                ops.gemm_nt(dY2, self.wT[i]["proj"], M1p, D, D, ops.EPI_BIAS_BF16, out0=self.dao)
             ops.gemv_acc(self.wT[i]["proj"], D, D, scr, self.G(pre + "attn.v_bias"),
                          x_acc=self.G(pre + "attn.proj.bias"), zero=self.bias_scr[(i & 1) ^ 1])
             if na > 0:
@@ -690,7 +702,7 @@ class ViTEngine:
                     self._wgrad(self.dqkv, a["h1"], M1, 3 * D, D, pre + "attn.qkv.weight")
                     self._side_read_done("dqkv")
                 self._on_side(wg_qkv)
-                ops.gemm_nt(self.dqkv, self.wT[i]["qkv"], M1, D, 3 * D, ops.EPI_BIAS_BF16, out0=self.dh_small)
+                ops.gemm_nt(self.dqkv, self.wT[i]["qkv"], M1p, D, 3 * D, ops.EPI_BIAS_BF16, out0=self.dh_small)
             if fuse and i > 0:
                 # norm1 backward of block i (rows its attention branch kept) + MLP-branch backward of block i - 1
                 pb = f"blocks.{i - 1}."
