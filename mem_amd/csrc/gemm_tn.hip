@@ -262,7 +262,11 @@ extern "C" int memhip_colsum_bf16(const void* in, int64_t ld, int R, int Cc, flo
   const int chunks = Cc / 8;
   const int tpr = chunks >= 256 ? 256 : chunks;       // threads per row; the other 256 / tpr thread rows take more rows
   const int gx = cdiv(chunks, tpr);
-  int gy = 1024 / gx;                                  // ~1024 workgroups in all: few atomics per column
+  // about one workgroup per CU, at most 128 row blocks: every row block ends in one atomic per column, and atomics on
+  // the same address serialise at ~0.17 us each (measured: 784 row blocks of a [50176, 768] matrix took 161 us, 135 of
+  // them in the atomics; 128 row blocks keep 3 MB of loads in flight, enough for the read itself)
+  int gy = 256 / gx;
+  if (gy > 128) gy = 128;
   if (gy < 1) gy = 1;
   int rows_per_block = cdiv(R, gy);
   if (rows_per_block < 64) rows_per_block = 64;

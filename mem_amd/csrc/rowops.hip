@@ -451,26 +451,48 @@ __global__ __launch_bounds__(256) void layerscale_grad_kernel(const __bf16* __re
 // ---------------------------------------------------------------- patch-embed / token backward
 // forward (modeling_pretrain.py:101-108): row b*(L+1) = cls ; row b*(L+1)+1+p = y*(1-w) + mask_token*w
 // backward: dcls += dx[cls rows]; dmask_token += sum dx*w; dy = bf16(dx*(1-w))
+// A workgroup takes samples b, b + gridDim.x, ... and keeps its column sums in registers: one atomic per column and
+// WORKGROUP (atomics on one address serialise at ~0.17 us each: with a workgroup per sample the 2 x 256 of them per column
+// were most of the kernel's 142 us); seven rows of loads in flight per thread.
 __global__ __launch_bounds__(256) void embed_bwd_kernel(const float* __restrict__ dx, long long lddx,
                                                         const unsigned char* __restrict__ mask, int B,
                                                         int L, int D, __bf16* __restrict__ dy,
                                                         long long lddy, float* __restrict__ dcls,
                                                         float* __restrict__ dmask) {
-  const int b = blockIdx.x;
+  constexpr int U = 7;
   for (int c = threadIdx.x * 4; c < D; c += 256 * 4) {
-    const float4 dc = *reinterpret_cast<const float4*>(dx + (long long)b * (L + 1) * lddx + c);
-    atomicAdd(dcls + c, dc.x); atomicAdd(dcls + c + 1, dc.y);
-    atomicAdd(dcls + c + 2, dc.z); atomicAdd(dcls + c + 3, dc.w);
-    float4 am{0, 0, 0, 0};
-    for (int p = 0; p < L; ++p) {
-      const float4 d = *reinterpret_cast<const float4*>(dx + ((long long)b * (L + 1) + 1 + p) * lddx + c);
-      const float w = (float)mask[(long long)b * L + p];
-      am.x += d.x * w; am.y += d.y * w; am.z += d.z * w; am.w += d.w * w;
-      const float u = 1.0f - w;
-      bf16x4 o;
-      o[0] = (__bf16)(d.x * u); o[1] = (__bf16)(d.y * u); o[2] = (__bf16)(d.z * u); o[3] = (__bf16)(d.w * u);
-      *reinterpret_cast<bf16x4*>(dy + ((long long)b * L + p) * lddy + c) = o;
+    float4 cls{0, 0, 0, 0}, am{0, 0, 0, 0};
+    for (int b = blockIdx.x; b < B; b += gridDim.x) {
+      const float* row0 = dx + (long long)b * (L + 1) * lddx + c;
+      const float4 dc = *reinterpret_cast<const float4*>(row0);
+      cls.x += dc.x; cls.y += dc.y; cls.z += dc.z; cls.w += dc.w;
+      const unsigned char* mk = mask + (long long)b * L;
+      __bf16* out = dy + (long long)b * L * lddy + c;
+      int p = 0;
+      for (; p + U <= L; p += U) {
+        float4 d[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) d[u] = *reinterpret_cast<const float4*>(row0 + (long long)(1 + p + u) * lddx);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const float w = (float)mk[p + u], q = 1.0f - w;
+          am.x += d[u].x * w; am.y += d[u].y * w; am.z += d[u].z * w; am.w += d[u].w * w;
+          bf16x4 o;
+          o[0] = (__bf16)(d[u].x * q); o[1] = (__bf16)(d[u].y * q); o[2] = (__bf16)(d[u].z * q); o[3] = (__bf16)(d[u].w * q);
+          *reinterpret_cast<bf16x4*>(out + (long long)(p + u) * lddy) = o;
+        }
+      }
+      for (; p < L; ++p) {
+        const float4 d = *reinterpret_cast<const float4*>(row0 + (long long)(1 + p) * lddx);
+        const float w = (float)mk[p], q = 1.0f - w;
+        am.x += d.x * w; am.y += d.y * w; am.z += d.z * w; am.w += d.w * w;
+        bf16x4 o;
+        o[0] = (__bf16)(d.x * q); o[1] = (__bf16)(d.y * q); o[2] = (__bf16)(d.z * q); o[3] = (__bf16)(d.w * q);
+        *reinterpret_cast<bf16x4*>(out + (long long)p * lddy) = o;
+      }
     }
+    atomicAdd(dcls + c, cls.x); atomicAdd(dcls + c + 1, cls.y);
+    atomicAdd(dcls + c + 2, cls.z); atomicAdd(dcls + c + 3, cls.w);
     atomicAdd(dmask + c, am.x); atomicAdd(dmask + c + 1, am.y);
     atomicAdd(dmask + c + 2, am.z); atomicAdd(dmask + c + 3, am.w);
   }
@@ -666,7 +688,7 @@ extern "C" int memhip_embed_bwd(const float* dx, int64_t lddx, const uint8_t* ma
   MEMHIP_REQUIRE(B >= 0 && L > 0 && D > 0 && D % 4 == 0, "embed_bwd: bad shape");
   if (B == 0) return MEMHIP_OK;
   MEMHIP_REQUIRE(dx && mask && dy && dcls && dmask_token, "embed_bwd: null pointer");
-  hipLaunchKernelGGL(embed_bwd_kernel, dim3(B), dim3(256), 0, as_stream(stream), dx, (long long)lddx, mask, B,
+  hipLaunchKernelGGL(embed_bwd_kernel, dim3(B < 128 ? B : 128), dim3(256), 0, as_stream(stream), dx, (long long)lddx, mask, B,
                      L, D, (__bf16*)dy, (long long)lddy, dcls, dmask_token);
   return check_launch("embed_bwd");
 }
@@ -710,7 +732,7 @@ extern "C" int memhip_layernorm_bwd_branch_map(const void* dy, int64_t lddy, con
   MEMHIP_REQUIRE(ldx % 4 == 0 && lddy % 4 == 0 && lddres % 4 == 0 && ldyb % 4 == 0 && lddyb % 4 == 0,
                  "layernorm_bwd_branch: ld must be a multiple of 4");
   int grid = cdiv(R, 4);
-  if (grid > 768) grid = 768;          // 3 resident workgroups per CU at this kernel's VGPR count: one full round
+  if (grid > opt(OPT_LN_BWD_GRID)) grid = opt(OPT_LN_BWD_GRID);   // 768 = 3 resident workgroups per CU at this kernel's VGPR count: one full round
 #define LBB_LAUNCH(N)                                                                                    \
   if (y_branch) LBB_LAUNCH2(N, true); else LBB_LAUNCH2(N, false)
 #define LBB_LAUNCH2(N, Y)                                                                                \
