@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define MEMHIP_ABI_VERSION 2
+#define MEMHIP_ABI_VERSION 3
 
 #define MEMHIP_OK 0
 #define MEMHIP_EINVAL (-1)   /* bad argument (shape / alignment / null) */
@@ -290,6 +290,13 @@ typedef struct memhip_gemm_args {
                              `resid` / `aux` is sample_map[c] * rows_per_sample + m % rows_per_sample.  The kept branch is
                              scaled by 1 / keep_prob; rowmask must be NULL.  The array must be readable for 256 entries
                              past the last compact sample.  NULL = rows map to themselves. */
+  int32_t colsum_copies;  /* > 1: `colsum` holds that many accumulator copies of N floats each (copy k at colsum + k * N;
+                             all zero on entry) and a workgroup adds into copy blockIdx % copies: atomics on one address
+                             serialise (~0.17 us each on gfx950), and with one copy the ~400 per column of a ViT-B
+                             launch sit in the in-order vector-memory queue in front of the operand stream (measured:
+                             +27 us on the 3072-wide GELU' GEMM, +100 us on a 768 x 768 one).  Fold the copies with
+                             memhip_colsum_fold.  0 / 1: a single accumulator (the bias gradient itself). */
+  int32_t reserved0;
 } memhip_gemm_args_t;
 int memhip_gemm_bf16_nt(const memhip_gemm_args_t* args, memhip_stream_t stream);
 
@@ -311,6 +318,9 @@ int memhip_gemm_bf16_tn_ws(const void* A, int64_t lda, const void* B, int64_t ld
                            memhip_stream_t stream);
 /* out f32 [C] += column sums of in bf16 [R, C]  (Linear bias gradients = grad_output.sum(0)) */
 int memhip_colsum_bf16(const void* in, int64_t ld, int R, int C, float* out, memhip_stream_t stream);
+/* out[n] += sum_k ws[k * N + n] for the `copies` accumulator copies a GEMM with colsum_copies > 1 filled; the copies
+ * are zeroed again (ready for the next GEMM).  Same reduction order every run. */
+int memhip_colsum_fold(float* ws, int copies, int N, float* out, memhip_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * LayerNorm (eps 1e-6) forward / backward          mem/modeling_pretrain.py:132,

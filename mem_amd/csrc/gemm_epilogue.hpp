@@ -23,12 +23,19 @@ struct GemmArgs {   // memhip_gemm_args_t, followed by launcher-internal fields
   int accumulate;
   float* colsum;   // optional: += column sums of the (rounded) primary output
   const int* sample_map;   // RESIDUAL: compact sample -> sample whose residual rows this output row updates (NULL: identity)
+  int colsum_copies;       // > 1: colsum holds that many accumulator copies of N floats; a workgroup uses copy blockIdx % copies
+  int reserved0;
   // ---- internal (not part of the C ABI; zero when the struct is copied from memhip_gemm_args_t)
   int m_base;      // row offset of this launch inside the caller's problem (a GEMM may be launched in two
                    // row ranges): only the per-sample row mask index needs the absolute row
 };
 
 __device__ __forceinline__ float bf16_round(float v) { return (float)(__bf16)v; }
+
+// the column-sum accumulator of this workgroup (memhip.h: colsum_copies)
+__device__ __forceinline__ float* colsum_base(const GemmArgs& p) {
+  return p.colsum_copies > 1 ? p.colsum + (long long)((int)blockIdx.x % p.colsum_copies) * p.N : p.colsum;
+}
 
 // erf(x) by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, i.e. fp32-erff class accuracy) -- one
 // rcp, one exp and five FMAs instead of libm's branchy erff: the GELU epilogues are VALU-bound
@@ -62,7 +69,7 @@ __device__ __forceinline__ void epilogue(const GemmArgs& p, int m, int n, float 
     __bf16 y = (__bf16)v;
     if (n < p.colscale_n) y = (__bf16)((float)y * p.colscale);
     reinterpret_cast<__bf16*>(p.out0)[(long long)m * p.ldo0 + n] = y;
-    if (p.colsum) atomicAdd(p.colsum + n, (float)y);
+    if (p.colsum) atomicAdd(colsum_base(p) + n, (float)y);
   } else if constexpr (EPI == MEMHIP_EPI_BIAS_GELU) {
     const __bf16 h = (__bf16)(acc + bias_n);
     reinterpret_cast<__bf16*>(p.out0)[(long long)m * p.ldo0 + n] = h;
@@ -76,7 +83,7 @@ __device__ __forceinline__ void epilogue(const GemmArgs& p, int m, int n, float 
     const float g = (float)reinterpret_cast<const __bf16*>(p.aux)[(long long)m * p.ldaux + n];
     const __bf16 o = (__bf16)(da * g);
     reinterpret_cast<__bf16*>(p.out0)[(long long)m * p.ldo0 + n] = o;
-    if (p.colsum) atomicAdd(p.colsum + n, (float)o);
+    if (p.colsum) atomicAdd(colsum_base(p) + n, (float)o);
   } else if constexpr (EPI == MEMHIP_EPI_RESIDUAL) {
     const __bf16 y = (__bf16)(acc + bias_n);
     if (p.out0) reinterpret_cast<__bf16*>(p.out0)[(long long)m * p.ldo0 + n] = y;
@@ -96,7 +103,7 @@ __device__ __forceinline__ void epilogue(const GemmArgs& p, int m, int n, float 
     const float h = (float)reinterpret_cast<const __bf16*>(p.aux)[(long long)m * p.ldaux + n];
     const __bf16 o = (__bf16)(da * gelu_grad_f(h));
     reinterpret_cast<__bf16*>(p.out0)[(long long)m * p.ldo0 + n] = o;
-    if (p.colsum) atomicAdd(p.colsum + n, (float)o);
+    if (p.colsum) atomicAdd(colsum_base(p) + n, (float)o);
   } else if constexpr (EPI == MEMHIP_EPI_F32) {
     float* o = reinterpret_cast<float*>(p.out0) + (long long)m * p.ldo0 + n;
     *o = p.accumulate ? (*o + acc) : acc;
@@ -484,17 +491,31 @@ __device__ __forceinline__ void epilogue8(const GemmArgs& p, int m, int n, const
 
 // Column sums when the 16 lanes with equal (lane >> 4) hold the same 8 columns n..n+7 for 16
 // different rows (accumulator-layout epilogue of gemm_p8.hip).
+// value of lane - N inside the 16-lane row, 0 for the first N lanes of a row (v_mov_b32_dpp row_shr:N, bound_ctrl)
+template <int N>
+__device__ __forceinline__ float dpp_row_shr(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x110 + N, 0xf, 0xf, true));
+}
 __device__ __forceinline__ void colsum_flush16(const GemmArgs& p, int n, float* cs, int lane) {
   if (!p.colsum) return;
+  float* const dst = colsum_base(p);
+  // sum over the 16 lanes of a row by DPP shifts (1, 2, 4, 8: the last lane of the row ends up with the whole sum) --
+  // four VALU instructions per column; the ds_bpermute form of __shfl_xor was 32 dependent LDS round trips per flush
+  // (~6 K cycles per output tile of the GELU' GEMM)
+  float t[8];
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
     float v = cs[k];
-    v += __shfl_xor(v, 1);
-    v += __shfl_xor(v, 2);
-    v += __shfl_xor(v, 4);
-    v += __shfl_xor(v, 8);
-    if ((lane & 15) == 0) atomicAdd(p.colsum + n + k, v);
+    v += dpp_row_shr<1>(v);
+    v += dpp_row_shr<2>(v);
+    v += dpp_row_shr<4>(v);
+    v += dpp_row_shr<8>(v);
+    t[k] = v;
     cs[k] = 0.f;
+  }
+  if ((lane & 15) == 15) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) atomicAdd(dst + n + k, t[k]);
   }
 }
 
@@ -503,13 +524,14 @@ __device__ __forceinline__ void colsum_flush16(const GemmArgs& p, int n, float* 
 // columns.  One atomic per column per wave.
 __device__ __forceinline__ void colsum_flush(const GemmArgs& p, int n, float* cs, int lane) {
   if (!p.colsum) return;
+  float* const dst = colsum_base(p);
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
     float v = cs[k];
     v += __shfl_xor(v, 8);
     v += __shfl_xor(v, 16);
     v += __shfl_xor(v, 32);
-    if ((lane >> 3) == 0) atomicAdd(p.colsum + n + k, v);
+    if ((lane >> 3) == 0) atomicAdd(dst + n + k, v);
     cs[k] = 0.f;
   }
 }

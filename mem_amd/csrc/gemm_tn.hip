@@ -255,6 +255,26 @@ extern "C" int memhip_gemm_bf16_tn_ws(const void* A, int64_t lda, const void* B,
   return check_launch("gemm_bf16_tn");
 }
 
+namespace {
+__global__ __launch_bounds__(256) void colsum_fold_kernel(float* __restrict__ ws, int copies, int N, float* __restrict__ out) {
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  if (n >= N) return;
+  float s = 0.f;
+  for (int k = 0; k < copies; ++k) {
+    s += ws[(long long)k * N + n];
+    ws[(long long)k * N + n] = 0.f;
+  }
+  out[n] += s;
+}
+}  // namespace
+
+extern "C" int memhip_colsum_fold(float* ws, int copies, int N, float* out, memhip_stream_t stream) {
+  MEMHIP_REQUIRE(copies >= 1 && N > 0, "colsum_fold: bad shape");
+  MEMHIP_REQUIRE(ws && out, "colsum_fold: null pointer");
+  hipLaunchKernelGGL(colsum_fold_kernel, dim3(cdiv(N, 256)), dim3(256), 0, as_stream(stream), ws, copies, N, out);
+  return check_launch("colsum_fold");
+}
+
 extern "C" int memhip_colsum_bf16(const void* in, int64_t ld, int R, int Cc, float* out, memhip_stream_t stream) {
   MEMHIP_REQUIRE(R >= 0 && Cc > 0 && Cc % 8 == 0 && ld % 8 == 0, "colsum: bad shape");
   if (R == 0) return MEMHIP_OK;

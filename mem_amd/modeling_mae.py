@@ -579,6 +579,8 @@ class MaeEngineBF16(MaeEngineF32):
         ops.transpose_cast_batched(self._tdesc, self._tprefix, self._tn, self._ttiles)
         self.weights_dirty = False
 
+    CS_COPIES = 8
+
     def ensure_batch(self, B, K):
         if B <= self.B and K == getattr(self, "K", None):
             return
@@ -605,6 +607,8 @@ class MaeEngineBF16(MaeEngineF32):
                         gp=torch.zeros((Dm, Dp), dtype=f, device=dev) if spec["hd"] == 32 else None,
                         gb=torch.zeros(3 * Dp, dtype=f, device=dev) if spec["hd"] == 32 else None)
         self.ea, self.da = acts(self.enc, Me, K + 1), acts(self.dec, Md, T)
+        self.cs_ws = torch.zeros(self.CS_COPIES * max(self.enc["hidden"], self.dec["hidden"], self.enc["Dp"], self.dec["Dp"]),
+                                 dtype=f, device=dev)         # column-sum accumulator copies of the fused GEMM epilogues
         self.latent16, self.meanE, self.rstdE = e16(Me, D), e(Me), e(Me)
         self.yd16, self.yd, self.dyd, self.dyd16 = e16(Me, Dd), e(Me, Dd), e(Me, Dd), e16(Me, Dd)
         self.hdn16, self.meanD, self.rstdD = e16(Md, Dd), e(Md), e(Md)
@@ -659,8 +663,10 @@ class MaeEngineBF16(MaeEngineF32):
         Gw = lambda n: Gr(n).view(self.named[n].shape[0], -1)       # noqa: E731
         # MLP branch: the branch output gradient IS dx (no layer scale, no drop path); Linear grad_outputs are bf16
         ops.branch_bwd(dx, None, None, dy, None, Gr(pre + "mlp.fc2.bias"), M, D)      # dy = bf16(dx) + its column sums, one pass
+        # (fused column sums go to CS_COPIES accumulator copies, folded by a tiny kernel: atomics on one address serialise)
         ops.gemm_nt(dy, self.wT16[pre + "mlp.fc2.weight"], M, Hd, D, ops.EPI_DGELU, out0=dbig, aux=a["hpre"],
-                    colsum=Gr(pre + "mlp.fc1.bias"))
+                    colsum=self.cs_ws, colsum_copies=self.CS_COPIES)
+        ops.colsum_fold(self.cs_ws, self.CS_COPIES, Hd, Gr(pre + "mlp.fc1.bias"))
         self._wgrad16(dy, a["a"], M, D, Hd, Gw(pre + "mlp.fc2.weight"))
         self._wgrad16(dbig, a["h2"], M, Hd, D, Gw(pre + "mlp.fc1.weight"))
         ops.gemm_nt(dbig, self.wT16[pre + "mlp.fc1.weight"], M, D, Hd, ops.EPI_BIAS_BF16, out0=dh)
@@ -674,7 +680,9 @@ class MaeEngineBF16(MaeEngineF32):
         gb = acts["gb"] if pad else Gr(pre + "attn.qkv.bias")
         if pad:
             gb.zero_()
-        ops.gemm_nt(dy, self.wT16[pre + "attn.proj.weight"], M, Dp, D, ops.EPI_BIAS_BF16, out0=dao, colsum=gb[2 * Dp:3 * Dp])
+        ops.gemm_nt(dy, self.wT16[pre + "attn.proj.weight"], M, Dp, D, ops.EPI_BIAS_BF16, out0=dao, colsum=self.cs_ws,
+                    colsum_copies=self.CS_COPIES)
+        ops.colsum_fold(self.cs_ws, self.CS_COPIES, Dp, gb[2 * Dp:3 * Dp])
         if pad:
             acts["gp"].zero_()
             self._wgrad16(dy, a["ao"], M, D, Dp, acts["gp"])

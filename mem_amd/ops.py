@@ -20,7 +20,7 @@ class GemmArgs(C.Structure):
                 ("bias", vp), ("vec1", vp), ("resid", vp), ("ldr", i64),
                 ("aux", vp), ("ldaux", i64), ("rowmask", vp), ("keep_prob", f32),
                 ("colscale", f32), ("colscale_n", i32), ("rows_per_sample", i32), ("accumulate", i32),
-                ("colsum", vp), ("sample_map", vp)]
+                ("colsum", vp), ("sample_map", vp), ("colsum_copies", i32), ("reserved0", i32)]
 
 
 declare({"memhip_gemm_bf16_nt": (i32, [C.POINTER(GemmArgs), vp])})
@@ -44,8 +44,9 @@ def _timer_event():
 
 def gemm_nt(A, B, M, N, K, epi, out0=None, out1=None, bias=None, vec1=None, resid=None, aux=None,
             rowmask=None, keep_prob=1.0, colscale=1.0, colscale_n=0, rows_per_sample=1, accumulate=False, colsum=None,
-            lda=None, ldb=None, ldo0=None, ldo1=None, ldr=None, ldaux=None, sample_map=None):
-    """C[M,N] = A[M,K] @ B[N,K]^T with a fused epilogue.  A/B bf16, row-major, K contiguous."""
+            lda=None, ldb=None, ldo0=None, ldo1=None, ldr=None, ldaux=None, sample_map=None, colsum_copies=0):
+    """C[M,N] = A[M,K] @ B[N,K]^T with a fused epilogue.  A/B bf16, row-major, K contiguous.
+    colsum_copies > 1: `colsum` is a zeroed [copies, N] workspace, folded into the bias gradient by colsum_fold."""
     a = GemmArgs()
     a.A, a.B = _p(A), _p(B)
     a.lda = A.stride(0) if lda is None else lda
@@ -64,6 +65,7 @@ def gemm_nt(A, B, M, N, K, epi, out0=None, out1=None, bias=None, vec1=None, resi
     a.rows_per_sample, a.accumulate = rows_per_sample, int(accumulate)
     a.colsum = _p(colsum)
     a.sample_map = _p(sample_map)
+    a.colsum_copies = colsum_copies
     if GEMM_TIMER is None:
         check(lib.memhip_gemm_bf16_nt(C.byref(a), stream_ptr()), "gemm_bf16_nt")
     else:
@@ -269,6 +271,7 @@ declare({
     "memhip_gemm_bf16_tn_ws": (i32, [vp, i64, vp, i64, i32, i32, i32, vp, i64, i32, vp, sz, vp]),
     "memhip_gemm_bf16_tn_workspace": (sz, [i32, i32, i32]),
     "memhip_colsum_bf16": (i32, [vp, i64, i32, i32, vp, vp]),
+    "memhip_colsum_fold": (i32, [vp, i32, i32, vp, vp]),
 })
 
 
@@ -290,6 +293,11 @@ def gemm_tn(A, B, R, N, K, out, accumulate=True, workspace=None):
                                          int(accumulate), ws, wsb, stream_ptr()), "gemm_bf16_tn")
         e1.record()
         GEMM_TIMER.append((e0, e1, 2.0 * R * N * K, 100))
+
+
+def colsum_fold(ws, copies, N, out):
+    """out[N] += the `copies` accumulator copies in ws (a GEMM with colsum_copies > 1 filled them); ws is zeroed again."""
+    check(lib.memhip_colsum_fold(ptr(ws), copies, N, ptr(out), stream_ptr()), "colsum_fold")
 
 
 def colsum_bf16(x, R, Cc, out):

@@ -239,6 +239,7 @@ class ViTEngine:
         self.delta_ws = e(2 * M + 4, self.heads, dt=f32)   # rowsum(dO*O), |dO|^2, 4 rows of per-head bounds
         self._tn_ws = torch.empty(0, dtype=torch.uint8, device=dev)     # partial tiles of the weight-gradient GEMMs
         self.bias_scr = torch.zeros(2, D, dtype=f32, device=dev)   # ping-pong colsum(dY) of the proj branch
+        self.cs_ws = torch.zeros(self.CS_COPIES, self.hidden, dtype=f32, device=dev)   # column-sum accumulator copies (zero between uses)
         self.dYpe = e(B * self.L, D)
         self.B, self.Mm_cap = B, Mm_cap
 
@@ -289,6 +290,8 @@ class ViTEngine:
         return None
 
     # ------------------------------------------------------------------ stochastic depth: per-step work plan
+    CS_COPIES = 8        # accumulator copies of a fused GEMM column sum (ops.gemm_nt colsum_copies): one per XCD
+
     def _dp_plan(self, dp_masks, B):
         """dp_masks [2*depth, B] (0/1; host tensor / ndarray preferred, a device tensor costs one sync) -> plan dict or
         None.  Per row j of the mask with a drop probability: the kept samples (count on the host: it sizes the launches),
@@ -649,7 +652,8 @@ class ViTEngine:
                 if M2p > M2:
                     dY[M2:M2p].zero_()      # rows of the padding: zero in, zero out (the epilogue's column sums see them)
                 ops.gemm_nt(dY, self.wT[i]["fc2"], M2p, Hd, D, self.epi_dgelu, out0=self.dbig, aux=a["hpre"],
-                            colsum=self.G(pre + "mlp.fc1.bias"))
+                            colsum=self.cs_ws, colsum_copies=self.CS_COPIES)
+                ops.colsum_fold(self.cs_ws, self.CS_COPIES, Hd, self.G(pre + "mlp.fc1.bias"))
 
                 def wg_mlp(i=i, pre=pre, a=a, has_g=has_g, M2=M2):
                     self._wgrad(dY, a["a"], M2, D, Hd, pre + "mlp.fc2.weight")
@@ -755,8 +759,11 @@ class ViTEngine:
                                None, self.G(pre + "mlp.fc2.bias"), M, D,
                                rowmask=dp_masks[2 * i + 1] if use_dp else None, keep_prob=keep, rows_per_sample=T)
             self._before_overwrite("dbig")
+            # fc1 bias grad = column sums of dh, accumulated in CS_COPIES copies (one per XCD: atomics on one address
+            # serialise and would sit in front of the GEMM's operand stream) and folded by a 3 us kernel
             ops.gemm_nt(dY, self.wT[i]["fc2"], M, Hd, D, self.epi_dgelu, out0=self.dbig, aux=a["hpre"],
-                        colsum=self.G(pre + "mlp.fc1.bias"))        # fc1 bias grad = column sums of dh
+                        colsum=self.cs_ws, colsum_copies=self.CS_COPIES)
+            ops.colsum_fold(self.cs_ws, self.CS_COPIES, Hd, self.G(pre + "mlp.fc1.bias"))
 
             def wg_mlp(i=i, pre=pre, a=a, has_g=has_g):
                 self._wgrad(dY, a["a"], M, D, Hd, pre + "mlp.fc2.weight")

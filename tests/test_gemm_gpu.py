@@ -214,6 +214,17 @@ def test_persistent_gemm_large_m_all_epilogues(M, N, K):
     torch.nn.functional.gelu(hg).backward(torch.ones_like(hg))
     torch.testing.assert_close(o.float(), (da * hg.grad).bfloat16().float(), rtol=3e-2, atol=3e-2)
     torch.testing.assert_close(cs, o.float().sum(0), rtol=1e-3, atol=5e-2)      # fused bias-gradient column sums
+    # the same sums through accumulator copies (colsum_copies) + fold: equal to the single accumulator up to fp32
+    # summation order; the workspace is zero again afterwards and the fold ADDS into its target
+    for copies in (8, 3):
+        ws = torch.zeros(copies, N, device="cuda")
+        o2 = torch.zeros_like(o)
+        tgt = torch.full((N,), 2.0, device="cuda")
+        ops.gemm_nt(A, B, M, N, K, ops.EPI_DGELU, out0=o2, aux=hh, colsum=ws, colsum_copies=copies)
+        ops.colsum_fold(ws, copies, N, tgt)
+        assert torch.equal(o2, o)
+        torch.testing.assert_close(tgt - 2.0, cs, rtol=1e-4, atol=1e-2)
+        assert float(ws.abs().max()) == 0.0
 
 
 @pytest.mark.parametrize("M,N,K", [(300, 256, 128), (4096 + 37, 1024, 256), (5000, 768, 768)])
