@@ -475,7 +475,8 @@ def cap_host_threads(limit=4):
     thread per visible core, spinning after every parallel region) exhausts the container's CPU quota and the launch
     thread gets throttled for the rest of the CFS period (measured on the GPU box: 76 s of CPU in a 10 s run, 80 ms
     stalls of the launch thread, GPU idle).  Caps the pool at min(limit, quota); never raises it."""
-    n = max(1, min(limit, host_cpu_budget(), torch.get_num_threads()))
+    ranks_here = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1")))        # torchrun: rank processes sharing this quota
+    n = max(1, min(limit, host_cpu_budget() // ranks_here, torch.get_num_threads()))
     if n < torch.get_num_threads():
         torch.set_num_threads(n)
     return n

@@ -101,3 +101,22 @@ def test_missing_data_path_fails_like_the_reference():
     assert "WARNING" in buf.getvalue() and "SYNTHETIC" in buf.getvalue() and len(ds) == 64      # warns also without a sensor keyword
     a = get("--data_path", "synthetic")
     assert len(_quiet(build_pretraining_dataset, a)) == 64
+
+
+def test_host_thread_cap_respects_the_container_quota(monkeypatch):
+    """cap_host_threads: never more threads than the CFS quota divided by the rank processes on the node, never raises
+    the pool (the launch thread was throttled for 80 ms at a time when torch's 128-thread pool burnt the 16-CPU quota)."""
+    import os
+    import torch
+    from mem_amd.utils import cap_host_threads, host_cpu_budget
+    before = torch.get_num_threads()
+    try:
+        budget = host_cpu_budget()
+        assert 1 <= budget <= (os.cpu_count() or 1)
+        monkeypatch.setenv("LOCAL_WORLD_SIZE", "8")
+        n = cap_host_threads(4)
+        assert 1 <= n <= max(1, min(4, budget // 8, before)) and torch.get_num_threads() <= before
+        monkeypatch.setenv("LOCAL_WORLD_SIZE", "1")
+        assert cap_host_threads(64) <= torch.get_num_threads()          # a larger limit does not raise the pool again
+    finally:
+        torch.set_num_threads(before)
