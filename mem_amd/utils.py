@@ -512,7 +512,9 @@ class HostStager:
         assert n <= self.host[k].numel(), "HostStager slot too small"
         self.host[k][:n].numpy()[:] = flat.view(np.uint8)
         self.dev[k][:n].copy_(self.host[k][:n], non_blocking=True)
-        e = torch.cuda.Event()
+        # blocking=True: a host that is a full ring ahead of the GPU SLEEPS in synchronize() instead of spinning (the launch
+        # thread shares the container's CPU quota with the DataLoader workers and, on a multi-GPU node, the other ranks)
+        e = torch.cuda.Event(blocking=True)
         e.record()
         self.ev[k] = e
         return self.dev[k][:n].view(torch.from_numpy(flat[:0]).dtype)
