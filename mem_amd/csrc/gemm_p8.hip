@@ -76,6 +76,23 @@ __device__ unsigned long long g_p8_stamps[256 * 32];
 #else
 #define P8_STAMP_AT(slot) do { } while (0)
 #endif
+// -DP8_STAMP=2: instead, one stamp per loop iteration (two K-tiles; taken before the epilogue of a tile's last iteration)
+// for the first 32 iterations of every workgroup: where inside a tile do the cycles beyond the steady state go?
+#if defined(P8_STAMP) && P8_STAMP == 2
+#undef P8_STAMP_AT
+#define P8_STAMP_AT(slot) do { } while (0)
+#define P8_STAMP_IT()                                                                                       \
+  do {                                                                                                      \
+    if (wave == 0 && stamp_it < 32) {                                                                       \
+      unsigned long long t_;                                                                                \
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                           \
+      if (lane == 0) g_p8_stamps[(blockIdx.x & 255) * 32 + stamp_it] = t_;                                  \
+    }                                                                                                       \
+    ++stamp_it;                                                                                             \
+  } while (0)
+#else
+#define P8_STAMP_IT() do { } while (0)
+#endif
 
 namespace {
 
@@ -419,6 +436,8 @@ __global__ __launch_bounds__(kThreads) void gemm_p8_kernel(GemmArgs p, int ntm, 
   // K-tiles go in pairs (K % 128 == 0), so that buffer parity and the B register roles are static
 #ifdef P8_STAMP
   int stamp_tile = 0;
+  int stamp_it = 0;
+  (void)stamp_it; (void)stamp_tile;
 #endif
   for (int c = 0; c < total; c += 2) {
     if (c_k == 0) P8_STAMP_AT(0);
@@ -436,6 +455,7 @@ __global__ __launch_bounds__(kThreads) void gemm_p8_kernel(GemmArgs p, int ntm, 
       advance2();
     }
 
+    P8_STAMP_IT();
     if (c_k == nk - 2) {
       // waves 0-3 wait for the last compute segment of waves 4-7, so that all eight waves run the
       // (VALU-bound, barrier-free) epilogue together; waves 4-7 fall half a phase behind again after it
