@@ -514,7 +514,7 @@ class HostStager:
         self.dev[k][:n].copy_(self.host[k][:n], non_blocking=True)
         # blocking=True: a host that is a full ring ahead of the GPU SLEEPS in synchronize() instead of spinning (the launch
         # thread shares the container's CPU quota with the DataLoader workers and, on a multi-GPU node, the other ranks)
-        e = torch.cuda.Event(blocking=True)
+        e = torch.cuda.Event(blocking=os.environ.get("MEMHIP_STAGER_SPIN") != "1")
         e.record()
         self.ev[k] = e
         return self.dev[k][:n].view(torch.from_numpy(flat[:0]).dtype)
