@@ -370,7 +370,14 @@ def test_vit_base_vs_reference_golden(C):
         lo = m(x.cuda(), mask.cuda())
     m.train()
     samp = lo.float().cpu()[::7, ::97].numpy()
-    assert np.abs(samp - g["bf16__logits_sample"]).max() <= 0.06
+    # 2 380 sampled logits (|logit| <= 2.6: one bf16 ulp = 0.0156).  Measured on MI355X: max 0.0195 / 0.0205, mean 0.0044 / 0.0043,
+    # rel-L2 0.0065 / 0.0068 (C = 2 / 3) -- and against the reference's fp32 run our bf16 logits deviate as much as the reference's
+    # own bf16-autocast logits do (mean 0.0060 vs 0.0059, max 0.024 vs 0.025): the bars below hold both statements
+    refl, ref32 = g["bf16__logits_sample"], g["fp32__logits_sample"]
+    dl = np.abs(samp - refl)
+    assert dl.max() <= 0.03 and dl.mean() <= 0.007, (dl.max(), dl.mean())
+    assert np.linalg.norm(samp - refl) / np.linalg.norm(refl) <= 0.01
+    assert np.abs(samp - ref32).mean() <= 1.25 * np.abs(refl - ref32).mean(), (np.abs(samp - ref32).mean(), np.abs(refl - ref32).mean())
     m.forward_loss(x.cuda(), mask.cuda(), labels.cuda())
     m.backward()
     names = meta[f"base_c{C}_param_names"]
