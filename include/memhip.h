@@ -429,6 +429,15 @@ int memhip_attn_bwd(const void* qkv, int64_t ldqkv, const void* dout, int64_t ld
                     float* delta, const float* table, int window_h, int window_w, int B, int T, int D,
                     int heads, float scale, void* dqkv, int64_t lddqkv, float* dtable, float* dq_bias,
                     float* dv_bias, memhip_stream_t stream);
+/* The same backward given the forward OUTPUT `out` (bf16 [B*T, D], leading dimension ldout) instead of a filled `delta`:
+ * rowsum(dout * out) is computed by the library -- inside the fused 14 x 14 kernel when that kernel applies (no separate
+ * pass over dout and out: 25 us per ViT-B layer at B = 256), otherwise by memhip_attn_delta into `delta` (then
+ * ldout == ldo is required).  `delta` is still the [(2*B*T + 4) * heads] workspace.  (Attention.forward backward,
+ * mem/modeling_finetune.py:137-154.) */
+int memhip_attn_bwd_out(const void* qkv, int64_t ldqkv, const void* dout, int64_t ldo, const void* out, int64_t ldout,
+                        const float* lse, float* delta, const float* table, int window_h, int window_w, int B, int T,
+                        int D, int heads, float scale, void* dqkv, int64_t lddqkv, float* dtable, float* dq_bias,
+                        float* dv_bias, memhip_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * fp32 PARITY MODE (`--precision fp32`): the ViT path with fp32 operands / accumulation and no bf16 rounding points --

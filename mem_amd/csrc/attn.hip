@@ -600,9 +600,9 @@ int attn_bwd_stream(const void* qkv, int64_t ldqkv, const void* dout, int64_t ld
 bool attn16_fits(int T, int window_h, int window_w);
 int attn16_fwd(const void* qkv, int64_t ldqkv, int B, int D, int heads, const float* table, void* out, int64_t ldo,
                float* lse, hipStream_t s);
-int attn16_bwd(const void* qkv, int64_t ldqkv, const void* dout, int64_t ldo, const float* lse, const float* delta,
-               const float* table, int B, int D, int heads, float scale, void* dqkv, int64_t lddqkv, float* dtable,
-               float* dq_bias, hipStream_t s);
+int attn16_bwd(const void* qkv, int64_t ldqkv, const void* dout, int64_t ldo, const void* out, int64_t ldout, const float* lse,
+               const float* delta, const float* table, int B, int D, int heads, float scale, void* dqkv, int64_t lddqkv,
+               float* dtable, float* dq_bias, hipStream_t s);
 }
 
 #define ATTN_DISPATCH(NKB_EXPR, MACRO)                                    \
@@ -661,6 +661,27 @@ extern "C" int memhip_attn_delta(const void* dout, const void* out, int64_t ldo,
   return check_launch("attn_delta");
 }
 
+// Attention backward from the forward OUTPUT: rowsum(dout * out) is computed by the library -- inside the fused 14 x 14
+// kernel when it applies (no separate pass), otherwise by memhip_attn_delta into `delta` in front of memhip_attn_bwd.
+extern "C" int memhip_attn_bwd_out(const void* qkv, int64_t ldqkv, const void* dout, int64_t ldo, const void* out, int64_t ldout,
+                                   const float* lse, float* delta, const float* table, int window_h, int window_w, int B,
+                                   int T, int D, int heads, float scale, void* dqkv, int64_t lddqkv, float* dtable,
+                                   float* dq_bias, float* dv_bias, memhip_stream_t stream) {
+  MEMHIP_REQUIRE(B >= 0 && T > 0 && heads > 0 && D == heads * HD, "attn_bwd: head_dim must be 64");
+  MEMHIP_REQUIRE(window_h > 0 && window_w > 0 && window_h * window_w + 1 == T, "attn_bwd: T must be window_h*window_w + 1");
+  if (B == 0) return MEMHIP_OK;
+  MEMHIP_REQUIRE(qkv && dout && out && lse && delta && table && dqkv, "attn_bwd: null pointer");
+  MEMHIP_REQUIRE(ldqkv % 8 == 0 && ldo % 8 == 0 && ldout % 8 == 0 && lddqkv % 8 == 0, "attn_bwd: ld must be a multiple of 8");
+  if (opt(OPT_ATTN16) && !dv_bias && memhip::attn16_fits(T, window_h, window_w))
+    return memhip::attn16_bwd(qkv, ldqkv, dout, ldo, out, ldout, lse, delta, table, B, D, heads, scale, dqkv, lddqkv, dtable,
+                              dq_bias, as_stream(stream));
+  MEMHIP_REQUIRE(ldo == ldout, "attn_bwd: dout and out must share a leading dimension on this path");
+  const int rc = memhip_attn_delta(dout, out, ldo, (int64_t)B * T, heads, delta, stream);
+  if (rc != MEMHIP_OK) return rc;
+  return memhip_attn_bwd(qkv, ldqkv, dout, ldo, lse, delta, table, window_h, window_w, B, T, D, heads, scale, dqkv, lddqkv, dtable,
+                         dq_bias, dv_bias, stream);
+}
+
 extern "C" int memhip_attn_bwd(const void* qkv, int64_t ldqkv, const void* dout, int64_t ldo, const float* lse,
                                float* delta, const float* table, int window_h, int window_w, int B,
                                int T, int D, int heads, float scale, void* dqkv, int64_t lddqkv, float* dtable,
@@ -673,7 +694,8 @@ extern "C" int memhip_attn_bwd(const void* qkv, int64_t ldqkv, const void* dout,
   hipStream_t s = as_stream(stream);
   // the fused kernel has no v_bias-gradient output (the engine derives it from the proj dgrad: vit_engine.py)
   if (opt(OPT_ATTN16) && !dv_bias && memhip::attn16_fits(T, window_h, window_w))
-    return memhip::attn16_bwd(qkv, ldqkv, dout, ldo, lse, delta, table, B, D, heads, scale, dqkv, lddqkv, dtable, dq_bias, s);
+    return memhip::attn16_bwd(qkv, ldqkv, dout, ldo, nullptr, 0, lse, delta, table, B, D, heads, scale, dqkv, lddqkv, dtable,
+                              dq_bias, s);
   const int nkb = (T + 31) / 32;
   const int nrd = (2 * window_h - 1) * (2 * window_w - 1) + 3;
   const int spb = pick_spb(B, heads);

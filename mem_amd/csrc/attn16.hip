@@ -32,6 +32,10 @@
 #include "attn_common.hpp"
 #include <type_traits>
 
+#ifndef ATTN16_FD_POS
+#define ATTN16_FD_POS 0   // where the fused-delta loads of the next sample are issued: 0 = in front of the Q / dO DMA (B = 256:
+                          // 300.5 us per layer), 1 = behind dQ's LDS staging (306.5 us); attn_delta + unfused backward: 314.4 us
+#endif
 #ifndef ATTN16_EXP
 #define ATTN16_EXP 0      // timing experiments (tools/build_variant.sh); 0 = the shipped kernel
 #endif
@@ -215,6 +219,13 @@ __device__ __forceinline__ void glds4(const void* gsrc, char* lds_dst) {     // 
   const unsigned lds = __builtin_amdgcn_readfirstlane(
       (unsigned)(unsigned long long)((__attribute__((address_space(3))) char*)lds_dst));
   asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(gsrc), "s"(lds) : "memory", "m0");
+}
+
+// the same with a wave-uniform base and a 32-bit lane offset (no 64-bit per-lane pointer to keep alive)
+__device__ __forceinline__ void glds4s(const void* sbase, unsigned voff, char* lds_dst) {
+  const unsigned lds = __builtin_amdgcn_readfirstlane(
+      (unsigned)(unsigned long long)((__attribute__((address_space(3))) char*)lds_dst));
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" ::"v"(voff), "s"(sbase), "s"(lds) : "memory", "m0");
 }
 
 // -DATTN16_TIMING: per-section s_memtime totals of wave 0 / wave 4 of every workgroup (tools/attn16_sections.py)
@@ -419,9 +430,14 @@ __device__ __forceinline__ float dpp_shr1(float v) {
 // ds_write_b64 of 16 consecutive rows and the transposing reads (32 lanes = 4 rows x 8 units) are both conflict-free
 __device__ __forceinline__ int exch_off(int row, int unit) { return row * 64 + ((unit ^ ((row >> 1) & 7)) << 3); }
 
-template <bool DT>
+// FD: delta = rowsum(dO * O) and |dO|^2 of a wave's queries are computed HERE from the forward output `oimg` (the rows of
+// its 32 queries, loaded a sample ahead into 16 registers by inline-asm loads that sit in front of the previous sample's
+// stores in the in-order queue) and the dO rows it reads from LDS anyway: 32 v_dot2_f32_bf16 per wave and sample instead of
+// the separate attn_delta pass over dO and O (25 us per layer at B = 256) and two of the three per-query row DMAs.
+template <bool DT, bool FD>
 __global__ __launch_bounds__(kThreads16) void attn16_bwd_kernel(const __bf16* __restrict__ qkv, long long ldq,
                                                                const __bf16* __restrict__ dout, long long ldo,
+                                                               const __bf16* __restrict__ oimg, long long ldoo,
                                                                const float* __restrict__ lse,
                                                                const float* __restrict__ delta,
                                                                const float* __restrict__ table,
@@ -473,15 +489,44 @@ __global__ __launch_bounds__(kThreads16) void attn16_bwd_kernel(const __bf16* __
   // per-query rows of the sample (lse, delta, |dO|^2) travel by LDS-DMA as well: a plain load into registers would make the
   // compiler wait for ALL vector-memory operations (the stores of the previous sample included) in front of the first use
   auto stage_rows = [&](int b) {
+    if (FD) {                                                // only the lse row; padding lanes read lse row entries < TP16 too
+      if (wave < 4) {
+        int tl = (int)threadIdx.x;
+        asm volatile("" : "+v"(tl));                         // (recomputed per call: see load_o)
+        const unsigned voff = (unsigned)((tl < TP16 ? tl : TP16 - 1) * 4);
+        glds4s(lse + ((long long)b * H + h) * TP16, voff, reinterpret_cast<char*>(rowsL) + wave * 256);
+      }
+      return;
+    }
     if (wave < 4) {
       const int t = wave * 64 + lane;
       const bool ok = t < T16;
       const void* z = g_attn_zero_page + (lane & 31) * 4;
       const long long row = (long long)b * T16 + t;
       glds4(ok ? (const void*)(lse + ((long long)b * H + h) * TP16 + t) : z, reinterpret_cast<char*>(rowsL) + wave * 256);
-      glds4(ok ? (const void*)(delta + row * H + h) : z, reinterpret_cast<char*>(rowsL + kRowsLd16) + wave * 256);
-      glds4(ok ? (const void*)(delta + ((long long)B * T16 + row) * H + h) : z, reinterpret_cast<char*>(rowsL + 2 * kRowsLd16) + wave * 256);
+      if (!FD) {
+        glds4(ok ? (const void*)(delta + row * H + h) : z, reinterpret_cast<char*>(rowsL + kRowsLd16) + wave * 256);
+        glds4(ok ? (const void*)(delta + ((long long)B * T16 + row) * H + h) : z, reinterpret_cast<char*>(rowsL + 2 * kRowsLd16) + wave * 256);
+      }
     }
+  };
+  // forward-output rows of this lane's query (dims 16 t + 8 hh .. + 7, t = 0..3: the layout of the row fragments), as asm
+  // loads: hipcc does not see them, so it neither waits for them nor for anything else in front of their first use; they
+  // are issued with the sample's LDS-DMA, i.e. in FRONT of the previous sample's stores, and have landed when the counted
+  // wait at the top of the sample has passed
+  // (scalar sample base + a 32-bit lane offset that is RECOMPUTED at every call from an opaque copy of the lane id: hoisted
+  // out of the sample loop it would be one more register that is live through the main loop, which has none to spare)
+  bf16x8 On[4];
+  auto load_o = [&](int b) {
+    int ql = (int)threadIdx.x;
+    asm volatile("" : "+v"(ql));
+    const int qq = (ql >> 6) * 32 + (ql & 31);
+    const int qcl = qq < T16 ? qq : T16 - 1;
+    const unsigned voff = (unsigned)((qcl * (int)ldoo + h * HD + 8 * ((ql >> 5) & 1)) * 2);     // bytes; rows * ld * 2 < 2^31
+    const __bf16* sb = oimg + (long long)b * T16 * ldoo;                                          // wave-uniform
+    asm volatile("global_load_dwordx4 %0, %4, %5\n\tglobal_load_dwordx4 %1, %4, %5 offset:32\n\t"
+                 "global_load_dwordx4 %2, %4, %5 offset:64\n\tglobal_load_dwordx4 %3, %4, %5 offset:96"
+                 : "=&v"(On[0]), "=&v"(On[1]), "=&v"(On[2]), "=&v"(On[3]) : "v"(voff), "s"(sb) : "memory");
   };
   auto stage_sample = [&](int b, bool kv) {                 // kv = false: K / V were staged early (last step of the sample before)
     const __bf16* s = qkv + (long long)b * T16 * ldq + h * HD;
@@ -494,6 +539,9 @@ __global__ __launch_bounds__(kThreads16) void attn16_bwd_kernel(const __bf16* __
   };
   stage_rows(b0);
   stage_sample(b0, true);
+  if (FD) load_o(b0);
+  // the first sample has no stores behind its DMA for the counted wait below to leave in flight: everything lands here
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   T16_DECL();
   for (int b = b0; b < b1; ++b) {
     T16_TICK(9);
@@ -503,7 +551,28 @@ __global__ __launch_bounds__(kThreads16) void attn16_bwd_kernel(const __bf16* __
     ATTN16_WAIT_VM(10);
     __syncthreads();                                         // images of sample b (first time: tables) are in LDS
     const float lq2 = q < T16 ? rowsL[q] * kLog2e : INFINITY;   // padding queries: p = exp2(-inf) = 0
-    const float dq_ = rowsL[kRowsLd16 + q], nqn = rowsL[2 * kRowsLd16 + q];
+    float dq_, nqn;
+    if constexpr (FD) {
+      asm volatile("" : "+v"(On[0]), "+v"(On[1]), "+v"(On[2]), "+v"(On[3]));      // landed (see load_o); named first here
+      const RowBase16 qr0 = row_base16(lo, lds_addr_of(Qs) + wave * 4096);
+      float dh = 0.f, nh = 0.f;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        union { bf16x8 v; bf16x2_t p[4]; } d, o;
+        d.v = lds_b128<IMG16>(qr0.a[t]);                   // dO row of this lane's query (zero rows for padding queries)
+        o.v = On[t];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          dh = __builtin_amdgcn_fdot2_f32_bf16(d.p[i], o.p[i], dh, false);
+          nh = __builtin_amdgcn_fdot2_f32_bf16(d.p[i], d.p[i], nh, false);
+        }
+      }
+      dq_ = dh + __shfl_xor(dh, 32);                       // the other half of the head dimension sits 32 lanes away
+      nqn = nh + __shfl_xor(nh, 32);
+    } else {
+      dq_ = rowsL[kRowsLd16 + q];
+      nqn = rowsL[2 * kRowsLd16 + q];
+    }
     T16_TICK(0);
     // ---- fixed-point scale of the bucket atomics: |dS| = p |dP - delta| <= max|dO_q| max|V_k| + max|delta_q| =: bound;
     // 2^19 / bound: fx_round() needs |x| < 2^22 and a chain sum has up to four terms (bf16-rounded dP may pass the bound by
@@ -688,6 +757,9 @@ __global__ __launch_bounds__(kThreads16) void attn16_bwd_kernel(const __bf16* __
     }
     __syncthreads();                                         // all reads of the images and all bucket atomics are done
     T16_TICK(8);
+#if ATTN16_FD_POS == 0
+    if constexpr (FD) load_o(b + 1 < b1 ? b + 1 : b);      // in front of the Q / dO DMA of the next sample
+#endif
     if (b + 1 < b1) { stage_rows(b + 1); stage_sample(b + 1, false); }
     // ---------------- epilogue of sample b (under the LDS-DMA of sample b + 1)
     if (DT) {
@@ -710,6 +782,13 @@ __global__ __launch_bounds__(kThreads16) void attn16_bwd_kernel(const __bf16* __
           for (int e = 0; e < 4; ++e) w[e] = (__bf16)(bfr(dQt[db][4 * g + e]) * scale);
           tile_put(st, r, hh, db, g, w);
         }
+      // (the forward-output rows of the next sample are requested HERE: the dQ accumulators are dead -- 16 registers are
+      // free -- and none of the sample's twelve stores has been issued yet, so the loads wait for nothing but the DMA in
+      // front of them and all twelve stores stay behind them for the counted wait at the top of the next sample)
+#if ATTN16_FD_POS == 1
+      // (issued for the last sample as well -- its own rows once more, never used: no branch, the loads stay in this block)
+      if constexpr (FD) load_o(b + 1 < b1 ? b + 1 : b);
+#endif
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int row = (lane >> 3) + 8 * i, qq = wave * 32 + row;
@@ -808,27 +887,27 @@ int attn16_fwd(const void* qkv, int64_t ldqkv, int B, int D, int heads, const fl
   return check_launch("attn_fwd(14x14)");
 }
 
-int attn16_bwd(const void* qkv, int64_t ldqkv, const void* dout, int64_t ldo, const float* lse, const float* delta,
-               const float* table, int B, int D, int heads, float scale, void* dqkv, int64_t lddqkv, float* dtable,
-               float* dq_bias, hipStream_t s) {
+int attn16_bwd(const void* qkv, int64_t ldqkv, const void* dout, int64_t ldo, const void* out, int64_t ldout, const float* lse,
+               const float* delta, const float* table, int B, int D, int heads, float scale, void* dqkv, int64_t lddqkv,
+               float* dtable, float* dq_bias, hipStream_t s) {
   static bool attr_done = false;
   if (!attr_done) {
-    MEMHIP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn16_bwd_kernel<true>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds));
-    MEMHIP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn16_bwd_kernel<false>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds));
+#define A16_ATTR(DT, FD) MEMHIP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn16_bwd_kernel<DT, FD>), \
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds))
+    A16_ATTR(true, true); A16_ATTR(true, false); A16_ATTR(false, true); A16_ATTR(false, false);
+#undef A16_ATTR
     attr_done = true;
   }
   const int nwg = nwg16(B, heads), stagger = opt(OPT_ATTN16_STAGGER);
   const int grid = nwg * heads;
-  if (dtable)
-    hipLaunchKernelGGL(attn16_bwd_kernel<true>, dim3(grid), dim3(kThreads16), kLdsBwd16, s, (const __bf16*)qkv,
-                       (long long)ldqkv, (const __bf16*)dout, (long long)ldo, lse, delta, table, (__bf16*)dqkv,
-                       (long long)lddqkv, dtable, dq_bias, B, D, heads, scale, nwg, stagger);
-  else
-    hipLaunchKernelGGL(attn16_bwd_kernel<false>, dim3(grid), dim3(kThreads16), kLdsBwd16, s, (const __bf16*)qkv,
-                       (long long)ldqkv, (const __bf16*)dout, (long long)ldo, lse, delta, table, (__bf16*)dqkv,
-                       (long long)lddqkv, dtable, dq_bias, B, D, heads, scale, nwg, stagger);
+#define A16_LAUNCH(DT, FD)                                                                                          \
+  hipLaunchKernelGGL((attn16_bwd_kernel<DT, FD>), dim3(grid), dim3(kThreads16), kLdsBwd16, s, (const __bf16*)qkv,     \
+                     (long long)ldqkv, (const __bf16*)dout, (long long)ldo, (const __bf16*)out, (long long)ldout, lse, \
+                     delta, table, (__bf16*)dqkv, (long long)lddqkv, dtable, dq_bias, B, D, heads, scale, nwg, stagger)
+  // out != NULL: delta is computed inside the kernel (the `delta` workspace is not read)
+  if (dtable) { if (out) A16_LAUNCH(true, true); else A16_LAUNCH(true, false); }
+  else { if (out) A16_LAUNCH(false, true); else A16_LAUNCH(false, false); }
+#undef A16_LAUNCH
   return check_launch("attn_bwd(14x14)");
 }
 

@@ -689,9 +689,8 @@ class MaeEngineBF16(MaeEngineF32):
             Gw(pre + "attn.proj.weight").view(D, heads, 32).add_(acts["gp"].view(D, heads, 64)[:, :, :32])
         else:
             self._wgrad16(dy, a["ao"], M, D, Dp, Gw(pre + "attn.proj.weight"))
-        ops.attn_delta(dao, a["ao"], M, heads, acts["delta"])
         ops.attn_bwd(a["qkv"], dao, a["lse"], acts["delta"], acts["table"], acts["window"], B, T, Dp, heads, scale, dqkv, None,
-                     dq_bias=gb[0:Dp])
+                     dq_bias=gb[0:Dp], out=a["ao"])
         if pad:
             acts["gq"].zero_()
             self._wgrad16(dqkv, a["h1"], M, 3 * Dp, D, acts["gq"])

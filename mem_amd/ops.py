@@ -94,6 +94,7 @@ declare({
     "memhip_attn_fwd": (i32, [vp, i64, i32, i32, i32, i32, vp, i32, i32, vp, i64, vp, vp]),
     "memhip_attn_delta": (i32, [vp, vp, i64, i64, i32, vp, vp]),
     "memhip_attn_bwd": (i32, [vp, i64, vp, i64, vp, vp, vp, i32, i32, i32, i32, i32, i32, f32, vp, i64, vp, vp, vp, vp]),
+    "memhip_attn_bwd_out": (i32, [vp, i64, vp, i64, vp, i64, vp, vp, vp, i32, i32, i32, i32, i32, i32, f32, vp, i64, vp, vp, vp, vp]),
     "memhip_cast_f32_bf16": (i32, [vp, vp, i64, vp]),
     "memhip_copy_samples_f32": (i32, [vp, vp, vp, i32, i64, vp]),
     "memhip_transpose_cast_f32_bf16": (i32, [vp, i64, i32, i32, vp, i64, vp]),
@@ -213,7 +214,14 @@ def attn_delta(dout, out, rows, heads, delta):
           "attn_delta")
 
 
-def attn_bwd(qkv, dout, lse, delta, table, window, B, T, D, heads, scale, dqkv, dtable, dq_bias=None, dv_bias=None):
+def attn_bwd(qkv, dout, lse, delta, table, window, B, T, D, heads, scale, dqkv, dtable, dq_bias=None, dv_bias=None, out=None):
+    """out = the forward output: rowsum(dout * out) is computed by the library (inside the fused 14 x 14 kernel when it
+    applies); without it `delta` must have been filled by attn_delta."""
+    if out is not None:
+        check(lib.memhip_attn_bwd_out(ptr(qkv), qkv.stride(0), ptr(dout), dout.stride(0), ptr(out), out.stride(0), ptr(lse),
+                                      ptr(delta), ptr(table), window[0], window[1], B, T, D, heads, scale, ptr(dqkv),
+                                      dqkv.stride(0), ptr(dtable), ptr(dq_bias), ptr(dv_bias), stream_ptr()), "attn_bwd_out")
+        return
     check(lib.memhip_attn_bwd(ptr(qkv), qkv.stride(0), ptr(dout), dout.stride(0), ptr(lse), ptr(delta), ptr(table),
                               window[0], window[1], B, T, D, heads, scale, ptr(dqkv), dqkv.stride(0), ptr(dtable),
                               ptr(dq_bias), ptr(dv_bias), stream_ptr()), "attn_bwd")

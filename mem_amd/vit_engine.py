@@ -697,10 +697,10 @@ class ViTEngine:
                                             self.P(pre + "attn.proj.bias"), self.G(pre + "attn.proj.bias"),
                                             self.P(pre + "gamma_1"), D, D, self.G(pre + "gamma_1"))
                 self._on_side(wg_proj)
-                ops.attn_delta(self.dao, a["ao"], M1, self.heads, self.delta_ws)
                 self._before_overwrite("dqkv")
+                # (rowsum(dO * O) is computed inside the fused 14 x 14 backward; other windows: a delta pass in the library)
                 ops.attn_bwd(a["qkv"], self.dao, a["lse"], self.delta_ws, table, self.window, na, T, D, self.heads,
-                             self.scale, self.dqkv, dtable, dq_bias=self.G(pre + "attn.q_bias"))
+                             self.scale, self.dqkv, dtable, dq_bias=self.G(pre + "attn.q_bias"), out=a["ao"])
 
                 def wg_qkv(pre=pre, a=a, M1=M1):
                     self._wgrad(self.dqkv, a["h1"], M1, 3 * D, D, pre + "attn.qkv.weight")
@@ -809,10 +809,10 @@ class ViTEngine:
                                         self.P(pre + "attn.proj.bias"), self.G(pre + "attn.proj.bias"),
                                         self.P(pre + "gamma_1"), D, D, self.G(pre + "gamma_1"))
             self._on_side(wg_proj)
-            ops.attn_delta(self.dao, a["ao"], M, self.heads, self.delta_ws)
             self._before_overwrite("dqkv")
+            # (rowsum(dO * O) is computed inside the fused 14 x 14 backward; other windows: a delta pass in the library)
             ops.attn_bwd(a["qkv"], self.dao, a["lse"], self.delta_ws, table, self.window, B, T, D, self.heads,
-                         self.scale, self.dqkv, dtable, dq_bias=self.G(pre + "attn.q_bias"))
+                         self.scale, self.dqkv, dtable, dq_bias=self.G(pre + "attn.q_bias"), out=a["ao"])
 
             def wg_qkv(pre=pre, a=a):
                 self._wgrad(self.dqkv, a["h1"], M, 3 * D, D, pre + "attn.qkv.weight")

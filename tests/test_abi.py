@@ -79,7 +79,8 @@ def test_attn16_counted_waits_match_the_instruction_stream(tmp_path):
                     "-o", out, src], check=True, capture_output=True)
     lines = open(out).read().split("\n")
     checked = 0
-    for kname, n_wait in (("attn16_fwd_kernel", 4), ("attn16_bwd_kernelILb1", 10), ("attn16_bwd_kernelILb0", 10)):
+    for kname, n_wait in (("attn16_fwd_kernel", 4), ("attn16_bwd_kernelILb1ELb0", 10), ("attn16_bwd_kernelILb0ELb0", 10),
+                          ("attn16_bwd_kernelILb1ELb1", 10), ("attn16_bwd_kernelILb0ELb1", 10)):
         i0 = next(i for i, l in enumerate(lines) if l.startswith("_ZN") and kname in l and l.rstrip().endswith(tuple(": ;"))
                   or (l.startswith("_ZN") and kname in l and ": ;" in l))
         j = i0
@@ -92,5 +93,11 @@ def test_attn16_counted_waits_match_the_instruction_stream(tmp_path):
         assert glds and waits, (kname, len(glds), len(waits))
         assert len(stores) >= n_wait, (kname, len(stores), n_wait)    # all of them sit in the sample loop, behind its DMA
         assert not any("scratch_" in l for l in body), kname        # a spill would add uncounted vector-memory operations
+        if kname.endswith("ELb1"):
+            # fused delta: the forward-output rows of the next sample are plain (asm) loads issued in front of the sample's stores; at
+            # least n_wait stores must follow the LAST of them in the sample loop, so that vmcnt(n_wait) covers them
+            loads = [k for k, l in enumerate(body) if re.search(r"\bglobal_load_dwordx4\b", l)]
+            assert len(loads) >= 8, (kname, len(loads))           # 4 in the prologue (first sample) + 4 in the loop
+            assert sum(1 for k in stores if k > loads[-1]) >= n_wait, (kname, loads[-1], stores)
         checked += 1
-    assert checked == 3
+    assert checked == 5

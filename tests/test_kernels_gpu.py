@@ -201,6 +201,44 @@ def test_attn16_equals_general_kernels():
         assert rel < tol, (name, rel)
 
 
+@pytest.mark.parametrize("B,T,H,win,with_table", [(29, 197, 3, (14, 14), True), (14, 197, 12, (14, 14), False), (1, 197, 2, (14, 14), True),
+                                                 (5, 25, 2, (4, 6), True), (2, 321, 2, (16, 20), True)])
+def test_attention_backward_from_the_forward_output(B, T, H, win, with_table):
+    """memhip_attn_bwd_out: rowsum(dO * O) computed by the library (inside the fused 14 x 14 backward; a delta pass in front
+    of the general / streaming kernels) == memhip_attn_delta + memhip_attn_bwd on the same inputs (Attention.forward backward,
+    mem/modeling_finetune.py:137-154).  B = 1 / 14 / 29: one, uneven and several samples per workgroup (first-sample path,
+    the next-sample loads of the last sample)."""
+    from mem_amd import ops
+    from oracle.vit_ref import rel_pos_index
+    D = 64 * H
+    TP = ops.attn_tokens_padded(T)
+    qkv = _rand((B * T, 3 * D), 160, 0.7)
+    qkv[:, :D] *= 0.5
+    qkv = qkv.bfloat16()
+    idx, nrd = rel_pos_index(win)
+    table = _rand((nrd, H), 161, 0.5)
+    dout = _rand((B * T, D), 162, 1.0).bfloat16()
+    out = torch.zeros((B * T, D), dtype=torch.bfloat16, device="cuda")
+    lse = torch.zeros((B, H, TP), device="cuda")
+    ops.attn_fwd(qkv, B, T, D, H, table, win, out, lse)
+    res = []
+    for fused in (False, True):
+        dqkv = torch.full((B * T, 3 * D), 3.0, dtype=torch.bfloat16, device="cuda")
+        dtable = torch.zeros((nrd, H), device="cuda") if with_table else None
+        delta = torch.full((2 * B * T + 4, H), 7.0, device="cuda")             # garbage: the fused path must not read it
+        dqb = torch.zeros(D, device="cuda")
+        if fused:
+            ops.attn_bwd(qkv, dout, lse, delta, table, win, B, T, D, H, 0.125, dqkv, dtable, dq_bias=dqb, out=out)
+        else:
+            ops.attn_delta(dout, out, B * T, H, delta)
+            ops.attn_bwd(qkv, dout, lse, delta, table, win, B, T, D, H, 0.125, dqkv, dtable, dq_bias=dqb)
+        res.append((dqkv.float(), dtable.clone() if with_table else torch.zeros(1, device="cuda"), dqb.clone()))
+    for name, a, b, tol in zip(("dqkv", "dtable", "dq_bias"), res[0], res[1], (2e-4, 2e-4, 2e-4)):
+        rel = ((a - b).norm() / (a.norm() + 1e-20)).item()
+        assert rel < tol, (name, rel)
+    assert (res[0][0] == res[1][0]).float().mean().item() > 0.999           # bf16 outputs: equal except rounding-boundary cases
+
+
 def _attention_case(B, T, H, win):
     from mem_amd import ops
     from oracle.vit_ref import rel_pos_index

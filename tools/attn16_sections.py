@@ -30,15 +30,15 @@ fn = ["top wait+barrier", "stage issue + S mfma", "bias + max", "exp + sum", "PV
 print("forward (cycles per workgroup-kernel)")
 for w in (0, 1):
     print(f"  wave {4 * w}: total {sum(buf[w * 16 + 6 + i] for i in range(6)) / (n * 252):9.0f}  " + "  ".join(f"{fn[i]} {buf[w * 16 + 6 + i] / (n * 252):.0f}" for i in range(6)))
-for dt in (dtable, None):
-    ops.attn_bwd(qkv, dout, lse, delta, table, (14, 14), B, T, D, H, 0.125, dqkv, dt, dqb, None)
+for dt, fo in ((dtable, None), (dtable, out), (None, None)):
+    ops.attn_bwd(qkv, dout, lse, delta, table, (14, 14), B, T, D, H, 0.125, dqkv, dt, dqb, None, out=fo)
     torch.cuda.synchronize(); f(None, 1)
     n = 5
     for _ in range(n):
-        ops.attn_bwd(qkv, dout, lse, delta, table, (14, 14), B, T, D, H, 0.125, dqkv, dt, dqb, None)
+        ops.attn_bwd(qkv, dout, lse, delta, table, (14, 14), B, T, D, H, 0.125, dqkv, dt, dqb, None, out=fo)
     torch.cuda.synchronize(); f(buf, 1)
     wgs = 240
-    print("dtable" if dt is not None else "no dtable", "(cycles per workgroup-kernel, wave 0 | wave 4)")
+    print("dtable" if dt is not None else "no dtable", "fused delta" if fo is not None else "delta from the workspace", "(cycles per workgroup-kernel, wave 0 | wave 4)")
     for w in (0, 1):
         tot = sum(buf[w * 16 + i] for i in range(12)) / (n * wgs)
         print(f"  wave {4 * w}: total {tot:9.0f}  " + "  ".join(f"{names[i]} {buf[w * 16 + i] / (n * wgs):.0f}" for i in range(10)))
