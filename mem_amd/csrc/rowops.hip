@@ -631,7 +631,8 @@ extern "C" int memhip_layernorm_bwd(const void* dy, int64_t lddy, const float* x
   MEMHIP_REQUIRE(dy && x && gamma && mean && rstd && dres && dgamma && dbeta, "layernorm_bwd: null pointer");
   MEMHIP_REQUIRE(ldx % 4 == 0 && lddy % 4 == 0 && lddres % 4 == 0, "layernorm_bwd: ld must be a multiple of 4");
   int grid = cdiv(R, 4);
-  if (grid > 1024) grid = 1024;                      // 4 workgroups per CU, ~50 rows per wave at ViT-B scale
+  const int cap = opt(OPT_LN_BWD_GRID) * 4 / 3;      // default 1024: 4 workgroups per CU, ~50 rows per wave at ViT-B scale
+  if (grid > cap) grid = cap;
 #define LNB_LAUNCH(N)                                                                                    \
   hipLaunchKernelGGL(ln_bwd_kernel<N>, dim3(grid), dim3(256), (size_t)8 * D * sizeof(float), as_stream(stream), \
                      (const __bf16*)dy, (long long)lddy, x, (long long)ldx, row_idx, R, D, gamma, mean, rstd, dres, \

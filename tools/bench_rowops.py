@@ -21,6 +21,14 @@ for grid in (768, 512, 384, 256, 192, 128):
     _lib.set_option("ln_bwd_grid", grid)
     us = t(lambda: ops.layernorm_bwd_branch(dy, x, g, mean, rstd, dres, dg, db, M, D, None, gb, dyb, None, dbb, rows_per_sample=T))
     print(f"ln_bwd_branch grid {grid:4d}: {us:7.1f} us  ({(M * D * (2 + 4 + 8 + 2)) / us / 1e6:5.2f} TB/s)")
+# the final-norm backward as the step runs it: 25 088 masked-token rows gathered from / scattered to the residual stream
+Mm = 25088
+ridx = torch.randperm(M, device=dev)[:Mm].sort().values.int()
+dyn = torch.randn(Mm, D, device=dev).bfloat16(); mn = torch.randn(Mm, device=dev); rn = torch.rand(Mm, device=dev) + 0.5
+for grid in (768, 576, 384, 192, 96):
+    _lib.set_option("ln_bwd_grid", grid)
+    us = t(lambda: ops.layernorm_bwd(dyn, x, g, mn, rn, dres, dg, db, Mm, D, accumulate=False, row_idx=ridx))
+    print(f"ln_bwd (gathered rows) workgroups {grid * 4 // 3:5d}: {us:7.1f} us  ({Mm * D * (2 + 4 + 4) / us / 1e6:5.2f} TB/s)")
 _lib.set_option("ln_bwd_grid", 768)
 for (R, Cc, name) in ((B * L, D, "patch-embed bias"), (25088, 8192, "lm_head bias"), (M, 512, "C=512")):
     a = torch.randn(R, Cc, device=dev).bfloat16(); o = torch.zeros(Cc, device=dev)
