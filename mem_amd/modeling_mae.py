@@ -580,6 +580,7 @@ class MaeEngineBF16(MaeEngineF32):
         self.weights_dirty = False
 
     CS_COPIES = 8
+    FUSE_LN_BRANCH = True      # LayerNorm backward fused with the following branch backward (the ViT engine's ln_bwd_branch kernel)
 
     def ensure_batch(self, B, K):
         if B <= self.B and K == getattr(self, "K", None):
@@ -661,8 +662,12 @@ class MaeEngineBF16(MaeEngineF32):
         scale = spec["hd"] ** -0.5
         pad = spec["hd"] == 32
         Gw = lambda n: Gr(n).view(self.named[n].shape[0], -1)       # noqa: E731
-        # MLP branch: the branch output gradient IS dx (no layer scale, no drop path); Linear grad_outputs are bf16
-        ops.branch_bwd(dx, None, None, dy, None, Gr(pre + "mlp.fc2.bias"), M, D)      # dy = bf16(dx) + its column sums, one pass
+        # MLP branch: the branch output gradient IS dx (no layer scale, no drop path); Linear grad_outputs are bf16.
+        # dy = bf16(dx) + its column sums: for every block but the last of a stack this already came out of the fused norm1
+        # backward of block i + 1 (below); FUSE_LN_BRANCH = False keeps the two-kernel form (A/B, tests)
+        fuse = self.FUSE_LN_BRANCH and D <= 1024
+        if i == spec["depth"] - 1 or not fuse:
+            ops.branch_bwd(dx, None, None, dy, None, Gr(pre + "mlp.fc2.bias"), M, D)
         # (fused column sums go to CS_COPIES accumulator copies, folded by a tiny kernel: atomics on one address serialise)
         ops.gemm_nt(dy, self.wT16[pre + "mlp.fc2.weight"], M, Hd, D, ops.EPI_DGELU, out0=dbig, aux=a["hpre"],
                     colsum=self.cs_ws, colsum_copies=self.CS_COPIES)
@@ -670,10 +675,14 @@ class MaeEngineBF16(MaeEngineF32):
         self._wgrad16(dy, a["a"], M, D, Hd, Gw(pre + "mlp.fc2.weight"))
         self._wgrad16(dbig, a["h2"], M, Hd, D, Gw(pre + "mlp.fc1.weight"))
         ops.gemm_nt(dbig, self.wT16[pre + "mlp.fc1.weight"], M, D, Hd, ops.EPI_BIAS_BF16, out0=dh)
-        ops.layernorm_bwd(dh, xmid, P(pre + "norm2.weight"), a["mean2"], a["rstd2"], dx, Gr(pre + "norm2.weight"),
-                          Gr(pre + "norm2.bias"), M, D, accumulate=True)
-        # attention branch
-        ops.branch_bwd(dx, None, None, dy, None, Gr(pre + "attn.proj.bias"), M, D)
+        # norm2 backward into dx + the attention branch's dy = bf16(dx) and proj-bias column sums: one pass over dx
+        if fuse:
+            ops.layernorm_bwd_branch(dh, xmid, P(pre + "norm2.weight"), a["mean2"], a["rstd2"], dx, Gr(pre + "norm2.weight"),
+                                     Gr(pre + "norm2.bias"), M, D, None, None, dy, None, Gr(pre + "attn.proj.bias"))
+        else:
+            ops.layernorm_bwd(dh, xmid, P(pre + "norm2.weight"), a["mean2"], a["rstd2"], dx, Gr(pre + "norm2.weight"),
+                              Gr(pre + "norm2.bias"), M, D, accumulate=True)
+            ops.branch_bwd(dx, None, None, dy, None, Gr(pre + "attn.proj.bias"), M, D)
         # qkv.bias gradient without a pass over dqkv: the v part is colsum(dao) (sum_k dV_k = sum_q dO_q: softmax rows sum to
         # one), fused into the GEMM that produces dao; the q part comes out of the attention backward kernel; the k part is
         # zero in real arithmetic (sum_k dS_qk = 0 for every query row) and is left at zero
@@ -699,8 +708,13 @@ class MaeEngineBF16(MaeEngineF32):
         else:
             self._wgrad16(dqkv, a["h1"], M, 3 * D, D, Gw(pre + "attn.qkv.weight"))
         ops.gemm_nt(dqkv, self.wT16[pre + "attn.qkv.weight"], M, D, 3 * Dp, ops.EPI_BIAS_BF16, out0=dh)
-        ops.layernorm_bwd(dh, xin, P(pre + "norm1.weight"), a["mean1"], a["rstd1"], dx, Gr(pre + "norm1.weight"),
-                          Gr(pre + "norm1.bias"), M, D, accumulate=True)
+        if fuse and i > 0:        # norm1 backward of block i + the MLP branch's dy / fc2-bias column sums of block i - 1
+            pb = f"{spec['pre']}{i - 1}."
+            ops.layernorm_bwd_branch(dh, xin, P(pre + "norm1.weight"), a["mean1"], a["rstd1"], dx, Gr(pre + "norm1.weight"),
+                                     Gr(pre + "norm1.bias"), M, D, None, None, dy, None, Gr(pb + "mlp.fc2.bias"))
+        else:
+            ops.layernorm_bwd(dh, xin, P(pre + "norm1.weight"), a["mean1"], a["rstd1"], dx, Gr(pre + "norm1.weight"),
+                              Gr(pre + "norm1.bias"), M, D, accumulate=True)
 
     def forward(self, imgs, ids_keep, ids_restore, mask):
         assert imgs.is_cuda and imgs.dtype == torch.float32 and imgs.is_contiguous()

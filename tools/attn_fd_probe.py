@@ -33,3 +33,13 @@ def t(f, n=20):
     e1.record(); torch.cuda.synchronize(); return e0.elapsed_time(e1) / n * 1e3
 for rep in range(3):
     print("attn_delta + attn_bwd %.1f us   fused %.1f us" % (t(old), t(new)), flush=True)
+# without the table gradient (the MAE decoder: zero table, no dtable)
+def t2(f, n=20):
+    dqkv = torch.zeros(M, 3 * D, device="cuda", dtype=torch.bfloat16); dqb = torch.zeros(D, device="cuda")
+    for _ in range(3): f(dqkv, None, dqb)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize(); e0.record()
+    for _ in range(n): f(dqkv, None, dqb)
+    e1.record(); torch.cuda.synchronize(); return e0.elapsed_time(e1) / n * 1e3
+for rep in range(2):
+    print("no table gradient: attn_delta + attn_bwd %.1f us   fused entry point %.1f us" % (t2(old), t2(new)), flush=True)
