@@ -317,6 +317,8 @@ def main():
     ap.add_argument("--no-dp-skip", action="store_true",
                     help="stochastic depth by masking (every sample computed, dropped ones multiplied by zero) instead of "
                          "work skipping: A/B switch")
+    ap.add_argument("--no-tail-rows", action="store_true",
+                    help="A/B switch: the last block's MLP branch on every row instead of only the rows that reach the head")
     ap.add_argument("--no-entrypoint-figure", action="store_true",
                     help="skip the measurement of the real entrypoint loop (train_one_epoch over a DataLoader)")
     ap.add_argument("--entrypoint-workers", type=int, default=10, help="DataLoader workers of the entrypoint figure")
@@ -390,6 +392,7 @@ def main():
     eng = model.engine
     eng.wgrad_side_stream = not a.no_side_stream
     eng.dp_skip = not a.no_dp_skip
+    eng.tail_rows = not a.no_tail_rows
     eng.fwd_two_streams = bool(a.fwd_split) and not a.no_fwd_split
     import contextlib, io
     with contextlib.redirect_stdout(io.StringIO()):
@@ -757,6 +760,14 @@ def main():
                 # (modeling_finetune.py:42-53); the work-skipping engine does not launch them: say how much that is
                 rates = [float(b.drop_prob) for b in model.blocks]
                 roof["whole_step"]["block_flops_not_executed_frac"] = round(sum(rates) / max(1, len(rates)), 4)
+            if eng.tail_rows and eng.cur.get("tail") is not None:
+                # dead-row elimination: the last block's MLP branch (2 GEMMs of D x 4D, fwd + dgrad + wgrad) runs on the
+                # rows that reach the head only (Mm of M token rows)
+                t_, d_, hd_ = eng.T, eng.D, eng.hidden
+                mlp_frac = 3.0 * 2.0 * 2.0 * t_ * d_ * hd_ / FLOP_PER_SAMPLE[C]
+                roof["whole_step"]["last_block_mlp_flops_not_executed_frac"] = round(
+                    mlp_frac * (1.0 - eng.cur["Mm"] / float(eng.cur["M"])), 4)
+            if eng.dp_skip:
                 roof["whole_step"]["note"] = ("algorithmic FLOPs are the reference's (masked stochastic depth computes dropped "
                                               "samples too); the engine skips them, so the executed rate is lower by about that fraction "
                                               "of the block FLOPs -- A/B with --no-dp-skip")
@@ -777,7 +788,8 @@ def main():
                           "global_batch": world * B, "events_per_sample": NE, "parallelism": f"dp{world}",
                           "model_flops_frac_of_peak": round(value / world * FLOP_PER_SAMPLE[C] / (PEAK_BF16_TFLOPS * 1e12), 4),
                           "last_loss": round(loss_last, 4), "host_threads": host_threads,
-                          "stochastic_depth": "work skipping" if eng.dp_skip else "masked"},
+                          "stochastic_depth": "work skipping" if eng.dp_skip else "masked",
+                          "last_block_mlp_rows": "rows that reach the head" if eng.tail_rows else "all"},
                "roofline": roof}
         if tok_ms is not None:
             out["with_tokenizer"] = {"value": round(world * B / (tok_step_ms * 1e-3), 1), "unit": "samples/sec",

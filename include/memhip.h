@@ -322,6 +322,17 @@ int memhip_colsum_bf16(const void* in, int64_t ld, int R, int C, float* out, mem
  * are zeroed again (ready for the next GEMM).  Same reduction order every run. */
 int memhip_colsum_fold(float* ws, int copies, int N, float* out, memhip_stream_t stream);
 
+/* Dead-row elimination in the LAST block (Block.forward, mem/modeling_finetune.py:160-189; the head reads only the masked
+ * tokens' rows, mem/modeling_pretrain.py:119-126): the MLP branch of the last block runs on those rows in compact form.
+ * residual_rows: out[i, :] = x[rows[i], :] + drop_path(gamma * y[i, :]) with y the bf16 output of the fc2 GEMM (+ bias) for
+ * compact row i -- the arithmetic of the RESIDUAL epilogue; gamma NULL = no layer scale; rowkeep f32 [R] (0/1 per compact
+ * row, NULL = no stochastic depth) with keep_prob.  scatter_rows: dst[rows[i], :] = src[i, :] (fp32 rows of D values). */
+int memhip_residual_rows(const float* x, int64_t ldx, const int32_t* rows, const void* y, int64_t ldy, const float* gamma,
+                         const float* rowkeep, float keep_prob, int R, int D, float* out, int64_t ldo,
+                         memhip_stream_t stream);
+int memhip_scatter_rows_f32(const float* src, int64_t lds, const int32_t* rows, int R, int D, float* dst, int64_t ldd,
+                            memhip_stream_t stream);
+
 /* ------------------------------------------------------------------------
  * LayerNorm (eps 1e-6) forward / backward          mem/modeling_pretrain.py:132,
  * mem/modeling_finetune.py:166,172,184-188; final norm mem/modeling_pretrain.py:117

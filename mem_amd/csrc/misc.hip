@@ -266,6 +266,74 @@ extern "C" int memhip_copy_samples_f32(const float* src, float* dst, const int32
   return check_launch("copy_samples");
 }
 
+// ---- dead-row elimination in the last block (vit_engine.py: tail rows).  Only the rows that reach the head (the masked
+// tokens) need the last block's MLP branch: it runs on those rows in compact form, and these two kernels connect the compact
+// rows with the token-major residual stream.
+//   residual_rows: out[i, :] = x[rows[i], :] + drop_path(gamma * y[i, :])   -- the arithmetic of the GEMM's RESIDUAL epilogue
+//   (gemm_epilogue.hpp) on the already rounded bf16 branch output y: gamma * y rounded, the drop-path quotient correctly
+//   rounded (reciprocal + one Newton step), times the row's keep flag, one rounding for the add.
+//   scatter_rows:  dst[rows[i], :] = src[i, :]
+__global__ __launch_bounds__(256) void residual_rows_kernel(const float* __restrict__ x, long long ldx, const int* __restrict__ rows,
+                                                            const __bf16* __restrict__ y, long long ldy,
+                                                            const float* __restrict__ gamma, const float* __restrict__ rowkeep,
+                                                            float keep_prob, int R, int D, float* __restrict__ out, long long ldo) {
+  const int per_row = D / 4;
+  const float kp = rowkeep ? keep_prob : 1.0f;
+  const float rk = __frcp_rn(kp);
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < (long long)R * per_row; i += (long long)gridDim.x * 256) {
+    const int r = (int)(i / per_row), c = (int)(i % per_row) * 4;
+    const float rm = rowkeep ? rowkeep[r] : 1.0f;
+    const float4 xv = *reinterpret_cast<const float4*>(x + (long long)rows[r] * ldx + c);
+    const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
+    float o[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float br = __fmul_rn(gamma ? gamma[c + k] : 1.0f, (float)y[(long long)r * ldy + c + k]);
+      const float q0 = br * rk;
+      const float q = fmaf(fmaf(-q0, kp, br), rk, q0);
+      br = __fmul_rn(q, rm);
+      o[k] = __fadd_rn(xs[k], br);
+    }
+    *reinterpret_cast<float4*>(out + (long long)r * ldo + c) = float4{o[0], o[1], o[2], o[3]};
+  }
+}
+
+__global__ __launch_bounds__(256) void scatter_rows_kernel(const float* __restrict__ src, long long lds, const int* __restrict__ rows,
+                                                           int R, int D, float* __restrict__ dst, long long ldd) {
+  const int per_row = D / 4;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < (long long)R * per_row; i += (long long)gridDim.x * 256) {
+    const int r = (int)(i / per_row), c = (int)(i % per_row) * 4;
+    *reinterpret_cast<float4*>(dst + (long long)rows[r] * ldd + c) = *reinterpret_cast<const float4*>(src + (long long)r * lds + c);
+  }
+}
+
+extern "C" int memhip_residual_rows(const float* x, int64_t ldx, const int32_t* rows, const void* y, int64_t ldy, const float* gamma,
+                                    const float* rowkeep, float keep_prob, int R, int D, float* out, int64_t ldo,
+                                    memhip_stream_t stream) {
+  MEMHIP_REQUIRE(R >= 0 && D > 0 && D % 4 == 0 && ldx % 4 == 0 && ldo % 4 == 0, "residual_rows: bad shape");
+  if (R == 0) return MEMHIP_OK;
+  MEMHIP_REQUIRE(x && rows && y && out, "residual_rows: null pointer");
+  long long n = (long long)R * (D / 4);
+  int grid = (int)((n + 255) / 256);
+  if (grid > 2048) grid = 2048;
+  hipLaunchKernelGGL(residual_rows_kernel, dim3(grid), dim3(256), 0, as_stream(stream), x, (long long)ldx, (const int*)rows,
+                     (const __bf16*)y, (long long)ldy, gamma, rowkeep, keep_prob, R, D, out, (long long)ldo);
+  return check_launch("residual_rows");
+}
+
+extern "C" int memhip_scatter_rows_f32(const float* src, int64_t lds, const int32_t* rows, int R, int D, float* dst, int64_t ldd,
+                                       memhip_stream_t stream) {
+  MEMHIP_REQUIRE(R >= 0 && D > 0 && D % 4 == 0 && lds % 4 == 0 && ldd % 4 == 0, "scatter_rows: bad shape");
+  if (R == 0) return MEMHIP_OK;
+  MEMHIP_REQUIRE(src && rows && dst, "scatter_rows: null pointer");
+  long long n = (long long)R * (D / 4);
+  int grid = (int)((n + 255) / 256);
+  if (grid > 2048) grid = 2048;
+  hipLaunchKernelGGL(scatter_rows_kernel, dim3(grid), dim3(256), 0, as_stream(stream), src, (long long)lds, (const int*)rows, R, D,
+                     dst, (long long)ldd);
+  return check_launch("scatter_rows");
+}
+
 extern "C" int memhip_fill_cls(float* x, int64_t ldx, int B, int T, int D, const float* cls,
                                memhip_stream_t stream) {
   MEMHIP_REQUIRE(B >= 0 && T > 0 && D > 0, "fill_cls: bad shape");

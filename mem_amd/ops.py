@@ -227,6 +227,17 @@ def attn_bwd(qkv, dout, lse, delta, table, window, B, T, D, heads, scale, dqkv, 
                               ptr(dq_bias), ptr(dv_bias), stream_ptr()), "attn_bwd")
 
 
+def residual_rows(x, rows_i32, y, gamma, rowkeep, keep_prob, R, D, out):
+    """out[i] = x[rows[i]] + drop_path(gamma * y[i]) (the RESIDUAL epilogue's arithmetic on compact rows)."""
+    check(lib.memhip_residual_rows(ptr(x), x.stride(0), ptr(rows_i32), ptr(y), y.stride(0), ptr(gamma), ptr(rowkeep), keep_prob,
+                                   R, D, ptr(out), out.stride(0), stream_ptr()), "residual_rows")
+
+
+def scatter_rows(src, rows_i32, R, D, dst):
+    check(lib.memhip_scatter_rows_f32(ptr(src), src.stride(0), ptr(rows_i32), R, D, ptr(dst), dst.stride(0), stream_ptr()),
+          "scatter_rows")
+
+
 def copy_samples(src, dst, ids_i32, n, n_per_sample):
     check(lib.memhip_copy_samples_f32(ptr(src), ptr(dst), ptr(ids_i32), n, n_per_sample, stream_ptr()), "copy_samples")
 
@@ -280,6 +291,8 @@ declare({
     "memhip_gemm_bf16_tn_workspace": (sz, [i32, i32, i32]),
     "memhip_colsum_bf16": (i32, [vp, i64, i32, i32, vp, vp]),
     "memhip_colsum_fold": (i32, [vp, i32, i32, vp, vp]),
+    "memhip_residual_rows": (i32, [vp, i64, vp, vp, i64, vp, vp, f32, i32, i32, vp, i64, vp]),
+    "memhip_scatter_rows_f32": (i32, [vp, i64, vp, i32, i32, vp, i64, vp]),
 })
 
 

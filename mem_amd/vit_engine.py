@@ -89,6 +89,7 @@ class ViTEngine:
         # LayerNorm gathers their rows, the GEMMs / attention run on kept * T rows, the residual epilogue and the backward
         # row kernels address the residual stream through a sample map.  ~5 % of all block work at drop_path 0.1.
         self.dp_skip = True
+        self.tail_rows = True             # last block: the MLP branch runs only on the rows that reach the head (forward())
         self._dp_stage = None
 
     # ------------------------------------------------------------------ parameter packing
@@ -227,6 +228,10 @@ class ViTEngine:
             self.logits = e(Mm_cap, V)
             self.row_loss, self.row_ok = e(Mm_cap, dt=f32), torch.empty(Mm_cap, dtype=torch.int32, device=dev)
             self.dhN = e(Mm_cap, D)
+            # dead-row elimination in the last block (tail rows): compact residual rows that reach the head, their
+            # gradient, and the bf16 fc2 output of the compact MLP branch (whole 256-row tiles)
+            self.x_tail, self.dxc = e(max(Mm_cap, 1), D, dt=f32), e(max(Mm_cap, 1), D, dt=f32)
+            self.y_tail = z(_pad(max(Mm_cap, 1), 256), D)
         else:
             self.zero_mask = torch.zeros(B * self.L, dtype=torch.uint8, device=dev)
         # backward temporaries (shared by all blocks)
@@ -350,13 +355,21 @@ class ViTEngine:
             f"Input image size ({x.shape[2]}*{x.shape[3]}) doesn't match model ({self.H}*{self.W})."
         Mm = rows_idx.numel()
         self.ensure_batch(B, Mm)
-        xl = self.forward_trunk(x, mask_u8, dp_masks)
+        # Dead-row elimination (tail rows): nothing behind the last block reads a row that is not in rows_idx, and no
+        # gradient flows into one, so the last block's MLP branch -- token-wise work -- runs on those rows only (98 of 197
+        # tokens per sample in pretraining: half of 64 % of a block).  The reference computes every row
+        # (mem/modeling_pretrain.py:110-126); loss and gradients are the same (logits bit-identical).
+        use_tail = (self.tail_rows and not all_tokens and self.depth >= 1 and 0 < Mm and 4 * Mm <= 3 * B * self.T)
+        xl = self.forward_trunk(x, mask_u8, dp_masks, tail_rows=rows_idx if use_tail else None)
         D, Hd, T, L, V = self.D, self.hidden, self.T, self.L, self.V
         M = B * T
         self.cur.update(Mm=Mm, rows=rows_idx, labels=labels)
         # final norm on exactly the rows that reach the head (x[:,1:][bool_masked_pos])
-        ops.layernorm_fwd(xl, self.P("norm.weight"), self.P("norm.bias"), self.hN, self.meanN, self.rstdN, Mm, D,
-                          row_idx=rows_idx)
+        if self.cur.get("tail") is not None:
+            ops.layernorm_fwd(self.x_tail, self.P("norm.weight"), self.P("norm.bias"), self.hN, self.meanN, self.rstdN, Mm, D)
+        else:
+            ops.layernorm_fwd(xl, self.P("norm.weight"), self.P("norm.bias"), self.hN, self.meanN, self.rstdN, Mm, D,
+                              row_idx=rows_idx)
         ops.gemm_nt(self.hN, self.W16("lm_head.weight", V, D), Mm, V, D, ops.EPI_BIAS_BF16, out0=self.logits,
                     bias=self.P("lm_head.bias"))
         if labels is not None:
@@ -395,9 +408,10 @@ class ViTEngine:
         g2 = self.P(pre + "gamma_2") if (pre + "gamma_2") in self.segs else None
         h1, qkv, ao, h2, hpre, aa = (a[k][r0:r1] for k in ("h1", "qkv", "ao", "h2", "hpre", "a"))
         plan = self.cur.get("plan")
+        tail = self.cur.get("tail") if (i == self.depth - 1 and b0 == 0 and b1 == self.cur["B"]) else None
         if plan is not None and (plan["n"][2 * i] is not None or plan["n"][2 * i + 1] is not None):
             assert b0 == 0 and b1 == plan["B"], "stochastic-depth work skipping runs the whole batch on one stream"
-            self._block_fwd_skip(i, plan, a, xin, xmid, xout, g1, g2, table, keep)
+            self._block_fwd_skip(i, plan, a, xin, xmid, xout, g1, g2, table, keep, tail=tail)
             return
         ops.layernorm_fwd(xin, self.P(pre + "norm1.weight"), self.P(pre + "norm1.bias"), h1, a["mean1"][r0:r1],
                           a["rstd1"][r0:r1], M, D)
@@ -407,6 +421,9 @@ class ViTEngine:
         ops.gemm_nt(ao, self.W16(pre + "attn.proj.weight", D, D), M, D, D, ops.EPI_RESIDUAL, out0=None,
                     bias=self.P(pre + "attn.proj.bias"), vec1=g1, resid=xmid, aux=xin, ldaux=D,
                     rowmask=dp_masks[2 * i][b0:b1] if use_dp else None, keep_prob=keep, rows_per_sample=T)
+        if tail is not None:
+            self._mlp_fwd_tail(i, a, self.x[2 * i + 1], g2, keep, tail)
+            return
         ops.layernorm_fwd(xmid, self.P(pre + "norm2.weight"), self.P(pre + "norm2.bias"), h2, a["mean2"][r0:r1],
                           a["rstd2"][r0:r1], M, D)
         ops.gemm_nt(h2, self.W16(pre + "mlp.fc1.weight", Hd, D), M, Hd, D, self.epi_gelu, out0=hpre,
@@ -415,7 +432,23 @@ class ViTEngine:
                     bias=self.P(pre + "mlp.fc2.bias"), vec1=g2, resid=xout, aux=xmid, ldaux=D,
                     rowmask=dp_masks[2 * i + 1][b0:b1] if use_dp else None, keep_prob=keep, rows_per_sample=T)
 
-    def _block_fwd_skip(self, i, plan, a, xin, xmid, xout, g1, g2, table, keep):
+    def _mlp_fwd_tail(self, i, a, xmid, g2, keep, tail):
+        """MLP branch of the LAST block on the rows that reach the head only (forward(): tail rows): norm2 on the gathered
+        rows, fc1 / fc2 on the compact rows (whole 256-row tiles; rows past Mm hold finite leftovers and are never used),
+        then x_tail[i] = x_mid[rows[i]] + drop_path(gamma_2 * y[i]) -- the residual epilogue's arithmetic, per compact row."""
+        D, Hd = self.D, self.hidden
+        pre = f"blocks.{i}."
+        rows, Mm = tail["rows"], tail["Mm"]
+        Mp = _pad(Mm, 256)
+        ops.layernorm_fwd(xmid, self.P(pre + "norm2.weight"), self.P(pre + "norm2.bias"), a["h2"], a["mean2"], a["rstd2"],
+                          Mm, D, row_idx=rows)
+        ops.gemm_nt(a["h2"], self.W16(pre + "mlp.fc1.weight", Hd, D), Mp, Hd, D, self.epi_gelu, out0=a["hpre"],
+                    out1=a["a"], bias=self.P(pre + "mlp.fc1.bias"))
+        ops.gemm_nt(a["a"], self.W16(pre + "mlp.fc2.weight", D, Hd), Mp, D, Hd, ops.EPI_BIAS_BF16, out0=self.y_tail,
+                    bias=self.P(pre + "mlp.fc2.bias"))
+        ops.residual_rows(xmid, rows, self.y_tail, g2, tail["rowkeep"], keep, Mm, D, self.x_tail)
+
+    def _block_fwd_skip(self, i, plan, a, xin, xmid, xout, g1, g2, table, keep, tail=None):
         """Block i with the dropped samples of each branch skipped (see dp_skip): compact activations."""
         D, Hd, T, B = self.D, self.hidden, self.T, plan["B"]
         pre = f"blocks.{i}."
@@ -438,6 +471,9 @@ class ViTEngine:
             ops.gemm_nt(a["ao"], self.W16(pre + "attn.proj.weight", D, D), M1p, D, D, ops.EPI_RESIDUAL, out0=None,
                         bias=self.P(pre + "attn.proj.bias"), vec1=g1, resid=xmid, aux=xin, ldaux=D,
                         keep_prob=keep if smap is not None else 1.0, rows_per_sample=T, sample_map=smap)
+        if tail is not None:                                  # last block: the rows that reach the head, every sample
+            self._mlp_fwd_tail(i, a, self.x[2 * i + 1], g2, keep, tail)      # (dropped samples: keep flag 0 per row)
+            return
         # -- MLP branch on the nm kept samples
         if plan["n"][jm] is not None:
             self._copy_dropped(plan, jm, xmid, xout, B)
@@ -454,7 +490,7 @@ class ViTEngine:
                         bias=self.P(pre + "mlp.fc2.bias"), vec1=g2, resid=xout, aux=xmid, ldaux=D,
                         keep_prob=keep if smap is not None else 1.0, rows_per_sample=T, sample_map=smap)
 
-    def forward_trunk(self, x, mask_u8=None, dp_masks=None):
+    def forward_trunk(self, x, mask_u8=None, dp_masks=None, tail_rows=None):
         """Patch embedding (+ mask-token blend, + abs. position embedding) and the blocks: x f32 [B,C,H,W] ->
         the fp32 residual stream after the last block, [B*T, D] (engine-owned, valid until the next forward)."""
         assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous()
@@ -471,7 +507,21 @@ class ViTEngine:
         plan = self._dp_plan(dp_masks, B)
         if plan is not None:
             dp_masks = None                                  # the plan replaces the keep masks everywhere below
-        self.cur = dict(B=B, M=M, Mm=0, mask=mask_u8, rows=None, dp=dp_masks, labels=None, plan=plan)
+        self.cur = dict(B=B, M=M, Mm=0, mask=mask_u8, rows=None, dp=dp_masks, labels=None, plan=plan, tail=None)
+        if tail_rows is not None and not self.fwd_two_streams:
+            # per compact row: did the last block's MLP branch keep the row's sample?  (stochastic depth of that branch is
+            # applied per row in the tail form, in both the masked and the work-skipping mode)
+            jm, lastb = 2 * self.depth - 1, self.model.blocks[self.depth - 1]
+            keepvec = None
+            if lastb.drop_prob > 0.0:
+                if plan is not None and plan["n"][jm] is not None:
+                    keepvec = (plan["cmap"][jm] >= 0).to(torch.float32)
+                elif dp_masks is not None:
+                    keepvec = dp_masks[jm]
+            rowkeep = None
+            if keepvec is not None:
+                rowkeep = keepvec.index_select(0, torch.div(tail_rows, T, rounding_mode="floor").long()).contiguous()
+            self.cur["tail"] = dict(rows=tail_rows, Mm=tail_rows.numel(), rowkeep=rowkeep)
         if self.head_kind == "cls" and not self.accumulate_grads:
             self.flat_g[: self.head_end].zero_()        # the torch tail accumulates its gradients here before backward_trunk
         ops.im2col(x, B, self.C, self.H, self.W, self.ph, self.pw, self.patches)
@@ -597,8 +647,14 @@ class ViTEngine:
         self._side_begin()
         ops.gemm_nt(dl, self.wT_lm, Mm, D, V, ops.EPI_BIAS_BF16, out0=self.dhN)
         self._on_side(lambda: self._wgrad(dl, self.hN, Mm, V, D, "lm_head.weight", bias_grads=((self.G("lm_head.bias"), 0, V),)))
-        ops.layernorm_bwd(self.dhN, self.x[2 * self.depth], self.P("norm.weight"), self.meanN, self.rstdN, dx,
-                          self.G("norm.weight"), self.G("norm.bias"), Mm, D, accumulate=False, row_idx=c["rows"])
+        if c.get("tail") is not None:
+            # the head's rows in compact form (the last block's MLP backward reads them), then into the residual gradient
+            ops.layernorm_bwd(self.dhN, self.x_tail, self.P("norm.weight"), self.meanN, self.rstdN, self.dxc,
+                              self.G("norm.weight"), self.G("norm.bias"), Mm, D, accumulate=False)
+            ops.scatter_rows(self.dxc, c["rows"], Mm, D, dx)
+        else:
+            ops.layernorm_bwd(self.dhN, self.x[2 * self.depth], self.P("norm.weight"), self.meanN, self.rstdN, dx,
+                              self.G("norm.weight"), self.G("norm.bias"), Mm, D, accumulate=False, row_idx=c["rows"])
         self._backward_trunk()
 
     def backward_trunk(self, dxl):
@@ -610,6 +666,39 @@ class ViTEngine:
         self.dx[:M].copy_(dxl.reshape(M, D))
         self._side_begin()
         self._backward_trunk()
+
+    def _mlp_bwd_tail(self, i, a, pre, has_g, keep, tail, attn_branch_bwd):
+        """Backward of _mlp_fwd_tail: the MLP branch of the last block on the compact rows that reached the head (their
+        gradient is self.dxc; every other row's is zero), norm2 backward scattered into dx, then the attention branch's
+        branch backward over all of dx (attn_branch_bwd: the caller's masked / work-skipping form)."""
+        D, Hd = self.D, self.hidden
+        rows, Mm, rk = tail["rows"], tail["Mm"], tail["rowkeep"]
+        Mp = _pad(Mm, 256)
+        dx, dY = self.dx, self.dY
+        self._before_overwrite("dY")
+        ops.branch_bwd(self.dxc, None, self.P(pre + "gamma_2") if has_g else None, dY, None, self.G(pre + "mlp.fc2.bias"),
+                       Mm, D, rowmask=rk, keep_prob=keep, rows_per_sample=1)
+        if Mp > Mm:
+            dY[Mm:Mp].zero_()
+        self._before_overwrite("dbig")
+        ops.gemm_nt(dY, self.wT[i]["fc2"], Mp, Hd, D, self.epi_dgelu, out0=self.dbig, aux=a["hpre"],
+                    colsum=self.cs_ws, colsum_copies=self.CS_COPIES)
+        ops.colsum_fold(self.cs_ws, self.CS_COPIES, Hd, self.G(pre + "mlp.fc1.bias"))
+
+        def wg_mlp():
+            self._wgrad(dY, a["a"], Mm, D, Hd, pre + "mlp.fc2.weight")
+            self._side_read_done("dY")
+            if has_g:
+                ops.layerscale_grad(self.W16(pre + "mlp.fc2.weight", D, Hd), self.G(pre + "mlp.fc2.weight").view(D, Hd),
+                                    self.P(pre + "mlp.fc2.bias"), self.G(pre + "mlp.fc2.bias"),
+                                    self.P(pre + "gamma_2"), D, Hd, self.G(pre + "gamma_2"))
+            self._wgrad(self.dbig, a["h2"], Mm, Hd, D, pre + "mlp.fc1.weight")
+            self._side_read_done("dbig")
+        self._on_side(wg_mlp)
+        ops.gemm_nt(self.dbig, self.wT[i]["fc1"], Mp, D, Hd, ops.EPI_BIAS_BF16, out0=self.dh_small)
+        ops.layernorm_bwd(self.dh_small, self.x[2 * i + 1], self.P(pre + "norm2.weight"), a["mean2"], a["rstd2"], dx,
+                          self.G(pre + "norm2.weight"), self.G(pre + "norm2.bias"), Mm, D, accumulate=True, row_idx=rows)
+        attn_branch_bwd()
 
     def _backward_trunk_skip(self, plan):
         """_backward_trunk with the dropped samples of every branch skipped (dp_skip): the branch gradients dY / dY2, the
@@ -642,12 +731,22 @@ class ViTEngine:
             has_g = (pre + "gamma_1") in self.segs
             table, dtable = self.table(i), self.dtable(i)
             dY, dY2 = self.dY, self.dY2
+            scr = self.bias_scr[i & 1]
+            tail = c.get("tail") if i == self.depth - 1 else None
+            if tail is not None:
+                # last block, MLP branch on the rows that reached the head only (forward(): tail rows); the helper ends with
+                # the attention branch's branch backward in this loop's form
+                def attn_bb(i=i, pre=pre, has_g=has_g, ja=ja, scr=scr):
+                    self._before_overwrite("dY2")
+                    ops.branch_bwd(dx, None, self.P(pre + "gamma_1") if has_g else None, dY2, None, scr, M, D,
+                                   keep_prob=kp(ja, i), rows_per_sample=T, out_map=cmap(ja))
+                self._mlp_bwd_tail(i, a, pre, has_g, 1.0 - self.model.blocks[i].drop_prob, tail, attn_bb)
             # -- MLP branch (for every block but the last dY already came out of the fused norm1 backward of block i + 1)
-            if i == self.depth - 1 or not fuse:
+            if tail is None and (i == self.depth - 1 or not fuse):
                 self._before_overwrite("dY")
                 ops.branch_bwd(dx, None, self.P(pre + "gamma_2") if has_g else None, dY, None, self.G(pre + "mlp.fc2.bias"),
                                M, D, keep_prob=kp(jm, i), rows_per_sample=T, out_map=cmap(jm))
-            if nm > 0:
+            if tail is None and nm > 0:
                 self._before_overwrite("dbig")
                 if M2p > M2:
                     dY[M2:M2p].zero_()      # rows of the padding: zero in, zero out (the epilogue's column sums see them)
@@ -666,8 +765,9 @@ class ViTEngine:
                     self._side_read_done("dbig")
                 self._on_side(wg_mlp)
                 ops.gemm_nt(self.dbig, self.wT[i]["fc1"], M2p, D, Hd, ops.EPI_BIAS_BF16, out0=self.dh_small)
-            scr = self.bias_scr[i & 1]
-            if fuse:
+            if tail is not None:
+                pass
+            elif fuse:
                 # norm2 backward (rows the MLP branch kept) + attention-branch backward (rows it kept) in one pass over dx
                 self._before_overwrite("dY2")
                 ops.layernorm_bwd_branch(self.dh_small, xmid, self.P(pre + "norm2.weight"), a["mean2"], a["rstd2"], dx,
@@ -753,50 +853,61 @@ class ViTEngine:
             # -- MLP branch (for every block but the last this already ran fused into the norm1 backward of
             # block i+1, see below).  dY = gradient of the MLP branch output, dY2 = of the attention branch output.
             dY, dY2 = self.dY, self.dY2
-            if i == self.depth - 1 or not fuse:
-                self._before_overwrite("dY")
-                ops.branch_bwd(dx, None, self.P(pre + "gamma_2") if has_g else None, dY,
-                               None, self.G(pre + "mlp.fc2.bias"), M, D,
-                               rowmask=dp_masks[2 * i + 1] if use_dp else None, keep_prob=keep, rows_per_sample=T)
-            self._before_overwrite("dbig")
-            # fc1 bias grad = column sums of dh, accumulated in CS_COPIES copies (one per XCD: atomics on one address
-            # serialise and would sit in front of the GEMM's operand stream) and folded by a 3 us kernel
-            ops.gemm_nt(dY, self.wT[i]["fc2"], M, Hd, D, self.epi_dgelu, out0=self.dbig, aux=a["hpre"],
-                        colsum=self.cs_ws, colsum_copies=self.CS_COPIES)
-            ops.colsum_fold(self.cs_ws, self.CS_COPIES, Hd, self.G(pre + "mlp.fc1.bias"))
+            tail = c.get("tail") if i == self.depth - 1 else None
+            if tail is not None:
+                # last block, MLP branch on the rows that reached the head only (forward(): tail rows)
+                scr = self.bias_scr[i & 1]
 
-            def wg_mlp(i=i, pre=pre, a=a, has_g=has_g):
-                self._wgrad(dY, a["a"], M, D, Hd, pre + "mlp.fc2.weight")
-                self._side_read_done("dY")
-                if has_g:
-                    # layer-scale gradient from the weight gradient (no branch output y kept): memhip_layerscale_grad
-                    ops.layerscale_grad(self.W16(pre + "mlp.fc2.weight", D, Hd), self.G(pre + "mlp.fc2.weight").view(D, Hd),
-                                        self.P(pre + "mlp.fc2.bias"), self.G(pre + "mlp.fc2.bias"),
-                                        self.P(pre + "gamma_2"), D, Hd, self.G(pre + "gamma_2"))
-                self._wgrad(self.dbig, a["h2"], M, Hd, D, pre + "mlp.fc1.weight")
-                self._side_read_done("dbig")
-            self._on_side(wg_mlp)
-            ops.gemm_nt(self.dbig, self.wT[i]["fc1"], M, D, Hd, ops.EPI_BIAS_BF16, out0=self.dh_small)
-            scr = self.bias_scr[i & 1]
-            if fuse:
-                # norm2 backward + attention-branch backward in one pass over dx (proj.bias column sums -> scr)
-                self._before_overwrite("dY2")
-                ops.layernorm_bwd_branch(self.dh_small, xmid, self.P(pre + "norm2.weight"), a["mean2"], a["rstd2"], dx,
-                                         self.G(pre + "norm2.weight"), self.G(pre + "norm2.bias"), M, D, None,
-                                         self.P(pre + "gamma_1") if has_g else None, dY2, None, scr,
-                                         rowmask=dp_masks[2 * i] if use_dp else None, keep_prob=keep, rows_per_sample=T)
+                def attn_bb(i=i, pre=pre, has_g=has_g, scr=scr, use_dp=use_dp, keep=keep):
+                    self._before_overwrite("dY2")
+                    ops.branch_bwd(dx, None, self.P(pre + "gamma_1") if has_g else None, dY2, None, scr, M, D,
+                                   rowmask=dp_masks[2 * i] if use_dp else None, keep_prob=keep, rows_per_sample=T)
+                self._mlp_bwd_tail(i, a, pre, has_g, keep, tail, attn_bb)
             else:
-                ops.layernorm_bwd(self.dh_small, xmid, self.P(pre + "norm2.weight"), a["mean2"], a["rstd2"], dx,
-                                  self.G(pre + "norm2.weight"), self.G(pre + "norm2.bias"), M, D, accumulate=True)
-            # -- attention branch
-            # proj.bias gradient (column sums of dY) goes to a scratch vector first: the v_bias gradient is
-            # derived from it.  sum_k dV[k] = sum_q dO[q] * sum_k P[q,k] and the softmax rows sum to one, so
-            # v_bias.grad = colsum(d attn_out) = colsum(dY) @ W_proj: one 768x768 GEMV instead of column
-            # sums inside the attention kernel (which cost it 32 VGPRs and its occupancy).
-            if not fuse:
-                self._before_overwrite("dY2")
-                ops.branch_bwd(dx, None, self.P(pre + "gamma_1") if has_g else None, dY2, None, scr, M, D,
-                               rowmask=dp_masks[2 * i] if use_dp else None, keep_prob=keep, rows_per_sample=T)
+                if i == self.depth - 1 or not fuse:
+                    self._before_overwrite("dY")
+                    ops.branch_bwd(dx, None, self.P(pre + "gamma_2") if has_g else None, dY,
+                                   None, self.G(pre + "mlp.fc2.bias"), M, D,
+                                   rowmask=dp_masks[2 * i + 1] if use_dp else None, keep_prob=keep, rows_per_sample=T)
+                self._before_overwrite("dbig")
+                # fc1 bias grad = column sums of dh, accumulated in CS_COPIES copies (one per XCD: atomics on one address
+                # serialise and would sit in front of the GEMM's operand stream) and folded by a 3 us kernel
+                ops.gemm_nt(dY, self.wT[i]["fc2"], M, Hd, D, self.epi_dgelu, out0=self.dbig, aux=a["hpre"],
+                            colsum=self.cs_ws, colsum_copies=self.CS_COPIES)
+                ops.colsum_fold(self.cs_ws, self.CS_COPIES, Hd, self.G(pre + "mlp.fc1.bias"))
+
+                def wg_mlp(i=i, pre=pre, a=a, has_g=has_g):
+                    self._wgrad(dY, a["a"], M, D, Hd, pre + "mlp.fc2.weight")
+                    self._side_read_done("dY")
+                    if has_g:
+                        # layer-scale gradient from the weight gradient (no branch output y kept): memhip_layerscale_grad
+                        ops.layerscale_grad(self.W16(pre + "mlp.fc2.weight", D, Hd), self.G(pre + "mlp.fc2.weight").view(D, Hd),
+                                            self.P(pre + "mlp.fc2.bias"), self.G(pre + "mlp.fc2.bias"),
+                                            self.P(pre + "gamma_2"), D, Hd, self.G(pre + "gamma_2"))
+                    self._wgrad(self.dbig, a["h2"], M, Hd, D, pre + "mlp.fc1.weight")
+                    self._side_read_done("dbig")
+                self._on_side(wg_mlp)
+                ops.gemm_nt(self.dbig, self.wT[i]["fc1"], M, D, Hd, ops.EPI_BIAS_BF16, out0=self.dh_small)
+                scr = self.bias_scr[i & 1]
+                if fuse:
+                    # norm2 backward + attention-branch backward in one pass over dx (proj.bias column sums -> scr)
+                    self._before_overwrite("dY2")
+                    ops.layernorm_bwd_branch(self.dh_small, xmid, self.P(pre + "norm2.weight"), a["mean2"], a["rstd2"], dx,
+                                             self.G(pre + "norm2.weight"), self.G(pre + "norm2.bias"), M, D, None,
+                                             self.P(pre + "gamma_1") if has_g else None, dY2, None, scr,
+                                             rowmask=dp_masks[2 * i] if use_dp else None, keep_prob=keep, rows_per_sample=T)
+                else:
+                    ops.layernorm_bwd(self.dh_small, xmid, self.P(pre + "norm2.weight"), a["mean2"], a["rstd2"], dx,
+                                      self.G(pre + "norm2.weight"), self.G(pre + "norm2.bias"), M, D, accumulate=True)
+                # -- attention branch
+                # proj.bias gradient (column sums of dY) goes to a scratch vector first: the v_bias gradient is
+                # derived from it.  sum_k dV[k] = sum_q dO[q] * sum_k P[q,k] and the softmax rows sum to one, so
+                # v_bias.grad = colsum(d attn_out) = colsum(dY) @ W_proj: one 768x768 GEMV instead of column
+                # sums inside the attention kernel (which cost it 32 VGPRs and its occupancy).
+                if not fuse:
+                    self._before_overwrite("dY2")
+                    ops.branch_bwd(dx, None, self.P(pre + "gamma_1") if has_g else None, dY2, None, scr, M, D,
+                                   rowmask=dp_masks[2 * i] if use_dp else None, keep_prob=keep, rows_per_sample=T)
             ops.gemm_nt(dY2, self.wT[i]["proj"], M, D, D, ops.EPI_BIAS_BF16, out0=self.dao)
             ops.gemv_acc(self.wT[i]["proj"], D, D, scr, self.G(pre + "attn.v_bias"),
                          x_acc=self.G(pre + "attn.proj.bias"), zero=self.bias_scr[(i & 1) ^ 1])

@@ -330,6 +330,7 @@ def test_drop_path_work_skipping_equals_masked_execution(fuse):
         m = m.cuda().train()
         m.engine.dp_skip = skip
         m.engine.fuse_ln_branch = fuse
+        m.engine.tail_rows = False                               # (the whole residual stream is compared below)
         la = m.forward_loss(x.cuda(), mask.cuda(), labels.cuda(), drop_path_masks=masks.cuda())
         m.backward()
         torch.cuda.synchronize()
@@ -346,6 +347,48 @@ def test_drop_path_work_skipping_equals_masked_execution(fuse):
         if float(a.norm()) > 0:
             rel = float((a - b).norm() / a.norm())
             assert rel <= 2e-3, (name, rel)                    # bf16 column-sum / split-order noise
+
+
+@pytest.mark.parametrize("skip", [False, True])
+def test_last_block_tail_rows_equal_full_execution(skip):
+    """Dead-row elimination in the last block (ViTEngine.tail_rows: its MLP branch runs only on the rows that reach the head,
+    mem/modeling_pretrain.py:119-126) against the full execution of the same step, with stochastic depth on the last block's
+    MLP branch, in the masked and in the work-skipping mode: the rows that reach the head are bit-identical (so are logits
+    and loss), gradients equal up to the order of fp32 sums."""
+    from mem_amd.modeling_pretrain import pt_vit
+    from oracle.gen_golden import BASE, vit_inputs
+    from oracle.vit_ref import fill_by_name
+    cfg = dict(BASE, in_chans=2, depth=3, drop_path_rate=0.3)
+    B = 40
+    x, mask, labels = vit_inputs(cfg, B, 23, 98)
+    g = torch.Generator().manual_seed(9)
+    masks = (torch.rand(6, B, generator=g) > 0.25).float()
+    res = {}
+    for tail in (False, True):
+        m = pt_vit(**cfg)
+        m.load_state_dict(fill_by_name(m.state_dict(), seed=1))
+        m = m.cuda().train()
+        m.engine.dp_skip = skip
+        m.engine.tail_rows = tail
+        la = m.forward_loss(x.cuda(), mask.cuda(), labels.cuda(), drop_path_masks=masks.cuda())
+        eng = m.engine
+        assert (eng.cur["tail"] is not None) == tail
+        rows = eng.cur["rows"].long()
+        xrows = eng.x_tail[: rows.numel()].clone() if tail else eng.x[2 * 3].index_select(0, rows)
+        m.backward()
+        torch.cuda.synchronize()
+        res[tail] = (la.clone(), eng.flat_g.clone(), xrows, dict(eng.segs))
+        del m
+    (l0, g0, x0, segs), (l1, g1, x1, _) = res[False], res[True]
+    assert torch.equal(x0, x1)                                   # the rows that reach the head: same arithmetic
+    assert l0[0].item() == l1[0].item() and l0[1].item() == l1[1].item()
+    cos = torch.dot(g0, g1) / (g0.norm() * g1.norm())
+    assert cos.item() >= 0.99999, cos.item()
+    for name, (o, k) in segs.items():
+        a, b = g0[o:o + k], g1[o:o + k]
+        if float(a.norm()) > 0:
+            rel = float((a - b).norm() / a.norm())
+            assert rel <= 2e-3, (name, rel)
 
 
 @pytest.mark.parametrize("C", [3, 2])
