@@ -297,6 +297,34 @@ def _attention_case(B, T, H, win):
     assert relb < 2e-2, relb
 
 
+def test_residual_rows_and_scatter_rows():
+    """The row kernels of the last block's tail form (ViTEngine.tail_rows): out[i] = x[rows[i]] + drop_path(gamma * y[i]) with
+    the RESIDUAL epilogue's arithmetic -- gamma * y rounded once, the quotient by keep_prob correctly rounded (== IEEE
+    division), times the row's keep flag, one rounding for the add -- so torch's fp32 ops in that order give the SAME bits;
+    scatter_rows is a row copy."""
+    from mem_amd import ops
+    M, R, D = 5000, 1234, 768
+    x = _rand((M, D), 300)
+    y = _rand((R, D), 301).bfloat16()
+    gamma = _rand((D,), 302, 0.1)
+    rows = torch.randperm(M, device="cuda")[:R].sort().values.int()
+    keep = (torch.rand(R, device="cuda") > 0.3).float()
+    for g, rk, kp in ((gamma, keep, 0.9), (None, None, 1.0), (gamma, None, 0.7), (None, keep, 0.8)):
+        out = torch.full((R, D), 7.0, device="cuda")
+        ops.residual_rows(x, rows, y, g, rk, kp, R, D, out)
+        br = (y.float() if g is None else g.view(1, D) * y.float()).cpu()      # (the quotient on the CPU: IEEE division)
+        if rk is not None:
+            br = br.div(kp) * rk.cpu().view(R, 1)
+        ref = x.index_select(0, rows.long()).cpu() + br
+        assert torch.equal(out.cpu(), ref), (g is not None, rk is not None, kp, float((out.cpu() - ref).abs().max()))
+    dst = torch.zeros((M, D), device="cuda")
+    src = _rand((R, D), 303)
+    ops.scatter_rows(src, rows, R, D, dst)
+    ref = torch.zeros((M, D), device="cuda")
+    ref.index_copy_(0, rows.long(), src)
+    assert torch.equal(dst, ref)
+
+
 def test_cast_and_transposes():
     from mem_amd import ops
     w = _rand((2304, 768), 30)
