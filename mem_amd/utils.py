@@ -3,6 +3,10 @@ SmoothedValue / MetricLogger (:34-183), distributed init (:235-299), NativeScale
 (:351-377), get_grad_norm_ (:380-392), cosine_scheduler (:395-412), save_model / auto_load_model
 (:425-447, :485-519), create_d_vae / get_event_vae (:559-578).
 
+SmoothedValue, MetricLogger, setup_for_distributed and cosine_scheduler are plain RESTATEMENTS of the reference's logging /
+schedule helpers (DeiT-lineage boilerplate that is part of the named surface: meter names, formats and the returned dict are
+observable), not designs of this repo; nothing on the hot path lives in them.
+
 Differences that are deliberate: device-agnostic (the reference hard-codes
 'cuda' / torch.cuda.synchronize), one packed all-reduce for all meters instead of one per meter,
 and a scaler that is a no-op for bf16 (no loss scaling needed) but keeps the checkpoint key.
