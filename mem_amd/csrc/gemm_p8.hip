@@ -324,6 +324,28 @@ __global__ __launch_bounds__(kThreads) void gemm_p8_kernel(GemmArgs p, int ntm, 
 #endif
 // X1..X4: vector-memory instructions besides the half-tile stream that the phase's wait must leave in flight as well
 // (the epilogue-operand prefetch, one LDS-DMA per wave and loop iteration: see `prefetch_aux`)
+#ifdef P8_EXP_HALFN
+// timing experiment (wrong results): the main loop of a 256 x 128 tile inside this kernel's skeleton -- the two quadrants of
+// B1 are not computed and B1 is not read from LDS (its DMA, the barriers and the waits of those phases stay): per K-tile
+// 8 + 8 + 4 fragment reads for 32 MFMAs, i.e. the LDS-read / MFMA mix a parked-accumulator 256 x 128 kernel would have,
+// with twice its barriers and 4/3 of its operand traffic.  How far above half the full K-tile time does it run?
+#define P8_PHASE_NOMMA(READS, STAGE_CALL, WAITN)                                                          \
+    READS;                                                                                                \
+    __builtin_amdgcn_sched_barrier(0);                                                                    \
+    STAGE_CALL;                                                                                           \
+    P8_WAIT_VM(WAITN);                                                                                    \
+    P8_BARRIER();                                                                                         \
+    P8_BARRIER();
+#define P8_KTILE(bq0, bq1, X1, X2, X3, X4)                                                                \
+  do {                                                                                                    \
+    const int bo = bc * kBuf;                                                                             \
+    (void)bo;                                                                                             \
+    P8_PHASE(P8_READ_A(0), stage(HA1, bc ^ 1, tm1, tn1, k1), G::kWaitB + (X1), AP, 0, bq0)                \
+    P8_PHASE_NOMMA((void)0, stage(HB0, bc, tm2, tn2, k2), G::kWaitA + (X2))                               \
+    P8_PHASE_NOMMA(P8_READ_A(1), stage(HA0, bc, tm2, tn2, k2), G::kWaitB + (X3))                          \
+    P8_PHASE(P8_READ_B(bq1, (bc ^ 1) * kBuf, 0), stage(HB1, bc, tm2, tn2, k2), G::kWaitA + (X4), 2, 2, bq0) \
+  } while (0)
+#else
 #define P8_KTILE(bq0, bq1, X1, X2, X3, X4)                                                                \
   do {                                                                                                    \
     const int bo = bc * kBuf;                                                                             \
@@ -336,6 +358,7 @@ __global__ __launch_bounds__(kThreads) void gemm_p8_kernel(GemmArgs p, int ntm, 
     /* phase 4: quadrant (A1, B0); B0 of the next K-tile comes from the other buffer */                   \
     P8_PHASE(P8_READ_B(bq1, (bc ^ 1) * kBuf, 0), stage(HB1, bc, tm2, tn2, k2), G::kWaitA + (X4), 2, 2, bq0) \
   } while (0)
+#endif
 #define P8_READ_B0_FIRST() P8_READ_B(bx, 0, 0)
 
   // ---- one extra LDS-DMA per wave and loop iteration (two K-tiles), always issued, so that the counted waits stay
