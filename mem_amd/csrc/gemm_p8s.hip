@@ -20,11 +20,11 @@
 //
 // RESULT (round 3, tools/p8s_check.py, M = 50 432): bit-equal to gemm_p8 on every shape, and SLOWER: N = 3072 K = 768 bias
 // 284 vs 263 us, GELU 365 vs 329; N = 768 K = 3072 bias 264 vs 209 us -- the main loop takes 1 650 ticks per K-tile of
-// 2 M MACs against 2 380 per 4 M MACs.  The LDS is the wall: 48 KiB in by LDS-DMA + 160 KiB out as fragments per K-tile =
-// 126 bytes per clock of the LDS's 128 (gemm_p8: 64 + 192 KiB in 2 380 clocks = 108 B/clk, matrix pipe 87 % busy).  The
-// streamed epilogue works (no stall at tile boundaries) but cannot win that back; only K = 256 shapes gain (35.6 vs
-// 42.6 us).  Kept as the measured form of the "second accumulator set" item, OFF by default (option `gemm_p8s`); epilogue
-// overlap has to come with fewer LDS bytes per flop (128x128 wave tiles), not more.
+// 2 M MACs against 2 380 per 4 M MACs.  Common to both kernels: 27-29 bytes per clock and CU through global_load_lds (48 KiB
+// per 1 650 clocks, 64 KiB per 2 380) -- the main loop runs at the LDS-DMA operand feed, and a 256x128 tile needs 1.5 x the
+// operand bytes per flop (matrix pipe 62 % vs 87 % busy).  The streamed epilogue works (no stall at tile boundaries) but
+// cannot win that back; only K = 256 shapes gain (35.6 vs 42.6 us).  Kept as the measured form of the "second accumulator
+// set" item, OFF by default (option `gemm_p8s`); epilogue overlap has to keep the 256x256 tile's bytes per flop.
 #include "common.h"
 #include "gemm_epilogue.hpp"
 #include <type_traits>
