@@ -11,7 +11,9 @@ def t(f, n=20):
     e1.record(); torch.cuda.synchronize(); return e0.elapsed_time(e1) / n * 1e3
 M = 256 * 197
 shapes = [(M, 3072, 768), (M, 2304, 768), (M, 768, 768), (M, 768, 3072), (M, 768, 2304), (M, 768, 256), (4096, 256, 512), (25088, 8192, 768)]
-if len(sys.argv) > 1: shapes = shapes[: int(sys.argv[1])]
+if len(sys.argv) > 1 and sys.argv[1] == 'mae':
+    shapes = [(M, 2048, 512), (M, 3072, 512), (M, 512, 512), (M, 1024, 512), (M, 512, 1024), (M, 512, 2048), (M, 768, 512), (12800, 3072, 768), (12800, 768, 3072)]
+elif len(sys.argv) > 1: shapes = shapes[: int(sys.argv[1])]
 for (m, n, k) in shapes:
     torch.manual_seed(m + n + k)
     A = torch.randn(m, k, device="cuda").bfloat16(); B = (torch.randn(n, k, device="cuda") * 0.05).bfloat16()
