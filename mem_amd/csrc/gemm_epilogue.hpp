@@ -304,12 +304,25 @@ __device__ __forceinline__ void st_branch_copy(const GemmArgs& p, int m, int n, 
   *dst = eu32x4{y[0], y[1], y[2], y[3]};
 }
 
+// Packed width (dwords per lane) of a finished 8-column row piece: what epi8_math leaves and epi8_store writes.
+template <int EPI> struct EpiPk { static constexpr int W = 4; };                       // 8 bf16
+template <> struct EpiPk<MEMHIP_EPI_BIAS_GELU> { static constexpr int W = 8; };        // h | gelu(h)
+template <> struct EpiPk<MEMHIP_EPI_BIAS_GELU_DG> { static constexpr int W = 8; };     // gelu'(h) | gelu(h)
+template <> struct EpiPk<MEMHIP_EPI_RESIDUAL> { static constexpr int W = 8; };         // 8 fp32 of the residual stream
+template <> struct EpiPk<MEMHIP_EPI_F32> { static constexpr int W = 8; };
+template <> struct EpiPk<MEMHIP_EPI_PATCH_EMBED> { static constexpr int W = 8; };
+
 // COPY (residual epilogue): 1 = the bf16 copy of the branch output goes to out0, or to a scratch line when out0 is NULL
 // (a select, which hipcc may turn into a branch); 0 = no copy is written (p.out0 is not looked at); 2 = out0 is known
 // to be non-NULL (no select: the row epilogue stays one basic block)
+//
+// The row epilogue in two halves: epi8_math is the ARITHMETIC of 8 consecutive output columns of row m (register only, plus
+// the optional bf16 branch copy of the residual epilogue, which leaves at once), epi8_store writes its result.  gemm_p8d.hip
+// runs the first half at the end of a tile and the second inside the next tile's main loop; everything else calls both
+// back to back (epilogue8).
 template <int EPI, int COPY = 1>
-__device__ __forceinline__ void epilogue8(const GemmArgs& p, int m, int n, const float* acc, float* cs, const EpiCols& c,
-                                          const EpiRow<EPI>& row) {
+__device__ __forceinline__ void epi8_math(const GemmArgs& p, int m, int n, const float* acc, float* cs, const EpiCols& c,
+                                          const EpiRow<EPI>& row, unsigned* out) {
   ef32x2 t[4];
 #pragma unroll
   for (int k = 0; k < 4; ++k) t[k] = ef32x2{acc[2 * k], acc[2 * k + 1]};
@@ -333,41 +346,34 @@ __device__ __forceinline__ void epilogue8(const GemmArgs& p, int m, int n, const
         cs[2 * k + 1] += f.y;
       }
     }
-    st_stream16(p.out0, (long long)m * p.ldo0 + n, y[0], y[1], y[2], y[3]);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) out[k] = y[k];
   } else if constexpr (EPI == MEMHIP_EPI_BIAS_GELU) {
-    unsigned h[4], a[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      h[k] = pack_bf16x2(t[k]);
-      a[k] = pack_bf16x2(gelu2(unpack_bf16x2(h[k])));
+      out[k] = pack_bf16x2(t[k]);
+      out[4 + k] = pack_bf16x2(gelu2(unpack_bf16x2(out[k])));
     }
-    st_stream16(p.out0, (long long)m * p.ldo0 + n, h[0], h[1], h[2], h[3]);
-    st_stream16(p.out1, (long long)m * p.ldo1 + n, a[0], a[1], a[2], a[3]);
   } else if constexpr (EPI == MEMHIP_EPI_BIAS_GELU_DG) {
-    unsigned dgp[4], a[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       ef32x2 g, dg;
       gelu_and_grad2(unpack_bf16x2(pack_bf16x2(t[k])), g, dg);
-      dgp[k] = pack_bf16x2(dg);
-      a[k] = pack_bf16x2(g);
+      out[k] = pack_bf16x2(dg);
+      out[4 + k] = pack_bf16x2(g);
     }
-    st_stream16(p.out0, (long long)m * p.ldo0 + n, dgp[0], dgp[1], dgp[2], dgp[3]);
-    st_stream16(p.out1, (long long)m * p.ldo1 + n, a[0], a[1], a[2], a[3]);
   } else if constexpr (EPI == MEMHIP_EPI_MUL_AUX) {
     const unsigned h[4] = {row.h.x, row.h.y, row.h.z, row.h.w};
-    unsigned o[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) o[k] = pack_bf16x2(unpack_bf16x2(pack_bf16x2(t[k])) * unpack_bf16x2(h[k]));
+    for (int k = 0; k < 4; ++k) out[k] = pack_bf16x2(unpack_bf16x2(pack_bf16x2(t[k])) * unpack_bf16x2(h[k]));
     if (p.colsum) {
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        const ef32x2 f = unpack_bf16x2(o[k]);
+        const ef32x2 f = unpack_bf16x2(out[k]);
         cs[2 * k] += f.x;
         cs[2 * k + 1] += f.y;
       }
     }
-    st_stream16(p.out0, (long long)m * p.ldo0 + n, o[0], o[1], o[2], o[3]);
   } else if constexpr (EPI == MEMHIP_EPI_RESIDUAL) {
     unsigned y[4];
     float x[8];
@@ -397,53 +403,81 @@ __device__ __forceinline__ void epilogue8(const GemmArgs& p, int m, int n, const
       }
     }
 #pragma unroll
-    for (int k = 0; k < 8; ++k) x[k] = __fadd_rn(x[k], br[k]);
+    for (int k = 0; k < 8; ++k) out[k] = __float_as_uint(__fadd_rn(x[k], br[k]));
     if constexpr (COPY == 1) st_branch_copy(p, m, n, y);
     if constexpr (COPY == 2)
       *(gu32x4_ptr)(reinterpret_cast<__bf16*>(p.out0) + (long long)m * p.ldo0 + n) = eu32x4{y[0], y[1], y[2], y[3]};
-    st8(p.resid + row.row * p.ldr + n, x);
   } else if constexpr (EPI == MEMHIP_EPI_DGELU) {
     const unsigned h[4] = {row.h.x, row.h.y, row.h.z, row.h.w};
-    unsigned o[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const ef32x2 da = unpack_bf16x2(pack_bf16x2(t[k]));            // the matmul output is bf16
-      o[k] = pack_bf16x2(da * gelu_grad2(unpack_bf16x2(h[k])));
+      out[k] = pack_bf16x2(da * gelu_grad2(unpack_bf16x2(h[k])));
     }
     if (p.colsum) {
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        const ef32x2 f = unpack_bf16x2(o[k]);
+        const ef32x2 f = unpack_bf16x2(out[k]);
         cs[2 * k] += f.x;
         cs[2 * k + 1] += f.y;
       }
     }
-    st_stream16(p.out0, (long long)m * p.ldo0 + n, o[0], o[1], o[2], o[3]);
   } else if constexpr (EPI == MEMHIP_EPI_F32) {
     float* o = reinterpret_cast<float*>(p.out0) + (long long)m * p.ldo0 + n;
-    float x[8];
     if (p.accumulate) {
+      float x[8];
       ld8(o, x);
 #pragma unroll
-      for (int k = 0; k < 8; ++k) x[k] += acc[k];
-      st8(o, x);
+      for (int k = 0; k < 8; ++k) out[k] = __float_as_uint(x[k] + acc[k]);
     } else {
-      st8(o, acc);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) out[k] = __float_as_uint(acc[k]);
     }
   } else if constexpr (EPI == MEMHIP_EPI_PATCH_EMBED) {
-    const int L = p.rows_per_sample;
-    const int b = m / L, pi = m - b * L;
     const float w = (float)reinterpret_cast<const unsigned char*>(p.aux)[m];
-    float mt[8], x[8];
+    float mt[8];
     ld8(p.vec1 + n, mt);
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const ef32x2 f = unpack_bf16x2(pack_bf16x2(t[k]));
-      x[2 * k] = __fadd_rn(__fmul_rn(f.x, 1.0f - w), __fmul_rn(mt[2 * k], w));
-      x[2 * k + 1] = __fadd_rn(__fmul_rn(f.y, 1.0f - w), __fmul_rn(mt[2 * k + 1], w));
+      out[2 * k] = __float_as_uint(__fadd_rn(__fmul_rn(f.x, 1.0f - w), __fmul_rn(mt[2 * k], w)));
+      out[2 * k + 1] = __float_as_uint(__fadd_rn(__fmul_rn(f.y, 1.0f - w), __fmul_rn(mt[2 * k + 1], w)));
     }
-    st8(p.resid + ((long long)b * (L + 1) + 1 + pi) * p.ldr + n, x);
   }
+}
+
+// second half: `out` of epi8_math to memory.  rrow: the residual-stream row of the RESIDUAL epilogue (EpiRow::row).
+template <int EPI>
+__device__ __forceinline__ void epi8_store(const GemmArgs& p, int m, int n, long long rrow, const unsigned* out) {
+  if constexpr (EPI == MEMHIP_EPI_BIAS_BF16 || EPI == MEMHIP_EPI_MUL_AUX || EPI == MEMHIP_EPI_DGELU) {
+    st_stream16(p.out0, (long long)m * p.ldo0 + n, out[0], out[1], out[2], out[3]);
+  } else if constexpr (EPI == MEMHIP_EPI_BIAS_GELU || EPI == MEMHIP_EPI_BIAS_GELU_DG) {
+    st_stream16(p.out0, (long long)m * p.ldo0 + n, out[0], out[1], out[2], out[3]);
+    st_stream16(p.out1, (long long)m * p.ldo1 + n, out[4], out[5], out[6], out[7]);
+  } else {
+    float x[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) x[k] = __uint_as_float(out[k]);
+    if constexpr (EPI == MEMHIP_EPI_RESIDUAL) {
+      st8(p.resid + rrow * p.ldr + n, x);
+    } else if constexpr (EPI == MEMHIP_EPI_F32) {
+      st8(reinterpret_cast<float*>(p.out0) + (long long)m * p.ldo0 + n, x);
+    } else if constexpr (EPI == MEMHIP_EPI_PATCH_EMBED) {
+      const int L = p.rows_per_sample;
+      const int b = m / L, pi = m - b * L;
+      st8(p.resid + ((long long)b * (L + 1) + 1 + pi) * p.ldr + n, x);
+    }
+  }
+}
+
+template <int EPI, int COPY = 1>
+__device__ __forceinline__ void epilogue8(const GemmArgs& p, int m, int n, const float* acc, float* cs, const EpiCols& c,
+                                          const EpiRow<EPI>& row) {
+  unsigned out[EpiPk<EPI>::W];
+  epi8_math<EPI, COPY>(p, m, n, acc, cs, c, row, out);
+  long long rrow = m;
+  if constexpr (EPI == MEMHIP_EPI_RESIDUAL) rrow = row.row;
+  epi8_store<EPI>(p, m, n, rrow, out);
 }
 
 // The residual epilogue from the already rounded and packed branch output y (8 columns = 4 bf16 pairs): see gemm_p8.hip
