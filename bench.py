@@ -317,6 +317,8 @@ def main():
     ap.add_argument("--no-dp-skip", action="store_true",
                     help="stochastic depth by masking (every sample computed, dropped ones multiplied by zero) instead of "
                          "work skipping: A/B switch")
+    ap.add_argument("--gelu-dg", type=int, default=None, choices=[0, 1],
+                    help="A/B switch: 1 = fc1 keeps gelu'(h) as fp16 for the backward (MUL_AUX), 0 = it keeps h (DGELU); default: the engine's")
     ap.add_argument("--no-tail-rows", action="store_true",
                     help="A/B switch: the last block's MLP branch on every row instead of only the rows that reach the head")
     ap.add_argument("--no-entrypoint-figure", action="store_true",
@@ -392,6 +394,8 @@ def main():
     eng = model.engine
     eng.wgrad_side_stream = not a.no_side_stream
     eng.dp_skip = not a.no_dp_skip
+    if a.gelu_dg is not None:
+        eng.set_gelu_dg(bool(a.gelu_dg))
     eng.tail_rows = not a.no_tail_rows
     eng.fwd_two_streams = bool(a.fwd_split) and not a.no_fwd_split
     import contextlib, io

@@ -264,9 +264,10 @@ int memhip_mask_random_location(uint32_t* mt_state, int H, int W, int num_maskin
 #define MEMHIP_EPI_DGELU 3       /* out0 bf16 = bf16(acc) * gelu'(aux bf16)                   (GELU backward) */
 #define MEMHIP_EPI_F32 4         /* out0 f32 (+)= acc                                         (weight gradients) */
 #define MEMHIP_EPI_PATCH_EMBED 5 /* resid f32[b*(L+1)+1+p] = bf16(acc+bias)*(1-w) + vec1*w    (modeling_pretrain.py:101-108) */
-#define MEMHIP_EPI_BIAS_GELU_DG 6 /* as BIAS_GELU, but out0 bf16 = gelu'(h) instead of h: the GELU backward then is a plain
-                                    product (MUL_AUX) -- erf/exp are evaluated once, in the forward epilogue */
-#define MEMHIP_EPI_MUL_AUX 7     /* out0 bf16 = bf16(acc) * aux bf16  (+ colsum)               (GELU backward with stored gelu') */
+#define MEMHIP_EPI_BIAS_GELU_DG 6 /* as BIAS_GELU, but out0 = gelu'(h) as FP16 (16 bits per value like bf16, 11 significant bits:
+                                    gelu' lies in [-0.13, 1.13]) instead of h: the GELU backward then is a plain product
+                                    (MUL_AUX) -- erf/exp are evaluated once, in the forward epilogue */
+#define MEMHIP_EPI_MUL_AUX 7     /* out0 bf16 = bf16(acc) * aux fp16  (+ colsum)               (GELU backward with stored gelu') */
 typedef struct memhip_gemm_args {
   const void* A; const void* B;
   int64_t lda, ldb;

@@ -76,11 +76,11 @@ __device__ __forceinline__ void epilogue(const GemmArgs& p, int m, int n, float 
     reinterpret_cast<__bf16*>(p.out1)[(long long)m * p.ldo1 + n] = (__bf16)gelu_f((float)h);
   } else if constexpr (EPI == MEMHIP_EPI_BIAS_GELU_DG) {
     const __bf16 h = (__bf16)(acc + bias_n);
-    reinterpret_cast<__bf16*>(p.out0)[(long long)m * p.ldo0 + n] = (__bf16)gelu_grad_f((float)h);
+    reinterpret_cast<_Float16*>(p.out0)[(long long)m * p.ldo0 + n] = (_Float16)gelu_grad_f((float)h);
     reinterpret_cast<__bf16*>(p.out1)[(long long)m * p.ldo1 + n] = (__bf16)gelu_f((float)h);
   } else if constexpr (EPI == MEMHIP_EPI_MUL_AUX) {
     const float da = bf16_round(acc);
-    const float g = (float)reinterpret_cast<const __bf16*>(p.aux)[(long long)m * p.ldaux + n];
+    const float g = (float)reinterpret_cast<const _Float16*>(p.aux)[(long long)m * p.ldaux + n];
     const __bf16 o = (__bf16)(da * g);
     reinterpret_cast<__bf16*>(p.out0)[(long long)m * p.ldo0 + n] = o;
     if (p.colsum) atomicAdd(colsum_base(p) + n, (float)o);
@@ -142,6 +142,14 @@ __device__ __forceinline__ unsigned pack_bf16x2(ef32x2 v) {
 }
 __device__ __forceinline__ ef32x2 unpack_bf16x2(unsigned u) {
   return ef32x2{__uint_as_float(u << 16), __uint_as_float(u & 0xffff0000u)};
+}
+// fp16 pairs (the stored GELU derivative: 11 significant bits instead of bf16's 8, same 16 bits per value)
+typedef __attribute__((ext_vector_type(2))) _Float16 ef16x2;
+__device__ __forceinline__ unsigned pack_f16x2(ef32x2 v) {
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, ef16x2));
+}
+__device__ __forceinline__ ef32x2 unpack_f16x2(unsigned u) {
+  return __builtin_convertvector(__builtin_bit_cast(ef16x2, u), ef32x2);
 }
 __device__ __forceinline__ ef32x2 fma2(ef32x2 a, ef32x2 b, ef32x2 c) { return __builtin_elementwise_fma(a, b, c); }
 __device__ __forceinline__ ef32x2 splat2(float v) { return ef32x2{v, v}; }
@@ -359,13 +367,13 @@ __device__ __forceinline__ void epi8_math(const GemmArgs& p, int m, int n, const
     for (int k = 0; k < 4; ++k) {
       ef32x2 g, dg;
       gelu_and_grad2(unpack_bf16x2(pack_bf16x2(t[k])), g, dg);
-      out[k] = pack_bf16x2(dg);
+      out[k] = pack_f16x2(dg);
       out[4 + k] = pack_bf16x2(g);
     }
   } else if constexpr (EPI == MEMHIP_EPI_MUL_AUX) {
     const unsigned h[4] = {row.h.x, row.h.y, row.h.z, row.h.w};
 #pragma unroll
-    for (int k = 0; k < 4; ++k) out[k] = pack_bf16x2(unpack_bf16x2(pack_bf16x2(t[k])) * unpack_bf16x2(h[k]));
+    for (int k = 0; k < 4; ++k) out[k] = pack_bf16x2(unpack_bf16x2(pack_bf16x2(t[k])) * unpack_f16x2(h[k]));
     if (p.colsum) {
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
@@ -521,6 +529,36 @@ __device__ __forceinline__ void epilogue8(const GemmArgs& p, int m, int n, const
   EpiCols c;
   epi_cols_load<EPI>(p, n, c);
   epilogue8<EPI>(p, m, n, acc, cs, c);
+}
+
+// FULL-LINE memory accesses out of the 16x16 accumulator layout (gemm_p8.hip).  A lane of that layout holds 8 consecutive
+// columns of ONE row (r = lane & 15) per column half, so a 16-byte-per-lane access covers 16 rows x 64 bytes: sixteen
+// half-used 128-byte lines.  The CU's vector-memory pipeline costs ~4.2 cycles per line TOUCHED per instruction (round 4:
+// 128 such stores per 256x256 bf16 tile = 8.5 K cycles, the same pipeline the operand stream needs), so the two 16-byte
+// pieces a and b of a lane that are 64 bytes apart in memory (the two column halves of a bf16 row; the two halves of a
+// lane's 32 bytes of an fp32 row) are exchanged between lanes r and r ^ 8 (DPP row_ror:8) into
+//   P = rows 0-7 of the fragment, 128 contiguous bytes each, and Q = rows 8-15:
+// lane (r, c) then accesses row (r & 7) [P] / 8 + (r & 7) [Q] at 16-byte chunk 4 (r >> 3) + c (bf16: a | b = 64 B | 64 B)
+// or 2 c + (r >> 3) (fp32: a, b = the lane's two 16-byte halves).  Two instructions, 8 full lines each.
+__device__ __forceinline__ unsigned swap8(unsigned v) {
+  return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x128 /* row_ror:8 */, 0xf, 0xf, false);
+}
+// hi = (lane & 8) != 0
+__device__ __forceinline__ void pq_pack(const unsigned* a, const unsigned* b, bool hi, unsigned* P, unsigned* Q) {
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const unsigned sb = swap8(b[k]), sa = swap8(a[k]);
+    P[k] = hi ? sb : a[k];
+    Q[k] = hi ? b[k] : sa;
+  }
+}
+__device__ __forceinline__ void pq_unpack(const unsigned* P, const unsigned* Q, bool hi, unsigned* a, unsigned* b) {
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const unsigned sq = swap8(Q[k]), sp = swap8(P[k]);
+    a[k] = hi ? sq : P[k];
+    b[k] = hi ? Q[k] : sp;
+  }
 }
 
 // Column sums when the 16 lanes with equal (lane >> 4) hold the same 8 columns n..n+7 for 16
