@@ -895,6 +895,8 @@ int gemm_p8_half_dispatch(const GemmArgs& p, hipStream_t s) {
     case MEMHIP_EPI_BIAS_GELU: return launch_p8<MEMHIP_EPI_BIAS_GELU, 128>(p, s, num_cu);
     case MEMHIP_EPI_RESIDUAL: return launch_p8<MEMHIP_EPI_RESIDUAL, 128>(p, s, num_cu);
     case MEMHIP_EPI_DGELU: return launch_p8<MEMHIP_EPI_DGELU, 128>(p, s, num_cu);
+    case MEMHIP_EPI_BIAS_GELU_DG: return launch_p8<MEMHIP_EPI_BIAS_GELU_DG, 128>(p, s, num_cu);
+    case MEMHIP_EPI_MUL_AUX: return launch_p8<MEMHIP_EPI_MUL_AUX, 128>(p, s, num_cu);
     case MEMHIP_EPI_F32: return launch_p8<MEMHIP_EPI_F32, 128>(p, s, num_cu);
     default: return MEMHIP_EUNSUPPORTED;
   }
