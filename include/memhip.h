@@ -555,6 +555,12 @@ int memhip_nchw_to_padded_nhwc4_f16x2(const float* x, int B, int C, int H, int W
  * Layout / dtype movers
  * ------------------------------------------------------------------------ */
 int memhip_cast_f32_bf16(const float* in, void* out_bf16, int64_t n, memhip_stream_t stream);
+/* Zero fills of the training step (the reference: optimizer.zero_grad(), mem/engine_for_pretraining.py:160; torch.zeros
+ * temporaries of autograd): `bytes` at p, or n ranges {byte offset, byte count} (device array of 2n int64, every value a
+ * multiple of 16, total_bytes = their sum: it sizes the grid) relative to base, in one launch -- e.g. every gradient that is
+ * accumulated by atomics, while the weight matrices are written, not accumulated, by the weight-gradient GEMM. */
+int memhip_zero(void* p, int64_t bytes, memhip_stream_t stream);
+int memhip_zero_ranges(void* base, const int64_t* ranges, int n, int64_t total_bytes, memhip_stream_t stream);
 /* dst[s] = src[s] for the n listed samples s = ids[k] (n_per_sample fp32 values each, a multiple of 4): the residual rows of
  * the samples a stochastic-depth branch dropped (mem/modeling_finetune.py:187-188 with a zero keep mask) */
 int memhip_copy_samples_f32(const float* src, float* dst, const int32_t* ids, int n, int64_t n_per_sample,

@@ -266,6 +266,42 @@ extern "C" int memhip_copy_samples_f32(const float* src, float* dst, const int32
   return check_launch("copy_samples");
 }
 
+// ---- zero fills of the step (gradient accumulators, padding rows): streaming 16-byte stores
+__global__ __launch_bounds__(256) void zero_kernel(uint4* __restrict__ p, long long n16) {
+  const long long step = (long long)gridDim.x * 256;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n16; i += step) p[i] = uint4{0u, 0u, 0u, 0u};
+}
+// ranges[2 r] = byte offset, ranges[2 r + 1] = byte count of range r (multiples of 16): every workgroup walks every range
+__global__ __launch_bounds__(256) void zero_ranges_kernel(char* __restrict__ base, const long long* __restrict__ ranges, int n) {
+  const long long step = (long long)gridDim.x * 256;
+  for (int r = 0; r < n; ++r) {
+    uint4* p = reinterpret_cast<uint4*>(base + ranges[2 * r]);
+    const long long n16 = ranges[2 * r + 1] >> 4;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n16; i += step) p[i] = uint4{0u, 0u, 0u, 0u};
+  }
+}
+
+extern "C" int memhip_zero(void* p, int64_t bytes, memhip_stream_t stream) {
+  MEMHIP_REQUIRE(bytes >= 0 && bytes % 16 == 0 && ((uintptr_t)p & 15) == 0, "zero: pointer and size must be multiples of 16 bytes");
+  if (bytes == 0) return MEMHIP_OK;
+  MEMHIP_REQUIRE(p, "zero: null pointer");
+  long long g = (bytes / 16 + 255) / 256;
+  if (g > 2048) g = 2048;
+  hipLaunchKernelGGL(zero_kernel, dim3((unsigned)g), dim3(256), 0, as_stream(stream), (uint4*)p, (long long)(bytes / 16));
+  return check_launch("zero");
+}
+
+extern "C" int memhip_zero_ranges(void* base, const int64_t* ranges, int n, int64_t total_bytes, memhip_stream_t stream) {
+  MEMHIP_REQUIRE(n >= 0 && total_bytes >= 0, "zero_ranges: bad count");
+  if (n == 0 || total_bytes == 0) return MEMHIP_OK;
+  MEMHIP_REQUIRE(base && ranges && ((uintptr_t)base & 15) == 0, "zero_ranges: null / unaligned pointer");
+  long long g = (total_bytes / 16 + 255) / 256;
+  if (g > 1024) g = 1024;
+  if (g < 1) g = 1;
+  hipLaunchKernelGGL(zero_ranges_kernel, dim3((unsigned)g), dim3(256), 0, as_stream(stream), (char*)base, (const long long*)ranges, n);
+  return check_launch("zero_ranges");
+}
+
 // ---- dead-row elimination in the last block (vit_engine.py: tail rows).  Only the rows that reach the head (the masked
 // tokens) need the last block's MLP branch: it runs on those rows in compact form, and these two kernels connect the compact
 // rows with the token-major residual stream.

@@ -97,6 +97,8 @@ declare({
     "memhip_attn_bwd_out": (i32, [vp, i64, vp, i64, vp, i64, vp, vp, vp, i32, i32, i32, i32, i32, i32, f32, vp, i64, vp, vp, vp, vp]),
     "memhip_cast_f32_bf16": (i32, [vp, vp, i64, vp]),
     "memhip_copy_samples_f32": (i32, [vp, vp, vp, i32, i64, vp]),
+    "memhip_zero": (i32, [vp, i64, vp]),
+    "memhip_zero_ranges": (i32, [vp, vp, i32, i64, vp]),
     "memhip_transpose_cast_f32_bf16": (i32, [vp, i64, i32, i32, vp, i64, vp]),
     "memhip_transpose_bf16": (i32, [vp, i64, i32, i32, vp, i64, i32, vp, i32, i32, vp, i32, i32, vp]),
     "memhip_im2col_bf16": (i32, [vp, i32, i32, i32, i32, i32, i32, vp, vp]),
@@ -240,6 +242,17 @@ def scatter_rows(src, rows_i32, R, D, dst):
 
 def copy_samples(src, dst, ids_i32, n, n_per_sample):
     check(lib.memhip_copy_samples_f32(ptr(src), ptr(dst), ptr(ids_i32), n, n_per_sample, stream_ptr()), "copy_samples")
+
+
+def zero_(t):
+    """t.zero_() by the library's fill kernel (t contiguous, 16-byte aligned, a multiple of 16 bytes)."""
+    nb = t.numel() * t.element_size()
+    assert t.is_contiguous() and nb % 16 == 0
+    check(lib.memhip_zero(ptr(t), nb, stream_ptr()), "zero")
+
+
+def zero_ranges(base, ranges_dev, n, total_bytes):
+    check(lib.memhip_zero_ranges(ptr(base), ptr(ranges_dev), n, total_bytes, stream_ptr()), "zero_ranges")
 
 
 def cast_f32_bf16(src, dst, n):

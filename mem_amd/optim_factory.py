@@ -93,7 +93,8 @@ class FlatAdamW:
         self.max_norm = 0.0           # set by the scaler (clip folded into the update kernel)
 
     def zero_grad(self, set_to_none=False):
-        self.engine.flat_g.zero_()
+        from . import ops
+        ops.zero_(self.engine.flat_g)
 
     def step(self):
         lrs = {g["lr"] for g in self.param_groups}
