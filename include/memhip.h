@@ -52,6 +52,12 @@ const char* memhip_arch(void);
  * Unknown name: MEMHIP_EINVAL.  Results do not depend on any option (same contract, different kernel or timing). */
 int memhip_set_option(const char* name, int value);
 int memhip_get_option(const char* name, int* value);
+/* CUs that launches on `stream` leave free (rounded up to a multiple of 8: every XCD gives up the same number; 0 clears
+ * it).  The persistent one-workgroup-per-CU launches (GEMMs, weight gradients, attention) size their grids for the device's
+ * CUs minus this: the data-parallel reducer sets it on ITS engine's streams while gradient buckets are in flight, so that
+ * RCCL's channel kernels find CUs of their own (mem_amd/parallel.py; DDP: mem/run_mem_pretraining.py:365-367).  Scoped to
+ * the caller's stream handle -- another engine / stream of the process is not affected; at most 32 streams at a time. */
+int memhip_stream_reserve_cus(memhip_stream_t stream, int cus);
 
 /* ------------------------------------------------------------------------
  * Event stream -> voxel/histogram image

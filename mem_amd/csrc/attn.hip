@@ -579,8 +579,8 @@ __global__ void attn_stats_zero_kernel(float* stats, int n) {
 // perfectly evenly (12 per workgroup, runs crossing into the next head) was tried and is no faster:
 // the crossing workgroups pay the per-head setup twice.  Smallest count for which the grid fits one
 // round, capped at 16 (the table-gradient buckets are sized for that).
-int pick_spb(int B, int heads) {
-  int num_cu = memhip::usable_cus();
+int pick_spb(int B, int heads, hipStream_t s) {
+  int num_cu = memhip::usable_cus(s);
   if (num_cu <= 0) num_cu = 256;
   for (int spb = 1; spb <= 16; ++spb)
     if ((long long)((B + spb - 1) / spb) * heads <= num_cu) return spb;
@@ -630,7 +630,7 @@ extern "C" int memhip_attn_fwd(const void* qkv, int64_t ldqkv, int B, int T, int
   const int nrd = (2 * window_h - 1) * (2 * window_w - 1) + 3;
   if (nkb > 8)
     return memhip::attn_fwd_stream(qkv, ldqkv, B, T, D, heads, table, window_h, window_w, out, ldo, lse, s);
-  const int spb = pick_spb(B, heads);
+  const int spb = pick_spb(B, heads, s);
 #define FWD(N)                                                                                          \
   {                                                                                                     \
     const size_t sm = (size_t)4 * N * 32 * 128 + (size_t)(rel_geom(window_h, window_w).len + 2 * N * 32) * 4 + 32; \
@@ -698,7 +698,7 @@ extern "C" int memhip_attn_bwd(const void* qkv, int64_t ldqkv, const void* dout,
                               dq_bias, s);
   const int nkb = (T + 31) / 32;
   const int nrd = (2 * window_h - 1) * (2 * window_w - 1) + 3;
-  const int spb = pick_spb(B, heads);
+  const int spb = pick_spb(B, heads, s);
   const int grid = ((B + spb - 1) / spb) * heads;
   const int glen = rel_geom(window_h, window_w).len;
   float* stats = delta + 2LL * B * T * heads;             // per-head bounds, written by the kv kernel for the q kernel

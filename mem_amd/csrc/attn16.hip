@@ -859,10 +859,10 @@ __global__ __launch_bounds__(kThreads16) void attn16_bwd_kernel(const __bf16* __
   }
 }
 
-int num_cu16() { const int n = memhip::usable_cus(); return n > 0 ? n : 256; }
+int num_cu16(hipStream_t s) { const int n = memhip::usable_cus(s); return n > 0 ? n : 256; }
 // workgroups per head: one workgroup per CU (LDS), as many as fit in one round
-int nwg16(int B, int heads) {
-  const int n = num_cu16() / heads;
+int nwg16(int B, int heads, hipStream_t s) {
+  const int n = num_cu16(s) / heads;
   return n < 1 ? 1 : (n > B ? B : n);
 }
 
@@ -881,7 +881,7 @@ int attn16_fwd(const void* qkv, int64_t ldqkv, int B, int D, int heads, const fl
                                    hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds));
     attr_done = true;
   }
-  const int nwg = nwg16(B, heads);
+  const int nwg = nwg16(B, heads, s);
   hipLaunchKernelGGL(attn16_fwd_kernel, dim3(nwg * heads), dim3(kThreads16), sm, s, (const __bf16*)qkv,
                      (long long)ldqkv, B, D, heads, table, (__bf16*)out, (long long)ldo, lse, nwg, opt(OPT_ATTN16_STAGGER_FWD));
   return check_launch("attn_fwd(14x14)");
@@ -898,7 +898,7 @@ int attn16_bwd(const void* qkv, int64_t ldqkv, const void* dout, int64_t ldo, co
 #undef A16_ATTR
     attr_done = true;
   }
-  const int nwg = nwg16(B, heads), stagger = opt(OPT_ATTN16_STAGGER);
+  const int nwg = nwg16(B, heads, s), stagger = opt(OPT_ATTN16_STAGGER);
   const int grid = nwg * heads;
 #define A16_LAUNCH(DT, FD)                                                                                          \
   hipLaunchKernelGGL((attn16_bwd_kernel<DT, FD>), dim3(grid), dim3(kThreads16), kLdsBwd16, s, (const __bf16*)qkv,     \

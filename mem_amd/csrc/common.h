@@ -32,7 +32,7 @@ int opt(int id);
 // the `reserve_cus` option (a multiple of 8 is kept, so that every XCD gives up the same number).  The data-parallel
 // reducer sets the option while gradient buckets are in flight: RCCL's channel kernels need CUs of their own -- a
 // persistent grid that covers every CU would otherwise finish its last workgroups one full workgroup-duration late.
-int usable_cus();
+int usable_cus(hipStream_t s = nullptr);
 
 inline hipStream_t as_stream(memhip_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 

@@ -1,6 +1,7 @@
 // ABI bookkeeping: version, arch, thread-local error string, kernel-selection options.
 #include "common.h"
 #include <atomic>
+#include <mutex>
 #include <cstring>
 
 namespace memhip {
@@ -18,7 +19,17 @@ static const char* const g_opt_name[OPT_COUNT_] = {"gemm_p8", "gemm256", "gemm_s
                                                    "gemm256_min_n", "tn_p8", "tn256", "raster_lds", "attn16", "attn16_stagger", "attn16_stagger_fwd", "gemm_stagger", "gemm_prefetch", "reserve_cus", "ln_bwd_grid", "gemm_p8s", "gemm_p8d"};
 int opt(int id) { return g_opt[id].load(std::memory_order_relaxed); }
 
-int usable_cus() {
+// CU reservations per stream (memhip_stream_reserve_cus): a small fixed table, keyed by the caller's stream handle
+struct StreamReserve { std::atomic<bool> used{false}; std::atomic<void*> stream{nullptr}; std::atomic<int> cus{0}; };
+static StreamReserve g_reserve[32];
+static int stream_reserved(hipStream_t s) {
+  for (auto& r : g_reserve)
+    if (r.used.load(std::memory_order_acquire) && r.stream.load(std::memory_order_relaxed) == (void*)s)
+      return r.cus.load(std::memory_order_relaxed);
+  return 0;
+}
+
+int usable_cus(hipStream_t s) {
   static std::atomic<int> device_cus{0};
   int n = device_cus.load(std::memory_order_relaxed);
   if (!n) {
@@ -28,7 +39,9 @@ int usable_cus() {
     n = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     device_cus.store(n, std::memory_order_relaxed);
   }
-  int r = opt(OPT_RESERVE_CUS);
+  int r = opt(OPT_RESERVE_CUS);                       // A/B tools: every stream
+  const int rs = stream_reserved(s);                   // the caller's reservation for launches on THIS stream
+  r = r > rs ? r : rs;
   r = r < 0 ? 0 : (r + 7) / 8 * 8;
   return n - r >= 8 ? n - r : (n >= 8 ? 8 : n);
 }
@@ -38,6 +51,28 @@ extern "C" {
 int memhip_abi_version(void) { return MEMHIP_ABI_VERSION; }
 const char* memhip_last_error(void) { return memhip::g_err; }
 const char* memhip_arch(void) { return "gfx950"; }
+
+int memhip_stream_reserve_cus(memhip_stream_t stream, int cus) {
+  MEMHIP_REQUIRE(cus >= 0, "stream_reserve_cus: negative count");
+  using memhip::g_reserve;
+  static std::mutex mu;                                 // writers only (a few calls per step); readers scan lock-free
+  std::lock_guard<std::mutex> lock(mu);
+  for (auto& r : g_reserve)
+    if (r.used.load(std::memory_order_relaxed) && r.stream.load(std::memory_order_relaxed) == stream) {
+      r.cus.store(cus, std::memory_order_relaxed);
+      if (cus == 0) r.used.store(false, std::memory_order_release);
+      return MEMHIP_OK;
+    }
+  if (cus == 0) return MEMHIP_OK;
+  for (auto& r : g_reserve)
+    if (!r.used.load(std::memory_order_relaxed)) {
+      r.stream.store(stream, std::memory_order_relaxed);
+      r.cus.store(cus, std::memory_order_relaxed);
+      r.used.store(true, std::memory_order_release);
+      return MEMHIP_OK;
+    }
+  return memhip::fail(MEMHIP_EINVAL, "stream_reserve_cus: more than 32 streams carry a reservation");
+}
 
 int memhip_set_option(const char* name, int value) {
   MEMHIP_REQUIRE(name, "set_option: null name");

@@ -190,7 +190,7 @@ namespace memhip {
 int gemm256_dispatch(const GemmArgs& p, hipStream_t s);
 int gemm_p8_dispatch(const GemmArgs& p, hipStream_t s);
 int gemm_p8s_dispatch(const GemmArgs& p, hipStream_t s);
-int gemm_p8_split_rows(const GemmArgs& p);
+int gemm_p8_split_rows(const GemmArgs& p, hipStream_t s);
 int gemm_p8_half_dispatch(const GemmArgs& p, hipStream_t s);
 }
 
@@ -237,7 +237,7 @@ extern "C" int memhip_gemm_bf16_nt(const memhip_gemm_args_t* a, memhip_stream_t 
     // below (finer tiles, 2-3 workgroups per CU).  Rows are independent, so this is two launches of
     // the same contract on two row ranges.
     const bool split_on = opt(OPT_GEMM_SPLIT) != 0;
-    const int split = split_on ? gemm_p8_split_rows(p) : 0;
+    const int split = split_on ? gemm_p8_split_rows(p, s) : 0;
     if (split > 0 && split < p.M && p.epilogue != MEMHIP_EPI_PATCH_EMBED) {
       GemmArgs head = p;
       head.M = split;

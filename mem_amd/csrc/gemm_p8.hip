@@ -828,7 +828,7 @@ extern "C" int memhip_debug_p8_stamps(unsigned long long* host_out) {
 
 namespace memhip {
 
-static int p8_num_cu() { return usable_cus(); }
+static int p8_num_cu(hipStream_t s) { return usable_cus(s); }
 
 static bool p8_fits(const GemmArgs& p) {
   const bool vec = ((p.ldo0 | p.ldo1 | p.ldr | p.ldaux | p.colscale_n) & 7) == 0;      // host twin of vec_ok()
@@ -845,9 +845,9 @@ static bool p8_fits(const GemmArgs& p) {
 
 // Rows the persistent launch should take when its last round of tiles would be less than half full
 // (0 = take everything): full rounds only, the caller runs the remaining rows on finer tiles.
-int gemm_p8_split_rows(const GemmArgs& p) {
+int gemm_p8_split_rows(const GemmArgs& p, hipStream_t s) {
   if (!p8_fits(p)) return 0;
-  const int num_cu = p8_num_cu();
+  const int num_cu = p8_num_cu(s);
   if (!num_cu) return 0;
   const int ntm = (p.M + BM - 1) / BM, ntn = p.N / BN;
   const int tiles = ntm * ntn, rounds = tiles / num_cu, rem = tiles % num_cu;
@@ -868,7 +868,7 @@ int gemm_p8_dispatch(const GemmArgs& p, hipStream_t s) {
 #ifdef P8_FORCE_HALF      // measurement build: every row on the 128-row form of the kernel
   { const int rc = gemm_p8_half_dispatch(p, s); if (rc != MEMHIP_EUNSUPPORTED) return rc; }
 #endif
-  const int num_cu = p8_num_cu();
+  const int num_cu = p8_num_cu(s);
   if (!num_cu) return MEMHIP_EUNSUPPORTED;
   switch (p.epilogue) {
     case MEMHIP_EPI_BIAS_BF16: return launch_p8<MEMHIP_EPI_BIAS_BF16, 256>(p, s, num_cu);
@@ -888,7 +888,7 @@ int gemm_p8_dispatch(const GemmArgs& p, hipStream_t s) {
 int gemm_p8_half_dispatch(const GemmArgs& p, hipStream_t s) {
   const bool vec = ((p.ldo0 | p.ldo1 | p.ldr | p.ldaux | p.colscale_n) & 7) == 0;
   if (p.M < 128 || p.N % BN != 0 || p.K % (2 * BK) != 0 || !vec) return MEMHIP_EUNSUPPORTED;
-  const int num_cu = p8_num_cu();
+  const int num_cu = p8_num_cu(s);
   if (!num_cu) return MEMHIP_EUNSUPPORTED;
   switch (p.epilogue) {
     case MEMHIP_EPI_BIAS_BF16: return launch_p8<MEMHIP_EPI_BIAS_BF16, 128>(p, s, num_cu);

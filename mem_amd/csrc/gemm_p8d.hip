@@ -552,7 +552,7 @@ int gemm_p8d_dispatch(const GemmArgs& p, hipStream_t s) {
   const bool rows_ok = (!(p.rowmask || p.sample_map) || (long long)p.M + p.m_base < (1 << 21)) &&
                        (!p.sample_map || p.rows_per_sample >= 86);
   if (p.M < 4096 || p.M % BM != 0 || p.N % BN != 0 || p.K % (2 * BK) != 0 || !vec || !rows_ok) return MEMHIP_EUNSUPPORTED;
-  const int num_cu = usable_cus();
+  const int num_cu = usable_cus(s);
   if (!num_cu) return MEMHIP_EUNSUPPORTED;
   switch (p.epilogue) {
     case MEMHIP_EPI_BIAS_BF16: return launch_p8d<MEMHIP_EPI_BIAS_BF16, false>(p, s, num_cu);

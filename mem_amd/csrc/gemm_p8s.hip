@@ -301,7 +301,7 @@ int gemm_p8s_dispatch(const GemmArgs& p, hipStream_t s) {
   const bool vec = ((p.ldo0 | p.ldo1) & 7) == 0;
   if (p.M < 4096 || p.M % BM != 0 || p.N % BN != 0 || p.K % BK != 0 || p.K < 4 * BK || !vec) return MEMHIP_EUNSUPPORTED;
   if (p.colsum) return MEMHIP_EUNSUPPORTED;
-  const int num_cu = usable_cus();
+  const int num_cu = usable_cus(s);
   if (!num_cu) return MEMHIP_EUNSUPPORTED;
   switch (p.epilogue) {
     case MEMHIP_EPI_BIAS_BF16: return launch_p8s<MEMHIP_EPI_BIAS_BF16>(p, s, num_cu);

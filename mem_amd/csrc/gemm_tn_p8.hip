@@ -303,7 +303,7 @@ static void tn_p8_plan(int R, int N, int K, int num_cu, int& tiles, int& splits,
   rows_per_split = cdiv(pairs, splits) * 2 * BR;
   splits = cdiv(R, rows_per_split);
 }
-static int tn_p8_num_cu() { return usable_cus(); }
+static int tn_p8_num_cu(hipStream_t s = nullptr) { return usable_cus(s); }
 
 // bytes of workspace with which the partial tiles go through plain stores + a reduction pass
 size_t gemm_tn_p8_workspace(int R, int N, int K) {
@@ -319,7 +319,7 @@ size_t gemm_tn_p8_workspace(int R, int N, int K) {
 int gemm_tn_p8_dispatch(const void* A, long long lda, const void* B, long long ldb, int R, int N, int K, float* out,
                         long long ldo, int accumulate, float* ws, size_t ws_bytes, hipStream_t s) {
   if (N % BM != 0 || K % BN != 0 || R < 2048) return MEMHIP_EUNSUPPORTED;
-  const int num_cu = tn_p8_num_cu();
+  const int num_cu = tn_p8_num_cu(s);
   if (!num_cu) return MEMHIP_EUNSUPPORTED;
   int tiles, splits, rows_per_split;
   tn_p8_plan(R, N, K, num_cu, tiles, splits, rows_per_split);

@@ -150,6 +150,17 @@ def train_one_epoch(model: torch.nn.Module, d_vae: torch.nn.Module, data_loader:
     start_steps = start_steps or 0
     reducer = getattr(model, "_reducer", None)
     pending = []
+    try:
+        return _train_steps(model, d_vae, data_loader, optimizer, device, loss_scaler, max_norm, log_writer, lr_scheduler,
+                            start_steps, lr_schedule_values, wd_schedule_values, run, MAE, metric_logger, header, print_freq,
+                            reducer, pending)
+    finally:
+        if reducer is not None and hasattr(reducer, "release"):
+            reducer.release()                       # no CU reservation outlives the epoch, whatever ended it
+
+
+def _train_steps(model, d_vae, data_loader, optimizer, device, loss_scaler, max_norm, log_writer, lr_scheduler, start_steps,
+                 lr_schedule_values, wd_schedule_values, run, MAE, metric_logger, header, print_freq, reducer, pending):
     for step, (batch, _) in enumerate(metric_logger.log_every(data_loader, print_freq, header)):
         it = start_steps + step
         if lr_schedule_values is not None or wd_schedule_values is not None:
@@ -164,8 +175,13 @@ def train_one_epoch(model: torch.nn.Module, d_vae: torch.nn.Module, data_loader:
         else:
             loss_acc = model.forward_loss(samples, bool_masked_pos, labels, **extra)
         model._fused_loss_pending = True
+        # samples the transform chain flagged (empty / outside the canvas) since the last check: this step's loss reads NaN
+        # and its update is skipped on the device; the deferred check below raises the reference's error (no host sync here)
+        bad = _BAD_SAMPLES.get(str(loss_acc.device))
+        if bad is not None:
+            loss_acc[0:1].add_(torch.where(bad > 0, float("nan"), 0.0).to(loss_acc.dtype))
         grad_norm = loss_scaler(loss_acc, optimizer, clip_grad=max_norm, parameters=model.parameters(),
-                                model=model, reducer=reducer)
+                                model=model, reducer=reducer, poison=bad)
         lrs = [g["lr"] for g in optimizer.param_groups]
         wds = [g["weight_decay"] for g in optimizer.param_groups if g["weight_decay"] > 0]
         pending.append((loss_acc.clone(), grad_norm.clone(),
@@ -192,6 +208,9 @@ def evaluate(data_loader, model, d_vae, device, args, plotting=False, MAE=False)
     metric_logger = utils.MetricLogger(delimiter="  ")
     header = "Test:"
     model.eval()
+    reducer = getattr(model, "_reducer", None)
+    if reducer is not None and hasattr(reducer, "release"):
+        reducer.release()
     for batch in metric_logger.log_every(data_loader, 10, header):
         samples, images, bool_masked_pos, labels, extra = _prep_batch(batch[0], device, model, d_vae, MAE)
         la = (model.forward_loss(samples) if MAE else model.forward_loss(samples, bool_masked_pos, labels, **extra)).tolist()

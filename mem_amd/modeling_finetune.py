@@ -275,9 +275,18 @@ class VisionTransformer(nn.Module):
         if getattr(eng, "dp_skip", False):
             # work-skipping stochastic depth (ViTEngine.dp_skip): the engine sizes its launches by the number of kept samples,
             # so the masks are drawn on the HOST (torch's CPU generator; timm draws on the device: another stream, same law)
-            return torch.floor((1.0 - torch.tensor(probs)).view(-1, 1) + torch.rand((2 * eng.depth, B)))
-        u = torch.rand((2 * eng.depth, B), device=eng.dev)
-        return torch.floor(keep[1] + u).contiguous()
+            # The stream is the model's OWN generator (seeded once from torch's seed of the moment, i.e. from the run seed +
+            # rank that the entrypoint sets): sampler seeds, num_workers = 0 augmentation draws and mask draws on the global
+            # CPU generator do not shift it, and the masked form below (the A/B) draws the same uniforms.
+            return torch.floor((1.0 - torch.tensor(probs)).view(-1, 1) + self._dp_uniform(2 * eng.depth, B))
+        return torch.floor(keep[1] + self._dp_uniform(2 * eng.depth, B).to(eng.dev)).contiguous()
+
+    def _dp_uniform(self, rows, B):
+        g = getattr(self, "_dp_gen", None)
+        if g is None:
+            g = self._dp_gen = torch.Generator(device="cpu")
+            g.manual_seed(int(torch.initial_seed()) ^ 0x5DEECE66D)
+        return torch.rand((rows, B), generator=g)
 
     def _trunk(self, x, drop_path_masks=None):
         eng = self.engine

@@ -98,6 +98,7 @@ declare({
     "memhip_cast_f32_bf16": (i32, [vp, vp, i64, vp]),
     "memhip_copy_samples_f32": (i32, [vp, vp, vp, i32, i64, vp]),
     "memhip_zero": (i32, [vp, i64, vp]),
+    "memhip_stream_reserve_cus": (i32, [vp, i32]),
     "memhip_zero_ranges": (i32, [vp, vp, i32, i64, vp]),
     "memhip_transpose_cast_f32_bf16": (i32, [vp, i64, i32, i32, vp, i64, vp]),
     "memhip_transpose_bf16": (i32, [vp, i64, i32, i32, vp, i64, i32, vp, i32, i32, vp, i32, i32, vp]),
@@ -242,6 +243,11 @@ def scatter_rows(src, rows_i32, R, D, dst):
 
 def copy_samples(src, dst, ids_i32, n, n_per_sample):
     check(lib.memhip_copy_samples_f32(ptr(src), ptr(dst), ptr(ids_i32), n, n_per_sample, stream_ptr()), "copy_samples")
+
+
+def stream_reserve_cus(stream, cus):
+    """Launches on `stream` (a torch.cuda.Stream) size their persistent grids for `cus` CUs fewer (0 clears it)."""
+    check(lib.memhip_stream_reserve_cus(C.c_void_p(stream.cuda_stream), int(cus)), "stream_reserve_cus")
 
 
 def zero_(t):

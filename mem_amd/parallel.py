@@ -13,9 +13,12 @@ Mean semantics (SUM / world) == DDP.  Works on CPU tensors with gloo for the CPU
 Options (both off by default = the reference's fp32 DDP exchange):
   * ``bucket_dtype=torch.bfloat16``: a bucket is rounded to bf16, pre-divided by the world size, summed over the ranks in
     bf16 and widened back (torch's bf16_compress_hook arithmetic): 184 MB instead of 367 MB per ViT-B step on the wire;
-  * ``reserve_cus=k``: while buckets are in flight the library sizes its persistent one-workgroup-per-CU grids (GEMMs,
-    attention) for k CUs fewer (memhip option ``reserve_cus``), so that RCCL's channel kernels find CUs of their own
-    instead of displacing workgroups of a grid that covers the whole chip (whose stragglers then run a second round).
+  * ``reserve_cus=k``: while buckets are in flight the library sizes the persistent one-workgroup-per-CU grids (GEMMs,
+    attention) it launches ON THIS ENGINE'S STREAMS for k CUs fewer (``memhip_stream_reserve_cus``: scoped to the stream
+    handles, another engine of the process is not affected), so that RCCL's channel kernels find CUs of their own instead
+    of displacing workgroups of a grid that covers the whole chip (whose stragglers then run a second round).  The
+    reservation is dropped by ``finish()`` / ``release()``; the training loops call ``release()`` on every exit path.
+    No measurement on more than one GPU exists yet: the entrypoint leaves it at 0.
 """
 import torch
 import torch.distributed as dist
@@ -23,8 +26,11 @@ import torch.distributed as dist
 
 class GradReducer:
     def __init__(self, flat_g, buckets, flat_p=None, group=None, coalesce_small=0, force=False, bucket_dtype=None,
-                 reserve_cus=0):
+                 reserve_cus=0, streams=None):
+        """streams: callable returning the torch.cuda.Stream objects the engine launches on (main + side stream): the CU
+        reservation is set on exactly these."""
         self.flat_g, self.buckets, self.group = flat_g, buckets, group
+        self._streams_fn, self._res_streams = streams, []
         self.bucket_dtype = bucket_dtype if bucket_dtype not in (None, torch.float32) else None
         self.reserve_cus = int(reserve_cus)
         self._reserved = False
@@ -44,9 +50,23 @@ class GradReducer:
 
     def _reserve(self, on):
         if self.reserve_cus > 0 and self._reserved != on and self.flat_g.is_cuda:
-            from ._lib import set_option
-            set_option("reserve_cus", self.reserve_cus if on else 0)
+            from . import ops
+            if on:
+                self._res_streams = [s for s in (self._streams_fn() if self._streams_fn else [torch.cuda.current_stream()])
+                                     if s is not None]
+            for s in self._res_streams:
+                ops.stream_reserve_cus(s, self.reserve_cus if on else 0)
             self._reserved = on
+
+    def release(self):
+        """Drop the CU reservation and forget pending handles (exception / early-return paths of a training loop)."""
+        self._reserve(False)
+
+    def __del__(self):
+        try:
+            self._reserve(False)
+        except Exception:
+            pass
 
     def __call__(self, bucket_index):
         if not self.active:

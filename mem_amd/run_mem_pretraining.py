@@ -237,8 +237,11 @@ def main(args):
     print("Number of training steps = %d" % num_training_steps_per_epoch)
     eng = model.engine                                   # packs parameters into the flat buffers
     if args.distributed:
-        # (16 CUs left to RCCL's channel kernels while buckets are in flight: parallel.py)
-        model._reducer = GradReducer(eng.flat_g, eng.buckets, flat_p=eng.flat_p, reserve_cus=16)
+        # (parallel.py: reserve_cus > 0 leaves CUs to RCCL's channel kernels while buckets are in flight; no measurement on
+        # more than one GPU exists yet, so the default is 0 -- MEMHIP_RESERVE_CUS=16 tries it)
+        model._reducer = GradReducer(eng.flat_g, eng.buckets, flat_p=eng.flat_p,
+                                     reserve_cus=int(os.environ.get("MEMHIP_RESERVE_CUS", "0")),
+                                     streams=lambda: [torch.cuda.current_stream(), eng._side])
         eng.grad_hook = model._reducer
         eng.weights_dirty = True
     optimizer = create_optimizer(args, model_without_ddp)

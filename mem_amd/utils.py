@@ -223,7 +223,7 @@ class NativeScalerWithGradNormCount:
     state_dict_key = "amp_scaler"
 
     def __call__(self, loss, optimizer, clip_grad=None, parameters=None, create_graph=False, update_grad=True,
-                 model=None, reducer=None):
+                 model=None, reducer=None, poison=None):
         if model is not None and getattr(model, "_fused_loss_pending", False):
             model.backward()
             model._fused_loss_pending = False
@@ -234,6 +234,10 @@ class NativeScalerWithGradNormCount:
         if reducer is not None:
             reducer.finish()
         norm = optimizer.engine.grad_norm()
+        if poison is not None:
+            # a sample of this batch was flagged by the transform chain (the reference raises inside the transform, before
+            # the sample reaches the model): a non-finite norm makes the update kernel skip this step on the device
+            norm.add_(torch.where(poison > 0, float("nan"), 0.0).to(norm.dtype))
         optimizer.max_norm = float(clip_grad) if clip_grad else 0.0
         optimizer.step()
         return norm

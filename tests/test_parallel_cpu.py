@@ -98,3 +98,138 @@ def test_reducer_single_process_noop():
     r = GradReducer(g, [("a", 0, 1024), ("b", 1024, 2048)])
     r(0); r(1); r.finish()
     assert torch.equal(g, torch.ones(2048))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# train_one_epoch on two gloo ranks with UNEQUAL masked-token counts: the reference's data-parallel semantics are a
+# mean of per-rank means -- every rank's loss is the mean over ITS masked tokens (nn.CrossEntropyLoss() on
+# outputs[bool_masked_pos], mem/engine_for_pretraining.py:152) and DDP averages the ranks' gradients with equal weights
+# (mem/run_mem_pretraining.py:365-367), whatever the token counts.  The product's loop (engine_for_pretraining.train_one_epoch
+# -> NativeScaler -> model.backward -> GradReducer buckets from the backward hook -> finish -> norm -> step) is run
+# with a small CPU model that implements the engine interface the loop uses (the HIP engine needs a GPU).
+class _ToyEngine:
+    def __init__(self, n):
+        self.flat_p = torch.zeros(n)
+        self.flat_g = torch.zeros(n)
+        self.buckets = [("head", 0, n // 2), ("embed", n // 2, n)]
+        self.grad_hook = None
+        self.gnorm = torch.zeros(1)
+
+    def grad_norm(self):
+        self.gnorm = self.flat_g.norm().reshape(1)
+        return self.gnorm
+
+
+class _ToyModel(torch.nn.Module):
+    """logits[token] = x[token] @ W (D -> V), loss = mean CE over the rank's masked tokens; W lives in the flat buffers."""
+    D, V = 8, 16
+
+    def __init__(self):
+        super().__init__()
+        n = self.D * self.V
+        self.engine = _ToyEngine(n)
+        g = torch.Generator().manual_seed(7)
+        self.engine.flat_p.copy_(torch.randn(n, generator=g) * 0.1)
+        self.patch_embed = torch.nn.Module()
+        self.patch_embed.proj = torch.nn.Conv2d(2, 4, 1)        # in_chans = 2 (the loop's 3 -> 2 channel view)
+        self._fused_loss_pending = False
+
+    def W(self):
+        return self.engine.flat_p.view(self.D, self.V)
+
+    def forward_loss(self, samples, bool_masked_pos, labels):
+        x = samples.flatten(2).transpose(1, 2)[..., : self.D]   # [B, tokens, D]
+        xm = x[bool_masked_pos]                                  # the rank's masked tokens
+        W = self.W().clone().requires_grad_(True)
+        loss = torch.nn.functional.cross_entropy(xm @ W, labels)
+        self._saved = (loss, W)
+        acc = ((xm @ W).argmax(-1) == labels).float().mean()
+        return torch.stack([loss.detach(), acc])
+
+    def backward(self):
+        loss, W = self._saved
+        loss.backward()
+        eng = self.engine
+        eng.flat_g.copy_(W.grad.reshape(-1))
+        for b in range(len(eng.buckets)):                        # buckets become final in this order
+            if eng.grad_hook:
+                eng.grad_hook(b)
+
+
+class _ToyOpt:
+    def __init__(self, model):
+        self.engine = model.engine
+        self.param_groups = [dict(lr=0.5, weight_decay=0.0, lr_scale=1.0)]
+        self.max_norm = 0.0
+
+    def step(self):
+        self.engine.flat_p.sub_(self.param_groups[0]["lr"] * self.engine.flat_g)
+
+
+class _ToyVae:
+    def get_codebook_indices(self, images):
+        return (images.flatten(2).sum(1) * 1000).long().abs() % _ToyModel.V      # [B, tokens]
+
+
+def _toy_batch(rank):
+    """(samples [B,8,4,4], images, mask [B,4,4]): rank 0 masks 3 tokens in all, rank 1 masks 11."""
+    g = torch.Generator().manual_seed(50 + rank)
+    samples = torch.randn(2, 8, 4, 4, generator=g)               # 8 "channels" = the D = 8 features of a token
+    images = torch.randn(2, 3, 4, 4, generator=g)
+    mask = torch.zeros(2, 16, dtype=torch.bool)
+    idx = torch.randperm(32, generator=g)[: (3 if rank == 0 else 11)]
+    mask.view(-1)[idx] = True
+    return samples, images, mask.view(2, 4, 4)
+
+
+def _toy_rank_grad(rank, W0):
+    samples, images, mask = _toy_batch(rank)
+    labels = _ToyVae().get_codebook_indices(images).flatten(1)[mask.flatten(1)]
+    x = samples.flatten(2).transpose(1, 2)[..., : _ToyModel.D][mask.flatten(1)]
+    W = W0.clone().requires_grad_(True)
+    loss = torch.nn.functional.cross_entropy(x @ W, labels)
+    loss.backward()
+    return float(loss), W.grad.reshape(-1), int(mask.sum())
+
+
+def _worker_loop(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from mem_amd.parallel import GradReducer
+    from mem_amd import utils
+    from mem_amd.engine_for_pretraining import train_one_epoch
+    model = _ToyModel()
+    eng = model.engine
+    W0 = model.W().clone()
+    model._reducer = GradReducer(eng.flat_g, eng.buckets, flat_p=eng.flat_p)
+    eng.grad_hook = model._reducer
+    opt = _ToyOpt(model)
+    samples, images, mask = _toy_batch(rank)
+    loader = [((samples, images, mask), None)]
+    stats = train_one_epoch(model, _ToyVae(), loader, opt, torch.device("cpu"), 0, utils.NativeScalerWithGradNormCount(),
+                            max_norm=0, lr_schedule_values=[0.5], start_steps=0)
+    # what the reference computes: every rank its own token mean, gradients averaged with equal weights
+    l0, g0, n0 = _toy_rank_grad(0, W0)
+    l1, g1, n1 = _toy_rank_grad(1, W0)
+    assert n0 != n1
+    want_g = (g0 + g1) / 2
+    pooled_g = (g0 * n0 + g1 * n1) / (n0 + n1)                   # the global token mean: NOT what DDP computes
+    ok = torch.allclose(eng.flat_g, want_g, atol=1e-6) and not torch.allclose(want_g, pooled_g, atol=1e-4)
+    ok = ok and torch.allclose(eng.flat_p, W0.reshape(-1) - 0.5 * want_g, atol=1e-6)
+    ok = ok and abs(stats["loss"] - (l0 + l1) / 2) < 1e-5        # MetricLogger.synchronize_between_processes: mean of means
+    q.put((rank, bool(ok), float(eng.flat_p.sum())))
+    dist.destroy_process_group()
+
+
+def test_train_one_epoch_world2_mean_of_means():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_loop, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(60)
+    assert sorted(r[:2] for r in res) == [(0, True), (1, True)], res
+    assert res[0][2] == res[1][2]                                # replicas hold identical parameters after the step
