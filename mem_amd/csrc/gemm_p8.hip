@@ -65,12 +65,16 @@
 // start, epilogue start and epilogue end of its first 10 tiles; memhip_debug_p8_stamps copies the table out.  Never part of
 // the shipped library (its fences forbid overlaps the real kernel has: read the SHARES, not the lengths).
 __device__ unsigned long long g_p8_stamps[256 * 32];
+__device__ unsigned long long g_p8_stamps_rt[256 * 32];     // s_memrealtime (constant 100 MHz) at the same points: the clock
 #define P8_STAMP_AT(slot)                                                                                   \
   do {                                                                                                      \
     if (wave == 0 && stamp_tile < 10) {                                                                     \
-      unsigned long long t_;                                                                                \
-      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                           \
-      if (lane == 0) g_p8_stamps[(blockIdx.x & 255) * 32 + stamp_tile * 3 + (slot)] = t_;                   \
+      unsigned long long t_, r_;                                                                            \
+      asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_), "=s"(r_)::"memory"); \
+      if (lane == 0) {                                                                                      \
+        g_p8_stamps[(blockIdx.x & 255) * 32 + stamp_tile * 3 + (slot)] = t_;                                \
+        g_p8_stamps_rt[(blockIdx.x & 255) * 32 + stamp_tile * 3 + (slot)] = r_;                             \
+      }                                                                                                     \
     }                                                                                                       \
   } while (0)
 #else
@@ -823,6 +827,9 @@ int launch_p8(const GemmArgs& p, hipStream_t s, int num_cu) {
 #ifdef P8_STAMP
 extern "C" int memhip_debug_p8_stamps(unsigned long long* host_out) {
   return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_p8_stamps), sizeof(unsigned long long) * 256 * 32) == hipSuccess ? 0 : -1;
+}
+extern "C" int memhip_debug_p8_stamps_rt(unsigned long long* host_out) {
+  return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_p8_stamps_rt), sizeof(unsigned long long) * 256 * 32) == hipSuccess ? 0 : -1;
 }
 #endif
 

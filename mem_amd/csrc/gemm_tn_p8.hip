@@ -42,6 +42,9 @@ typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 __device__ __attribute__((aligned(256))) unsigned char g_tnp8_zero[256];   // zero-initialised
+#ifdef P8_STAMP
+__device__ unsigned long long g_tnp8_stamps[256 * 4];
+#endif
 
 __device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
@@ -218,6 +221,15 @@ __global__ __launch_bounds__(kThreads) void gemm_tn_p8_kernel(const __bf16* __re
   } while (0)
 
   TP_READ_B(bx, 0, 0);
+#ifdef P8_STAMP
+  // diagnostic build (tools/build_variant.sh stamp -DP8_STAMP): wave 0 stamps s_memtime / s_memrealtime around its main
+  // loop; the quotient is the shader clock the chip holds inside this kernel (tools/clock_probe.py)
+  if (wave == 0) {
+    unsigned long long t_, r_;
+    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_), "=s"(r_)::"memory");
+    if (lane == 0) { g_tnp8_stamps[(blockIdx.x & 255) * 4 + 0] = t_; g_tnp8_stamps[(blockIdx.x & 255) * 4 + 1] = r_; }
+  }
+#endif
   for (int c = 0; c < total; c += 2) {
     {
       constexpr int bc = 0;
@@ -228,6 +240,13 @@ __global__ __launch_bounds__(kThreads) void gemm_tn_p8_kernel(const __bf16* __re
       TP_KTILE(by, bx);
     }
   }
+#ifdef P8_STAMP
+  if (wave == 0) {
+    unsigned long long t_, r_;
+    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_), "=s"(r_)::"memory");
+    if (lane == 0) { g_tnp8_stamps[(blockIdx.x & 255) * 4 + 2] = t_; g_tnp8_stamps[(blockIdx.x & 255) * 4 + 3] = r_; }
+  }
+#endif
   if (wr == 0) TP_BARRIER();                               // balances the stagger barrier of waves 4-7
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the idle tail of the prefetch stream has landed
   TP_BARRIER();                                            // every wave is done with the ring
@@ -291,6 +310,12 @@ __global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict_
 }
 
 }  // namespace
+
+#ifdef P8_STAMP
+extern "C" int memhip_debug_tnp8_stamps(unsigned long long* host_out) {
+  return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_tnp8_stamps), sizeof(unsigned long long) * 256 * 4) == hipSuccess ? 0 : -1;
+}
+#endif
 
 namespace memhip {
 
