@@ -107,6 +107,89 @@ class _CachedEvents:
         return self.items[i % len(self.items)]
 
 
+def config5_figure(B=32, steps=5, warmup=2):
+    """BASELINE configs[4] on ONE GPU: MEM pretrain ViT-Large/16 (D 1024, depth 24, 16 heads, layer scale 1e-5,
+    mem/modeling_pretrain.py:22-140 with the reference's `pt_vit_large`-style arguments) on 480 x 640 2-bin voxels = 30 x 40 + 1
+    = 1201 tokens (streaming attention, 4664-entry bias table), 600 masked patches per sample, bf16, stochastic depth 0.1,
+    AdamW; a step = masks + forward + CE + backward + clip + AdamW on a batch resident in HBM.  B = 32 per GPU: the best
+    samples/s measured (B 16: 208, B 32: 236, B 64 -- the reference's global 512 over 8 GPUs -- 174 samples/s, 88 GB); 47 GB of
+    the 288 GB.  FLOPs: 2 635.5 GFLOP per sample fwd + bwd (GEMMs only)."""
+    import contextlib
+    import io
+    import numpy as np
+    import torch
+    from mem_amd import ops
+    from mem_amd.masking_generator import MaskingGenerator
+    from mem_amd.modeling_pretrain import pt_vit
+    from mem_amd.optim_factory import FlatAdamW, get_parameter_groups
+    H, W, FL = 480, 640, 2635.5e9
+    torch.manual_seed(0)
+    model = pt_vit(img_size=(H, W), patch_size=(16, 16), in_chans=2, vocab_size=8192, embed_dim=1024, depth=24, num_heads=16,
+                   mlp_ratio=4, drop_path_rate=0.1, use_shared_rel_pos_bias=True, use_abs_pos_emb=False,
+                   init_values=1e-5).cuda().train()
+    eng = model.engine
+    with contextlib.redirect_stdout(io.StringIO()):
+        groups = get_parameter_groups(model, 0.05, model.no_weight_decay())
+    opt = FlatAdamW(model, groups, lr=1e-4)
+    opt.max_norm = 30.0
+    g = torch.Generator(device="cuda").manual_seed(1)
+    x = torch.rand((B, 2, H, W), generator=g, device="cuda") * (torch.rand((B, 2, H, W), generator=g, device="cuda") < 0.3)
+    masker = MaskingGenerator((30, 40), 600, min_num_patches=16, seed=1)
+    pool = torch.randint(0, 8192, (B * 600,), device="cuda")
+
+    def step():
+        m = torch.from_numpy(masker.batch_u8(B).reshape(B, -1).astype(bool)).cuda()
+        la = model.forward_loss(x, m, pool[: int(m.sum())])
+        model.backward()
+        eng.grad_norm()
+        opt.step()
+        return la
+    for _ in range(warmup):
+        la = step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    exec_fl = 0.0
+    for _ in range(steps):
+        la = step()
+        exec_fl += executed_flop_per_sample(eng, 2)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    exec_fl /= steps
+    # one instrumented step (HIP events around every GEMM product and attention launch, one stream): family shares
+    ops.GEMM_EVENT_POOL = [torch.cuda.Event(enable_timing=True) for _ in range(2 * 700)]
+    for e in ops.GEMM_EVENT_POOL:
+        e.record()
+    torch.cuda.synchronize()
+    ops.GEMM_TIMER = log = []
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(); step(); e1.record()
+    torch.cuda.synchronize()
+    ops.GEMM_TIMER = None
+    inst_ms = e0.elapsed_time(e1)
+    fam = {"nt_gemm": [0.0, 0.0], "weight_gradient_gemm": [0.0, 0.0], "attention_forward": [0.0, 0.0], "attention_backward": [0.0, 0.0]}
+    for a0, a1, fl, code in log:
+        k = ("attention_forward" if code == 200 else "attention_backward" if code == 201 else
+             "weight_gradient_gemm" if code == 100 else "nt_gemm")
+        fam[k][0] += a0.elapsed_time(a1); fam[k][1] += fl
+    out = {"workload": "BASELINE configs[4], one GPU: MEM pretrain ViT-Large/16, 480x640 2-bin voxels (1201 tokens, 600 masked), bf16, "
+                       f"batch {B}; step = masks + fwd/CE/bwd + clip + AdamW",
+           "batch": B, "value": round(B / dt, 2), "unit": "samples/sec", "ms_per_step": round(dt * 1e3, 2), "steps": steps,
+           "model_flops_frac_of_peak": round(B / dt * exec_fl / (PEAK_BF16_TFLOPS * 1e12), 4),
+           "model_flops_frac_of_peak_reference_count": round(B / dt * FL / (PEAK_BF16_TFLOPS * 1e12), 4),
+           "executed_flop_per_sample": round(exec_fl), "reference_flop_per_sample": FL,
+           "last_loss": round(float(la[0].item()), 4), "max_mem_GB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
+           "family_split_one_stream_step": {k: {"ms": round(v[0], 2), "share": round(v[0] / inst_ms, 3),
+                                                "tflops": round(v[1] / (v[0] * 1e-3) / 1e12, 1) if v[0] else None}
+                                            for k, v in fam.items()},
+           "instrumented_step_ms": round(inst_ms, 2),
+           "note": "family split: HIP events around every launch of one extra step run on ONE stream (the default step overlaps the "
+                   "weight gradients with the dgrad chain on a second stream); rocprofv3 summary of the same workload: "
+                   "profiles/r04_vitl_kernel_stats.csv"}
+    del model, opt, eng, x
+    torch.cuda.empty_cache()
+    return out
+
+
 def entrypoint_figure(model, opt, B, steps, warmup, workers, lr_sched):
     """The drop-in entrypoint as a user runs it (run_mem_pretraining.py:330-347,392-412): engine_for_pretraining.
     train_one_epoch over torch DataLoader(num_workers, pin_memory) of RawEventDataset -- N-Caltech101 geometry (240 x 180
@@ -347,6 +430,8 @@ def main():
     ap.add_argument("--no-entrypoint-figure", action="store_true",
                     help="skip the measurement of the real entrypoint loop (train_one_epoch over a DataLoader)")
     ap.add_argument("--entrypoint-workers", type=int, default=10, help="DataLoader workers of the entrypoint figure")
+    ap.add_argument("--no-config5-figure", action="store_true", help="skip the ViT-L/16 480x640 single-GPU figure (BASELINE configs[4])")
+    ap.add_argument("--config5-batch", type=int, default=32)
     ap.add_argument("--no-config4-figure", action="store_true",
                     help="skip the secondary figure for BASELINE configs[3] end to end (1 M events per sample feeding ViT-B)")
     ap.add_argument("--rendezvous-only", action="store_true",
@@ -740,6 +825,14 @@ def main():
             del ev4
         except Exception as e:                                        # the figure is optional
             print(f"[bench] config #4 figure skipped: {e}", file=sys.stderr)
+    cfg5 = None
+    if world == 1 and not a.no_config5_figure:
+        try:
+            cfg5 = config5_figure(a.config5_batch)
+        except Exception as e:                                        # the figure is optional
+            import traceback
+            traceback.print_exc()
+            print(f"[bench] config #5 figure skipped: {e}", file=sys.stderr)
     if rank == 0:
         ms = dt / a.steps * 1e3
         value = world * B * a.steps / dt
@@ -747,8 +840,13 @@ def main():
         if timer:
             n_inst = len(inst)
             tot_ms, tot_fl, per = 0.0, 0.0, {}
+            attn_per = {}
             for e0, e1, fl, epi in timer:
                 d = e0.elapsed_time(e1)
+                if int(epi) >= 200:                                   # fused attention launches (ops._timed): own family
+                    k = attn_per.setdefault(int(epi), [0, 0.0, 0.0])
+                    k[0] += 1; k[1] += d; k[2] += fl
+                    continue
                 tot_ms += d
                 tot_fl += fl
                 k = per.setdefault(int(epi), [0, 0.0, 0.0])
@@ -810,6 +908,10 @@ def main():
                                           "samples per stochastic-depth branch, masked rows in the last block's MLP); "
                                           "frac_on_reference_flop_count prices the same step time with the reference's count "
                                           "(every sample in every branch, BASELINE.md section 2) -- A/B with --no-dp-skip --no-tail-rows")
+            if attn_per:
+                roof["attention_family"] = {("forward" if k == 200 else "backward"): {
+                    "launches": v[0], "avg_us": round(v[1] / v[0] * 1e3, 2), "tflops": round(v[2] / (v[1] * 1e-3) / 1e12, 1),
+                    "share_of_step": round(v[1] / (dt * 1e3 * n_inst / a.steps), 3)} for k, v in sorted(attn_per.items())}
             roof["gemm_family"] = {"kernels": "gemm_p8_kernel<EPI>, gemm_nt_kernel<EPI>, gemm_tn_p8_kernel",
                                    "achieved": round(ach, 1), "frac": round(ach / PEAK_BF16_TFLOPS, 4),
                                    "launches": len(timer), "avg_launch_us": round(tot_ms / len(timer) * 1e3, 2),
@@ -863,6 +965,8 @@ def main():
             out["rasterizer_1m_events"] = raster_fig
         if cfg4 is not None:
             out["config4_end_to_end"] = cfg4
+        if cfg5 is not None:
+            out["config5_vitl_1gpu"] = cfg5
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         result_line = json.dumps(out)

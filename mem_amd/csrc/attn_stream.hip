@@ -12,6 +12,7 @@
 // The head's extended bias table (5*off+4 floats, 46.6 KB for a 30 x 40 window) stays in LDS for the
 // whole workgroup; bucket indices are code differences (attn_common.hpp), no [H,N,N] tensor exists.
 #include "attn_common.hpp"
+#include <type_traits>
 
 namespace {
 
@@ -85,24 +86,29 @@ __global__ __launch_bounds__(512) void attn_fwd_stream_kernel(const __bf16* __re
       for (int t = 0; t < 4; ++t) s[kb] = MFMA32(row_frag_o(Ks, lo, kb, t), Qf[t], s[kb]);
     }
     float cmax = -INFINITY;
+    // keys >= T only exist in the last chunk (a wave-uniform fact): every other chunk runs without the per-element
+    // compare + select (2 of ~13 vector instructions per score in a VALU-issue-bound loop)
+    auto scores = [&](auto PAD) {
 #pragma unroll
-    for (int kb = 0; kb < CKB; ++kb) {
+      for (int kb = 0; kb < CKB; ++kb) {
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int key0 = c * CT + kb * 32 + 8 * g + 4 * hh;
-        const int4 kc = *reinterpret_cast<const int4*>(codeK + key0);
-        const int kcs[4] = {kc.x, kc.y, kc.z, kc.w};
-        bfr2(s[kb], 4 * g);
-        bfr2(s[kb], 4 * g + 2);
+        for (int g = 0; g < 4; ++g) {
+          const int key0 = c * CT + kb * 32 + 8 * g + 4 * hh;
+          const int4 kc = *reinterpret_cast<const int4*>(codeK + key0);
+          const int kcs[4] = {kc.x, kc.y, kc.z, kc.w};
+          bfr2(s[kb], 4 * g);
+          bfr2(s[kb], 4 * g + 2);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          float v = fmaf(s[kb][4 * g + e], kLog2e, lds_f32_abs(cq4 - kcs[e]));
-          if (key0 + e >= T) v = -INFINITY;
-          s[kb][4 * g + e] = v;
-          cmax = fmaxf(cmax, v);
+          for (int e = 0; e < 4; ++e) {
+            float v = fmaf(s[kb][4 * g + e], kLog2e, lds_f32_abs(cq4 - kcs[e]));
+            if (decltype(PAD)::value && key0 + e >= T) v = -INFINITY;
+            s[kb][4 * g + e] = v;
+            cmax = fmaxf(cmax, v);
+          }
         }
       }
-    }
+    };
+    if ((c + 1) * CT > T) scores(std::true_type{}); else scores(std::false_type{});
     cmax = fmaxf(cmax, __shfl_xor(cmax, 32));
     const float mn = fmaxf(m, cmax);         // finite from the first chunk on (key 0 is never masked)
     const float alpha = fexp2(m - mn);
@@ -235,6 +241,8 @@ __global__ __launch_bounds__(512) void attn_bwd_kv_stream_kernel(
       stage_chunk(imgs + (cur ^ 1) * 2 * IMG + IMG, d0, ldo, (c + 1) * CT, T, CT);
     }
     if (!active) continue;
+    const bool qpad = (c + 1) * CT > T;                                     // this chunk holds queries >= T
+    const bool kpad = __builtin_amdgcn_readfirstlane(kbg) * 32 + 32 > T;    // this wave holds keys >= T
     const int ck4 = codeK[kc_tok] - (int)lds_addr_of(reinterpret_cast<const char*>(tabX));   // (folds the table's LDS base)
     const float* lseC = lseS + cur * CT;
     const float* delC = delS + cur * CT;
@@ -261,14 +269,27 @@ __global__ __launch_bounds__(512) void attn_bwd_kv_stream_kernel(
         bfr2(S, 4 * g + 2);
         bfr2(dP, 4 * g);
         bfr2(dP, 4 * g + 2);
+        // (padding keys: only the wave that holds them multiplies; padding queries: only the last chunk selects -- both
+        // conditions are wave-uniform, the common path has neither instruction)
+        if (!kpad && !qpad) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int i = 4 * g + e;
-          const float sv = fmaf(S[i], kLog2e, lds_f32_abs(qcs[e] - ck4));
-          float p = fexp2(sv - ll[e]) * kmask;                 // kmask = 0 for padding keys
-          if (q0 + e >= T) p = 0.f;
-          S[i] = p;
-          dP[i] = p * (dP[i] - dd[e]);
+          for (int e = 0; e < 4; ++e) {
+            const int i = 4 * g + e;
+            const float sv = fmaf(S[i], kLog2e, lds_f32_abs(qcs[e] - ck4));
+            const float p = fexp2(sv - ll[e]);
+            S[i] = p;
+            dP[i] = p * (dP[i] - dd[e]);
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int i = 4 * g + e;
+            const float sv = fmaf(S[i], kLog2e, lds_f32_abs(qcs[e] - ck4));
+            float p = fexp2(sv - ll[e]) * kmask;               // kmask = 0 for padding keys
+            if (q0 + e >= T) p = 0.f;
+            S[i] = p;
+            dP[i] = p * (dP[i] - dd[e]);
+          }
         }
       }
 #pragma unroll
@@ -409,6 +430,8 @@ __global__ __launch_bounds__(512) void attn_bwd_q_stream_kernel(
         stage_chunk(imgs + (cur ^ 1) * 2 * IMG + IMG, s0 + 2 * D, ldq, (c + 1) * CT, T, CT);
       }
       if (!active) continue;
+      const bool kpadc = (c + 1) * CT > T;                                   // this chunk holds keys >= T
+      const bool qpadw = __builtin_amdgcn_readfirstlane(qb) * 32 + 32 > T;   // this wave holds queries >= T
       const int cq4 = codeQ[qc] + (int)lds_addr_of(reinterpret_cast<const char*>(tabX));   // absolute LDS address of the lane's table window
       const int bins_delta = (int)(lds_addr_of(reinterpret_cast<const char*>(binsi)) - lds_addr_of(reinterpret_cast<const char*>(tabX)));
 #pragma unroll
@@ -430,16 +453,28 @@ __global__ __launch_bounds__(512) void attn_bwd_q_stream_kernel(
           bfr2(St, 4 * g + 2);
           bfr2(dPt, 4 * g);
           bfr2(dPt, 4 * g + 2);
+          if (!qpadw && !kpadc) {                                // (wave-uniform: no padding query in this wave, no padding key in this chunk)
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const int i = 4 * g + e;
-            const int idx4 = cq4 - kcs[e];
-            const float sv = fmaf(St[i], kLog2e, lds_f32_abs(idx4));
-            float p = fexp2(sv - lq) * qmask;                   // qmask = 0 for padding queries
-            if (key0 + e >= T) p = 0.f;
-            const float ds = p * (dPt[i] - dq_);
-            dPt[i] = ds;
-            if (DT) lds_add_i32_abs(idx4 + bins_delta, fx_round(ds, fx));
+            for (int e = 0; e < 4; ++e) {
+              const int i = 4 * g + e;
+              const int idx4 = cq4 - kcs[e];
+              const float sv = fmaf(St[i], kLog2e, lds_f32_abs(idx4));
+              const float ds = fexp2(sv - lq) * (dPt[i] - dq_);
+              dPt[i] = ds;
+              if (DT) lds_add_i32_abs(idx4 + bins_delta, fx_round(ds, fx));
+            }
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const int i = 4 * g + e;
+              const int idx4 = cq4 - kcs[e];
+              const float sv = fmaf(St[i], kLog2e, lds_f32_abs(idx4));
+              float p = fexp2(sv - lq) * qmask;                 // qmask = 0 for padding queries
+              if (key0 + e >= T) p = 0.f;
+              const float ds = p * (dPt[i] - dq_);
+              dPt[i] = ds;
+              if (DT) lds_add_i32_abs(idx4 + bins_delta, fx_round(ds, fx));
+            }
           }
         }
         bf16x8 ckf[2][2];

@@ -217,6 +217,9 @@ __global__ __launch_bounds__(kThreads) void gemm_p8_kernel(GemmArgs p, int ntm, 
     tm = grp * kGroupM + (rem - tn * rows);
   };
   auto stage = [&](int H, int buf, int tm, int tn, int kt) {
+#ifdef P8_EXP_NODMA      // timing experiment (wrong results): no operand stream at all -- what do reads + MFMAs + barriers take?
+    return;
+#endif
     if (H == HA0 || H == HA1) {
       char* slot = smem + buf * kBuf + (H == HA1 ? kAHalf : 0) + wave * AP * 1024;
       const int r0 = tm * BMT + (H == HA1 ? BMT / 2 : 0);

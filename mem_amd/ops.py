@@ -207,9 +207,22 @@ def relpos_gather(table, index_i32, T, TP, heads, bias_pad, biasT_pad=None):
                                    stream_ptr()), "relpos_gather")
 
 
+def _timed(code, flops, fn):
+    """Run fn() between two HIP events on the launch stream when the per-launch timer is armed (bench.py)."""
+    if GEMM_TIMER is None:
+        fn()
+        return
+    e0, e1 = _timer_event(), _timer_event()
+    e0.record()
+    fn()
+    e1.record()
+    GEMM_TIMER.append((e0, e1, flops, code))
+
+
 def attn_fwd(qkv, B, T, D, heads, table, window, out, lse):
-    check(lib.memhip_attn_fwd(ptr(qkv), qkv.stride(0), B, T, D, heads, ptr(table), window[0], window[1], ptr(out),
-                              out.stride(0), ptr(lse), stream_ptr()), "attn_fwd")
+    _timed(200, 4.0 * B * T * T * D, lambda: check(
+        lib.memhip_attn_fwd(ptr(qkv), qkv.stride(0), B, T, D, heads, ptr(table), window[0], window[1], ptr(out),
+                            out.stride(0), ptr(lse), stream_ptr()), "attn_fwd"))
 
 
 def attn_delta(dout, out, rows, heads, delta):
@@ -221,13 +234,15 @@ def attn_bwd(qkv, dout, lse, delta, table, window, B, T, D, heads, scale, dqkv, 
     """out = the forward output: rowsum(dout * out) is computed by the library (inside the fused 14 x 14 kernel when it
     applies); without it `delta` must have been filled by attn_delta."""
     if out is not None:
-        check(lib.memhip_attn_bwd_out(ptr(qkv), qkv.stride(0), ptr(dout), dout.stride(0), ptr(out), out.stride(0), ptr(lse),
-                                      ptr(delta), ptr(table), window[0], window[1], B, T, D, heads, scale, ptr(dqkv),
-                                      dqkv.stride(0), ptr(dtable), ptr(dq_bias), ptr(dv_bias), stream_ptr()), "attn_bwd_out")
+        _timed(201, 10.0 * B * T * T * D, lambda: check(
+            lib.memhip_attn_bwd_out(ptr(qkv), qkv.stride(0), ptr(dout), dout.stride(0), ptr(out), out.stride(0), ptr(lse),
+                                    ptr(delta), ptr(table), window[0], window[1], B, T, D, heads, scale, ptr(dqkv),
+                                    dqkv.stride(0), ptr(dtable), ptr(dq_bias), ptr(dv_bias), stream_ptr()), "attn_bwd_out"))
         return
-    check(lib.memhip_attn_bwd(ptr(qkv), qkv.stride(0), ptr(dout), dout.stride(0), ptr(lse), ptr(delta), ptr(table),
-                              window[0], window[1], B, T, D, heads, scale, ptr(dqkv), dqkv.stride(0), ptr(dtable),
-                              ptr(dq_bias), ptr(dv_bias), stream_ptr()), "attn_bwd")
+    _timed(201, 10.0 * B * T * T * D, lambda: check(
+        lib.memhip_attn_bwd(ptr(qkv), qkv.stride(0), ptr(dout), dout.stride(0), ptr(lse), ptr(delta), ptr(table),
+                            window[0], window[1], B, T, D, heads, scale, ptr(dqkv), dqkv.stride(0), ptr(dtable),
+                            ptr(dq_bias), ptr(dv_bias), stream_ptr()), "attn_bwd"))
 
 
 def residual_rows(x, rows_i32, y, gamma, rowkeep, keep_prob, R, D, out):

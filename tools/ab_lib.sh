@@ -2,7 +2,7 @@
 # tools/ab_lib.sh <libA.so|""> <libB.so|""> [reps] [bench args]: interleaved runs of bench.py with two builds of libmemhip.so ("" = the
 # shipped one) on ONE box
 A="$1"; B="$2"; R=${3:-2}; shift 3
-common="--no-cpu-baseline --no-tokenizer-figure --no-raster-figure --no-config4-figure --no-entrypoint-figure --no-gemm-timer --steps 20 --warmup 5"
+common="--no-cpu-baseline --no-tokenizer-figure --no-raster-figure --no-config4-figure --no-config5-figure --no-entrypoint-figure --no-gemm-timer --steps 20 --warmup 5"
 for i in $(seq $R); do
   for v in A B; do
     if [ $v = A ]; then lib="$A"; else lib="$B"; fi

@@ -7,7 +7,7 @@ PY
 st() { grep -E "nr_throttled|throttled_usec|nr_periods|usage_usec" /sys/fs/cgroup/cpu.stat | tr '\n' ' '; echo; }
 for cfg in "" "--no-dp-skip" "" "--no-dp-skip"; do
   st
-  MEMHIP_BENCH_STEP_TIMES=1 python bench.py --no-cpu-baseline --no-tokenizer-figure --no-raster-figure --no-config4-figure --no-entrypoint-figure --no-gemm-timer --steps 60 --warmup 5 $cfg 2>&1 | python -c "
+  MEMHIP_BENCH_STEP_TIMES=1 python bench.py --no-cpu-baseline --no-tokenizer-figure --no-raster-figure --no-config4-figure --no-config5-figure --no-entrypoint-figure --no-gemm-timer --steps 60 --warmup 5 $cfg 2>&1 | python -c "
 import sys,re,json
 for l in sys.stdin:
     if 'per-step ms' in l and 'host' not in l:
