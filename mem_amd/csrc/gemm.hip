@@ -189,7 +189,6 @@ int launch(const GemmArgs& p, hipStream_t s) {
 namespace memhip {
 int gemm256_dispatch(const GemmArgs& p, hipStream_t s);
 int gemm_p8_dispatch(const GemmArgs& p, hipStream_t s);
-int gemm_p8s_dispatch(const GemmArgs& p, hipStream_t s);
 int gemm_p8_split_rows(const GemmArgs& p, hipStream_t s);
 int gemm_p8_half_dispatch(const GemmArgs& p, hipStream_t s);
 }
@@ -226,11 +225,6 @@ extern "C" int memhip_gemm_bf16_nt(const memhip_gemm_args_t* a, memhip_stream_t 
   // kernel (gemm256.hip) takes shapes it does not (K a multiple of 64 but not of 128, or MEMHIP_GEMM_P8=0)
   const bool k256_on = opt(OPT_GEMM256) != 0;
   const bool p8_on = opt(OPT_GEMM_P8) != 0;
-  if (p8_on && opt(OPT_GEMM_P8S) != 0) {
-    // 256x128 tiles with the epilogue streamed into the next tile's main loop (gemm_p8s.hip): the shapes / epilogues it takes
-    const int rc = gemm_p8s_dispatch(p, s);
-    if (rc != MEMHIP_EUNSUPPORTED) return rc;
-  }
   if (p8_on) {
     // A persistent 256x256-tile launch whose last round would be poorly filled (N = 768: 591 tiles on
     // 256 CUs) only takes the rows of the full rounds; the remaining rows go to the 128x128 kernel

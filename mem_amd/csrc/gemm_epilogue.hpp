@@ -325,9 +325,9 @@ template <> struct EpiPk<MEMHIP_EPI_PATCH_EMBED> { static constexpr int W = 8; }
 // to be non-NULL (no select: the row epilogue stays one basic block)
 //
 // The row epilogue in two halves: epi8_math is the ARITHMETIC of 8 consecutive output columns of row m (register only, plus
-// the optional bf16 branch copy of the residual epilogue, which leaves at once), epi8_store writes its result.  gemm_p8d.hip
-// runs the first half at the end of a tile and the second inside the next tile's main loop; everything else calls both
-// back to back (epilogue8).
+// the optional bf16 branch copy of the residual epilogue, which leaves at once), epi8_store writes its result.  gemm_p8.hip
+// computes both column halves of a row fragment with epi8_math and stores them in full 128-byte lines (pq_pack); everything
+// else calls both back to back (epilogue8).
 template <int EPI, int COPY = 1>
 __device__ __forceinline__ void epi8_math(const GemmArgs& p, int m, int n, const float* acc, float* cs, const EpiCols& c,
                                           const EpiRow<EPI>& row, unsigned* out) {

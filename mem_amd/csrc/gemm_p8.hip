@@ -868,13 +868,8 @@ int gemm_p8_split_rows(const GemmArgs& p, hipStream_t s) {
 
 // Returns MEMHIP_EUNSUPPORTED when the shape does not fit this structure (caller falls back).
 int gemm_p8_half_dispatch(const GemmArgs& p, hipStream_t s);
-int gemm_p8d_dispatch(const GemmArgs& p, hipStream_t s);
 int gemm_p8_dispatch(const GemmArgs& p, hipStream_t s) {
   if (!p8_fits(p) || p.M % BM != 0) return MEMHIP_EUNSUPPORTED;   // whole 256-row tiles only (no row guard in the epilogue)
-  if (opt(OPT_GEMM_P8D) != 0) {     // the same tiles with the stores deferred into the next tile's main loop (gemm_p8d.hip)
-    const int rc = gemm_p8d_dispatch(p, s);
-    if (rc != MEMHIP_EUNSUPPORTED) return rc;
-  }
 #ifdef P8_FORCE_HALF      // measurement build: every row on the 128-row form of the kernel
   { const int rc = gemm_p8_half_dispatch(p, s); if (rc != MEMHIP_EUNSUPPORTED) return rc; }
 #endif

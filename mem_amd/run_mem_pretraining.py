@@ -57,12 +57,14 @@ def get_args(argv=None):
     p.add_argument("--save_ckpt_freq", "--pt_save_ckpt_freq", default=20, type=int)
     p.add_argument("--discrete_vae_weight_path", type=str)
     p.add_argument("--discrete_vae_type", type=str, default="event")
-    p.add_argument("--tokenizer_impl", type=str, default="hip", choices=["hip", "hip_fp16x2", "hip_bf16", "torch"],
-                   help="hip: hand-written fp32 implicit-GEMM tokenizer forward (csrc/conv_f32.hip; fp32 operands and "
-                        "accumulation like the reference, exact labels); hip_fp16x2: two-plane fp16 operands, three fp16 MFMAs per "
-                        "product (logits within ~1e-5 of fp32, ~2x faster than hip); hip_bf16: the bf16-operand kernels of "
-                        "csrc/conv.hip (~7x faster, 1-3 %% of the labels differ at near ties); torch: the fp32 module on "
-                        "stock PyTorch-ROCm convolutions")
+    p.add_argument("--tokenizer_impl", type=str, default="hip_fp16x2", choices=["hip", "hip_fp16x2", "hip_bf16", "torch"],
+                   help="hip_fp16x2 (default since round 4): two-plane fp16 operands (22 significant bits), three fp16 MFMAs per "
+                        "product, fp32 accumulation: logits within ~3e-5 of the fp32 mode at a spread of 1.8, labels EQUAL to the fp32 "
+                        "mode's on both reference fixtures and on 1.5e5 tokens of rasterised synthetic streams (bench.py: "
+                        "label_mismatch_per_million; tests/test_tokenizer_gpu.py), ~2x faster; hip: the fp32 implicit-GEMM forward "
+                        "(csrc/conv_f32.hip; fp32 operands and accumulation like the reference); hip_bf16: the bf16-operand kernels "
+                        "of csrc/conv.hip (~6x faster, 1-3 %% of the labels differ at near ties); torch: the fp32 module on stock "
+                        "PyTorch-ROCm convolutions")
     p.add_argument("--timesurface", type=int, default=0)
     p.add_argument("--hotpixfilter", type=int, default=1)
     p.add_argument("--hotpix_num_stds", type=float, default=10)

@@ -271,3 +271,38 @@ def test_tokenizer_fp16x2_mode():
     got = (out2[0].float() + out2[1].float() / 2048.0)[:, 1:-1, 1:-1].permute(0, 3, 1, 2).double()
     assert (got - torch.relu(ref)).abs().max().item() <= 3e-6 * float(ref.abs().max())
     assert out2[:, :, 0].abs().max() == 0 and out2[:, :, :, 0].abs().max() == 0
+
+
+def test_tokenizer_fp16x2_labels_equal_fp32_on_rasterised_streams():
+    """The entrypoint's default tokenizer mode (--tokenizer_impl hip_fp16x2) against the fp32-operand mode on the ViT-B
+    tokenizer shape (hidden 384, 3 ResBlocks, 8192 tokens, 224^2) over 2 x 256 rasterised synthetic event streams (positive /
+    time-surface / negative planes; the second batch mirrored in x) = 100 352 tokens: every label equal (bench.py reports the
+    same statistic as with_tokenizer.label_mismatch_per_million_vs_fp32_mode), although near-ties exist in the set (smallest
+    top-2 gap of the fp32 logits below 1e-6)."""
+    import numpy as np
+    from mem_amd import datasets as D
+    from mem_amd.vae_model import DiscreteVAE, HipTokenizer
+    torch.manual_seed(3)
+    B, NE, H, W = 256, 30000, 224, 224
+    vae = DiscreteVAE(input_H=H, input_W=W, num_tokens=8192, codebook_dim=512, num_layers=4, num_resnet_blocks=3,
+                      hidden_dim=384, channels=3).cuda().eval()
+    g = np.random.default_rng(1234)
+    ev = np.empty((B * NE, 4), dtype=np.float64)
+    ev[:, 0] = g.integers(0, W, B * NE)
+    ev[:, 1] = g.integers(0, H, B * NE)
+    ev[:, 2] = np.sort(g.integers(0, 300000, (B, NE)), axis=1).reshape(-1)
+    ev[:, 3] = g.integers(0, 2, B * NE) * 2 - 1
+    ev = torch.from_numpy(ev).cuda()
+    off = (torch.arange(B + 1, dtype=torch.int64) * NE).cuda()
+    imgs = [D.rasterize(ev, off, H, W, True, strict=False).float() / 255.0]
+    ev[:, 0] = (W - 1) - ev[:, 0]
+    imgs.append(D.rasterize(ev, off, H, W, True, strict=False).float() / 255.0)
+    t32 = HipTokenizer(vae, max_batch=B)
+    ids32 = [t32.get_codebook_indices(im).clone() for im in imgs]
+    gap = min(float(t32.last_top2_gap(B).min()) for _ in (0,))
+    del t32
+    t16 = HipTokenizer(vae, max_batch=B, precision="fp16x2")
+    bad = sum(int((t16.get_codebook_indices(im) != a).sum()) for im, a in zip(imgs, ids32))
+    n = sum(a.numel() for a in ids32)
+    assert n >= 100_000
+    assert bad == 0, f"{bad} of {n} labels differ (smallest fp32 top-2 gap of the last batch {gap:.2e})"

@@ -5,7 +5,6 @@ d(s_memtime) / d(s_memrealtime) x 100 MHz is the clock the chip holds under that
 import ctypes as C, json, os, sys, time, numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mem_amd import ops, _lib
-_lib.set_option("gemm_p8d", 0)
 M = 256 * 192
 out = {"method": "median over workgroups of d(s_memtime) / d(s_memrealtime) x 100 MHz around the main loop of one launch, "
                  "taken after >= 2 s of back-to-back launches of the same kernel on random bf16 data (stamp build)",
