@@ -96,6 +96,23 @@ def mfma_util_by_kernel(uj=None):
     return {k.lstrip("_"): v["mfma_util"] for k, v in uj.items() if isinstance(v, dict) and "mfma_util" in v}
 
 
+def kernel_clock(cj=None):
+    """In-kernel shader clock of the GEMM main loops from profiles/r04_clock.json (tools/clock_probe.py: stamp build,
+    d(s_memtime) / d(s_memrealtime) x 100 MHz after 2 s of back-to-back launches): {"gemm_p8_ghz", "gemm_tn_p8_ghz",
+    "at_clock_peak_tflops", ...} or None.  The dense bf16 peak the chip can issue at that clock is 2.5 PFLOP/s x clock / 2.4."""
+    cj = _load_profile("r04_clock.json") if cj is None else cj
+    if not cj or "kernels" not in cj:
+        return None
+    nt = [v["clock_ghz"] for k, v in cj["kernels"].items() if k.startswith("gemm_p8 ")]
+    tn = [v["clock_ghz"] for k, v in cj["kernels"].items() if k.startswith("gemm_tn_p8 ")]
+    if not nt or not tn:
+        return None
+    nt_g, tn_g = sum(nt) / len(nt), sum(tn) / len(tn)
+    return {"gemm_p8_ghz": round(nt_g, 3), "gemm_tn_p8_ghz": round(tn_g, 3), "spec_clock_ghz": cj.get("spec_clock_ghz", 2.4),
+            "at_clock_peak_tflops": round(PEAK_BF16_TFLOPS * min(nt_g, tn_g) / cj.get("spec_clock_ghz", 2.4), 1),
+            "spec_peak_tflops": PEAK_BF16_TFLOPS, "source": "profiles/r04_clock.json (tools/clock_probe.py; " + cj.get("method", "") + ")"}
+
+
 class _CachedEvents:
     """Event streams held in host memory (what a page-cached .npy folder is to the reference's loaders): built once in the
     parent, shared with the forked DataLoader workers.  source(i) -> (N,4) float64 ndarray."""
@@ -912,6 +929,12 @@ def main():
             util = mfma_util_by_kernel()
             if util is not None:
                 roof["mfma_util_pmc"] = util
+            # the clock the chip holds inside the GEMM main loops (a committed measurement, not this run's), and what the
+            # achieved rate is against the peak AT THAT CLOCK next to the 2.5 PFLOP/s spec peak
+            clk = kernel_clock()
+            if clk is not None:
+                clk["frac_of_at_clock_peak"] = round(roof["achieved"] / clk["at_clock_peak_tflops"], 4)
+                roof["clock"] = clk
             # the honest headline next to the dominant kernel: the model-level rate of the WHOLE step (all kernels, all
             # gaps) against the dense bf16 peak, and the GEMM family as a whole (below)
             ws = value / world * exec_flop / 1e12

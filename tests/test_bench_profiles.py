@@ -16,6 +16,9 @@ def test_profile_readers_find_their_keys():
     util = bench.mfma_util_by_kernel()
     assert util and "whole_step" in util and all(0.0 <= v <= 1.0 for v in util.values())
     assert any(k.startswith("gemm_tn_p8_kernel") for k in util)
+    clk = bench.kernel_clock()
+    assert clk and 1.0 < clk["gemm_p8_ghz"] <= 2.4 and 1.0 < clk["gemm_tn_p8_ghz"] <= 2.4
+    assert abs(clk["at_clock_peak_tflops"] - 2500.0 * min(clk["gemm_p8_ghz"], clk["gemm_tn_p8_ghz"]) / 2.4) < 1.0
 
 
 def test_profile_readers_report_a_missing_layout_as_none():
@@ -25,6 +28,7 @@ def test_profile_readers_report_a_missing_layout_as_none():
                                             "raster_bin_accum": {"hbm_bytes_per_launch": 6},
                                             "_meta": {"samples_per_launch": 4}}) == 4.0
     assert bench.gemm_traffic_per_launch("nope", {}) is None
+    assert bench.kernel_clock({"kernels": {}}) is None
 
 
 def test_every_profile_json_parses():
