@@ -109,9 +109,10 @@ __device__ __forceinline__ int slot_tok(int s) {
   return kx < W16 ? 1 + (s >> 4) * W16 + kx : (s == W16 ? 0 : -1);
 }
 // Stage a head slice in SLOT order (LDS image layout of attn_common.hpp, the "token" of the swizzle is the slot).
-__device__ __forceinline__ void stage_slots(char* dst, const __bf16* src, long long ld) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int inst = wave; inst < TP16 / 8; inst += NB16) {
+// (instructions first, first + step, ...: all waves share an image, or one wave stages it alone)
+__device__ __forceinline__ void stage_slots(char* dst, const __bf16* src, long long ld, int first, int step) {
+  const int lane = threadIdx.x & 63;
+  for (int inst = first; inst < TP16 / 8; inst += step) {
     const int slot = inst * 8 + (lane >> 3), cpos = lane & 7;
     const int chunk = cpos ^ img_key(slot);
     const int tok = slot_tok(slot);
@@ -119,6 +120,9 @@ __device__ __forceinline__ void stage_slots(char* dst, const __bf16* src, long l
                              : (const void*)(g_attn_zero_page + cpos * 16);
     glds16(g, dst + inst * 1024);
   }
+}
+__device__ __forceinline__ void stage_slots(char* dst, const __bf16* src, long long ld) {
+  stage_slots(dst, src, ld, threadIdx.x >> 6, NB16);
 }
 // natural token order, 224 rows (tokens >= 197: zero rows)
 __device__ __forceinline__ void stage_tokens(char* dst, const __bf16* src, long long ld) {
@@ -141,6 +145,25 @@ __device__ __forceinline__ void table16_setup(float* tabR, const float* table, i
     else if (a >= CLSQ16) v = table[(long long)(NRD16 - 3) * H + h];
     tabR[a] = v;
   }
+}
+// Forward: TWO copies of that table, the second shifted by one entry.  The four keys of a register group are consecutive
+// entries; a pair starting at an EVEN entry of one of the copies is an aligned ds_read_b64 (2 LDS cycles for 2 values per
+// lane; the ds_read2_b32 the compiler makes of unaligned pairs takes 4 -- the bias reads were 2/3 of the kernel's LDS time).
+// Copy 1 holds entry a at index a + 1: a lane whose pair starts at an odd entry reads copy 1.
+constexpr int TAB2LEN16 = 2 * TABLEN16 + 4;
+__device__ __forceinline__ void table16_setup2(float* tabR, const float* table, int H, int h) {
+  for (int a = threadIdx.x; a < TABLEN16; a += blockDim.x) {
+    float v = 0.f;
+    if (a <= M16) v = table[(long long)(M16 - a) * H + h];
+    else if (a >= CLSQ16) v = table[(long long)(NRD16 - 3) * H + h];
+    tabR[a] = v;
+    tabR[TABLEN16 + 2 + a + 1] = v;
+  }
+}
+// (as two separate instructions: the compiler would fuse neighbouring pairs into ds_read2_b64, 8 LDS cycles for 4 values)
+// (volatile: the load/store optimizer would fuse neighbouring pairs into ds_read2_b64 -- 8 LDS cycles for 4 values)
+__device__ __forceinline__ f32x2_t lds_f32x2_abs(unsigned lds_byte_addr) {
+  return *reinterpret_cast<const volatile __attribute__((address_space(3))) f32x2_t*>(lds_byte_addr);
 }
 // per-lane index base of query q: a = base + keycode
 __device__ __forceinline__ int q_base16(int q) {
@@ -240,13 +263,19 @@ __device__ unsigned long long g_attn16_prof[2][16];
 #define T16_FLUSH()
 #endif
 // ------------------------------------------------------------------------------------------------ forward
-__global__ __launch_bounds__(kThreads16) void attn16_fwd_kernel(const __bf16* __restrict__ qkv, long long ldq, int B, int D,
+// 8 waves: 7 compute a block of 32 queries each, the 8th only issues the LDS-DMA of the next sample.  Measured (B = 256,
+// tools/r04_run13.sh): with the K / V staging of the next sample left out the 7-wave kernel took 83 us instead of 109 --
+// not memory time (the DMA has a whole sample period to land) but ISSUE time: a global_load_lds takes its wave 100+ cycles
+// among busy neighbours, 8 per wave and sample, plus the slot -> token address arithmetic.  Wave 7 shares SIMD 3 with
+// wave 3, the only SIMD of a 7-wave workgroup that held one wave.
+constexpr int kThreadsFwd16 = kThreads16 + 64;
+__global__ __launch_bounds__(kThreadsFwd16) void attn16_fwd_kernel(const __bf16* __restrict__ qkv, long long ldq, int B, int D,
                                                                int H, const float* __restrict__ table,
                                                                __bf16* __restrict__ out, long long ldo,
                                                                float* __restrict__ lse, int nwg, int stagger) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* tabR = reinterpret_cast<float*>(smem);
-  char* imgs = smem + TABLEN16 * 4;
+  char* imgs = smem + TAB2LEN16 * 4;
   char* stg = imgs + 4 * IMG16;                // [7 waves][4 KiB] output staging
   const int h = blockIdx.x % H;
   const Share16 sh = share16(blockIdx.x / H, B, nwg);
@@ -258,15 +287,36 @@ __global__ __launch_bounds__(kThreads16) void attn16_fwd_kernel(const __bf16* __
   const bool hh1 = hh != 0;
   const unsigned sel_lo = sel_lo_reg();
   const Lane16 lo = lane16(lane);
-  table16_setup(tabR, table, H, h);
+  table16_setup2(tabR, table, H, h);
   const int q = wave * 32 + r;
   const int qc = q < T16 ? q : T16 - 1;
-  const unsigned bb = lds_addr_of(reinterpret_cast<const char*>(tabR)) + 4 * (q_base16(q) + 4 * hh);
+  // register groups of grid rows 2 kb (g = 0, 1) start at entry base + even, those of rows 2 kb + 1 (g = 2, 3) at base + odd
+  unsigned bbe, bbo;
+  {
+    const int base = q_base16(q) + 4 * hh;
+    const unsigned t0 = lds_addr_of(reinterpret_cast<const char*>(tabR));
+    const unsigned c0 = t0 + 4 * base, c1 = t0 + 4 * (TABLEN16 + 2 + base + 1);
+    bbe = (base & 1) ? c1 : c0;
+    bbo = (base & 1) ? c0 : c1;
+  }
   const float clsb = table[(long long)(q == 0 ? NRD16 - 1 : NRD16 - 2) * H + h];
   {
     const __bf16* s0 = qkv + (long long)b0 * T16 * ldq + h * HD;
-    stage_slots(imgs, s0 + D, ldq);
-    stage_slots(imgs + IMG16, s0 + 2 * D, ldq);
+    stage_slots(imgs, s0 + D, ldq, wave, NB16 + 1);
+    stage_slots(imgs + IMG16, s0 + 2 * D, ldq, wave, NB16 + 1);
+  }
+  if (wave == NB16) {                          // the staging wave
+    for (int b = b0; b < b1; ++b) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();                         // sample b landed; b-1 consumed: its buffers are free
+      if (b + 1 < b1) {
+        const __bf16* s1 = qkv + (long long)(b + 1) * T16 * ldq + h * HD;
+        char* dst = imgs + (((b - b0) & 1) ^ 1) * 2 * IMG16;
+        stage_slots(dst, s1 + D, ldq, 0, 1);
+        stage_slots(dst + IMG16, s1 + 2 * D, ldq, 0, 1);
+      }
+    }
+    return;
   }
   bf16x8 Qn[4];
 #pragma unroll
@@ -280,10 +330,10 @@ __global__ __launch_bounds__(kThreads16) void attn16_fwd_kernel(const __bf16* __
     bf16x8 Qf[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) Qf[t] = Qn[t];
-    // vector-memory operations complete in issue order: everything up to the LDS-DMA of this sample has landed once at
-    // most the 4 output stores of the previous sample (issued after the DMA, every wave issues all four: padding rows go
-    // to the trash page) are still in flight.  The count must never exceed the stores really issued behind the DMA, so
-    // the lse store (predicated; the oldest of the five) is not counted.
+    // vector-memory operations complete in issue order: the Q rows of this sample (and, the first time, this wave's
+    // share of the first images) have landed once at most the 4 output stores of the previous sample (issued after them,
+    // every wave issues all four: padding rows go to the trash page) are still in flight.  The count must never exceed the
+    // stores really issued behind the loads, so the lse store (predicated; the oldest of the five) is not counted.
     ATTN16_WAIT_VM(4);
     __syncthreads();                         // sample b's images (and, the first time, the table) landed; b-1 consumed
     T16_TICK(0);
@@ -291,8 +341,6 @@ __global__ __launch_bounds__(kThreads16) void attn16_fwd_kernel(const __bf16* __
       const __bf16* s1 = qkv + (long long)(b + 1) * T16 * ldq + h * HD;
 #pragma unroll
       for (int t = 0; t < 4; ++t) Qn[t] = ld16(s1 + (long long)qc * ldq + 16 * t + 8 * hh);
-      stage_slots(imgs + (cur ^ 1) * 2 * IMG16, s1 + D, ldq);
-      stage_slots(imgs + (cur ^ 1) * 2 * IMG16 + IMG16, s1 + 2 * D, ldq);
     }
     const RowBase16 kr = row_base16(lo, lds_addr_of(Ks));
     const ColBase16 vc = col_base16(lo, lds_addr_of(Vs));
@@ -311,17 +359,31 @@ __global__ __launch_bounds__(kThreads16) void attn16_fwd_kernel(const __bf16* __
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         float bias[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) bias[e] = lds_f32_abs((int)bb + kb * kBlockStep16 + KOFF16(g, e));
+        {
+          const unsigned a0 = ((g >> 1) ? bbo : bbe) + kb * kBlockStep16 + KOFF16(g, 0);
+          const f32x2_t b01 = lds_f32x2_abs(a0), b23 = lds_f32x2_abs(a0 + 8);
+          bias[0] = b01[0]; bias[1] = b01[1]; bias[2] = b23[0]; bias[3] = b23[1];
+        }
         if (g & 1) {                           // slots 14, 15 of a grid row: padding, except the cls key (block 0)
           bias[2] = hh1 ? (kb == 0 && g == 1 ? clsb : -INFINITY) : bias[2];
           bias[3] = hh1 ? -INFINITY : bias[3];
         }
+#if ATTN16_EXP == 14
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s[kb][4 * g + e] += bias[e];
+#elif ATTN16_EXP == 17
+        const unsigned p0 = pk_bf16(s[kb][4 * g], s[kb][4 * g + 1]), p1 = pk_bf16(s[kb][4 * g + 2], s[kb][4 * g + 3]);
+        s[kb][4 * g] = __uint_as_float(p0 << 16) + bias[0];
+        s[kb][4 * g + 1] = __uint_as_float(p0 & 0xffff0000u) + bias[1];
+        s[kb][4 * g + 2] = __uint_as_float(p1 << 16) + bias[2];
+        s[kb][4 * g + 3] = __uint_as_float(p1 & 0xffff0000u) + bias[3];
+#else
         const unsigned p0 = pk_bf16(s[kb][4 * g], s[kb][4 * g + 1]), p1 = pk_bf16(s[kb][4 * g + 2], s[kb][4 * g + 3]);
         s[kb][4 * g] = add_lo(p0, bias[0], sel_lo);
         s[kb][4 * g + 1] = add_hi(p0, bias[1]);
         s[kb][4 * g + 2] = add_lo(p1, bias[2], sel_lo);
         s[kb][4 * g + 3] = add_hi(p1, bias[3]);
+#endif
 #pragma unroll
         for (int e = 0; e < 4; ++e) mx = fmaxf(mx, s[kb][4 * g + e]);
       }
@@ -334,7 +396,11 @@ __global__ __launch_bounds__(kThreads16) void attn16_fwd_kernel(const __bf16* __
     for (int kb = 0; kb < NB16; ++kb)
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
+#if ATTN16_EXP == 15
+        const float p = fmaf(s[kb][i], kLog2e, mneg);
+#else
         const float p = fexp2(fmaf(s[kb][i], kLog2e, mneg));
+#endif
         s[kb][i] = p;
         sum += p;
       }
@@ -380,8 +446,12 @@ __global__ __launch_bounds__(kThreads16) void attn16_fwd_kernel(const __bf16* __
       for (int i = 0; i < 4; ++i) {
         const int row = (lane >> 3) + 8 * i, qq = wave * 32 + row;
         const bf16x8 v = tile_get(st, row, lane & 7);
+#if ATTN16_EXP == 16
+        __bf16* dst = reinterpret_cast<__bf16*>(g_attn16_trash) + lane * 8;
+#else
         __bf16* dst = qq < T16 ? out + ((long long)b * T16 + qq) * ldo + h * HD + (lane & 7) * 8
                                : reinterpret_cast<__bf16*>(g_attn16_trash) + lane * 8;
+#endif
         *reinterpret_cast<bf16x8*>(dst) = v;
       }
     }
@@ -874,7 +944,7 @@ bool attn16_fits(int T, int window_h, int window_w) { return window_h == W16 && 
 
 int attn16_fwd(const void* qkv, int64_t ldqkv, int B, int D, int heads, const float* table, void* out, int64_t ldo,
                float* lse, hipStream_t s) {
-  const size_t sm = (size_t)TABLEN16 * 4 + 4 * IMG16 + NB16 * 4096;
+  const size_t sm = (size_t)TAB2LEN16 * 4 + 4 * IMG16 + NB16 * 4096;
   static bool attr_done = false;
   if (!attr_done) {
     MEMHIP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn16_fwd_kernel),
@@ -882,7 +952,7 @@ int attn16_fwd(const void* qkv, int64_t ldqkv, int B, int D, int heads, const fl
     attr_done = true;
   }
   const int nwg = nwg16(B, heads, s);
-  hipLaunchKernelGGL(attn16_fwd_kernel, dim3(nwg * heads), dim3(kThreads16), sm, s, (const __bf16*)qkv,
+  hipLaunchKernelGGL(attn16_fwd_kernel, dim3(nwg * heads), dim3(kThreadsFwd16), sm, s, (const __bf16*)qkv,
                      (long long)ldqkv, B, D, heads, table, (__bf16*)out, (long long)ldo, lse, nwg, opt(OPT_ATTN16_STAGGER_FWD));
   return check_launch("attn_fwd(14x14)");
 }
