@@ -36,6 +36,9 @@
 #define ATTN16_FD_POS 0   // where the fused-delta loads of the next sample are issued: 0 = in front of the Q / dO DMA (B = 256:
                           // 300.5 us per layer), 1 = behind dQ's LDS staging (306.5 us); attn_delta + unfused backward: 314.4 us
 #endif
+#ifndef ATTN16_SKEW
+#define ATTN16_SKEW 1     // forward: waves 4..6 half a sample behind waves 0..3 (0: lockstep, one barrier per sample)
+#endif
 #ifndef ATTN16_EXP
 #define ATTN16_EXP 0      // timing experiments (tools/build_variant.sh); 0 = the shipped kernel
 #endif
@@ -251,6 +254,74 @@ __device__ __forceinline__ void glds4s(const void* sbase, unsigned voff, char* l
   asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" ::"v"(voff), "s"(sbase), "s"(lds) : "memory", "m0");
 }
 
+// 16 bytes per lane, wave-uniform base + 32-bit lane offset, LDS address given as a value
+__device__ __forceinline__ void glds16s(const void* sbase, unsigned voff, unsigned lds) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds) : "memory", "m0");
+}
+// The staging wave of the forward kernel keeps the lane offsets of all 28 instructions of a slot-ordered image in registers
+// (it has nothing else to hold): an instruction is s_mov m0 + the load.  Padding slots read the cls row instead of the zero
+// page (one base for all lanes): their scores get a bias of -inf and their probabilities are exactly 0, so any FINITE row
+// serves.
+struct SlotOffs16 { unsigned v[TP16 / 8]; };
+__device__ __forceinline__ SlotOffs16 slot_offs16(long long ld) {
+  const int lane = threadIdx.x & 63;
+  SlotOffs16 o;
+#pragma unroll
+  for (int inst = 0; inst < TP16 / 8; ++inst) {
+    const int slot = inst * 8 + (lane >> 3), cpos = lane & 7;
+    const int tok = slot_tok(slot);
+    o.v[inst] = (unsigned)(((tok >= 0 ? tok : 0) * (int)ld + (cpos ^ img_key(slot)) * 8) * 2);
+  }
+  return o;
+}
+__device__ __forceinline__ void stage_slots_fast(unsigned lds_dst, const __bf16* src, const SlotOffs16& o) {
+#pragma unroll
+  for (int inst = 0; inst < TP16 / 8; ++inst) glds16s(src, o.v[inst], lds_dst + inst * 1024);
+}
+// The backward kernel has no register to spare and no idle SIMD slot for an eighth wave to pay (measured: 299 - 330 us
+// with a staging wave instead of 288, tools/exp/attn16_bwd_staging_wave.patch), so its seven waves stage their own share:
+// instructions wave, wave + 7, wave + 14, wave + 21 of an image.  The general form above costs ~35 instructions per piece
+// (64-bit multiplies, the zero-page select as EXEC-masked branches); here the grid row / token block of an instruction is
+// wave-uniform (SCALAR base) and a lane's offset depends only on the PARITY of the instruction: two lane offsets,
+// recomputed at every call from an opaque copy of the lane id (nothing stays live through the main loop), then
+// s_mul / s_add + s_mov m0 + the load per piece.  Padding rows read a neighbouring REAL row (finite, see above).
+__device__ __forceinline__ int img_key3(int k) { return img_key(2 * k); }     // key of the tokens 2 k, 2 k + 1 (k < 8)
+__device__ __forceinline__ void stage_slots_lean(unsigned lds_dst, const __bf16* src, int ld, int wave) {
+  int tl = (int)threadIdx.x;
+  asm volatile("" : "+v"(tl));
+  const int l3 = (tl >> 3) & 7, cpos = tl & 7;
+  // even instruction: slots 16 ky + l3 (kx = l3); odd: kx = 8 + l3, slots 14 / 15 clamp to kx = 13
+  const unsigned ve = (unsigned)(((1 + l3) * ld + (cpos ^ img_key3(l3 >> 1)) * 8) * 2);
+  const int kxo = 8 + l3 < W16 ? 8 + l3 : W16 - 1;
+  const unsigned co = (unsigned)((cpos ^ img_key3(4 + (l3 >> 1))) * 16);
+  const unsigned vo = (unsigned)((1 + kxo) * ld * 2) + co;
+  const unsigned vc = l3 == 6 ? co : vo;                   // instruction 1 holds slot 14 = the cls key: token 0
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int inst = wave + NB16 * k;                      // wave-uniform
+    const __bf16* sb = src + (long long)((inst >> 1) * W16) * ld;
+    const unsigned v = (inst & 1) ? (inst == 1 ? vc : vo) : ve;
+    glds16s(sb, v, lds_dst + inst * 1024);
+  }
+}
+// token order (Q, dO): tokens 8 inst + l3; rows >= 197 read token 192 + min(l3, 4)
+__device__ __forceinline__ void stage_tokens_lean(unsigned lds_dst, const __bf16* src, int ld, int wave) {
+  int tl = (int)threadIdx.x;
+  asm volatile("" : "+v"(tl));
+  const int l3 = (tl >> 3) & 7, cpos = tl & 7;
+  const unsigned ce = (unsigned)((cpos ^ img_key3(l3 >> 1)) * 16), co = (unsigned)((cpos ^ img_key3(4 + (l3 >> 1))) * 16);
+  const unsigned ve = (unsigned)(l3 * ld * 2) + ce, vo = (unsigned)(l3 * ld * 2) + co;
+  const unsigned vt = (unsigned)((l3 < 4 ? l3 : 4) * ld * 2) + ce;            // instruction 24: tokens 192 .. 196 are real
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int inst = wave + NB16 * k;
+    const bool tail = inst >= (T16 - 1) / 8;               // 24 and up
+    const __bf16* sb = src + (long long)((tail ? (T16 - 1) / 8 : inst) * 8) * ld;
+    const unsigned v = tail ? vt : ((inst & 1) ? vo : ve);
+    glds16s(sb, v, lds_dst + inst * 1024);
+  }
+}
+
 // -DATTN16_TIMING: per-section s_memtime totals of wave 0 / wave 4 of every workgroup (tools/attn16_sections.py)
 #ifdef ATTN16_TIMING
 __device__ unsigned long long g_attn16_prof[2][16];
@@ -306,22 +377,52 @@ __global__ __launch_bounds__(kThreadsFwd16) void attn16_fwd_kernel(const __bf16*
     stage_slots(imgs + IMG16, s0 + 2 * D, ldq, wave, NB16 + 1);
   }
   if (wave == NB16) {                          // the staging wave
+    const SlotOffs16 so = slot_offs16(ldq);
+#if ATTN16_SKEW
+    // barrier j = 2 b: the early waves start the scores of sample b (K image), the late ones the softmax / PV of b - 1 (V);
+    // j = 2 b + 1: the other way round.  K(b - 1) is dead at barrier 2 b, V(b - 1) at 2 b + 1: K(b + 1) / V(b + 1) are
+    // issued there and have a whole period (two barriers) to land; the piece issued after barrier j - 1 may still be in
+    // flight at barrier j (vector-memory operations complete in order: vmcnt(28) = all but the newest image).
+    const int n = b1 - b0;
+    bool pend = false;
+    for (int j = 0; j <= 2 * n; ++j) {
+      if (pend) asm volatile("s_waitcnt vmcnt(28)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      const int b = j >> 1;
+      pend = b + 1 < n;
+      if (pend) {
+        const __bf16* s1 = qkv + (long long)(b0 + b + 1) * T16 * ldq + h * HD;
+        const unsigned dst = lds_addr_of(imgs + ((b + 1) & 1) * 2 * IMG16);
+        if (j & 1) stage_slots_fast(dst + IMG16, s1 + 2 * D, so);
+        else stage_slots_fast(dst, s1 + D, so);
+      }
+    }
+#else
     for (int b = b0; b < b1; ++b) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();                         // sample b landed; b-1 consumed: its buffers are free
       if (b + 1 < b1) {
         const __bf16* s1 = qkv + (long long)(b + 1) * T16 * ldq + h * HD;
-        char* dst = imgs + (((b - b0) & 1) ^ 1) * 2 * IMG16;
-        stage_slots(dst, s1 + D, ldq, 0, 1);
-        stage_slots(dst + IMG16, s1 + 2 * D, ldq, 0, 1);
+        const unsigned dst = lds_addr_of(imgs + (((b - b0) & 1) ^ 1) * 2 * IMG16);
+        stage_slots_fast(dst, s1 + D, so);
+        stage_slots_fast(dst + IMG16, s1 + 2 * D, so);
       }
     }
+#endif
     return;
   }
   bf16x8 Qn[4];
 #pragma unroll
   for (int t = 0; t < 4; ++t) Qn[t] = ld16(qkv + ((long long)b0 * T16 + qc) * ldq + h * HD + 16 * t + 8 * hh);
   T16_DECL();
+#if ATTN16_SKEW
+  // waves 4..6 (the second wave of SIMD 0..2) run HALF A SAMPLE behind waves 0..3: while one wave of a SIMD is in its MFMA
+  // phases the other is in its VALU phases (in lockstep the two add up: 28 + 28 MFMAs with the vector ALU idle, then
+  // bias / max / exp with the matrix core idle).  Same code, one barrier more in front (late) or behind (early).
+  const bool late = __builtin_amdgcn_readfirstlane(wave) >= 4;
+  if (late) { ATTN16_WAIT_VM(4); __syncthreads(); }
+#endif
   for (int b = b0; b < b1; ++b) {
     T16_TICK(5);
     const int cur = (b - b0) & 1;
@@ -389,6 +490,9 @@ __global__ __launch_bounds__(kThreadsFwd16) void attn16_fwd_kernel(const __bf16*
       }
     }
     T16_TICK(2);
+#if ATTN16_SKEW
+    __syncthreads();                         // the V image of sample b has landed
+#endif
     mx = fmaxf(mx, __shfl_xor(mx, 32));
     const float mneg = -mx * kLog2e;
     float sum = 0.f;
@@ -456,6 +560,9 @@ __global__ __launch_bounds__(kThreadsFwd16) void attn16_fwd_kernel(const __bf16*
       }
     }
   }
+#if ATTN16_SKEW
+  if (!late) __syncthreads();
+#endif
   T16_TICK(5);
 #ifdef ATTN16_TIMING
   if (lane == 0 && (wave == 0 || wave == 4))
@@ -801,8 +908,8 @@ __global__ __launch_bounds__(kThreads16) void attn16_bwd_kernel(const __bf16* __
       T16_TICK(5);
       if (s == NB16 - 1 && b + 1 < b1) {                     // ... and finished its last produce: the K / V images are dead
         const __bf16* sn = qkv + (long long)(b + 1) * T16 * ldq + h * HD;
-        stage_slots(Ks, sn + D, ldq);
-        stage_slots(Vs, sn + 2 * D, ldq);
+        stage_slots_lean(lds_addr_of(Ks), sn + D, (int)ldq, wave);
+        stage_slots_lean(lds_addr_of(Vs), sn + 2 * D, (int)ldq, wave);
       }
       {
         const unsigned mine = lds_addr_of(exch) + wave * 4096;
@@ -830,7 +937,11 @@ __global__ __launch_bounds__(kThreads16) void attn16_bwd_kernel(const __bf16* __
 #if ATTN16_FD_POS == 0
     if constexpr (FD) load_o(b + 1 < b1 ? b + 1 : b);      // in front of the Q / dO DMA of the next sample
 #endif
-    if (b + 1 < b1) { stage_rows(b + 1); stage_sample(b + 1, false); }
+    if (b + 1 < b1) {
+      stage_rows(b + 1);
+      stage_tokens_lean(lds_addr_of(Qs), qkv + (long long)(b + 1) * T16 * ldq + h * HD, (int)ldq, wave);
+      stage_tokens_lean(lds_addr_of(dOs), dout + (long long)(b + 1) * T16 * ldo + h * HD, (int)ldo, wave);
+    }
     // ---------------- epilogue of sample b (under the LDS-DMA of sample b + 1)
     if (DT) {
       const float inv = fx > 0.f ? 1.0f / fx : 0.f;
