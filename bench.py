@@ -918,7 +918,7 @@ def main():
                         "instrumented_steps": n_inst,
                         "note": "HIP events around one weight-gradient product = gemm_tn_p8_kernel + its tn_reduce_kernel; the "
                                 "instrumented steps run on ONE stream (the events serialise the side stream), so compare with the "
-                                "sequential rocprofv3 summary (profiles/r03_final_seq_kernel_stats.csv: 136.6 + 13.8 us), not with the "
+                                "sequential rocprofv3 summary (profiles/r04_final_seq_kernel_stats.csv: 136.1 + 11.8 us; the steady-state steps alone: r04_final_seq_step_kernels.txt), not with the "
                                 "two-stream one, where concurrent launches stretch every kernel"}
             else:
                 roof = {"bound": "mfma", "kernel": "bf16 MFMA GEMM family", "achieved": round(ach, 1),

@@ -239,14 +239,35 @@ class ViTEngine:
 
     # ------------------------------------------------------------------ buffers per batch size
     def ensure_batch(self, B, Mm_max):
-        if B <= self.B and Mm_max <= getattr(self, "Mm_cap", 0):
-            return
-        B = max(B, self.B)
-        Mm_cap = max(Mm_max, getattr(self, "Mm_cap", 0))
+        """Buffers for a batch of B samples with Mm_max rows reaching the head.  The two grow independently: the number of
+        masked rows differs from step to step (block-wise masks), and a new maximum must not re-allocate (and zero-fill) the
+        ~100 per-block buffers of the batch -- found in the round-4 step trace as ~80 torch fill kernels inside a step."""
+        if B > self.B:
+            self._alloc_batch(B)
+        if Mm_max > getattr(self, "Mm_cap", 0) or (self.head_kind == "mlm" and not hasattr(self, "hN")):
+            # headroom: a few per cent above the largest count seen, whole 256-row tiles, never more than every patch
+            self._alloc_head(min(self.B * self.L, _pad(Mm_max + Mm_max // 16 + 1, 256)))
+
+    def _alloc_head(self, Mm_cap):
         dev, bf, f32 = self.dev, torch.bfloat16, torch.float32
-        D, Hd, T, V = self.D, self.hidden, self.T, self.V
+        D, V = self.D, self.V
+        e = lambda *s, dt=bf: torch.empty(s, dtype=dt, device=dev)   # noqa: E731
+        if self.head_kind == "mlm":
+            self.hN = e(Mm_cap, D)
+            self.meanN, self.rstdN = e(Mm_cap, dt=f32), e(Mm_cap, dt=f32)
+            self.logits = e(Mm_cap, V)
+            self.row_loss, self.row_ok = e(Mm_cap, dt=f32), torch.empty(Mm_cap, dtype=torch.int32, device=dev)
+            self.dhN = e(Mm_cap, D)
+            # dead-row elimination in the last block (tail rows): compact residual rows that reach the head, their
+            # gradient, and the bf16 fc2 output of the compact MLP branch (whole 256-row tiles)
+            self.x_tail, self.dxc = e(max(Mm_cap, 1), D, dt=f32), e(max(Mm_cap, 1), D, dt=f32)
+            self.y_tail = torch.zeros((_pad(max(Mm_cap, 1), 256), D), dtype=bf, device=dev)
+        self.Mm_cap = Mm_cap
+
+    def _alloc_batch(self, B):
+        dev, bf, f32 = self.dev, torch.bfloat16, torch.float32
+        D, Hd, T = self.D, self.hidden, self.T
         M = B * T
-        Mp = _pad(M, 64)
         # Work-skipping stochastic depth runs the GEMMs of a branch on its kept samples' rows ROUNDED UP to whole 256-row
         # tiles (a ragged row count costs every product an extra launch on the 128-row kernel): the token-major buffers
         # carry 256 rows of slack (zero-initialised, only ever finite), and the residual snapshots one dummy sample that the
@@ -261,18 +282,7 @@ class ViTEngine:
             self.act.append(dict(h1=z(Ma, D), qkv=z(Ma, 3 * D), ao=z(Ma, D), h2=z(Ma, D), hpre=z(Ma, Hd),
                                  a=z(Ma, Hd), lse=e(B, self.heads, self.TP, dt=f32),
                                  mean1=e(M, dt=f32), rstd1=e(M, dt=f32), mean2=e(M, dt=f32), rstd2=e(M, dt=f32)))
-        # head
-        if self.head_kind == "mlm":
-            self.hN = e(Mm_cap, D)
-            self.meanN, self.rstdN = e(Mm_cap, dt=f32), e(Mm_cap, dt=f32)
-            self.logits = e(Mm_cap, V)
-            self.row_loss, self.row_ok = e(Mm_cap, dt=f32), torch.empty(Mm_cap, dtype=torch.int32, device=dev)
-            self.dhN = e(Mm_cap, D)
-            # dead-row elimination in the last block (tail rows): compact residual rows that reach the head, their
-            # gradient, and the bf16 fc2 output of the compact MLP branch (whole 256-row tiles)
-            self.x_tail, self.dxc = e(max(Mm_cap, 1), D, dt=f32), e(max(Mm_cap, 1), D, dt=f32)
-            self.y_tail = z(_pad(max(Mm_cap, 1), 256), D)
-        else:
+        if self.head_kind != "mlm":
             self.zero_mask = torch.zeros(B * self.L, dtype=torch.uint8, device=dev)
         # backward temporaries (shared by all blocks)
         self.dx = torch.zeros((M, D), dtype=f32, device=dev)
@@ -286,7 +296,7 @@ class ViTEngine:
         self.bias_scr = torch.zeros(2, D, dtype=f32, device=dev)   # ping-pong colsum(dY) of the proj branch
         self.cs_ws = torch.zeros(self.CS_COPIES, self.hidden, dtype=f32, device=dev)   # column-sum accumulator copies (zero between uses)
         self.dYpe = e(B * self.L, D)
-        self.B, self.Mm_cap = B, Mm_cap
+        self.B = B
 
     # ------------------------------------------------------------------ weights
     def sync_weights(self):
