@@ -211,8 +211,8 @@ def entrypoint_figure(model, opt, B, steps, warmup, workers, lr_sched):
     """The drop-in entrypoint as a user runs it (run_mem_pretraining.py:330-347,392-412): engine_for_pretraining.
     train_one_epoch over torch DataLoader(num_workers, pin_memory) of RawEventDataset -- N-Caltech101 geometry (240 x 180
     sensor, per-sample extents, data-dependent canvases), SliceRandomMaxEvs 30 000, the ncaltech.conf augmentation chain
-    (random shift / flips, Resize(antialias), EventRandAugment, ColorJitter) batched on the GPU, the exact fp32 tokenizer
-    producing the labels, block-wise masks drawn per sample in the workers -- with the 246 MB of events of every batch
+    (random shift / flips, Resize(antialias), EventRandAugment, ColorJitter) batched on the GPU, the CLI's default tokenizer
+    (fp16x2 since round 4; labels equal to the fp32 mode's, `with_tokenizer`) producing the labels, block-wise masks drawn per sample in the workers -- with the 246 MB of events of every batch
     crossing PCIe inside the timed region.  Returns samples/s over `steps` steps after `warmup`, and the stages timed alone."""
     import contextlib
     import io
@@ -233,7 +233,9 @@ def entrypoint_figure(model, opt, B, steps, warmup, workers, lr_sched):
         ds.source = _CachedEvents(ds.source, 512)
     vae = DiscreteVAE(input_H=224, input_W=224, num_tokens=8192, codebook_dim=512, num_layers=4, num_resnet_blocks=3,
                       hidden_dim=384, channels=3).cuda().eval()
-    tok = HipTokenizer(vae, max_batch=B)
+    # the tokenizer the CLI builds by default (run_mem_pretraining.py: --tokenizer_impl, round 4: hip_fp16x2)
+    tok_prec = {"hip": "fp32", "hip_fp16x2": "fp16x2", "hip_bf16": "bf16"}[args.tokenizer_impl]
+    tok = HipTokenizer(vae, max_batch=B, precision=tok_prec)
     loader = torch.utils.data.DataLoader(ds, batch_size=B, shuffle=False, num_workers=workers, pin_memory=bool(args.pin_mem),
                                          drop_last=True, collate_fn=ds.collate, prefetch_factor=2 if workers else None)
     marks = {}
@@ -281,10 +283,10 @@ def entrypoint_figure(model, opt, B, steps, warmup, workers, lr_sched):
     return {"value": round(B * steps / dt, 1), "unit": "samples/sec", "ms_per_step": round(dt / steps * 1e3, 2), "steps": steps,
             "warmup": warmup, "workers": workers, "pin_memory": bool(args.pin_mem), "batch": B,
             "events_bytes_per_step": int(batch["events"].numel() * 8), "last_loss": round(float(stats["loss"]), 4),
-            "stages_alone_ms": {"h2d_events": round(h2d, 2), "augment_chain": round(aug, 2), "tokenizer_fp32": round(tok_ms, 2),
+            "stages_alone_ms": {"h2d_events": round(h2d, 2), "augment_chain": round(aug, 2), "tokenizer_" + tok_prec: round(tok_ms, 2),
                                 "host_pack_draws": round(pack_ms, 2)},
             "workload": "mem_amd.engine_for_pretraining.train_one_epoch over DataLoader(RawEventDataset): N-Caltech101 geometry "
-                        "(data-dependent canvases), ncaltech.conf augmentations, fp32 tokenizer labels, ViT-B/16 bf16, "
+                        "(data-dependent canvases), ncaltech.conf augmentations, " + tok_prec + " tokenizer labels (the CLI default), ViT-B/16 bf16, "
                         "events cross PCIe inside the timed region; event streams served from host memory"}
 
 

@@ -99,5 +99,15 @@ def test_attn16_counted_waits_match_the_instruction_stream(tmp_path):
             loads = [k for k, l in enumerate(body) if re.search(r"\bglobal_load_dwordx4\b", l)]
             assert len(loads) >= 8, (kname, len(loads))           # 4 in the prologue (first sample) + 4 in the loop
             assert sum(1 for k in stores if k > loads[-1]) >= n_wait, (kname, loads[-1], stores)
+        if kname == "attn16_fwd_kernel":
+            # round 4: the staging wave waits with vmcnt(28) = "all but the newest IMAGE": an image must be exactly 28 pieces
+            # issued back to back through the scalar-base form (nothing else of that wave in between), two images per sample
+            assert any(re.search(r"s_waitcnt vmcnt\(28\)", l) for l in body), kname
+            sb = [k for k, l in enumerate(body) if re.search(r"global_load_lds_dwordx4 v\d+, s\[", l)]
+            assert len(sb) == 56, (kname, len(sb))
+            for img in (sb[:28], sb[28:]):
+                between = body[img[0]:img[-1] + 1]
+                assert not any(re.search(r"\b(global_load|global_store|buffer_|scratch_)", l) and "global_load_lds_dwordx4" not in l
+                               for l in between), kname
         checked += 1
     assert checked == 5
