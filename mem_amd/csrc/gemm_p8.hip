@@ -52,6 +52,9 @@
 #endif
 
 #ifndef P8_PRIO_MODE
+#ifndef P8_BAR_MID
+#define P8_BAR_MID 0   // n > 0: 2 n MFMAs of a phase in front of its first barrier (see P8_PHASE; measured: n = 1 neutral, 2 and 4 slower)
+#endif
 #define P8_PRIO_MODE 0   // 0: s_setprio 1 around every MFMA block; 1: none; 2: none + waves 4-7 at priority 1 for the whole kernel
 #endif
 #if P8_PRIO_MODE == 0
@@ -134,6 +137,16 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 __device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
                                    (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
+}
+
+#ifndef P8_SADDR
+#define P8_SADDR 1     // 1: operand pieces as global_load_lds with a scalar base + 32-bit lane offset (inline asm) instead of a
+                       // 64-bit address per lane (two VALU adds per piece and twice the address traffic): NT GEMMs +0.5-1 %,
+                       // weight gradients +2-3 %, step -0.2 ms (tools/r04_run19.sh)
+#endif
+__device__ __forceinline__ void glds16s(const void* sbase, unsigned voff, const void* lds_dst) {
+  const unsigned lds = (unsigned)(unsigned long long)((const __attribute__((address_space(3))) char*)lds_dst);
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds) : "memory", "m0");
 }
 
 // LDS image of a half-tile: 128-byte rows, 16-byte chunk c of row r at position c ^ key(r).  The 16
@@ -233,14 +246,20 @@ __global__ __launch_bounds__(kThreads) void gemm_p8_kernel(GemmArgs p, int ntm, 
         }
       } else {
 #pragma unroll
-        for (int j = 0; j < AP; ++j) glds16(base + offA[j], slot + j * 1024);
+        for (int j = 0; j < AP; ++j) {
+          if (P8_SADDR) glds16s(base, offA[j], slot + j * 1024);
+          else glds16(base + offA[j], slot + j * 1024);
+        }
       }
     } else {
       char* slot = smem + buf * kBuf + G::kBOff + (H == HB1 ? kHalf : 0) + wave * 2048;
       const int c0 = tn * BN + (H == HB1 ? 32 : 0);
       const char* base = reinterpret_cast<const char*>(p.B) + ((long long)c0 * p.ldb + kt * BK) * 2;
 #pragma unroll
-      for (int j = 0; j < 2; ++j) glds16(base + offB[j], slot + j * 1024);
+      for (int j = 0; j < 2; ++j) {
+        if (P8_SADDR) glds16s(base, offB[j], slot + j * 1024);
+        else glds16(base + offB[j], slot + j * 1024);
+      }
     }
   };
   // K-tile cursors of the prefetch stream (clamped to the last K-tile at the end of the stream)
@@ -293,6 +312,9 @@ __global__ __launch_bounds__(kThreads) void gemm_p8_kernel(GemmArgs p, int ntm, 
 #define P8_MFMA_HALF(q, bsrc, kh)                                                                         \
   _Pragma("unroll") for (int mf = 0; mf < MF; ++mf) _Pragma("unroll") for (int nf = 0; nf < 2; ++nf)      \
       acc[q][mf][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bsrc[nf][kh], a[mf][kh], acc[q][mf][nf], 0, 0, 0)
+#define P8_MFMA_PART(q, bsrc, kh, m0, m1)                                                                 \
+  _Pragma("unroll") for (int mf = (m0); mf < (m1) && mf < MF; ++mf) _Pragma("unroll") for (int nf = 0; nf < 2; ++nf) \
+      acc[q][mf][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bsrc[nf][kh], a[mf][kh], acc[q][mf][nf], 0, 0, 0)
 #define P8_MFMA(q, bsrc)                                                                                  \
   do {                                                                                                    \
     P8_PRIO(1);                                                                        \
@@ -321,6 +343,21 @@ __global__ __launch_bounds__(kThreads) void gemm_p8_kernel(GemmArgs p, int ntm, 
     P8_WAIT_VM((WAITN) - (PIECES));                                                                       \
     P8_BARRIER();                                                                                         \
     P8_MFMA_STAGE(q, bsrc, STAGE_CALL);                                                                   \
+    P8_BARRIER();
+#elif P8_BAR_MID
+// the phase's first barrier sits in the MIDDLE of its MFMA block: the wave that arrives at a barrier from its load segment
+// still has MFMAs in the pipe, and the wave that leaves it for the second half of its block has its operands in registers
+#define P8_PHASE(READS, STAGE_CALL, WAITN, PIECES, q, bsrc)                                               \
+    READS;                                                                                                \
+    __builtin_amdgcn_sched_barrier(0);                                                                    \
+    STAGE_CALL;                                                                                           \
+    P8_WAIT_VM(WAITN);                                                                                    \
+    P8_PRIO(1);                                                                                           \
+    P8_MFMA_PART(q, bsrc, 0, 0, P8_BAR_MID);                                                              \
+    P8_BARRIER();                                                                                         \
+    P8_MFMA_PART(q, bsrc, 0, P8_BAR_MID, MF);                                                             \
+    P8_MFMA_HALF(q, bsrc, 1);                                                                             \
+    P8_PRIO(0);                                                                                           \
     P8_BARRIER();
 #else
 #define P8_PHASE(READS, STAGE_CALL, WAITN, PIECES, q, bsrc)                                               \

@@ -50,6 +50,15 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
                                    (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
 }
+#ifndef P8_SADDR
+#define P8_SADDR 1     // 1: operand pieces as global_load_lds with a scalar base + 32-bit lane offset (inline asm) instead of a
+                       // 64-bit address per lane (two VALU adds per piece and twice the address traffic): NT GEMMs +0.5-1 %,
+                       // weight gradients +2-3 %, step -0.2 ms (tools/r04_run19.sh)
+#endif
+__device__ __forceinline__ void glds16s(const void* sbase, unsigned voff, const void* lds_dst) {
+  const unsigned lds = (unsigned)(unsigned long long)((const __attribute__((address_space(3))) char*)lds_dst);
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds) : "memory", "m0");
+}
 // Transposing LDS read as inline asm.  With the builtin, hipcc (ROCm 7.2) cannot tell the read from
 // the in-flight LDS-DMA writes and puts s_waitcnt vmcnt(0) in front of every group of reads -- the
 // whole prefetch stream drained four times per K-tile (measured: 0.86 -> 1.1 PFLOP/s without it).
@@ -125,7 +134,10 @@ __global__ __launch_bounds__(kThreads) void gemm_tn_p8_kernel(const __bf16* __re
     const char* base = reinterpret_cast<const char*>(isA ? A : B) + ((long long)r0 * (isA ? lda : ldb) + c0) * 2;
     if (r0 + BR <= rend) {
 #pragma unroll
-      for (int j = 0; j < 2; ++j) glds16(base + (isA ? offA[j] : offB[j]), slot + j * 1024);
+      for (int j = 0; j < 2; ++j) {
+        if (P8_SADDR) glds16s(base, isA ? offA[j] : offB[j], slot + j * 1024);
+        else glds16(base + (isA ? offA[j] : offB[j]), slot + j * 1024);
+      }
     } else {                                                // tail of the slice: rows >= rend add zeros
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
