@@ -233,6 +233,9 @@ __global__ __launch_bounds__(kThreads) void gemm_p8_kernel(GemmArgs p, int ntm, 
 #ifdef P8_EXP_NODMA      // timing experiment (wrong results): no operand stream at all -- what do reads + MFMAs + barriers take?
     return;
 #endif
+#ifdef P8_EXP_L2HOT      // timing experiment (wrong results): every piece comes from the first tile's first two K-tiles (L2-hot):
+    { int z_; asm volatile("s_mov_b32 %0, 0" : "=s"(z_)); tm = z_; tn = z_; kt &= 1; }   // the issue cost of the stream without its memory latency
+#endif
     if (H == HA0 || H == HA1) {
       char* slot = smem + buf * kBuf + (H == HA1 ? kAHalf : 0) + wave * AP * 1024;
       const int r0 = tm * BMT + (H == HA1 ? BMT / 2 : 0);
@@ -302,6 +305,16 @@ __global__ __launch_bounds__(kThreads) void gemm_p8_kernel(GemmArgs p, int ntm, 
 
   int c_tile = first, c_k = 0;
   bf16x8 a[MF][2], bx[2][2], by[2][2];
+#ifdef P8_EXP_NOREAD
+#pragma unroll
+  for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+    for (int kh = 0; kh < 2; ++kh) asm volatile("" : "=v"(a[mf][kh]));
+#pragma unroll
+  for (int nf = 0; nf < 2; ++nf)
+#pragma unroll
+    for (int kh = 0; kh < 2; ++kh) { asm volatile("" : "=v"(bx[nf][kh])); asm volatile("" : "=v"(by[nf][kh])); }
+#endif
 
 #define P8_READ_A(half)                                                                                   \
   _Pragma("unroll") for (int mf = 0; mf < MF; ++mf) _Pragma("unroll") for (int kh = 0; kh < 2; ++kh)      \
@@ -391,6 +404,18 @@ __global__ __launch_bounds__(kThreads) void gemm_p8_kernel(GemmArgs p, int ntm, 
     P8_PHASE_NOMMA((void)0, stage(HB0, bc, tm2, tn2, k2), G::kWaitA + (X2))                               \
     P8_PHASE_NOMMA(P8_READ_A(1), stage(HA0, bc, tm2, tn2, k2), G::kWaitB + (X3))                          \
     P8_PHASE(P8_READ_B(bq1, (bc ^ 1) * kBuf, 0), stage(HB1, bc, tm2, tn2, k2), G::kWaitA + (X4), 2, 2, bq0) \
+  } while (0)
+#elif defined(P8_EXP_NOREAD)
+// timing experiment (wrong results): the operand stream and the MFMAs as shipped, no fragment reads in the main loop (the
+// registers keep what the prologue read): how much of the loop is the LDS array shared between ds_read and LDS-DMA writes?
+#define P8_KTILE(bq0, bq1, X1, X2, X3, X4)                                                                \
+  do {                                                                                                    \
+    const int bo = bc * kBuf;                                                                             \
+    (void)bo;                                                                                             \
+    P8_PHASE((void)0, stage(HA1, bc ^ 1, tm1, tn1, k1), G::kWaitB + (X1), AP, 0, bq0)                     \
+    P8_PHASE((void)0, stage(HB0, bc, tm2, tn2, k2), G::kWaitA + (X2), 2, 1, bq1)                          \
+    P8_PHASE((void)0, stage(HA0, bc, tm2, tn2, k2), G::kWaitB + (X3), AP, 3, bq1)                         \
+    P8_PHASE((void)0, stage(HB1, bc, tm2, tn2, k2), G::kWaitA + (X4), 2, 2, bq0)                          \
   } while (0)
 #else
 #define P8_KTILE(bq0, bq1, X1, X2, X3, X4)                                                                \
