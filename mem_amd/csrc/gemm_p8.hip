@@ -229,9 +229,15 @@ __global__ __launch_bounds__(kThreads) void gemm_p8_kernel(GemmArgs p, int ntm, 
     tn = rem / rows;
     tm = grp * kGroupM + (rem - tn * rows);
   };
+#ifdef P8_EXP_NODMA
+  int exp_calls = 0;
+#endif
   auto stage = [&](int H, int buf, int tm, int tn, int kt) {
 #ifdef P8_EXP_NODMA      // timing experiment (wrong results): no operand stream at all -- what do reads + MFMAs + barriers take?
-    return;
+    if (P8_EXP_NODMA + 0 <= 1) return;          // (2: no B half-tiles, 3: no A half-tiles)
+    if (P8_EXP_NODMA + 0 == 2 && (H == HB0 || H == HB1)) return;
+    if (P8_EXP_NODMA + 0 == 3 && (H == HA0 || H == HA1)) return;
+    if (P8_EXP_NODMA + 0 == 4 && exp_calls++ >= 8) return;   // (4: the first two K-tiles are staged -- both buffers hold real data -- then the stream stops)
 #endif
 #ifdef P8_EXP_L2HOT      // timing experiment (wrong results): every piece comes from the first tile's first two K-tiles (L2-hot):
     { int z_; asm volatile("s_mov_b32 %0, 0" : "=s"(z_)); tm = z_; tn = z_; kt &= 1; }   // the issue cost of the stream without its memory latency
@@ -322,6 +328,17 @@ __global__ __launch_bounds__(kThreads) void gemm_p8_kernel(GemmArgs p, int ntm, 
 #define P8_READ_B(dst, boff, half)                                                                        \
   _Pragma("unroll") for (int nf = 0; nf < 2; ++nf) _Pragma("unroll") for (int kh = 0; kh < 2; ++kh)       \
       dst[nf][kh] = *reinterpret_cast<const bf16x8*>(rdB[kh] + (boff) + (half) * kHalf + nf * 512)
+// P8_EXP_NOREAD = 1: no fragment reads at all, 2: A fragments are not read, 3: B fragments are not read
+#if defined(P8_EXP_NOREAD) && P8_EXP_NOREAD + 0 == 2
+#define P8_NR_A(h) (void)0
+#define P8_NR_B(d, o, h) P8_READ_B(d, o, h)
+#elif defined(P8_EXP_NOREAD) && P8_EXP_NOREAD + 0 == 3
+#define P8_NR_A(h) P8_READ_A(h)
+#define P8_NR_B(d, o, h) (void)0
+#else
+#define P8_NR_A(h) (void)0
+#define P8_NR_B(d, o, h) (void)0
+#endif
 #define P8_MFMA_HALF(q, bsrc, kh)                                                                         \
   _Pragma("unroll") for (int mf = 0; mf < MF; ++mf) _Pragma("unroll") for (int nf = 0; nf < 2; ++nf)      \
       acc[q][mf][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bsrc[nf][kh], a[mf][kh], acc[q][mf][nf], 0, 0, 0)
@@ -412,10 +429,10 @@ __global__ __launch_bounds__(kThreads) void gemm_p8_kernel(GemmArgs p, int ntm, 
   do {                                                                                                    \
     const int bo = bc * kBuf;                                                                             \
     (void)bo;                                                                                             \
-    P8_PHASE((void)0, stage(HA1, bc ^ 1, tm1, tn1, k1), G::kWaitB + (X1), AP, 0, bq0)                     \
-    P8_PHASE((void)0, stage(HB0, bc, tm2, tn2, k2), G::kWaitA + (X2), 2, 1, bq1)                          \
-    P8_PHASE((void)0, stage(HA0, bc, tm2, tn2, k2), G::kWaitB + (X3), AP, 3, bq1)                         \
-    P8_PHASE((void)0, stage(HB1, bc, tm2, tn2, k2), G::kWaitA + (X4), 2, 2, bq0)                          \
+    P8_PHASE(P8_NR_A(0), stage(HA1, bc ^ 1, tm1, tn1, k1), G::kWaitB + (X1), AP, 0, bq0)                  \
+    P8_PHASE(P8_NR_B(bq1, bo, 1), stage(HB0, bc, tm2, tn2, k2), G::kWaitA + (X2), 2, 1, bq1)              \
+    P8_PHASE(P8_NR_A(1), stage(HA0, bc, tm2, tn2, k2), G::kWaitB + (X3), AP, 3, bq1)                      \
+    P8_PHASE(P8_NR_B(bq1, (bc ^ 1) * kBuf, 0), stage(HB1, bc, tm2, tn2, k2), G::kWaitA + (X4), 2, 2, bq0) \
   } while (0)
 #else
 #define P8_KTILE(bq0, bq1, X1, X2, X3, X4)                                                                \
