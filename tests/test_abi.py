@@ -111,3 +111,50 @@ def test_attn16_counted_waits_match_the_instruction_stream(tmp_path):
                                for l in between), kname
         checked += 1
     assert checked == 5
+
+
+def test_gemm_p8_residual_epilogue_counted_waits(tmp_path):
+    """The residual epilogue of the 256-row gemm_p8 kernel loads its rows with inline asm and waits with HAND-COUNTED
+    s_waitcnt vmcnt(N): N = the vector-memory operations issued behind a row's three loads (later rows' loads, earlier rows'
+    stores).  If a toolchain change made hipcc emit FEWER stores per row than the count assumes, a row would be consumed before
+    it has landed -- silently wrong.  Replay the compiler's instruction stream: at the k-th counted wait of the epilogue, the
+    three loads of row k must be older than the N youngest vector-memory operations issued so far."""
+    import re, shutil, subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        import pytest
+        pytest.skip("no hipcc")
+    src = os.path.join(ROOT, "mem_amd", "csrc", "gemm_p8.hip")
+    out = str(tmp_path / "gemm_p8.s")
+    subprocess.run([hipcc, "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-fno-fast-math", "-S", "--cuda-device-only",
+                    "-o", out, src], check=True, capture_output=True)
+    lines = open(out).read().split("\n")
+    i0 = next(i for i, l in enumerate(lines) if l.startswith("_ZN") and "gemm_p8_kernelILi2ELi256ELb0ELb0E" in l and ":" in l)
+    j = i0
+    while "s_endpgm" not in lines[j]:
+        j += 1
+    body = lines[i0:j]
+    assert not any("scratch_" in l for l in body)               # a spill would add uncounted vector-memory operations
+    rm = [k for k, l in enumerate(body) if re.search(r"\bglobal_load_dword v\d+, v\[", l)]      # the row-mask load closes a row's 3 loads
+    assert len(rm) == 16, len(rm)
+    # the epilogue's operation stream from the first row's loads on: L = asm row loads, S = stores, D = LDS-DMA, W = counted waits
+    start = min(k for k in range(rm[0] - 4, rm[0] + 1) if re.search(r"\bglobal_load_dwordx4\b", body[k]) or k == rm[0])
+    ops, row_last_load, waits = 0, [], []
+    for k in range(start, len(body)):
+        l = body[k]
+        if re.search(r"\bglobal_load_dword(x4)? v", l) and "lds" not in l:
+            ops += 1
+            if k in rm:
+                row_last_load.append(ops)                      # ordinal of the last load of this row
+        elif re.search(r"\bglobal_store_dword", l) or "global_load_lds" in l or re.search(r"\bbuffer_(load|store)", l):
+            ops += 1
+        else:
+            m = re.search(r"s_waitcnt vmcnt\((\d+)\)", l)
+            if m and len(waits) < 16 and len(row_last_load) > len(waits):
+                waits.append((ops, int(m.group(1))))
+        if len(waits) == 16:
+            break
+    assert len(waits) == 16 and len(row_last_load) == 16, (len(waits), len(row_last_load))
+    for r, (issued, n) in enumerate(waits):
+        assert row_last_load[r] <= issued - n, (r, row_last_load[r], issued, n)     # row r's loads are not among the n youngest
+        assert n <= 10
