@@ -430,3 +430,51 @@ def test_attn16_random_shapes_and_repeated_launches():
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "bitwise equal every time" in r.stdout
+
+
+def test_stream_reservation_changes_grids_not_results():
+    """memhip_stream_reserve_cus (round 4): launches on a stream that carries a reservation size their persistent grids for fewer
+    CUs -- the partition of tiles / samples over workgroups changes, the arithmetic does not: GEMM outputs and the attention
+    forward are bit-equal, the attention backward equal up to the order of its fp32 atomics; another stream is unaffected and
+    a reservation of 0 restores the full grid."""
+    from mem_amd import ops
+    from oracle.vit_ref import rel_pos_index
+    M, N, K = 256 * 24, 768, 768
+    A = _rand((M, K), 70).bfloat16(); W = _rand((N, K), 71, 0.05).bfloat16(); bias = _rand((N,), 72)
+    B, T, H, win = 40, 197, 12, (14, 14)
+    D = 64 * H
+    TP = ops.attn_tokens_padded(T)
+    qkv = _rand((B * T, 3 * D), 73, 0.6).bfloat16()
+    idx, nrd = rel_pos_index(win)
+    table = _rand((nrd, H), 74, 0.4)
+    dout = _rand((B * T, D), 75).bfloat16()
+
+    def run():
+        o = torch.empty((M, N), dtype=torch.bfloat16, device="cuda")
+        ops.gemm_nt(A, W, M, N, K, ops.EPI_BIAS_BF16, out0=o, bias=bias)
+        out = torch.zeros((B * T, D), dtype=torch.bfloat16, device="cuda")
+        lse = torch.zeros((B, H, TP), device="cuda")
+        dqkv = torch.zeros((B * T, 3 * D), dtype=torch.bfloat16, device="cuda")
+        dtable = torch.zeros((nrd, H), device="cuda")
+        delta = torch.zeros((2 * B * T + 4, H), device="cuda")
+        dqb = torch.zeros(D, device="cuda")
+        ops.attn_fwd(qkv, B, T, D, H, table, win, out, lse)
+        ops.attn_delta(dout, out, B * T, H, delta)
+        ops.attn_bwd(qkv, dout, lse, delta, table, win, B, T, D, H, 0.125, dqkv, dtable, dq_bias=dqb)
+        torch.cuda.synchronize()
+        return o, out, lse, dqkv, dtable
+    base = run()
+    st = torch.cuda.current_stream()
+    try:
+        ops.stream_reserve_cus(st, 32)
+        res = run()
+        other = torch.cuda.Stream()
+        with torch.cuda.stream(other):
+            oth = run()
+    finally:
+        ops.stream_reserve_cus(st, 0)
+    again = run()
+    for r in (res, oth, again):
+        assert torch.equal(r[0], base[0]) and torch.equal(r[1], base[1]) and torch.equal(r[2], base[2])
+        assert torch.equal(r[3], base[3])
+        assert ((r[4] - base[4]).norm() / base[4].norm()).item() < 1e-5
