@@ -444,6 +444,9 @@ def main():
                          "work skipping: A/B switch")
     ap.add_argument("--gelu-dg", type=int, default=None, choices=[0, 1],
                     help="A/B switch: 1 = fc1 keeps gelu'(h) as fp16 for the backward (MUL_AUX), 0 = it keeps h (DGELU); default: the engine's")
+    ap.add_argument("--opt-overlap", action="store_true",
+                    help="A/B: AdamW + bf16 cast + transposed copies per layer bucket on their own stream beside the next forward "
+                         "(ViTEngine.overlap_optimizer; measured slower, off by default) instead of one block in front of it")
     ap.add_argument("--no-tail-rows", action="store_true",
                     help="A/B switch: the last block's MLP branch on every row instead of only the rows that reach the head")
     ap.add_argument("--no-entrypoint-figure", action="store_true",
@@ -524,6 +527,7 @@ def main():
     if a.gelu_dg is not None:
         eng.set_gelu_dg(bool(a.gelu_dg))
     eng.tail_rows = not a.no_tail_rows
+    eng.overlap_optimizer = bool(a.opt_overlap)
     eng.fwd_two_streams = bool(a.fwd_split) and not a.no_fwd_split
     import contextlib, io
     with contextlib.redirect_stdout(io.StringIO()):
@@ -986,6 +990,8 @@ def main():
                           "model_flops_frac_of_peak_reference_count": round(value / world * FLOP_PER_SAMPLE[C] / (PEAK_BF16_TFLOPS * 1e12), 4),
                           "last_loss": round(loss_last, 4), "host_threads": host_threads,
                           "stochastic_depth": "work skipping" if eng.dp_skip else "masked",
+                          "optimizer": ("AdamW + bf16 cast + transposed copies per layer bucket on their own stream, the next forward waits "
+                                        "per bucket" if eng.overlap_optimizer else "AdamW as one launch in front of the next forward"),
                           "last_block_mlp_rows": "rows that reach the head" if eng.tail_rows else "all"},
                "roofline": roof}
         if tok_ms is not None:

@@ -94,6 +94,8 @@ class FlatAdamW:
 
     def zero_grad(self, set_to_none=False):
         from . import ops
+        if hasattr(self.engine, "wait_optimizer"):
+            self.engine.wait_optimizer()          # a pipelined update may still be reading the gradients
         ops.zero_(self.engine.flat_g)
 
     def step(self):
@@ -144,6 +146,8 @@ class FlatAdamW:
             tab[gi, 1] = np.float32(g["lr"] / bc1)
         tab[ng] = (1.0, 0.0)
         self._group_table.copy_(torch.from_numpy(tab), non_blocking=True)
+        if hasattr(e, "wait_optimizer"):
+            e.wait_optimizer()
         ops.adamw_groups(e.flat_p, e.flat_g, self.exp_avg, self.exp_avg_sq, e.nflat, self._group_of_chunk, self._group_table,
                          ng + 1, g0["betas"][0], g0["betas"][1], g0["eps"], self.steps, gnorm=e.gnorm,
                          max_norm=self.max_norm or 0.0)
@@ -155,6 +159,8 @@ class FlatAdamW:
 
     def state_dict(self):
         e = self.engine
+        if hasattr(e, "wait_optimizer"):
+            e.wait_optimizer()                    # a pipelined update may still be writing the moments
         name_of = {id(p): n for n, p in e.named.items()}
         state, idx = {}, 0
         groups = []
@@ -173,6 +179,8 @@ class FlatAdamW:
 
     def load_state_dict(self, sd):
         e = self.engine
+        if hasattr(e, "wait_optimizer"):
+            e.wait_optimizer()
         name_of = {id(p): n for n, p in e.named.items()}
         params = self._param_list()
         for g, sg in zip(self.param_groups, sd["param_groups"]):

@@ -64,6 +64,8 @@ class ViTEngine:
         self.TP = ops.attn_tokens_padded(self.T)
         self._pack_parameters()
         self._build_static()
+        if hasattr(model, "register_state_dict_pre_hook"):
+            model.register_state_dict_pre_hook(lambda *_a, **_k: self.wait_optimizer())
         self.B = 0
         self.step_masks = None
         self.weights_dirty = True
@@ -77,6 +79,18 @@ class ViTEngine:
         # caller's optimizer.zero_grad() clears it (every gradient kernel accumulates; the layer-scale gradient is a
         # linear function of the accumulated weight gradient)
         self.accumulate_grads = False
+        # Optimizer pipelined with the NEXT forward (round 4, OFF by default): AdamW, the bf16 cast and the transposed copies
+        # run per layer bucket on their own stream in FORWARD order (embedding, block 0, ...), and the next forward waits per
+        # bucket, so the ~0.7 ms of HBM-bound update work run beside the next step's first blocks instead of in front of them.
+        # Bit-equal to the blocking update (tests/test_train_gpu.py) -- and SLOWER on MI355X: interleaved A/B on one box,
+        # p50 35.86 / 35.73 / 35.75 ms blocking against 36.08 / 36.00 / 36.18 pipelined (tools/r04_run22.sh): the update's
+        # HBM traffic beside the power-limited GEMMs costs them more than the 0.7 ms it hides.  Kept as an option.
+        # Every other reader of the parameters / writer of the gradients on the launch stream goes through
+        # wait_optimizer() (backward, zero_grad, state_dict, sync_weights).  Pretraining engine only.
+        self.overlap_optimizer = False
+        self._opt_stream = None
+        self._opt_ev = None               # bucket name -> event (parameters of that bucket are updated, cast)
+        self._opt_done = None             # everything incl. the transposed copies
         self.wgrad_side_stream = True
         self.fwd_two_streams = False      # forward: uneven two-stream split (see forward_trunk / _split_point).  It paid
                                           # -0.24 ms at B = 256 while the GEMM epilogues stalled on their own stores (the
@@ -301,6 +315,7 @@ class ViTEngine:
     # ------------------------------------------------------------------ weights
     def sync_weights(self):
         """fp32 masters -> bf16 shadows (+ [in,out]-major copies for the dgrad GEMMs)."""
+        self.wait_optimizer()
         ops.cast_f32_bf16(self.flat_p, self.flat_w16, self.nflat)
         if self._tdesc is None:
             self._build_transpose_descs()
@@ -328,6 +343,20 @@ class ViTEngine:
         self._tdesc = torch.from_numpy(desc).to(self.dev)
         self._tprefix = torch.from_numpy(prefix).to(self.dev)
         self._tn, self._ttiles = len(items), int(prefix[-1])
+        # the same per layer bucket (the pipelined optimizer transposes a bucket's matrices as soon as they are updated):
+        # bucket -> (first item, count, local prefix, tiles)
+        self._tbucket = {}
+        locs = []
+        for i in range(self.depth):
+            locs.append((f"block{i}", 4 * i, 4))
+        if self.head_kind == "mlm":
+            locs.append(("head", 4 * self.depth, 1))
+        loc_prefix = []
+        for name, k0, n in locs:
+            pl = (prefix[k0:k0 + n + 1] - prefix[k0]).astype(np.int32)
+            self._tbucket[name] = (k0, n, len(loc_prefix), int(pl[-1]))
+            loc_prefix += list(pl)
+        self._tprefix_loc = torch.from_numpy(np.asarray(loc_prefix, dtype=np.int32)).to(self.dev)
 
     def table(self, i):
         """Relative-position bucket table of block i ([nrd, heads] fp32 master)."""
@@ -414,6 +443,7 @@ class ViTEngine:
         D, Hd, T, L, V = self.D, self.hidden, self.T, self.L, self.V
         M = B * T
         self.cur.update(Mm=Mm, rows=rows_idx, labels=labels)
+        self._wait_params("head")
         # final norm on exactly the rows that reach the head (x[:,1:][bool_masked_pos])
         if self.cur.get("tail") is not None:
             ops.layernorm_fwd(self.x_tail, self.P("norm.weight"), self.P("norm.bias"), self.hN, self.meanN, self.rstdN, Mm, D)
@@ -550,6 +580,9 @@ class ViTEngine:
         self.ensure_batch(B, getattr(self, "Mm_cap", 0))
         if self.weights_dirty:
             self.sync_weights()
+        if self.fwd_two_streams:
+            self.wait_optimizer()
+        self._wait_params("embed")
         if mask_u8 is None:
             mask_u8 = self.zero_mask[: B * self.L]
         D, Hd, T, L = self.D, self.hidden, self.T, self.L
@@ -604,6 +637,7 @@ class ViTEngine:
             torch.cuda.current_stream().wait_event(e1)
         else:
             for i in range(self.depth):
+                self._wait_params(f"block{i}")
                 self._block_fwd(i, 0, B, dp_masks)
         return self.x[2 * self.depth][:M]
 
@@ -689,6 +723,7 @@ class ViTEngine:
         B, M, Mm = c["B"], c["M"], c["Mm"]
         D, Hd, T, L, V = self.D, self.hidden, self.T, self.L, self.V
         dp_masks = c["dp"]
+        self.wait_optimizer()                # (the transposed copies; the gradient buffer is free again)
         if dlogits is not None:
             self.logits[:Mm].copy_(dlogits)
         if not self.accumulate_grads:
@@ -1032,6 +1067,50 @@ class ViTEngine:
         return self.gnorm
 
     def adamw_step(self, m, v, lr, wd, step, betas=(0.9, 0.95), eps=1e-8, max_norm=0.0):
-        ops.adamw(self.flat_p, self.flat_g, m, v, self.nflat, self.wd_flags, lr, betas[0], betas[1], eps, wd, step,
-                  gnorm=self.gnorm, max_norm=max_norm or 0.0)
-        self.weights_dirty = True
+        if not (self.overlap_optimizer and self.head_kind == "mlm" and not self.fwd_two_streams):
+            self.wait_optimizer()
+            ops.adamw(self.flat_p, self.flat_g, m, v, self.nflat, self.wd_flags, lr, betas[0], betas[1], eps, wd, step,
+                      gnorm=self.gnorm, max_norm=max_norm or 0.0)
+            self.weights_dirty = True
+            return
+        # ---- pipelined with the next forward (see __init__): bucket by bucket in forward order on the optimizer stream
+        self.wait_optimizer()
+        if self._tdesc is None:
+            self._build_transpose_descs()
+        if self._opt_stream is None:
+            self._opt_stream = torch.cuda.Stream(device=self.dev)
+            self._opt_events = {b[0]: torch.cuda.Event() for b in self.buckets}
+            self._opt_events["__done__"] = torch.cuda.Event()
+            self._opt_start = torch.cuda.Event()
+        main, st = torch.cuda.current_stream(), self._opt_stream
+        self._opt_start.record(main)                          # gradients and their norm are final
+        with torch.cuda.stream(st):
+            st.wait_event(self._opt_start)
+            for name, b0, b1 in reversed(self.buckets):       # embed, block 0 .. block depth-1, head
+                if b1 == b0:
+                    self._opt_events[name].record(st)
+                    continue
+                ops.adamw(self.flat_p[b0:b1], self.flat_g[b0:b1], m[b0:b1], v[b0:b1], b1 - b0,
+                          self.wd_flags[b0 // ALIGN: b1 // ALIGN], lr, betas[0], betas[1], eps, wd, step,
+                          gnorm=self.gnorm, max_norm=max_norm or 0.0)
+                ops.cast_f32_bf16(self.flat_p[b0:b1], self.flat_w16[b0:b1], b1 - b0)
+                self._opt_events[name].record(st)
+            for name, (k0, n, p0, tiles) in self._tbucket.items():      # [in,out]-major copies: only backward reads them
+                ops.transpose_cast_batched(self._tdesc[k0:k0 + n], self._tprefix_loc[p0:p0 + n + 1], n, tiles)
+            self._opt_events["__done__"].record(st)
+        self._opt_ev = self._opt_events
+        self._opt_done = self._opt_events["__done__"]
+        self.weights_dirty = False
+
+    def _wait_params(self, bucket):
+        """The launch stream waits until the pipelined optimizer has updated (and cast) the parameters of `bucket`."""
+        if self._opt_ev is not None:
+            torch.cuda.current_stream().wait_event(self._opt_ev[bucket])
+
+    def wait_optimizer(self):
+        """The launch stream waits for everything the pipelined optimizer has in flight (parameters, bf16 shadows, transposed
+        copies; it has then also finished reading the gradient buffer)."""
+        if self._opt_done is not None:
+            torch.cuda.current_stream().wait_event(self._opt_done)
+            self._opt_ev = None
+            self._opt_done = None
