@@ -453,7 +453,7 @@ def main():
                     help="skip the measurement of the real entrypoint loop (train_one_epoch over a DataLoader)")
     ap.add_argument("--entrypoint-workers", type=int, default=10, help="DataLoader workers of the entrypoint figure")
     ap.add_argument("--no-config5-figure", action="store_true", help="skip the ViT-L/16 480x640 single-GPU figure (BASELINE configs[4])")
-    ap.add_argument("--config5-batch", type=int, default=32)
+    ap.add_argument("--config5-batch", type=int, default=64)
     ap.add_argument("--no-config4-figure", action="store_true",
                     help="skip the secondary figure for BASELINE configs[3] end to end (1 M events per sample feeding ViT-B)")
     ap.add_argument("--rendezvous-only", action="store_true",
