@@ -124,13 +124,13 @@ class _CachedEvents:
         return self.items[i % len(self.items)]
 
 
-def config5_figure(B=32, steps=5, warmup=2):
+def config5_figure(B=64, steps=5, warmup=2):
     """BASELINE configs[4] on ONE GPU: MEM pretrain ViT-Large/16 (D 1024, depth 24, 16 heads, layer scale 1e-5,
     mem/modeling_pretrain.py:22-140 with the reference's `pt_vit_large`-style arguments) on 480 x 640 2-bin voxels = 30 x 40 + 1
     = 1201 tokens (streaming attention, 4664-entry bias table), 600 masked patches per sample, bf16, stochastic depth 0.1,
-    AdamW; a step = masks + forward + CE + backward + clip + AdamW on a batch resident in HBM.  B = 32 per GPU: the best
-    samples/s measured (B 16: 208, B 32: 236, B 64 -- the reference's global 512 over 8 GPUs -- 174 samples/s, 88 GB); 47 GB of
-    the 288 GB.  FLOPs: 2 635.5 GFLOP per sample fwd + bwd (GEMMs only)."""
+    AdamW; a step = masks + forward + CE + backward + clip + AdamW on a batch resident in HBM.  B = 64 per GPU (the
+    reference's global 512 over 8 GPUs; profiles/r04_vitl_batch.log: B 16: 222, B 32: 248, B 48: 259, B 64: 267 samples/s,
+    73.5 GB of the 288 GB).  FLOPs: 2 635.5 GFLOP per sample fwd + bwd (GEMMs only)."""
     import contextlib
     import io
     import numpy as np
