@@ -598,9 +598,13 @@ __device__ __forceinline__ float wave_max(float v) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
-// value of lane - 1 within the 16-lane row (0 for the first lane of a row): v_mov_b32_dpp row_shr:1
+// value of lane - 1 / lane + 1 of the WAVE (0 beyond its ends): v_mov_b32_dpp wave_shr:1 / wave_shl:1 -- the GFX9 whole-wave
+// shifts exist on gfx950 and cross the 16-lane rows (tools/micro/dpp_wave.hip)
 __device__ __forceinline__ float dpp_shr1(float v) {
-  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x111, 0xf, 0xf, true));
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float dpp_shl1(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130, 0xf, 0xf, true));
 }
 
 // exchange tile [32 queries][32 keys] bf16, 64-byte rows, 8-byte unit u of row r at position u ^ ((r >> 1) & 7): the
@@ -658,10 +662,32 @@ __global__ __launch_bounds__(kThreads16) void attn16_bwd_kernel(const __bf16* __
 #pragma unroll
   for (int i = 0; i < 8; ++i) bsum[i] = 0.f;
   // diagonal chains of the bucket sums (see the produce step)
-  const bool has_left = (r & 15) != 0 && q < T16 && q >= 2 && (q - 1) % W16 != 0;          // lane - 1: query q - 1, same grid row
-  const bool has_right = (r & 15) != 15 && q + 1 < T16 && q >= 1 && q % W16 != 0;          // lane + 1 continues this lane's chains
+  // RUNS of linked lanes: lane r of a half-wave is linked to lane r - 1 when query q - 1 sits in the same grid row (padding queries
+  // -- all their terms are exactly 0 -- form one run of their own).  A run's last lane (`chain_end`) is left with three unfinished
+  // chains (keys 0, 0..1, 0..2 of a register group); their buckets are bucket(lane; key e) = bucket(lane - e; key 0) inside a
+  // run, so lanes t, t - 1, t - 2 of the run add them -- at their OWN key-0 address, in ONE wave-wide atomic (fEnd / fD1 / fD2
+  // select a lane's term; every other lane adds 0).  Only runs shorter than three lanes (the cls query; query 127, alone between
+  // a grid-row boundary and the end of wave 3) still need the separate adds s1 / s2: wave-uniform branches, taken by two
+  // of the seven waves.  Per register group: 2 atomic instructions instead of 4 (an LDS atomic costs its wave ~52 cycles
+  // whatever its lane count).
+  auto has_left_of = [&](int rr, int qq) {
+    if (rr <= 0 || rr > 31) return false;
+    return qq >= T16 ? qq - 1 >= T16 : (qq >= 2 && (qq - 1) % W16 != 0);
+  };
+  auto is_end_of = [&](int rr, int qq) { return rr <= 31 && !has_left_of(rr + 1, qq + 1); };
+  const bool has_left = has_left_of(r, q);
   const float link = has_left ? 1.f : 0.f;
-  const bool chain_end = !has_right;
+  const bool chain_end = is_end_of(r, q);
+  const float fEnd = chain_end ? 1.f : 0.f;
+  // (the neighbours' flags through the same whole-wave shifts the chains use: lanes 31 / 32 never link, so nothing crosses halves)
+  const float e1 = fEnd * link;                                  // a run end with a lane to its left
+  const float e2 = e1 * dpp_shr1(link);                          // ... and one more
+  const float fD1 = dpp_shl1(e1);                                // lane + 1 is such an end: its chain 1 is added here
+  const float fD2 = dpp_shl1(dpp_shl1(e2));                      // lane + 2 is: its chain 2 is added here
+  const bool s1 = chain_end && !has_left;                        // run of one lane: chains 1 and 2 stay with it
+  const bool s2 = chain_end && e2 == 0.f;                        // run of one or two lanes: chain 2 stays with its end
+  const float fS1 = s1 ? 1.f : 0.f, fS2 = s2 ? 1.f : 0.f;
+  const bool any_s1 = __builtin_amdgcn_ballot_w64(s1) != 0, any_s2 = __builtin_amdgcn_ballot_w64(s2) != 0;
   float dcls = 0.f;                                          // gradient of the (token -> cls) / (cls -> cls) bucket
   // per-query rows of the sample (lse, delta, |dO|^2) travel by LDS-DMA as well: a plain load into registers would make the
   // compiler wait for ALL vector-memory operations (the stores of the previous sample included) in front of the first use
@@ -867,9 +893,9 @@ __global__ __launch_bounds__(kThreads16) void attn16_bwd_kernel(const __bf16* __
             xb[2] = hh1 ? 0.f : xb[2];
           }
           // (query + 1, key + 1) is the bucket of (query, key): the four keys of a register group are summed along the
-          // diagonal over neighbouring lanes first (row_shr:1; `link` = 0 where the left neighbour is in another grid row
-          // or another 16-lane row), so a lane adds ONE chain sum instead of four elements; the lanes at which chains
-          // break off (`chain_end`: about 5 of 32) add their three unfinished chains themselves.
+          // diagonal over neighbouring lanes first (wave_shr:1; `link` = 0 where the left neighbour is in another grid row
+          // or the other half-wave), so a lane adds ONE chain sum instead of four elements; the three unfinished chains of a
+          // run's last lane go out in one more wave-wide atomic (see the run flags above).
           const float c1 = fmaf(dpp_shr1(xb[0]), link, xb[1]);
           const float c2 = fmaf(dpp_shr1(c1), link, xb[2]);
           const float c3 = fmaf(dpp_shr1(c2), link, xb[3]);
@@ -878,13 +904,44 @@ __global__ __launch_bounds__(kThreads16) void attn16_bwd_kernel(const __bf16* __
 #elif ATTN16_EXP == 2    // timing experiment: only the full-wave atomic
           lds_add_i32_abs(na + KOFF16(g, 3), fx_round(c3, fx));
           dcls += __int_as_float(fx_round(xb[0], fx) ^ fx_round(c1, fx) ^ fx_round(c2, fx));
-#else
+#elif ATTN16_EXP == 3    // debugging: whole-wave chains, every run end adds its three unfinished chains itself
           lds_add_i32_abs(na + KOFF16(g, 3), fx_round(c3, fx));
           if (chain_end) {
             lds_add_i32_abs(na + KOFF16(g, 0), fx_round(xb[0], fx));
             lds_add_i32_abs(na + KOFF16(g, 1), fx_round(c1, fx));
             lds_add_i32_abs(na + KOFF16(g, 2), fx_round(c2, fx));
           }
+#elif ATTN16_EXP == 4    // debugging: only chain 1 is delegated
+          lds_add_i32_abs(na + KOFF16(g, 3), fx_round(c3, fx));
+          lds_add_i32_abs(na + KOFF16(g, 0), fx_round(fmaf(fD1, dpp_shl1(c1), fEnd * xb[0]), fx));
+          if (chain_end) {
+            if (s1) lds_add_i32_abs(na + KOFF16(g, 1), fx_round(c1, fx));
+            lds_add_i32_abs(na + KOFF16(g, 2), fx_round(c2, fx));
+          }
+#elif ATTN16_EXP == 7    // debugging: chain 1 delegated, the neighbour's value through ds_bpermute instead of DPP
+          lds_add_i32_abs(na + KOFF16(g, 3), fx_round(c3, fx));
+          lds_add_i32_abs(na + KOFF16(g, 0), fx_round(fmaf(fD1, __shfl_down(c1, 1), fEnd * xb[0]), fx));
+          if (chain_end) {
+            if (s1) lds_add_i32_abs(na + KOFF16(g, 1), fx_round(c1, fx));
+            lds_add_i32_abs(na + KOFF16(g, 2), fx_round(c2, fx));
+          }
+#elif ATTN16_EXP == 5    // debugging: only chain 2 is delegated
+          lds_add_i32_abs(na + KOFF16(g, 3), fx_round(c3, fx));
+          lds_add_i32_abs(na + KOFF16(g, 0), fx_round(fmaf(fD2, dpp_shl1(dpp_shl1(c2)), fEnd * xb[0]), fx));
+          if (chain_end) {
+            lds_add_i32_abs(na + KOFF16(g, 1), fx_round(c1, fx));
+            if (s2) lds_add_i32_abs(na + KOFF16(g, 2), fx_round(c2, fx));
+          }
+#else
+          lds_add_i32_abs(na + KOFF16(g, 3), fx_round(c3, fx));
+          {
+            const float wsum = fmaf(fD2, dpp_shl1(dpp_shl1(c2)), fmaf(fD1, dpp_shl1(c1), fEnd * xb[0]));
+            lds_add_i32_abs(na + KOFF16(g, 0), fx_round(wsum, fx));
+          }
+          // (wave-uniform branches; the other lanes of such a wave add 0 -- a per-lane `if (s1)` here was compiled by hipcc
+          // (ROCm 7.2) into a test of an unrelated data register: tools/dt_dbg.py)
+          if (any_s1) lds_add_i32_abs(na + KOFF16(g, 1), fx_round(fS1 * c1, fx));
+          if (any_s2) lds_add_i32_abs(na + KOFF16(g, 2), fx_round(fS2 * c2, fx));
 #endif
         }
       }
