@@ -477,4 +477,4 @@ def test_stream_reservation_changes_grids_not_results():
     for r in (res, oth, again):
         assert torch.equal(r[0], base[0]) and torch.equal(r[1], base[1]) and torch.equal(r[2], base[2])
         assert torch.equal(r[3], base[3])
-        assert ((r[4] - base[4]).norm() / base[4].norm()).item() < 1e-5
+        assert ((r[4] - base[4]).norm() / base[4].norm()).item() < 1e-4     # (fp32 summation order over samples / workgroups)
