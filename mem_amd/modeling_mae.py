@@ -505,6 +505,11 @@ class MaeEngineBF16(MaeEngineF32):
         assert self.Kpe % 64 == 0 and self.Pp % 8 == 0
         self.w16, self.wT16, self.bpad = {}, {}, {}
         self.tn_ws = None
+        self.set_gelu_dg(True)
+
+    def set_gelu_dg(self, on):
+        """fc1 keeps gelu'(h) (fp16) for the backward instead of the pre-activation (vit_engine.ViTEngine.set_gelu_dg)."""
+        self.epi_gelu, self.epi_dgelu = (ops.EPI_BIAS_GELU_DG, ops.EPI_MUL_AUX) if on else (ops.EPI_BIAS_GELU, ops.EPI_DGELU)
 
     # ---- bf16 shadows of the Linear weights ([out,in] for forward, [in,out] for dgrad), padded where heads are 32 wide
     def _padded(self, spec, kind, W):
@@ -643,7 +648,8 @@ class MaeEngineBF16(MaeEngineF32):
         ops.gemm_nt(a["ao"], self.w16[pre + "attn.proj.weight"], M, D, Dp, ops.EPI_RESIDUAL, bias=P(pre + "attn.proj.bias"),
                     resid=xmid, aux=xin, ldaux=D, rows_per_sample=T)
         ops.layernorm_fwd(xmid, P(pre + "norm2.weight"), P(pre + "norm2.bias"), a["h2"], a["mean2"], a["rstd2"], M, D, eps=self.eps)
-        ops.gemm_nt(a["h2"], self.w16[pre + "mlp.fc1.weight"], M, Hd, D, ops.EPI_BIAS_GELU, out0=a["hpre"], out1=a["a"],
+        # (round 4: fc1 stores gelu'(h) as fp16 instead of the pre-activation, the backward multiplies: ViTEngine.set_gelu_dg)
+        ops.gemm_nt(a["h2"], self.w16[pre + "mlp.fc1.weight"], M, Hd, D, self.epi_gelu, out0=a["hpre"], out1=a["a"],
                     bias=P(pre + "mlp.fc1.bias"))
         ops.gemm_nt(a["a"], self.w16[pre + "mlp.fc2.weight"], M, D, Hd, ops.EPI_RESIDUAL, bias=P(pre + "mlp.fc2.bias"),
                     resid=xout, aux=xmid, ldaux=D, rows_per_sample=T)
@@ -669,7 +675,7 @@ class MaeEngineBF16(MaeEngineF32):
         if i == spec["depth"] - 1 or not fuse:
             ops.branch_bwd(dx, None, None, dy, None, Gr(pre + "mlp.fc2.bias"), M, D)
         # (fused column sums go to CS_COPIES accumulator copies, folded by a tiny kernel: atomics on one address serialise)
-        ops.gemm_nt(dy, self.wT16[pre + "mlp.fc2.weight"], M, Hd, D, ops.EPI_DGELU, out0=dbig, aux=a["hpre"],
+        ops.gemm_nt(dy, self.wT16[pre + "mlp.fc2.weight"], M, Hd, D, self.epi_dgelu, out0=dbig, aux=a["hpre"],
                     colsum=self.cs_ws, colsum_copies=self.CS_COPIES)
         ops.colsum_fold(self.cs_ws, self.CS_COPIES, Hd, Gr(pre + "mlp.fc1.bias"))
         self._wgrad16(dy, a["a"], M, D, Hd, Gw(pre + "mlp.fc2.weight"))
