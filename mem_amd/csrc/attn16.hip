@@ -28,7 +28,13 @@
 //     160 KiB of LDS, so the images are single-buffered: the LDS-DMA of the next sample is issued as soon as the last
 //     step has passed its barrier and runs under the sample's epilogue (stores, bucket fold).
 //   * the bias-table gradient uses the same constant offsets for its fixed-point LDS atomics (ds_add_u32); the bound of
-//     the fixed-point scale is computed per sample inside the kernel (no per-head statistics pass).
+//     the fixed-point scale is computed per sample inside the kernel (no per-head statistics pass).  (query + 1, key + 1) is
+//     the bucket of (query, key), so the four keys of a register group are summed along the diagonal over neighbouring
+//     lanes of the whole wave (wave_shr:1) and a group costs 2 wave-wide atomics (round 4; an LDS atomic costs its wave
+//     ~52 cycles whatever its lane count).
+//   * FORWARD (round 4): eight waves -- the eighth only issues the LDS-DMA of the next sample (issue time, not memory
+//     time, was 23 % of the seven-wave kernel), and waves 4-6 run half a sample behind waves 0-3 so that the two waves of a
+//     SIMD alternate between their MFMA and VALU phases; K and V are double-buffered separately.
 #include "attn_common.hpp"
 #include <type_traits>
 
