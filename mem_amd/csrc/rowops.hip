@@ -755,7 +755,10 @@ extern "C" int memhip_layernorm_bwd_branch_map(const void* dy, int64_t lddy, con
   MEMHIP_REQUIRE(ldx % 4 == 0 && lddy % 4 == 0 && lddres % 4 == 0 && ldyb % 4 == 0 && lddyb % 4 == 0,
                  "layernorm_bwd_branch: ld must be a multiple of 4");
   int grid = cdiv(R, 4);
-  if (grid > opt(OPT_LN_BWD_GRID)) grid = opt(OPT_LN_BWD_GRID);   // 768 = 3 resident workgroups per CU at this kernel's VGPR count: one full round
+  int cap = opt(OPT_LN_BWD_GRID);                      // 768 = 3 resident workgroups per CU at this kernel's VGPR count: one full round
+  if (D > 768 && cap > 512) cap = 512;                 // D = 1024: 64 KiB of LDS and 212 VGPRs per workgroup, two per CU (tools/ln_bwd_probe.py:
+                                                       // 76 864 rows 301 -> 262 us, 19 216 rows 69 -> 64 us)
+  if (grid > cap) grid = cap;
 #define LBB_LAUNCH(N)                                                                                    \
   if (y_branch) LBB_LAUNCH2(N, true); else LBB_LAUNCH2(N, false)
 #define LBB_LAUNCH2(N, Y)                                                                                \
