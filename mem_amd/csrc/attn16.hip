@@ -344,7 +344,7 @@ __device__ unsigned long long g_attn16_prof[2][16];
 #endif
 // ------------------------------------------------------------------------------------------------ forward
 // 8 waves: 7 compute a block of 32 queries each, the 8th only issues the LDS-DMA of the next sample.  Measured (B = 256,
-// tools/r04_run13.sh): with the K / V staging of the next sample left out the 7-wave kernel took 83 us instead of 109 --
+// tools/exp/r04_run13.sh): with the K / V staging of the next sample left out the 7-wave kernel took 83 us instead of 109 --
 // not memory time (the DMA has a whole sample period to land) but ISSUE time: a global_load_lds takes its wave 100+ cycles
 // among busy neighbours, 8 per wave and sample, plus the slot -> token address arithmetic.  Wave 7 shares SIMD 3 with
 // wave 3, the only SIMD of a 7-wave workgroup that held one wave.

@@ -142,7 +142,7 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst) {
 #ifndef P8_SADDR
 #define P8_SADDR 1     // 1: operand pieces as global_load_lds with a scalar base + 32-bit lane offset (inline asm) instead of a
                        // 64-bit address per lane (two VALU adds per piece and twice the address traffic): NT GEMMs +0.5-1 %,
-                       // weight gradients +2-3 %, step -0.2 ms (tools/r04_run19.sh)
+                       // weight gradients +2-3 %, step -0.2 ms (tools/exp/r04_run19.sh)
 #endif
 __device__ __forceinline__ void glds16s(const void* sbase, unsigned voff, const void* lds_dst) {
   const unsigned lds = (unsigned)(unsigned long long)((const __attribute__((address_space(3))) char*)lds_dst);

@@ -83,7 +83,7 @@ class ViTEngine:
         # run per layer bucket on their own stream in FORWARD order (embedding, block 0, ...), and the next forward waits per
         # bucket, so the ~0.7 ms of HBM-bound update work run beside the next step's first blocks instead of in front of them.
         # Bit-equal to the blocking update (tests/test_train_gpu.py) -- and SLOWER on MI355X: interleaved A/B on one box,
-        # p50 35.86 / 35.73 / 35.75 ms blocking against 36.08 / 36.00 / 36.18 pipelined (tools/r04_run22.sh): the update's
+        # p50 35.86 / 35.73 / 35.75 ms blocking against 36.08 / 36.00 / 36.18 pipelined (tools/exp/r04_run22.sh): the update's
         # HBM traffic beside the power-limited GEMMs costs them more than the 0.7 ms it hides.  Kept as an option.
         # Every other reader of the parameters / writer of the gradients on the launch stream goes through
         # wait_optimizer() (backward, zero_grad, state_dict, sync_weights).  Pretraining engine only.
