@@ -54,7 +54,9 @@ class ViTEngineF32(ViTEngine):
         if B <= self.B and Mm_max <= getattr(self, "Mm_cap", 0):
             return
         B = max(B, self.B)
-        Mm_cap = max(Mm_max, getattr(self, "Mm_cap", 0))
+        # (every patch of the batch: the masked-row count differs from step to step, and a new maximum must not re-allocate the
+        # whole buffer set -- the bf16 engine's round-4 finding)
+        Mm_cap = max(Mm_max, getattr(self, "Mm_cap", 0), B * self.L)
         dev, f = self.dev, torch.float32
         D, Hd, T, V = self.D, self.hidden, self.T, self.V
         M = B * T
