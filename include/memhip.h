@@ -10,9 +10,14 @@
  * Conventions (all entry points):
  *   - plain pointers + sizes only; pointers are caller-owned DEVICE buffers
  *     (tensor.data_ptr()) unless a parameter is documented "host".
- *   - no allocation, no host synchronisation, no global mutable state inside;
- *     scratch comes in through (workspace, workspace_bytes); work is enqueued
- *     on `stream` (a hipStream_t passed as void*; NULL = default stream).
+ *   - no allocation, no host synchronisation, no global mutable state inside
+ *     that the product path writes; scratch comes in through (workspace,
+ *     workspace_bytes); work is enqueued on `stream` (a hipStream_t passed as
+ *     void*; NULL = default stream).  The two exceptions, both explicit calls:
+ *     memhip_set_option (a process-wide kernel-selection table for A/B
+ *     measurements; the mem_amd package never calls it outside tools and
+ *     tests) and memhip_stream_reserve_cus (a reservation keyed by the
+ *     caller's stream handle, set and cleared by the data-parallel reducer).
  *   - return 0 on success, a negative MEMHIP_E* code on failure; a message is
  *     available from memhip_last_error() (thread-local).  No C++ exception
  *     crosses the boundary.
