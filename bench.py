@@ -439,6 +439,8 @@ def main():
                     help="N > 1: CUs the persistent GEMM / attention grids leave to RCCL while gradient buckets are in flight "
                          "(-1 = 16 when more than one rank runs, 0 in a one-rank run; one-rank dry-run A/B: "
                          "profiles/r03_rccl_dryrun.json -- reserving 16 CUs costs <= 0.3 ms of a 39 ms step)")
+    ap.add_argument("--hook-join", action="store_true",
+                    help="A/B: the gradient-bucket hook runs on the main stream behind a per-layer join of the two streams (round 4)")
     ap.add_argument("--no-dp-skip", action="store_true",
                     help="stochastic depth by masking (every sample computed, dropped ones multiplied by zero) instead of "
                          "work skipping: A/B switch")
@@ -527,6 +529,7 @@ def main():
     if a.gelu_dg is not None:
         eng.set_gelu_dg(bool(a.gelu_dg))
     eng.tail_rows = not a.no_tail_rows
+    eng.hook_on_side = not a.hook_join
     eng.overlap_optimizer = bool(a.opt_overlap)
     eng.fwd_two_streams = bool(a.fwd_split) and not a.no_fwd_split
     import contextlib, io
@@ -658,15 +661,28 @@ def main():
         reducer.release()
         reducer.active = True
         ref_ms = sorted(ref_ev[i].elapsed_time(ref_ev[i + 1]) for i in range(n_ref))
-        med = torch.tensor([plain[len(plain) // 2] if plain else step_ms[len(step_ms) // 2], ref_ms[len(ref_ms) // 2]],
-                           dtype=torch.float64, device="cuda")
+        # ... and once more with NO bucket hook at all (= the single-GPU headline path on this rank): what the data-parallel
+        # plumbing itself costs (stream waits of the hook, the join before the norm)
+        hook, eng.grad_hook = eng.grad_hook, None
+        nh_ev = [torch.cuda.Event(enable_timing=True) for _ in range(n_ref + 1)]
+        nh_ev[0].record()
+        for it in range(n_ref):
+            step(a.warmup + a.steps + n_ref + it)
+            nh_ev[it + 1].record()
+        fence()
+        eng.grad_hook = hook
+        nh_ms = sorted(nh_ev[i].elapsed_time(nh_ev[i + 1]) for i in range(n_ref))
+        med = torch.tensor([plain[len(plain) // 2] if plain else step_ms[len(step_ms) // 2], ref_ms[len(ref_ms) // 2],
+                            nh_ms[len(nh_ms) // 2]], dtype=torch.float64, device="cuda")
         dist.all_reduce(med, op=dist.ReduceOp.MAX)
-        with_x, without_x = float(med[0].item()), float(med[1].item())
+        with_x, without_x, no_hook = float(med[0].item()), float(med[1].item()), float(med[2].item())
         rccl_info = {"world_size": dist.get_world_size(), "backend": dist.get_backend(), "ranks": ranks,
                      "buckets_per_step": len(eng.buckets), "bytes_per_step": reducer.bytes_per_step,
                      "bucket_dtype": a.bucket_dtype, "reserve_cus": a.reserve_cus,
                      "ms_per_step_p50_with_exchange": round(with_x, 3), "ms_per_step_p50_without_exchange": round(without_x, 3),
                      "allreduce_exposed_ms": round(with_x - without_x, 3),
+                     "ms_per_step_p50_no_hook": round(no_hook, 3), "exchange_minus_no_hook_ms": round(with_x - no_hook, 3),
+                     "hook_stream": "side (main stream never joins per layer)" if eng.hook_on_side else "main (per-layer join)",
                      "note": "exchange = one asynchronous all-reduce per gradient bucket, issued from backward's bucket hook, "
                              "joined before the gradient norm; `without` = the same steps on the same ranks with no collective "
                              "issued (medians of per-step HIP-event times, MAX over ranks)"}

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define MEMHIP_ABI_VERSION 3
+#define MEMHIP_ABI_VERSION 4   /* 4 (round 5): epilogues 6 / 7 carry the stored GELU derivative as FP16 (since round 4), certified-tokenizer entry points */
 
 #define MEMHIP_OK 0
 #define MEMHIP_EINVAL (-1)   /* bad argument (shape / alignment / null) */
@@ -549,6 +549,33 @@ int memhip_nchw_to_padded_nhwc4_f32(const float* x, int B, int C, int H, int W, 
                                     float* out, memhip_stream_t stream);
 int memhip_argmax_rows_f32(const float* logits, int64_t ld, int M, int N, int64_t* ids, float* top2_gap,
                            memhip_stream_t stream);
+
+/* Certified split-precision tokenizer (round 5; replaces the same reference lines: eventvae/vae/vae_model.py:153-158, called
+ * at mem/engine_for_pretraining.py:139-145 in fp32).  The fp16x2 convolutions below produce the logits; a label is ACCEPTED
+ * only where its top-2 gap exceeds kappa x the row's rms (kappa = twice a stated bound on the fp16x2 logit deviation relative
+ * to the row rms: then the fp32 argmax is the same index); every sample that holds a token below the margin is recomputed
+ * on the fp32 path above and its labels are replaced.  Everything is decided on the device (no host synchronisation):
+ *   argmax_rows_f32_ex   argmax_rows_f32 + row_rms (f32 [M], may be NULL) = sqrt(mean_n logit^2); with n_samples (device
+ *                        int32, may be NULL) only the first *n_samples x rows_per_sample rows exist
+ *   tok_flag_samples     list (int32 [B]) = indices of the samples with a token whose gap is not > kappa x rms (ascending),
+ *                        count[0] = their number; stats (int64 [2], may be NULL): += flagged samples, += 1 call
+ *   tok_gather_images_f32  nchw_to_padded_nhwc4_f32 of the samples list[offset + j], j < n_round[0] = clamp(count - offset, 0, R)
+ *                        into slots 0.. of `out` (n_round is written: the dynamic batch of the round)
+ *   conv2d_nhwc_f32_dyn  conv2d_nhwc_f32 on a buffer with capacity B of which only the first *n_active samples are live
+ *                        (the grid covers the capacity; tiles behind the live rows return at once)
+ *   tok_scatter_ids      ids_out[list[offset + j] * tokens_per_sample + t] = ids_in[j * tokens_per_sample + t], j < *n_round */
+int memhip_argmax_rows_f32_ex(const float* logits, int64_t ld, int M, int N, int64_t* ids, float* top2_gap, float* row_rms,
+                              const int32_t* n_samples, int rows_per_sample, memhip_stream_t stream);
+int memhip_tok_flag_samples(const float* top2_gap, const float* row_rms, int B, int tokens_per_sample, float kappa,
+                            int32_t* list, int32_t* count, int64_t* stats, memhip_stream_t stream);
+int memhip_tok_gather_images_f32(const float* x, int C, int H, int W, const float* mean, const float* stdv,
+                                 const int32_t* list, const int32_t* count, int offset, int R, float* out, int32_t* n_round,
+                                 memhip_stream_t stream);
+int memhip_conv2d_nhwc_f32_dyn(const float* in, const float* weight, const float* bias, const float* add, float* out,
+                               int B, int H, int W, int Cin, int Cout, int ksize, int stride, int pad, int relu,
+                               int out_padded, const int32_t* n_active, memhip_stream_t stream);
+int memhip_tok_scatter_ids(const int64_t* ids_in, const int32_t* list, const int32_t* n_round, int offset, int R,
+                           int tokens_per_sample, int64_t* ids_out, memhip_stream_t stream);
 
 /* "fp16 x 2" mode (opt-in, `--tokenizer_impl hip_fp16x2`): every fp32 value travels as two fp16 planes hi = fp16(v),
  * lo = fp16((v - hi) * 2048); a product is three fp16 MFMAs (hi*hi + (hi*lo + lo*hi) / 2048, exact products, fp32

@@ -32,6 +32,7 @@ struct ConvArgsF32 {
   float* out;
   int B, Hp, Wp, Cin, Ho, Wo, Cout, kw, stride, off, K;
   int out_padded, relu;
+  const int* n_active;  // device: samples actually present (<= B), or null = B (certified tokenizer: the count is made on the device)
 };
 
 __global__ __launch_bounds__(kThreads, 2) void conv_gemm_f32_kernel(ConvArgsF32 p) {
@@ -39,7 +40,12 @@ __global__ __launch_bounds__(kThreads, 2) void conv_gemm_f32_kernel(ConvArgsF32 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wr = wave >> 1, wc = wave & 1;
-  const int M = p.B * p.Ho * p.Wo;
+  int nb = p.B;
+  if (p.n_active) {                                  // the grid covers the capacity B; tiles behind the live samples leave at once
+    const int na = *p.n_active;
+    nb = na < nb ? (na > 0 ? na : 0) : nb;
+  }
+  const int M = nb * p.Ho * p.Wo;
   const int nwg = gridDim.x;
   int pid = blockIdx.x;
   {                                                  // XCD-aware bijective remap, n fastest
@@ -48,6 +54,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_gemm_f32_kernel(ConvArgsF32 
   }
   const int ntn = (p.Cout + BN - 1) / BN;
   const int m0 = (pid / ntn) * BM, n0 = (pid % ntn) * BN;
+  if (m0 >= M) return;
 
   // global -> register staging: load j of this thread covers row (wave*4 + j)*8 + lane/8, chunk lane%8 (4 floats)
   long long abase[4], bbase[4];
@@ -200,21 +207,34 @@ __device__ __forceinline__ bool argmax_better(float a, int ai, float b, int bi) 
 }
 
 // ids[m] = argmax_n logits[m, n] (first maximum, NaN wins like torch.argmax), one wave per row
+// (rms, optional: sqrt(mean_n logits[m, n]^2), the scale of the row the certified tokenizer compares the gap with;
+//  rows_dyn, optional device int: only the first min(M, *rows_dyn) rows exist)
 __global__ __launch_bounds__(256) void argmax_rows_f32_kernel(const float* __restrict__ logits, long long ld, int M, int N,
-                                                              long long* __restrict__ ids, float* __restrict__ gap) {
+                                                              long long* __restrict__ ids, float* __restrict__ gap,
+                                                              float* __restrict__ rms, const int* __restrict__ samples_dyn,
+                                                              int rows_per_sample) {
   const int lane = threadIdx.x & 63;
   const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (samples_dyn) {
+    const long long live = (long long)(*samples_dyn) * rows_per_sample;
+    if (m >= live) return;
+  }
   if (m >= M) return;
   float best = -INFINITY, second = -INFINITY;
+  float sq = 0.f;
   int bi = 0x7fffffff;
   for (int n = lane * 4; n < N; n += 256) {
     const float4 v = *reinterpret_cast<const float4*>(logits + (long long)m * ld + n);
     const float f[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
+      sq = fmaf(f[k], f[k], sq);
       if (argmax_better(f[k], n + k, best, bi)) { second = best; best = f[k]; bi = n + k; }
       else if (f[k] > second) second = f[k];
     }
+  }
+  if (rms) {
+    for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
   }
   for (int o = 32; o > 0; o >>= 1) {
     const float ob = __shfl_xor(best, o), os = __shfl_xor(second, o);
@@ -229,14 +249,97 @@ __global__ __launch_bounds__(256) void argmax_rows_f32_kernel(const float* __res
   if (lane == 0) {
     ids[m] = bi;
     if (gap) gap[m] = best - second;
+    if (rms) rms[m] = sqrtf(sq / (float)N);
   }
+}
+
+// ---- certified split-precision tokenizer (mem_amd/vae_model.py, precision "fp16x2"): which samples hold a token whose
+// fp16x2 top-2 gap is NOT above kappa x the row's rms (the proven-safe margin: there the fp32 argmax may differ)?  One
+// workgroup; list = the flagged sample indices in ascending order, count[0] = how many, stats[0] += count, stats[1] += 1.
+// A NaN gap or rms flags its sample (the comparison is written so that NaN fails it).
+__global__ __launch_bounds__(256) void tok_flag_samples_kernel(const float* __restrict__ gap, const float* __restrict__ rms,
+                                                               int B, int hw, float kappa, int* __restrict__ list,
+                                                               int* __restrict__ count, long long* __restrict__ stats) {
+  __shared__ int s_flag[256];
+  __shared__ int s_base;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) s_base = 0;
+  __syncthreads();
+  for (int b0 = 0; b0 < B; b0 += 256) {
+    // every wave decides 64 samples of this group, one sample at a time (hw tokens over the lanes)
+    for (int i = 0; i < 64; ++i) {
+      const int b = b0 + wave * 64 + i;
+      int bad = 0;
+      if (b < B) {
+        for (int t = lane; t < hw; t += 64) {
+          const float g = gap[(long long)b * hw + t], r = rms[(long long)b * hw + t];
+          if (!(g > kappa * r)) bad = 1;
+        }
+      }
+      bad = __any(bad);
+      if (lane == 0) s_flag[wave * 64 + i] = bad;
+    }
+    __syncthreads();
+    // ordered compaction of the group's 256 flags
+    const int f = s_flag[tid];
+    const unsigned long long bal = __ballot(f);
+    __shared__ int s_wcnt[4];
+    if (lane == 0) s_wcnt[wave] = __popcll(bal);
+    __syncthreads();
+    int before = s_base;
+    for (int w = 0; w < wave; ++w) before += s_wcnt[w];
+    if (f) list[before + __popcll(bal & ((1ull << lane) - 1ull))] = b0 + tid;
+    __syncthreads();
+    if (tid == 0) s_base += s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3];
+    __syncthreads();
+  }
+  if (tid == 0) {
+    count[0] = s_base;
+    if (stats) { stats[0] += s_base; stats[1] += 1; }
+  }
+}
+
+// images f32 NCHW [*, C<=4, H, W] -> fp32 padded NHWC4 interior of slot j, for the samples list[off + j], j < min(R, count - off)
+__global__ __launch_bounds__(256) void gather_nchw_to_padded_nhwc4_f32_kernel(const float* __restrict__ x, int C, int H, int W,
+                                                                              const float* __restrict__ mean,
+                                                                              const float* __restrict__ stdv,
+                                                                              const int* __restrict__ list,
+                                                                              const int* __restrict__ count, int off, int R,
+                                                                              float* __restrict__ out, int* __restrict__ n_round) {
+  int live = *count - off;
+  live = live < 0 ? 0 : (live > R ? R : live);
+  if (blockIdx.x == 0 && threadIdx.x == 0) *n_round = live;
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long long)live * H * W) return;
+  const int xw = (int)(i % W);
+  const long long t = i / W;
+  const int y = (int)(t % H), j = (int)(t / H);
+  const int b = list[off + j];
+  float v[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int c = 0; c < C; ++c) {
+    float u = x[(((long long)b * C + c) * H + y) * W + xw];
+    if (mean) u = (u - mean[c]) / stdv[c];
+    v[c] = u;
+  }
+  *reinterpret_cast<float4*>(out + (((long long)j * (H + 2) + y + 1) * (W + 2) + xw + 1) * 4) =
+      make_float4(v[0], v[1], v[2], v[3]);
+}
+
+// ids_out[list[off + j] * hw + t] = ids_in[j * hw + t] for the live slots of the round
+__global__ __launch_bounds__(256) void scatter_ids_kernel(const long long* __restrict__ ids_in, const int* __restrict__ list,
+                                                          const int* __restrict__ n_round, int off, int hw,
+                                                          long long* __restrict__ ids_out) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long long)(*n_round) * hw) return;
+  const int j = (int)(i / hw), t = (int)(i - (long long)j * hw);
+  ids_out[(long long)list[off + j] * hw + t] = ids_in[i];
 }
 
 }  // namespace
 
-extern "C" int memhip_conv2d_nhwc_f32(const float* in, const float* weight, const float* bias, const float* add, float* out,
-                                      int B, int H, int W, int Cin, int Cout, int ksize, int stride, int pad, int relu,
-                                      int out_padded, memhip_stream_t stream) {
+static int conv2d_nhwc_f32_impl(const float* in, const float* weight, const float* bias, const float* add, float* out,
+                                int B, int H, int W, int Cin, int Cout, int ksize, int stride, int pad, int relu,
+                                int out_padded, const int* n_active, memhip_stream_t stream) {
   MEMHIP_REQUIRE(B >= 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "conv2d_f32: bad shape");
   if (B == 0) return MEMHIP_OK;
   MEMHIP_REQUIRE(in && weight && out, "conv2d_f32: null pointer");
@@ -248,7 +351,7 @@ extern "C" int memhip_conv2d_nhwc_f32(const float* in, const float* weight, cons
   p.B = B; p.Hp = H + 2; p.Wp = W + 2; p.Cin = Cin;
   p.Ho = (H + 2 * pad - ksize) / stride + 1; p.Wo = (W + 2 * pad - ksize) / stride + 1;
   p.Cout = Cout; p.kw = ksize; p.stride = stride; p.off = 1 - pad; p.K = ksize * ksize * Cin;
-  p.out_padded = out_padded; p.relu = relu;
+  p.out_padded = out_padded; p.relu = relu; p.n_active = n_active;
   MEMHIP_REQUIRE(p.Ho > 0 && p.Wo > 0, "conv2d_f32: empty output");
   MEMHIP_REQUIRE(p.K % BK == 0, "conv2d_f32: K = %d must be a multiple of %d", p.K, BK);
   const long long M = (long long)B * p.Ho * p.Wo;
@@ -263,6 +366,19 @@ extern "C" int memhip_conv2d_nhwc_f32(const float* in, const float* weight, cons
   }
   hipLaunchKernelGGL(conv_gemm_f32_kernel, dim3(grid), dim3(kThreads), lds, as_stream(stream), p);
   return check_launch("conv2d_nhwc_f32");
+}
+
+extern "C" int memhip_conv2d_nhwc_f32(const float* in, const float* weight, const float* bias, const float* add, float* out,
+                                      int B, int H, int W, int Cin, int Cout, int ksize, int stride, int pad, int relu,
+                                      int out_padded, memhip_stream_t stream) {
+  return conv2d_nhwc_f32_impl(in, weight, bias, add, out, B, H, W, Cin, Cout, ksize, stride, pad, relu, out_padded, nullptr, stream);
+}
+
+extern "C" int memhip_conv2d_nhwc_f32_dyn(const float* in, const float* weight, const float* bias, const float* add, float* out,
+                                          int B, int H, int W, int Cin, int Cout, int ksize, int stride, int pad, int relu,
+                                          int out_padded, const int32_t* n_active, memhip_stream_t stream) {
+  MEMHIP_REQUIRE(n_active, "conv2d_f32_dyn: null n_active");
+  return conv2d_nhwc_f32_impl(in, weight, bias, add, out, B, H, W, Cin, Cout, ksize, stride, pad, relu, out_padded, n_active, stream);
 }
 
 extern "C" int memhip_nchw_to_padded_nhwc4_f32(const float* x, int B, int C, int H, int W, const float* mean,
@@ -282,6 +398,48 @@ extern "C" int memhip_argmax_rows_f32(const float* logits, int64_t ld, int M, in
   if (M == 0) return MEMHIP_OK;
   MEMHIP_REQUIRE(logits && ids, "argmax_rows_f32: null pointer");
   hipLaunchKernelGGL(argmax_rows_f32_kernel, dim3((M + 3) / 4), dim3(256), 0, as_stream(stream), logits, (long long)ld, M, N,
-                     (long long*)ids, top2_gap);
+                     (long long*)ids, top2_gap, (float*)nullptr, (const int*)nullptr, 0);
   return check_launch("argmax_rows_f32");
+}
+
+extern "C" int memhip_argmax_rows_f32_ex(const float* logits, int64_t ld, int M, int N, int64_t* ids, float* top2_gap,
+                                         float* row_rms, const int32_t* n_samples, int rows_per_sample,
+                                         memhip_stream_t stream) {
+  MEMHIP_REQUIRE(M >= 0 && N > 0 && N % 4 == 0 && ld % 4 == 0, "argmax_rows_f32_ex: N and ld must be multiples of 4");
+  MEMHIP_REQUIRE(!n_samples || rows_per_sample > 0, "argmax_rows_f32_ex: rows_per_sample");
+  if (M == 0) return MEMHIP_OK;
+  MEMHIP_REQUIRE(logits && ids, "argmax_rows_f32_ex: null pointer");
+  hipLaunchKernelGGL(argmax_rows_f32_kernel, dim3((M + 3) / 4), dim3(256), 0, as_stream(stream), logits, (long long)ld, M, N,
+                     (long long*)ids, top2_gap, row_rms, (const int*)n_samples, rows_per_sample);
+  return check_launch("argmax_rows_f32_ex");
+}
+
+extern "C" int memhip_tok_flag_samples(const float* top2_gap, const float* row_rms, int B, int tokens_per_sample, float kappa,
+                                       int32_t* list, int32_t* count, int64_t* stats, memhip_stream_t stream) {
+  MEMHIP_REQUIRE(B >= 0 && tokens_per_sample > 0 && kappa >= 0.f, "tok_flag_samples: bad shape");
+  MEMHIP_REQUIRE(top2_gap && row_rms && list && count, "tok_flag_samples: null pointer");
+  hipLaunchKernelGGL(tok_flag_samples_kernel, dim3(1), dim3(256), 0, as_stream(stream), top2_gap, row_rms, B, tokens_per_sample,
+                     kappa, (int*)list, (int*)count, (long long*)stats);
+  return check_launch("tok_flag_samples");
+}
+
+extern "C" int memhip_tok_gather_images_f32(const float* x, int C, int H, int W, const float* mean, const float* stdv,
+                                            const int32_t* list, const int32_t* count, int offset, int R, float* out,
+                                            int32_t* n_round, memhip_stream_t stream) {
+  MEMHIP_REQUIRE(C >= 1 && C <= 4 && H > 0 && W > 0 && offset >= 0 && R > 0, "tok_gather_images_f32: bad shape");
+  MEMHIP_REQUIRE(x && out && list && count && n_round && (!mean == !stdv), "tok_gather_images_f32: null pointer");
+  const long long n = (long long)R * H * W;
+  hipLaunchKernelGGL(gather_nchw_to_padded_nhwc4_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream),
+                     x, C, H, W, mean, stdv, (const int*)list, (const int*)count, offset, R, out, (int*)n_round);
+  return check_launch("tok_gather_images_f32");
+}
+
+extern "C" int memhip_tok_scatter_ids(const int64_t* ids_in, const int32_t* list, const int32_t* n_round, int offset, int R,
+                                      int tokens_per_sample, int64_t* ids_out, memhip_stream_t stream) {
+  MEMHIP_REQUIRE(offset >= 0 && R > 0 && tokens_per_sample > 0, "tok_scatter_ids: bad shape");
+  MEMHIP_REQUIRE(ids_in && list && n_round && ids_out, "tok_scatter_ids: null pointer");
+  const long long n = (long long)R * tokens_per_sample;
+  hipLaunchKernelGGL(scatter_ids_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream),
+                     (const long long*)ids_in, (const int*)list, (const int*)n_round, offset, tokens_per_sample, (long long*)ids_out);
+  return check_launch("tok_scatter_ids");
 }

@@ -133,6 +133,7 @@ constexpr int kGroupM = 8;            // tile rows per group of the tile order
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 __device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
@@ -301,6 +302,18 @@ __global__ __launch_bounds__(kThreads) void gemm_p8_kernel(GemmArgs p, int ntm, 
   const int roffb = (((bi >> 2) * 8 + (bi & 3)) * 128) + (((lane >> 4) ^ key_b((bi >> 2) * 8 + (bi & 3))) << 4);
   const char* rdB[2] = {smem + G::kBOff + wc * 4096 + roffb, smem + G::kBOff + wc * 4096 + (roffb ^ 64)};
 
+#ifdef P8_EXP_MFMA32
+  // timing experiment (WRONG results: the fragments are read for the 16x16x32 layout): the main loop on
+  // v_mfma_f32_32x32x16_bf16 -- half the MFMA issues and half the operand-register reads per FLOP, same LDS reads
+  f32x16 acc32[4][MF / 2];
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int i = 0; i < MF / 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) acc32[q][i][j] = 0.f;
+#define ACC_EL(q, mf, nf, r) acc32[q][(mf) >> 1][((((mf) & 1) * 2 + (nf)) << 2) + (r)]
+#else
   f32x4 acc[4][MF][2];
 #pragma unroll
   for (int q = 0; q < 4; ++q)
@@ -308,6 +321,8 @@ __global__ __launch_bounds__(kThreads) void gemm_p8_kernel(GemmArgs p, int ntm, 
     for (int i = 0; i < MF; ++i)
 #pragma unroll
       for (int j = 0; j < 2; ++j) acc[q][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#define ACC_EL(q, mf, nf, r) acc[q][mf][nf][r]
+#endif
 
   int c_tile = first, c_k = 0;
   bf16x8 a[MF][2], bx[2][2], by[2][2];
@@ -339,9 +354,15 @@ __global__ __launch_bounds__(kThreads) void gemm_p8_kernel(GemmArgs p, int ntm, 
 #define P8_NR_A(h) (void)0
 #define P8_NR_B(d, o, h) (void)0
 #endif
+#ifdef P8_EXP_MFMA32
+#define P8_MFMA_HALF(q, bsrc, kh)                                                                         \
+  _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int mb = 0; mb < MF / 2; ++mb)  \
+      acc32[q][mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bsrc[ks][kh], a[2 * mb + ks][kh], acc32[q][mb], 0, 0, 0)
+#else
 #define P8_MFMA_HALF(q, bsrc, kh)                                                                         \
   _Pragma("unroll") for (int mf = 0; mf < MF; ++mf) _Pragma("unroll") for (int nf = 0; nf < 2; ++nf)      \
       acc[q][mf][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bsrc[nf][kh], a[mf][kh], acc[q][mf][nf], 0, 0, 0)
+#endif
 #define P8_MFMA_PART(q, bsrc, kh, m0, m1)                                                                 \
   _Pragma("unroll") for (int mf = (m0); mf < (m1) && mf < MF; ++mf) _Pragma("unroll") for (int nf = 0; nf < 2; ++nf) \
       acc[q][mf][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bsrc[nf][kh], a[mf][kh], acc[q][mf][nf], 0, 0, 0)
@@ -679,7 +700,7 @@ __global__ __launch_bounds__(kThreads) void gemm_p8_kernel(GemmArgs p, int ntm, 
 #pragma unroll
           for (int nf = 0; nf < 2; ++nf)
 #pragma unroll
-            for (int c = 0; c < 4; ++c) v[nf * 4 + c] = acc[q][mf][nf][c];
+            for (int c = 0; c < 4; ++c) v[nf * 4 + c] = ACC_EL(q, mf, nf, c);
           // the row's loads have landed (and its registers are named here, so nothing reads or reuses them earlier)
           asm volatile("s_waitcnt vmcnt(%3)" : "+v"(xa[slot]), "+v"(xb[slot]), "+v"(rmv[slot]) : "n"(decltype(waitc)::value) : "memory");
           EpiRow<EPI> row;
@@ -765,7 +786,7 @@ __global__ __launch_bounds__(kThreads) void gemm_p8_kernel(GemmArgs p, int ntm, 
 #pragma unroll
           for (int nf = 0; nf < 2; ++nf)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { v0[nf * 4 + r] = acc[i * 2][mf][nf][r]; v1[nf * 4 + r] = acc[i * 2 + 1][mf][nf][r]; }
+            for (int r = 0; r < 4; ++r) { v0[nf * 4 + r] = ACC_EL(i * 2, mf, nf, r); v1[nf * 4 + r] = ACC_EL(i * 2 + 1, mf, nf, r); }
           unsigned o0[4 * NOUT], o1[4 * NOUT];
           if constexpr (kEdge) {                     // rows past M (clamped loads) are computed, never stored, and not summed
             float c0[8] = {0, 0, 0, 0, 0, 0, 0, 0}, c1[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -837,7 +858,7 @@ __global__ __launch_bounds__(kThreads) void gemm_p8_kernel(GemmArgs p, int ntm, 
 #pragma unroll
             for (int nf = 0; nf < 2; ++nf)
 #pragma unroll
-              for (int r = 0; r < 4; ++r) v[nf * 4 + r] = acc[i * 2 + j][mf][nf][r];
+              for (int r = 0; r < 4; ++r) v[nf * 4 + r] = ACC_EL(i * 2 + j, mf, nf, r);
             if (!kEdge || m < p.M) epilogue8<EPI, COPY ? 2 : 0>(p, m, n, v, cs, cols, rows[b][mf]);
             if (!kEdge) __builtin_amdgcn_sched_barrier(0);     // one row at a time (register budget)
           }
@@ -851,7 +872,7 @@ __global__ __launch_bounds__(kThreads) void gemm_p8_kernel(GemmArgs p, int ntm, 
 #pragma unroll
           for (int nf = 0; nf < 2; ++nf)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) acc[q][mf][nf][r] = 0.f;
+            for (int r = 0; r < 4; ++r) ACC_EL(q, mf, nf, r) = 0.f;
       P8_STAMP_AT(2);
 #ifdef P8_STAMP
       ++stamp_tile;

@@ -40,6 +40,7 @@ enum { HA0 = 0, HA1 = 1, HB0 = 2, HB1 = 3 };
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 __device__ __attribute__((aligned(256))) unsigned char g_tnp8_zero[256];   // zero-initialised
 #ifdef P8_STAMP
@@ -166,6 +167,17 @@ __global__ __launch_bounds__(kThreads) void gemm_tn_p8_kernel(const __bf16* __re
 #pragma unroll
   for (int f = 0; f < 2; ++f) boff[f] = lds0 + 2 * kHalf + row0 * 256 + (((wc * 2 + f) ^ r7) << 5) + pp * 8;
 
+#ifdef P8_EXP_MFMA32
+  // timing experiment (WRONG results): the main loop on v_mfma_f32_32x32x16_bf16 (see gemm_p8.hip)
+  f32x16 acc32[4][2];
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) acc32[q][i][j] = 0.f;
+#define TP_ACC_EL(q, nf, kf, r) acc32[q][(nf) >> 1][((((nf) & 1) * 2 + (kf)) << 2) + (r)]
+#else
   f32x4 acc[4][4][2];
 #pragma unroll
   for (int q = 0; q < 4; ++q)
@@ -173,6 +185,8 @@ __global__ __launch_bounds__(kThreads) void gemm_tn_p8_kernel(const __bf16* __re
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int j = 0; j < 2; ++j) acc[q][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#define TP_ACC_EL(q, nf, kf, r) acc[q][nf][kf][r]
+#endif
   bf16x8 a[4][2], bx[2][2], by[2][2];
 
 #define TP_READ_A(half)                                                                                   \
@@ -185,14 +199,23 @@ __global__ __launch_bounds__(kThreads) void gemm_tn_p8_kernel(const __bf16* __re
     dst[kf][0] = tr_pair<(half) * kHalf>(boff[kf] + (boff_));                                             \
     dst[kf][1] = tr_pair<(half) * kHalf + 8192>(boff[kf] + (boff_));                                      \
   }
+#ifdef P8_EXP_MFMA32
+#define TP_MFMA_BODY(q, bsrc)                                                                             \
+    _Pragma("unroll") for (int rh = 0; rh < 2; ++rh) _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)     \
+        _Pragma("unroll") for (int nb = 0; nb < 2; ++nb) acc32[q][nb] =                                   \
+            __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2 * nb + ks][rh], bsrc[ks][rh], acc32[q][nb], 0, 0, 0)
+#else
+#define TP_MFMA_BODY(q, bsrc)                                                                             \
+    _Pragma("unroll") for (int rh = 0; rh < 2; ++rh) _Pragma("unroll") for (int nf = 0; nf < 4; ++nf)     \
+        _Pragma("unroll") for (int kf = 0; kf < 2; ++kf) acc[q][nf][kf] =                                 \
+            __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[nf][rh], bsrc[kf][rh], acc[q][nf][kf], 0, 0, 0)
+#endif
 #define TP_MFMA(q, bsrc)                                                                                  \
   do {                                                                                                    \
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   /* the asm reads are not tracked by the compiler */ \
     __builtin_amdgcn_sched_barrier(0);                                                                    \
     P8_PRIO(1);                                                                        \
-    _Pragma("unroll") for (int rh = 0; rh < 2; ++rh) _Pragma("unroll") for (int nf = 0; nf < 4; ++nf)     \
-        _Pragma("unroll") for (int kf = 0; kf < 2; ++kf) acc[q][nf][kf] =                                 \
-            __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[nf][rh], bsrc[kf][rh], acc[q][nf][kf], 0, 0, 0);    \
+    TP_MFMA_BODY(q, bsrc);                                                                                \
     P8_PRIO(0);                                                                        \
   } while (0)
 #define TP_KTILE(bq0, bq1)                                                                                \
@@ -280,7 +303,7 @@ __global__ __launch_bounds__(kThreads) void gemm_tn_p8_kernel(const __bf16* __re
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int row = (lane >> 4) * 4 + r;
-            wreg[row * 64 + ((j * 32 + kf * 16 + (lane & 15)) ^ (((row >> 2) & 1) << 4))] = acc[i * 2 + j][nf][kf][r];
+            wreg[row * 64 + ((j * 32 + kf * 16 + (lane & 15)) ^ (((row >> 2) & 1) << 4))] = TP_ACC_EL(i * 2 + j, nf, kf, r);
           }
       const int nrow = n0 + i * 128 + wr * 64 + nf * 16;
       if constexpr (WS) {

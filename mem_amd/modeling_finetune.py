@@ -279,14 +279,16 @@ class VisionTransformer(nn.Module):
             # rank that the entrypoint sets): sampler seeds, num_workers = 0 augmentation draws and mask draws on the global
             # CPU generator do not shift it, and the masked form below (the A/B) draws the same uniforms.
             return torch.floor((1.0 - torch.tensor(probs)).view(-1, 1) + self._dp_uniform(2 * eng.depth, B))
-        return torch.floor(keep[1] + self._dp_uniform(2 * eng.depth, B).to(eng.dev)).contiguous()
+        return torch.floor(keep[1] + self._dp_uniform(2 * eng.depth, B, eng.dev)).contiguous()
 
-    def _dp_uniform(self, rows, B):
-        g = getattr(self, "_dp_gen", None)
-        if g is None:
-            g = self._dp_gen = torch.Generator(device="cpu")
-            g.manual_seed(int(torch.initial_seed()) ^ 0x5DEECE66D)
-        return torch.rand((rows, B), generator=g)
+    def _dp_uniform(self, rows, B, device=None):
+        """U[0,1) draws of the model's own generator (utils.DropPathStream: explicit seed, checkpointed state, pinned upload)."""
+        st = getattr(self, "_dp_stream", None)
+        if st is None:
+            from .utils import DropPathStream
+            st = self._dp_stream = DropPathStream()
+        return st.uniform(rows, B, device)
+
 
     def _trunk(self, x, drop_path_masks=None):
         eng = self.engine

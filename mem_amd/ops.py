@@ -111,6 +111,11 @@ declare({
     "memhip_conv2d_nhwc_f32": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
     "memhip_nchw_to_padded_nhwc4_f32": (i32, [vp, i32, i32, i32, i32, vp, vp, vp, vp]),
     "memhip_argmax_rows_f32": (i32, [vp, i64, i32, i32, vp, vp, vp]),
+    "memhip_argmax_rows_f32_ex": (i32, [vp, i64, i32, i32, vp, vp, vp, vp, i32, vp]),
+    "memhip_tok_flag_samples": (i32, [vp, vp, i32, i32, f32, vp, vp, vp, vp]),
+    "memhip_tok_gather_images_f32": (i32, [vp, i32, i32, i32, vp, vp, vp, vp, i32, i32, vp, vp, vp]),
+    "memhip_conv2d_nhwc_f32_dyn": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp]),
+    "memhip_tok_scatter_ids": (i32, [vp, vp, vp, i32, i32, i32, vp, vp]),
     "memhip_grad_norm_workspace": (sz, []),
     "memhip_grad_norm": (i32, [vp, i64, vp, vp, sz, vp]),
     "memhip_adamw": (i32, [vp, vp, vp, vp, i64, vp, f64, f64, f64, f64, f64, i32, vp, f64, vp]),
@@ -159,10 +164,17 @@ def gemv_acc(W, N, K, x, y, x_acc=None, zero=None):
           "gemv_bf16_acc")
 
 
-def conv2d_nhwc(x_pad, weight, bias, out, B, H, W, Cin, Cout, ksize, stride, pad, relu=False, add=None, out_padded=True):
-    """x_pad [B,H+2,W+2,Cin] -> out [B,Ho+2,Wo+2,Cout] interior (or dense [B*Ho*Wo,Cout]); bf16 or fp32 by x_pad.dtype."""
+def conv2d_nhwc(x_pad, weight, bias, out, B, H, W, Cin, Cout, ksize, stride, pad, relu=False, add=None, out_padded=True,
+                n_active=None):
+    """x_pad [B,H+2,W+2,Cin] -> out [B,Ho+2,Wo+2,Cout] interior (or dense [B*Ho*Wo,Cout]); bf16 or fp32 by x_pad.dtype.
+    n_active (fp32 only): device int32 [1], the number of live samples of the capacity B."""
     if x_pad.dtype == torch.float32:
         assert weight.dtype == torch.float32 and out.dtype == torch.float32 and (add is None or add.dtype == torch.float32)
+        if n_active is not None:
+            check(lib.memhip_conv2d_nhwc_f32_dyn(ptr(x_pad), ptr(weight), ptr(bias), ptr(add), ptr(out), B, H, W, Cin, Cout,
+                                                 ksize, stride, pad, int(relu), int(out_padded), ptr(n_active), stream_ptr()),
+                  "conv2d_nhwc_f32_dyn")
+            return
         check(lib.memhip_conv2d_nhwc_f32(ptr(x_pad), ptr(weight), ptr(bias), ptr(add), ptr(out), B, H, W, Cin, Cout, ksize,
                                          stride, pad, int(relu), int(out_padded), stream_ptr()), "conv2d_nhwc_f32")
         return
@@ -180,12 +192,32 @@ def nchw_to_padded_nhwc4(x, out, mean=None, std=None):
           "nchw_to_padded_nhwc4")
 
 
-def argmax_rows(logits, M, N, ids, gap=None):
+def argmax_rows(logits, M, N, ids, gap=None, rms=None, n_samples=None, rows_per_sample=0):
     if logits.dtype == torch.float32:
+        if rms is not None or n_samples is not None:
+            check(lib.memhip_argmax_rows_f32_ex(ptr(logits), logits.stride(0), M, N, ptr(ids), ptr(gap), ptr(rms), ptr(n_samples),
+                                                rows_per_sample, stream_ptr()), "argmax_rows_f32_ex")
+            return
         check(lib.memhip_argmax_rows_f32(ptr(logits), logits.stride(0), M, N, ptr(ids), ptr(gap), stream_ptr()),
               "argmax_rows_f32")
         return
     check(lib.memhip_argmax_rows_bf16(ptr(logits), logits.stride(0), M, N, ptr(ids), stream_ptr()), "argmax_rows_bf16")
+
+
+def tok_flag_samples(gap, rms, B, hw, kappa, lst, count, stats=None):
+    check(lib.memhip_tok_flag_samples(ptr(gap), ptr(rms), B, hw, float(kappa), ptr(lst), ptr(count), ptr(stats), stream_ptr()),
+          "tok_flag_samples")
+
+
+def tok_gather_images(x, mean, std, lst, count, offset, R, out, n_round):
+    _, Cc, H, W = x.shape
+    check(lib.memhip_tok_gather_images_f32(ptr(x), Cc, H, W, ptr(mean), ptr(std), ptr(lst), ptr(count), offset, R, ptr(out),
+                                           ptr(n_round), stream_ptr()), "tok_gather_images_f32")
+
+
+def tok_scatter_ids(ids_in, lst, n_round, offset, R, hw, ids_out):
+    check(lib.memhip_tok_scatter_ids(ptr(ids_in), ptr(lst), ptr(n_round), offset, R, hw, ptr(ids_out), stream_ptr()),
+          "tok_scatter_ids")
 
 
 def embed_bwd(dx, mask_u8, B, L, D, dy, dcls, dmask_token):

@@ -5,7 +5,10 @@ One process per GPU, torch.distributed backend "nccl" (= RCCL over xGMI).  The e
 flat gradient buffer out in reverse-layer order, so each bucket (head, block L-1 ... block 0,
 embedding) is final the moment backward leaves that layer: ``GradReducer`` is the engine's
 ``grad_hook`` and enqueues one asynchronous all-reduce per bucket right there.  RCCL runs them on
-its own stream behind an event on the compute stream, i.e. overlapped with the rest of backward;
+its own stream behind an event on the CURRENT stream of the call -- the engine calls the hook with its
+weight-gradient (side) stream current, after that stream has waited for the main stream's position
+(``ViTEngine._bucket_ready``), so the collective is ordered behind every writer of the bucket while
+the main stream never waits for a weight gradient -- i.e. overlapped with the rest of backward;
 ``finish()`` joins them before the gradient norm / AdamW.  ~30 MB fp32 per ViT-B block: large
 enough for xGMI link bandwidth, small enough to pipeline 14 messages per step.
 Mean semantics (SUM / world) == DDP.  Works on CPU tensors with gloo for the CPU tests.
@@ -61,6 +64,7 @@ class GradReducer:
     def release(self):
         """Drop the CU reservation and forget pending handles (exception / early-return paths of a training loop)."""
         self._reserve(False)
+        self.handles = []
 
     def __del__(self):
         try:

@@ -286,6 +286,12 @@ def save_model(args, epoch, model, model_without_ddp, optimizer, loss_scaler, mo
     output_dir = Path(args.output_dir)
     to_save = {"model": model_without_ddp.state_dict(), "optimizer": optimizer.state_dict(), "epoch": epoch,
                "scaler": loss_scaler.state_dict(), "args": args}
+    # additions to the reference's keys (its loaders index the five above and ignore the rest): the numerics switches the run
+    # was trained with (tokenizer mode, stored GELU derivative, precision), and the state of the model's drop-path generator
+    to_save["numerics"] = getattr(args, "numerics", None)
+    dps = getattr(model_without_ddp, "_dp_stream", None)
+    if dps is not None:
+        to_save["drop_path_rng"] = dps.state()
     save_on_master(to_save, output_dir / ("checkpoint-%s.pth" % str(epoch)))
 
 
@@ -312,6 +318,12 @@ def auto_load_model(args, model, model_without_ddp, optimizer, loss_scaler, mode
             args.start_epoch = epoch + 1
             if "scaler" in checkpoint:
                 loss_scaler.load_state_dict(checkpoint["scaler"])
+            if "drop_path_rng" in checkpoint and hasattr(model_without_ddp, "_dp_stream"):
+                model_without_ddp._dp_stream.load_state(checkpoint["drop_path_rng"])
+            was = checkpoint.get("numerics")
+            now = getattr(args, "numerics", None)
+            if was is not None and now is not None and was != now:
+                print(f"WARNING: checkpoint was trained with numerics {was}, this run uses {now}")
             print("With optim & sched!")
 
 
@@ -488,6 +500,42 @@ def cap_host_threads(limit=4):
     if n < torch.get_num_threads():
         torch.set_num_threads(n)
     return n
+
+
+class DropPathStream:
+    """The model's own stochastic-depth generator (modeling_pretrain / modeling_finetune `_dp_uniform`): a CPU torch.Generator
+    that no other consumer of the global stream shifts.  Seeded EXPLICITLY by the entrypoint (`seed(args.seed + rank)`), lazily
+    from torch's seed of the moment otherwise; `state()` / `load_state()` travel with the checkpoint (utils.save_model /
+    auto_load_model: key "drop_path_rng"), so a resumed run continues the mask stream instead of replaying it from step 0.
+    `uniform(rows, B, device)` uploads through a pinned ring (HostStager): no host-blocking copy on the launch stream."""
+
+    def __init__(self):
+        self.gen = None
+        self._stager = None
+
+    def _g(self):
+        if self.gen is None:
+            self.seed(int(torch.initial_seed()))
+        return self.gen
+
+    def seed(self, seed):
+        self.gen = torch.Generator(device="cpu")
+        self.gen.manual_seed((int(seed) ^ 0x5DEECE66D) & ((1 << 63) - 1))
+
+    def state(self):
+        return self._g().get_state().clone()
+
+    def load_state(self, st):
+        self._g().set_state(torch.as_tensor(st, dtype=torch.uint8).cpu())
+
+    def uniform(self, rows, B, device=None):
+        u = torch.rand((rows, B), generator=self._g())
+        if device is None:
+            return u
+        n = rows * B * 4
+        if self._stager is None or self._stager.host[0].numel() < n:
+            self._stager = HostStager(n, device)
+        return self._stager.put(u.numpy()).view(rows, B)
 
 
 class HostStager:

@@ -82,16 +82,30 @@ class HipTokenizer:
       (mem/engine_for_pretraining.py:140-147).  The ids are integers: the parity bar is EQUALITY with the fp32
       reference (tests/test_tokenizer_gpu.py).
     precision="fp16x2" (csrc/conv_f16x2.hip): every value as two fp16 planes (hi, (v - hi) * 2048), three fp16 MFMAs per
-      product: logits within ~1e-5 of fp32 (fp32 summation-order noise is ~3e-6), ids equal the reference's on the
-      fixtures; ~2x faster than fp32 -- opt-in (`--tokenizer_impl hip_fp16x2`).
+      product: logits within ~3e-5 of fp32 at a logit rms of ~1.8 (fp32 summation-order noise is ~3e-6); ~2x faster than
+      fp32.  CERTIFIED (round 5, `certify=True`, the default of this mode): a label is accepted only where its top-2 gap
+      exceeds CERT_KAPPA x the row's rms -- twice a 4x-padded bound on the measured fp16x2 logit deviation, so the fp32
+      argmax is provably the same index there; every sample holding a token below that margin is recomputed ON THE
+      DEVICE, without a host synchronisation, by the fp32 kernels (an inner fp32 tokenizer with a capacity of
+      `exact_capacity` samples per round, dynamic batch read from device memory) and its labels are replaced.  The ids
+      therefore equal the fp32 mode's BY CONSTRUCTION (tests plant near-ties); `certify=False` is the raw mode.
     precision="bf16" (csrc/conv.hip): bf16 operands, fp32 accumulation; ~6x faster, 97-99 % of the ids agree (the rest
       are near ties) -- an explicit opt-in (`--tokenizer_impl hip_bf16`), never the default."""
 
-    def __init__(self, vae: "DiscreteVAE", max_batch=256, precision="fp32"):
+    # flag a token when gap <= CERT_KAPPA * rms(row).  Measured (tests/test_tokenizer_gpu.py, bench.py `with_tokenizer`):
+    # max |logit_fp16x2 - logit_fp32| <= 1.8e-5 x the row rms on every set tried (3.1e-5 at rms 1.77); the bound used is
+    # 4 x that (7e-5 x rms) and a label can only flip when the gap is below TWICE the deviation bound.
+    CERT_KAPPA = 1.4e-4
+
+    def __init__(self, vae: "DiscreteVAE", max_batch=256, precision="fp32", certify=True, exact_capacity=64):
         from . import ops
         self.ops = ops
         assert precision in ("fp32", "bf16", "fp16x2")
         self.precision = precision
+        self.certify = bool(certify) and precision == "fp16x2"
+        self.exact_capacity = int(exact_capacity)
+        self._vae = vae if self.certify else None
+        self._exact = None
         self.dt = {"fp32": torch.float32, "bf16": torch.bfloat16, "fp16x2": torch.float16}[precision]
         self.planes = 2 if precision == "fp16x2" else 1
         dev = next(vae.parameters()).device
@@ -165,6 +179,16 @@ class HipTokenizer:
         self.logits = torch.empty((B * h * w, self.num_tokens), dtype=lt, device=dev)
         self.ids = torch.empty((B * h * w,), dtype=torch.int64, device=dev)
         self.gap = torch.empty((B * h * w,), dtype=torch.float32, device=dev) if lt == torch.float32 else None
+        if self.certify:
+            self.rms = torch.empty((B * h * w,), dtype=torch.float32, device=dev)
+            self.flag_list = torch.zeros((B,), dtype=torch.int32, device=dev)
+            self.flag_count = torch.zeros((1,), dtype=torch.int32, device=dev)
+            self.n_round = torch.zeros((1,), dtype=torch.int32, device=dev)
+            if not hasattr(self, "cert_stats"):
+                self.cert_stats = torch.zeros((2,), dtype=torch.int64, device=dev)    # [flagged samples, calls] so far
+            R = max(1, min(self.exact_capacity, B))
+            if self._exact is None or self._exact.max_batch < R:
+                self._exact = HipTokenizer(self._vae, max_batch=R, precision="fp32")
 
     @torch.no_grad()
     def get_codebook_indices(self, images):
@@ -226,8 +250,55 @@ class HipTokenizer:
                 _, wp, b, ci, co, k, s, p, _ = L
                 conv(cur, wp, b, self.logits, B, h, w, ci, co, k, s, p, relu=False, out_padded=False)
         M = B * h * w
-        ops.argmax_rows(self.logits, M, self.num_tokens, self.ids, self.gap)
+        if not self.certify:
+            ops.argmax_rows(self.logits, M, self.num_tokens, self.ids, self.gap)
+            return self.ids[:M].view(B, h * w).clone()
+        # ---- certification: margins on the device, flagged samples recomputed in fp32 (no host synchronisation)
+        hw = h * w
+        ops.argmax_rows(self.logits, M, self.num_tokens, self.ids, self.gap, rms=self.rms)
+        ops.tok_flag_samples(self.gap, self.rms, B, hw, self.CERT_KAPPA, self.flag_list, self.flag_count, self.cert_stats)
+        ex = self._exact
+        R = ex.max_batch
+        for off in range(0, B, R):                   # ceil(B / R) rounds cover ANY number of flagged samples
+            ex._forward_dyn(images, self.norm, self.flag_list, self.flag_count, off, self.n_round)
+            ops.tok_scatter_ids(ex.ids, self.flag_list, self.n_round, off, R, hw, self.ids)
         return self.ids[:M].view(B, h * w).clone()
+
+    def _forward_dyn(self, images, norm, lst, count, off, n_round):
+        """fp32 path on the samples lst[off : off + min(capacity, count - off)] of `images` (count on the device): every launch
+        covers the capacity and returns at once behind the live rows; ids of the live slots land in self.ids[: live * hw]."""
+        ops = self.ops
+        assert self.precision == "fp32"
+        R = self.max_batch
+        ops.tok_gather_images(images, norm[0] if norm else None, norm[1] if norm else None, lst, count, off, R, self.x0, n_round)
+        cur, h, w = self.x0, self.H, self.W
+        for L in self.layers:
+            if L[0] == "conv":
+                _, wp, b, ci, co, k, s, p, relu = L
+                ho, wo = (h + 2 * p - k) // s + 1, (w + 2 * p - k) // s + 1
+                out = self.bufs[(ho, wo, co)][0]
+                ops.conv2d_nhwc(cur, wp, b, out, R, h, w, ci, co, k, s, p, relu=relu, n_active=n_round)
+                cur, h, w = out, ho, wo
+            elif L[0] == "res":
+                (w1, b1, ci, co, k1, s1, p1), (w2, b2, _, _, k2, s2, p2), (w3, b3, _, _, k3, s3, p3) = L[1], L[2], L[3]
+                pool = self.bufs[(h, w, co)]
+                t1 = next(t for t in pool if t is not cur)
+                t2 = next(t for t in pool if t is not cur and t is not t1)
+                ops.conv2d_nhwc(cur, w1, b1, t1, R, h, w, ci, co, k1, s1, p1, relu=True, n_active=n_round)
+                ops.conv2d_nhwc(t1, w2, b2, t2, R, h, w, co, co, k2, s2, p2, relu=True, n_active=n_round)
+                ops.conv2d_nhwc(t2, w3, b3, t1, R, h, w, co, co, k3, s3, p3, relu=False, add=cur, n_active=n_round)
+                cur = t1
+            else:
+                _, wp, b, ci, co, k, s, p, _ = L
+                ops.conv2d_nhwc(cur, wp, b, self.logits, R, h, w, ci, co, k, s, p, relu=False, out_padded=False, n_active=n_round)
+        ops.argmax_rows(self.logits, R * h * w, self.num_tokens, self.ids, self.gap, n_samples=n_round, rows_per_sample=h * w)
+
+    def certification_stats(self):
+        """(flagged samples, calls) since construction -- one device->host read; for logs and the bench line."""
+        if not self.certify:
+            return None
+        f, c = self.cert_stats.tolist()
+        return {"flagged_samples": int(f), "calls": int(c), "kappa": self.CERT_KAPPA, "exact_capacity": self._exact.max_batch}
 
     def last_top2_gap(self, B):
         """fp32 mode: best-minus-runner-up logit of every token of the last call (f32 [B, h*w]) -- how far each label

@@ -71,6 +71,7 @@ class ViTEngine:
         self.weights_dirty = True
         self._zero_plans = {}
         self.grad_hook = None            # called as grad_hook(bucket_index) when a bucket's grads are final
+        self.hook_on_side = True         # the hook runs on the weight-gradient stream: no per-layer join (_bucket_ready)
         # Weight-gradient products on a second HIP stream (backward only): every dgrad GEMM has an independent wgrad
         # GEMM beside it (both only read dY), and both are persistent one-workgroup-per-CU launches, so the CUs that a
         # launch leaves idle in its last partial round of tiles (N = 768: 591 tiles on 256 CUs) pick up workgroups of
@@ -716,6 +717,27 @@ class ViTEngine:
         e.record(self._side)
         torch.cuda.current_stream().wait_event(e)
 
+    def _bucket_ready(self, k):
+        """Backward has left layer bucket k: hand it to the reducer (grad_hook).  The bucket's last writers are the main
+        stream (bias / LayerNorm / table gradients, all enqueued by now) AND the side stream (the weight-gradient GEMMs).
+        The MAIN stream never waits here: the side stream waits for the main stream's position and the hook runs with the
+        side stream current, so the collective is ordered behind both while the main stream goes on with the next layer's
+        dgrad chain (round 5; `hook_on_side = False` restores the per-layer join of the two streams, the A/B switch)."""
+        if not self.grad_hook:
+            return
+        if not self._use_side:
+            self.grad_hook(k)
+            return
+        if not self.hook_on_side:
+            self._side_join()
+            self.grad_hook(k)
+            return
+        e = self._event()
+        e.record()
+        with torch.cuda.stream(self._side):
+            self._side.wait_event(e)
+            self.grad_hook(k)
+
     def backward(self, dlogits=None):
         """Gradients of mean-CE (dlogits already in self.logits after forward(labels=...)) or of a
         caller-supplied dlogits (bf16 [Mm,V]) w.r.t. every parameter, into the flat grad buffer."""
@@ -797,9 +819,7 @@ class ViTEngine:
         B, M = c["B"], c["M"]
         D, Hd, T, L = self.D, self.hidden, self.T, self.L
         dx = self.dx
-        if self.grad_hook:
-            self._side_join()
-            self.grad_hook(0)
+        self._bucket_ready(0)
         ops.zero_(self.bias_scr)
         fuse = D <= 1024 and self.fuse_ln_branch
         nk = lambda j: B if plan["n"][j] is None else plan["n"][j]               # noqa: E731  kept samples of branch j
@@ -915,9 +935,7 @@ class ViTEngine:
                 ops.layernorm_bwd(self.dh_small, xin, self.P(pre + "norm1.weight"), a["mean1"], a["rstd1"], dx,
                                   self.G(pre + "norm1.weight"), self.G(pre + "norm1.bias"), M1, D, accumulate=True,
                                   row_idx=ridx(ja))
-            if self.grad_hook:
-                self._side_join()
-                self.grad_hook(self.depth - i)
+            self._bucket_ready(self.depth - i)
         self._backward_embed(c, B, M)
 
     def _backward_trunk(self):
@@ -928,9 +946,7 @@ class ViTEngine:
         D, Hd, T, L = self.D, self.hidden, self.T, self.L
         dp_masks = c["dp"]
         dx = self.dx
-        if self.grad_hook:
-            self._side_join()
-            self.grad_hook(0)
+        self._bucket_ready(0)
         # both ping-pong rows of the proj-bias scratch start clean: block i accumulates into row i&1 and clears the
         # other one, which leaves row (depth-1)&1 dirty for the next backward when depth is odd
         ops.zero_(self.bias_scr)
@@ -1039,9 +1055,7 @@ class ViTEngine:
             else:
                 ops.layernorm_bwd(self.dh_small, xin, self.P(pre + "norm1.weight"), a["mean1"], a["rstd1"], dx,
                                   self.G(pre + "norm1.weight"), self.G(pre + "norm1.bias"), M, D, accumulate=True)
-            if self.grad_hook:
-                self._side_join()
-                self.grad_hook(self.depth - i)
+            self._bucket_ready(self.depth - i)
         self._backward_embed(c, B, M)
 
     def _backward_embed(self, c, B, M):

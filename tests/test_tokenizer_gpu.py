@@ -306,3 +306,82 @@ def test_tokenizer_fp16x2_labels_equal_fp32_on_rasterised_streams():
     n = sum(a.numel() for a in ids32)
     assert n >= 100_000
     assert bad == 0, f"{bad} of {n} labels differ (smallest fp32 top-2 gap of the last batch {gap:.2e})"
+
+
+def test_certified_tokenizer_planted_near_ties():
+    """Round 5: the fp16x2 mode is CERTIFIED -- a label is kept only where its top-2 gap exceeds CERT_KAPPA x the row rms, every
+    sample with a token below that margin is recomputed on the fp32 path on the device.  Near-ties are PLANTED: the upper half
+    of the 512 classes are copies of the lower half with a relative weight perturbation of 1e-5 (independent rounding on both
+    sides of every pair, twin gaps from ~1e-8 to ~1e-4 of the logit scale), so nearly every token sits at a near-tie between a
+    class and its twin.  The certified ids must equal the fp32 mode's on EVERY token; the capacity of the fp32 recompute (8
+    samples per round) is far below the number of flagged samples (every one of 40), so the multi-round path is what runs."""
+    from mem_amd.vae_model import HipTokenizer
+    vae = _vae(64, 512, 2, 64, seed=4)
+    head = vae.encoder[-1]
+    g = torch.Generator(device="cuda").manual_seed(9)
+    with torch.no_grad():
+        head.weight[256:] = head.weight[:256] * (1.0 + 1e-5 * torch.randn(head.weight[:256].shape, generator=g, device="cuda"))
+        head.bias[256:] = head.bias[:256]
+    B = 40
+    img = torch.rand(B, 3, 64, 64, generator=g, device="cuda")
+    t32 = HipTokenizer(vae, max_batch=B)
+    ids32 = t32.get_codebook_indices(img).clone()
+    gap32 = t32.last_top2_gap(B)
+    rms = t32.logits.float().pow(2).mean(1).sqrt().view(B, -1)
+    rel = (gap32 / rms).flatten()
+    assert (rel < 1e-4).float().mean() > 0.9 and rel.min() < 1e-6 and rel.max() > 1e-7, (rel.min(), rel.median(), rel.max())
+    raw = HipTokenizer(vae, max_batch=B, precision="fp16x2", certify=False)
+    n_raw = int((raw.get_codebook_indices(img) != ids32).sum())
+    cert = HipTokenizer(vae, max_batch=B, precision="fp16x2", exact_capacity=8)
+    assert cert._exact.max_batch == 8
+    ids = cert.get_codebook_indices(img)
+    st = cert.certification_stats()
+    print(f"planted near-ties: raw fp16x2 differs from fp32 on {n_raw} of {ids32.numel()} labels; flagged samples {st}")
+    assert torch.equal(ids, ids32)
+    assert st["flagged_samples"] == B and st["calls"] == 1
+    # a second, smaller batch through the same object (stale slots of the earlier rounds must not leak), and a batch of one
+    ids_b = cert.get_codebook_indices(img[5:18])
+    assert torch.equal(ids_b, ids32[5:18])
+    assert torch.equal(cert.get_codebook_indices(img[39:40]), ids32[39:40])
+
+
+def test_certified_tokenizer_margin_and_unflagged_path():
+    """(a) The stated error model: max |logit_fp16x2 - logit_fp32| relative to the row rms, measured on both reference
+    fixtures and on random weights, stays below CERT_KAPPA / 8 (the margin is 2 x a 4 x padded bound).  (b) Samples that are
+    NOT flagged keep their fp16x2 labels and these equal the fp32 ids (the reference fixtures: no token near a tie), with zero
+    samples recomputed; ids == the reference's golden ids."""
+    import os
+    import numpy as np
+    from oracle.vae_ref import BASE_VAE, TINY_VAE, fill_vae_by_name, vae_inputs
+    from mem_amd.vae_model import DiscreteVAE, HipTokenizer
+    gdir = os.path.join(os.path.dirname(__file__), "golden")
+    worst = 0.0
+    for cfg, seed, fix, B in ((TINY_VAE, 0, "vae_tiny.npz", 6), (BASE_VAE, 1, "vae_base.npz", 2)):
+        g = np.load(os.path.join(gdir, fix))
+        m = DiscreteVAE(**cfg).eval()
+        m.load_state_dict(fill_vae_by_name(m.state_dict(), seed=seed))
+        m = m.cuda()
+        img = (vae_inputs(cfg, 6, 11) if cfg is TINY_VAE else vae_inputs(cfg, 2, 12) * (vae_inputs(cfg, 2, 13) < 0.3)).cuda()
+        tok = HipTokenizer(m, max_batch=B, precision="fp16x2")
+        ids = tok.get_codebook_indices(img).cpu().numpy()
+        assert np.array_equal(ids, g["ids"]), fix
+        st = tok.certification_stats()
+        tok32 = HipTokenizer(m, max_batch=B)
+        tok32.get_codebook_indices(img)
+        rms = tok32.logits.pow(2).mean(1, keepdim=True).sqrt()
+        dev = ((tok.logits - tok32.logits).abs() / rms).max().item()
+        relgap = (tok32.last_top2_gap(B).flatten() / rms.flatten()).min().item()
+        print(f"{fix}: max deviation / rms = {dev:.2e}, smallest gap / rms = {relgap:.2e}, stats {st}")
+        worst = max(worst, dev)
+        if relgap > 2 * HipTokenizer.CERT_KAPPA:
+            assert st["flagged_samples"] == 0, st
+    for hidden, tokens, res, size in ((64, 512, 2, 64), (128, 1024, 1, 96)):
+        vae = _vae(hidden, tokens, res, size, seed=2)
+        img = torch.rand(4, 3, size, size, device="cuda")
+        a = HipTokenizer(vae, max_batch=4, precision="fp16x2", certify=False)
+        b = HipTokenizer(vae, max_batch=4)
+        a.get_codebook_indices(img); b.get_codebook_indices(img)
+        rms = b.logits.pow(2).mean(1, keepdim=True).sqrt()
+        worst = max(worst, ((a.logits - b.logits).abs() / rms).max().item())
+    print(f"worst deviation / rms {worst:.2e} vs CERT_KAPPA {HipTokenizer.CERT_KAPPA:.1e}")
+    assert worst * 8 <= HipTokenizer.CERT_KAPPA, worst

@@ -49,4 +49,4 @@ for name, (n, k) in {"gemm_tn_p8 768x3072 (fc2 weight gradient)": (768, 3072), "
                             "launches_before_the_stamp": launches, "at_clock_peak_tflops": round(2500.0 * float(ghz) / 2.4, 1)}
     print(name, out["kernels"][name], flush=True)
 os.makedirs("gpurun_out", exist_ok=True)
-json.dump(out, open("gpurun_out/r04_clock.json", "w"), indent=1)
+json.dump(out, open(os.environ.get("MEMHIP_CLOCK_OUT", "gpurun_out/r05_clock.json"), "w"), indent=1)
