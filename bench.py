@@ -756,9 +756,16 @@ def main():
                 return (time.perf_counter() - t1) / n_tok_steps * 1e3
             tok_step_ms = combined_ms(tok)
             del tok
+            # raw split-precision forward (no certification) beside the certified default: what the margins + the fp32
+            # recompute of the flagged samples cost
+            tok = HipTokenizer(vae, max_batch=B, precision="fp16x2", certify=False)
+            tok_f16x2_raw_ms = _time(lambda: tok.get_codebook_indices(img), 5)
+            raw_bad = sum(int((tok.get_codebook_indices(im) != ids32[name]).sum()) for name, im in label_sets.items())
+            del tok
             tok = HipTokenizer(vae, max_batch=B, precision="fp16x2")
             tok_f16x2_ms = _time(lambda: tok.get_codebook_indices(img), 5)
             tok_f16x2_step_ms = combined_ms(tok)
+            cert0 = tok.certification_stats()
             n_tok = n_bad = 0
             bad_gaps, min_gap = [], float("inf")
             for name, im in label_sets.items():
@@ -772,6 +779,11 @@ def main():
                               "label_mismatch_per_million": round(n_bad / n_tok * 1e6, 2),
                               "fp32_top2_gap_at_mismatches_max": (max(bad_gaps) if bad_gaps else None),
                               "fp32_top2_gap_min_over_all_tokens": min_gap,
+                              "certified": True, "raw_fp16x2_label_mismatches": raw_bad,
+                              "raw_fp16x2_tokenizer_ms": round(tok_f16x2_raw_ms, 3),
+                              "certification": (lambda c1: {"kappa": c1["kappa"], "exact_capacity": c1["exact_capacity"],
+                                                            "flagged_samples_in_label_sets": c1["flagged_samples"] - cert0["flagged_samples"],
+                                                            "samples_in_label_sets": 3 * B})(tok.certification_stats()),
                               "inputs": "2 x %d rasterised synthetic event streams (3 planes, the second mirrored) + %d uniform-random "
                                         "images, 196 tokens each; ids of the fp32 mode are the reference (equal to the reference "
                                         "tokenizer's on the committed fixtures, tests/test_tokenizer_gpu.py)" % (B, B)}

@@ -48,6 +48,11 @@ def _config_file_args(argv):
     return extra + rest
 
 
+def ops_mod():
+    from . import ops
+    return ops
+
+
 def get_args(argv=None):
     p = argparse.ArgumentParser("Pretraining script", add_help=False, allow_abbrev=False)
     p.add_argument("--expweek", type=str, required=True)
@@ -58,10 +63,11 @@ def get_args(argv=None):
     p.add_argument("--discrete_vae_weight_path", type=str)
     p.add_argument("--discrete_vae_type", type=str, default="event")
     p.add_argument("--tokenizer_impl", type=str, default="hip_fp16x2", choices=["hip", "hip_fp16x2", "hip_bf16", "torch"],
-                   help="hip_fp16x2 (default since round 4): two-plane fp16 operands (22 significant bits), three fp16 MFMAs per "
-                        "product, fp32 accumulation: logits within ~3e-5 of the fp32 mode at a spread of 1.8, labels EQUAL to the fp32 "
-                        "mode's on both reference fixtures and on 1.5e5 tokens of rasterised synthetic streams (bench.py: "
-                        "label_mismatch_per_million; tests/test_tokenizer_gpu.py), ~2x faster; hip: the fp32 implicit-GEMM forward "
+                   help="hip_fp16x2 (default): two-plane fp16 operands (22 significant bits), three fp16 MFMAs per product, fp32 "
+                        "accumulation, CERTIFIED since round 5: a label is kept only where its top-2 logit gap exceeds a stated "
+                        "multiple of the fp16x2 error bound; every sample with a token below that margin is recomputed by the fp32 "
+                        "kernels on the device, so the labels equal the fp32 mode's by construction (vae_model.HipTokenizer; "
+                        "tests/test_tokenizer_gpu.py plants near-ties), ~2x faster than fp32; hip: the fp32 implicit-GEMM forward "
                         "(csrc/conv_f32.hip; fp32 operands and accumulation like the reference); hip_bf16: the bf16-operand kernels "
                         "of csrc/conv.hip (~6x faster, 1-3 %% of the labels differ at near ties); torch: the fp32 module on stock "
                         "PyTorch-ROCm convolutions")
@@ -238,6 +244,18 @@ def main(args):
     print("Batch size = %d" % total_batch_size)
     print("Number of training steps = %d" % num_training_steps_per_epoch)
     eng = model.engine                                   # packs parameters into the flat buffers
+    # the model's drop-path generator is seeded from the run seed + rank HERE (not from whatever torch's seed is at the first
+    # draw), and the numerics switches of the run travel with args and the checkpoints (utils.save_model: "numerics")
+    if hasattr(model, "_dp_uniform"):
+        from .utils import DropPathStream
+        model._dp_stream = DropPathStream()
+        model._dp_stream.seed(args.seed + utils.get_rank())
+    args.numerics = {"precision": getattr(args, "precision", "bf16"),
+                     "tokenizer_impl": args.tokenizer_impl if not isinstance(d_vae, torch.nn.Module) else "torch",
+                     "tokenizer_certified": bool(getattr(d_vae, "certify", False)),
+                     "gelu_dg": int(getattr(eng, "epi_gelu", None) == getattr(ops_mod(), "EPI_BIAS_GELU_DG", -1)),
+                     "dp_skip": bool(getattr(eng, "dp_skip", False))}
+    print("numerics:", args.numerics)
     if args.distributed:
         # (parallel.py: reserve_cus > 0 leaves CUs to RCCL's channel kernels while buckets are in flight; no measurement on
         # more than one GPU exists yet, so the default is 0 -- MEMHIP_RESERVE_CUS=16 tries it)

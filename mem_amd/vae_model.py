@@ -97,7 +97,7 @@ class HipTokenizer:
     # 4 x that (7e-5 x rms) and a label can only flip when the gap is below TWICE the deviation bound.
     CERT_KAPPA = 1.4e-4
 
-    def __init__(self, vae: "DiscreteVAE", max_batch=256, precision="fp32", certify=True, exact_capacity=64):
+    def __init__(self, vae: "DiscreteVAE", max_batch=256, precision="fp32", certify=True, exact_capacity=128):
         from . import ops
         self.ops = ops
         assert precision in ("fp32", "bf16", "fp16x2")
