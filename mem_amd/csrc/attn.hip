@@ -596,6 +596,10 @@ int attn_bwd_stream(const void* qkv, int64_t ldqkv, const void* dout, int64_t ld
                     float* stats, const float* table, int window_h, int window_w, int B, int T, int D, int heads,
                     float scale, void* dqkv, int64_t lddqkv, float* dtable, float* dq_bias, float* dv_bias,
                     hipStream_t s);
+// attn_win.hip: long windows 40 / 20 wide in the slot layout (round 5)
+bool attn_win_fits(int T, int window_h, int window_w);
+int attn_fwd_win(const void* qkv, int64_t ldqkv, int B, int T, int D, int heads, const float* table, int window_h, int window_w,
+                 void* out, int64_t ldo, float* lse, hipStream_t s);
 // attn16.hip: the 14 x 14 window (197 tokens) -- key-slot layout, fused backward
 bool attn16_fits(int T, int window_h, int window_w);
 int attn16_fwd(const void* qkv, int64_t ldqkv, int B, int D, int heads, const float* table, void* out, int64_t ldo,
@@ -628,8 +632,13 @@ extern "C" int memhip_attn_fwd(const void* qkv, int64_t ldqkv, int B, int T, int
     return memhip::attn16_fwd(qkv, ldqkv, B, D, heads, table, out, ldo, lse, s);
   const int nkb = (T + 31) / 32;
   const int nrd = (2 * window_h - 1) * (2 * window_w - 1) + 3;
-  if (nkb > 8)
+  if (nkb > 8) {
+    if (opt(OPT_ATTN_WIN) && memhip::attn_win_fits(T, window_h, window_w)) {
+      const int rc = memhip::attn_fwd_win(qkv, ldqkv, B, T, D, heads, table, window_h, window_w, out, ldo, lse, s);
+      if (rc != MEMHIP_EUNSUPPORTED) return rc;
+    }
     return memhip::attn_fwd_stream(qkv, ldqkv, B, T, D, heads, table, window_h, window_w, out, ldo, lse, s);
+  }
   const int spb = pick_spb(B, heads, s);
 #define FWD(N)                                                                                          \
   {                                                                                                     \
