@@ -59,6 +59,45 @@ __device__ __forceinline__ void stage_chunk_win(char* dst, const __bf16* src, lo
 }
 
 struct __attribute__((packed, aligned(4))) F2u { float a, b; };
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+
+// (idioms of attn16.hip) two fp32 values rounded to one packed bf16 pair; c + (low / high half of the pair) in ONE
+// instruction: v_dot2c_f32_bf16 with the selector pair (1, 0) / (0, 1) -- unpack + bias add (the fp32 sum is truncated, not
+// rounded: 1 ulp of fp32, tools/micro/dot2_bf16.hip).  The low selector must live in a register (hipcc encodes 0x3f80 as the
+// inline constant 1.0, which the instruction reads as the HIGH half).
+__device__ __forceinline__ unsigned pk_bf16(float a, float b) {
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{a, b}, bf16x2_t));
+}
+__device__ __forceinline__ unsigned sel_lo_reg() {
+  unsigned v;
+  asm volatile("s_mov_b32 %0, 0x3f80" : "=s"(v));
+  return v;
+}
+__device__ __forceinline__ float add_lo(unsigned pk, float c, unsigned sel_lo) {
+  return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, pk), __builtin_bit_cast(bf16x2_t, sel_lo), c, false);
+}
+__device__ __forceinline__ float add_hi(unsigned pk, float c) {
+  return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, pk), __builtin_bit_cast(bf16x2_t, 0x3F800000u), c, false);
+}
+// transposing column fragment with the block offset as an IMMEDIATE (col_frag_o adds kb * 4096 per read: 32 v_add per chunk)
+struct ColAddr { unsigned a[2][2][2]; };           // absolute LDS addresses of block 0: [ss][db][lo / hi]
+__device__ __forceinline__ ColAddr col_addr(const char* img, const LaneOffs& o) {
+  ColAddr c;
+  const unsigned b = lds_addr_of(img);
+#pragma unroll
+  for (int ss = 0; ss < 2; ++ss)
+#pragma unroll
+    for (int db = 0; db < 2; ++db) { c.a[ss][db][0] = b + o.col[ss][db][0]; c.a[ss][db][1] = b + o.col[ss][db][1]; }
+  return c;
+}
+template <int OFF>
+__device__ __forceinline__ bf16x8 col_frag_i(const ColAddr& c, int ss, int db) {
+  union { struct { s16x4 l, h; } s; bf16x8 v; } u;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(u.s.l) : "v"(c.a[ss][db][0]), "n"(OFF) : "memory");
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(u.s.h) : "v"(c.a[ss][db][1]), "n"(OFF) : "memory");
+  return u.v;
+}
 // two consecutive floats at an ABSOLUTE LDS byte address + compile-time offset (4-byte aligned: ds_read2_b32 base offset0 offset1)
 template <int OFF>
 __device__ __forceinline__ void lds_pair(unsigned base, float& a, float& b) {
@@ -82,11 +121,222 @@ __device__ __forceinline__ void win_setup(float* R, float* Cq, const float* tabl
 }
 
 // ------------------------------------------------------------------------------- forward
-// a wave owns 32 resident queries (token order), the workgroup streams K / V slot chunks; persistent over `nbz`-strided samples
+// Phase A of a chunk: S^T = K_chunk Q^T (lane = resident query, registers = streamed slots), bf16 rounding, + bias (log2 domain),
+// static / ragged masks, the cls key of chunk 0; returns the lane's maximum over the chunk's scores.
 template <int WW>
-__global__ __launch_bounds__(512) void attn_fwd_win_kernel(const __bf16* __restrict__ qkv, long long ldq, int B, int T, int TP,
-                                                           int D, int H, const float* __restrict__ table, int nrd, int Wh,
-                                                           __bf16* __restrict__ out, long long ldo, float* __restrict__ lse) {
+__device__ __forceinline__ void fwd_phase_a(const char* Ks, const LaneOffs& lo, const bf16x8 (&Qf)[4], unsigned base, int rows_left,
+                                            int c, int hh, float bcls, f32x16 (&s)[4], float& cmax_out) {
+  using G = WinGeo<WW>;
+  constexpr int CKB = G::CT / 32;
+  const unsigned sel_lo = sel_lo_reg();
+  // Software pipeline over the four 32-slot blocks: the score MFMAs of block kb + 1 are INTERLEAVED with the vector work of
+  // block kb (one MFMA per ~9 vector instructions: a wave issues in order, so a run of 16 back-to-back MFMAs would hold it for
+  // 512 cycles while the SIMD's vector issue idles -- both waves of a SIMD run this phase at about the same time); the K
+  // fragments and bias words of block kb + 2 are read meanwhile (the bias reads depend on nothing but the lane's base).
+  float bz[2][16];
+  auto bias_issue = [&](int kb) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int s0i = kb * 32 + 8 * g;
+      if (!G::valid(s0i) && !G::valid(s0i + 4)) continue;
+      const auto* p = reinterpret_cast<const __attribute__((address_space(3))) F2u*>(base + 4u * (unsigned)G::imm(s0i));
+#if defined(WIN_EXP) && WIN_EXP == 2     // timing experiment (wrong results): no bias reads
+      (void)p;
+      bz[kb & 1][4 * g] = bz[kb & 1][4 * g + 1] = bz[kb & 1][4 * g + 2] = bz[kb & 1][4 * g + 3] = bcls;
+#else
+      bz[kb & 1][4 * g] = p[0].a; bz[kb & 1][4 * g + 1] = p[0].b; bz[kb & 1][4 * g + 2] = p[1].a; bz[kb & 1][4 * g + 3] = p[1].b;
+#endif
+    }
+  };
+  bf16x8 kf[2][4];
+  auto kread = [&](int kb) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) kf[kb & 1][t] = row_frag_o(Ks, lo, kb, t);
+  };
+  auto chain = [&](int kb) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s[kb][i] = 0.f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) s[kb] = MFMA32(kf[kb & 1][t], Qf[t], s[kb]);
+  };
+  float cmax = -INFINITY;
+  float cls_raw = 0.f;
+  auto process = [&](int kb, auto RAGGED) {
+    if (kb == G::CLS_KB) cls_raw = s[kb][4 * G::CLS_G];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int s0i = kb * 32 + 8 * g;                   // slot of (hh = 0, e = 0); hh = 1: + 4
+      const bool v0 = G::valid(s0i), v1 = G::valid(s0i + 4);
+      if (!v0 && !v1) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s[kb][4 * g + e] = -INFINITY;
+        continue;
+      }
+      const unsigned p0 = pk_bf16(s[kb][4 * g], s[kb][4 * g + 1]), p1 = pk_bf16(s[kb][4 * g + 2], s[kb][4 * g + 3]);
+      float vv[4];
+      vv[0] = add_lo(p0, bz[kb & 1][4 * g], sel_lo);
+      vv[1] = add_hi(p0, bz[kb & 1][4 * g + 1]);
+      vv[2] = add_lo(p1, bz[kb & 1][4 * g + 2], sel_lo);
+      vv[3] = add_hi(p1, bz[kb & 1][4 * g + 3]);
+      const bool rowdead = decltype(RAGGED)::value && G::row(s0i) >= rows_left;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float v = vv[e];
+        if (v0 != v1) v = (hh ? v1 : v0) ? v : -INFINITY;
+        if (rowdead) v = -INFINITY;
+        s[kb][4 * g + e] = v;
+        cmax = fmaxf(cmax, v);
+      }
+    }
+  };
+  auto run = [&](auto RAGGED) {
+    kread(0);
+    kread(1);
+    bias_issue(0);
+    bias_issue(1);
+    chain(0);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int kb = 0; kb < CKB; ++kb) {
+      if (kb + 1 < CKB) chain(kb + 1);
+      process(kb, RAGGED);
+      if (kb + 2 < CKB) {
+        kread(kb + 2);
+        bias_issue(kb + 2);
+      }
+      if (kb + 1 < CKB) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     // one MFMA
+          __builtin_amdgcn_sched_group_barrier(0x002, 9, 0);     // nine vector instructions
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  if (rows_left < G::RPC) run(std::true_type{}); else run(std::false_type{});
+  if (c == 0) {                            // the cls key: slot PAD0 = register (CLS_KB, CLS_G, e = 0) of the hh = 0 lanes
+    const float v = hh == 0 ? bfr(cls_raw) + bcls : -INFINITY;
+    s[G::CLS_KB][4 * G::CLS_G] = v;
+    cmax = fmaxf(cmax, v);
+  }
+  cmax_out = cmax;
+}
+
+// Phase B: running maximum / sum (natural-log domain, exp2 of a packed fma), P = exp(S - m), O += P V.  Per 32-slot block:
+// the exponentials of block kb + 1 are issued behind the PV MFMAs of block kb (the matrix pipe runs under the VALU work).
+template <int WW>
+__device__ __forceinline__ void fwd_phase_b(const char* Vs, const LaneOffs& lo, f32x16 (&s)[4], float cmax, float& m, float& l,
+                                            f32x16 (&o)[2]) {
+  using G = WinGeo<WW>;
+  constexpr int CKB = G::CT / 32;
+  cmax = fmaxf(cmax, __shfl_xor(cmax, 32));
+  const float mn = fmaxf(m, cmax);         // finite from the first chunk on
+  const float alpha = fexp2((m - mn) * kLog2e);
+  const f32x2_t mneg2 = {-mn * kLog2e, -mn * kLog2e}, l2e2 = {kLog2e, kLog2e};
+  f32x2_t sum2 = {0.f, 0.f};
+  m = mn;
+#pragma unroll
+  for (int db = 0; db < 2; ++db)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) o[db][i] *= alpha;
+  const ColAddr vc = col_addr(Vs, lo);
+  auto exps = [&](int kb) {
+#pragma unroll
+    for (int i = 0; i < 16; i += 2) {
+#if defined(WIN_EXP) && WIN_EXP == 1     // timing experiment (wrong results): no exp / fma / add per element
+      const f32x2_t p = {s[kb][i], s[kb][i + 1]};
+#else
+      const f32x2_t a = f32x2_t{s[kb][i], s[kb][i + 1]} * l2e2 + mneg2;
+      const f32x2_t p = {fexp2(a[0]), fexp2(a[1])};
+      sum2 += p;
+#endif
+      s[kb][i] = p[0];
+      s[kb][i + 1] = p[1];
+    }
+  };
+  // V fragments of block kb + 1 are read (transposing LDS reads, asm) BEFORE the exponentials of block kb + 1: the reads'
+  // latency runs under that VALU work instead of in front of the block's MFMAs
+  bf16x8 vf[2][2][2];
+  auto vread = [&](auto KB) {
+    constexpr int kb = decltype(KB)::value;
+#pragma unroll
+    for (int ss = 0; ss < 2; ++ss)
+#pragma unroll
+      for (int db = 0; db < 2; ++db) vf[kb & 1][ss][db] = col_frag_i<kb * 4096>(vc, ss, db);
+  };
+  auto pv = [&](auto KB) {
+    constexpr int kb = decltype(KB)::value;
+    bf16x8 pf[2];
+#pragma unroll
+    for (int ss = 0; ss < 2; ++ss) pf[ss] = acc_frag(s[kb], ss, 1.0f);
+    // the block's own 8 reads are complete; the 8 reads of the next block (issued behind them) may stay in flight
+    // (the fragments are named as operands of the wait: an MFMA that reads them cannot be scheduled above it)
+    if (kb + 1 < CKB)
+      asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(vf[kb & 1][0][0]), "+v"(vf[kb & 1][0][1]), "+v"(vf[kb & 1][1][0]), "+v"(vf[kb & 1][1][1])::"memory");
+    else
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(vf[kb & 1][0][0]), "+v"(vf[kb & 1][0][1]), "+v"(vf[kb & 1][1][0]), "+v"(vf[kb & 1][1][1])::"memory");
+#if defined(WIN_EXP) && WIN_EXP == 3     // timing experiment (wrong results): no PV MFMAs
+    o[0][0] += (float)vf[kb & 1][0][0][0] + (float)vf[kb & 1][1][1][0] + (float)vf[kb & 1][0][1][0] + (float)vf[kb & 1][1][0][0] + (float)pf[0][0] + (float)pf[1][0];
+#else
+#pragma unroll
+    for (int ss = 0; ss < 2; ++ss)
+#pragma unroll
+      for (int db = 0; db < 2; ++db) o[db] = MFMA32(vf[kb & 1][ss][db], pf[ss], o[db]);
+#endif
+  };
+  static_assert(CKB == 4, "four 32-slot blocks per chunk");
+  using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+  using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
+  auto hint = [&]() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);       // one MFMA
+      __builtin_amdgcn_sched_group_barrier(0x002, 10, 0);      // ten vector instructions (two of them exponentials)
+    }
+  };
+  vread(I0{});
+  exps(0);
+  vread(I1{});
+  __builtin_amdgcn_sched_barrier(0);
+  pv(I0{});
+  exps(1);
+  hint();
+  __builtin_amdgcn_sched_barrier(0);
+  vread(I2{});
+  pv(I1{});
+  exps(2);
+  hint();
+  __builtin_amdgcn_sched_barrier(0);
+  vread(I3{});
+  pv(I2{});
+  exps(3);
+  hint();
+  __builtin_amdgcn_sched_barrier(0);
+  pv(I3{});
+  float sum = sum2[0] + sum2[1];
+  sum += __shfl_xor(sum, 32);
+  l = fmaf(l, alpha, sum);
+}
+
+// A wave owns 32 resident queries (token order), the workgroup streams K / V slot chunks and is persistent over the samples
+// b = blockIdx.z, + gridDim.z, ...  Two shapes (NW = waves per workgroup):
+//   NW = 8: one workgroup per CU, K / V chunks double-buffered, one barrier per chunk;
+//   NW = 4: TWO independent workgroups per CU (51.5 KB of LDS each): K and V single-buffered -- K(c+1) is staged while phase B
+//           of chunk c runs, V(c+1) while phase A of chunk c+1 runs, two barriers per chunk.  The two workgroups of a CU are
+//           not synchronised with each other, so on every SIMD one wave's MFMA phases meet the other's VALU phases.
+#ifdef WIN_STAMP
+// diagnostic build (tools/build_variant_fast.sh ... -DWIN_STAMP): waves 0 and 4 of every workgroup accumulate shader cycles
+// (s_memtime) per section of the chunk loop: [0] DMA wait + barrier + staging issue, [1] phase A, [2] phase B, [3] chunks
+__device__ unsigned long long g_win_stamps[1024 * 8];
+#define WIN_T(var) do { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory"); } while (0)
+#else
+#define WIN_T(var) do { } while (0)
+#endif
+template <int WW, int NW>
+__global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_fwd_win_kernel(
+    const __bf16* __restrict__ qkv, long long ldq, int B, int T, int TP, int D, int H, const float* __restrict__ table, int nrd,
+    int Wh, __bf16* __restrict__ out, long long ldo, float* __restrict__ lse) {
   using G = WinGeo<WW>;
   constexpr int CT = G::CT, IMG = CT * 128, CKB = CT / 32;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -98,8 +348,8 @@ __global__ __launch_bounds__(512) void attn_fwd_win_kernel(const __bf16* __restr
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 31, hh = lane >> 5;
   const LaneOffs lo = lane_offs(lane);
-  win_setup<WW>(R, Cq, table, nrd, H, h, Wh, kLog2e, true, nrd - 3);
-  const int qb = blockIdx.x * 8 + wave;
+  win_setup<WW>(R, Cq, table, nrd, H, h, Wh, 1.0f, true, nrd - 3);
+  const int qb = blockIdx.x * NW + wave;
   const bool active = qb * 32 < T;
   const int q = qb * 32 + r;
   const int qc = q < T ? q : T - 1;
@@ -114,8 +364,11 @@ __global__ __launch_bounds__(512) void attn_fwd_win_kernel(const __bf16* __restr
     cstep = 4u * G::RPC * G::P;
   }
   base0 += 16u * hh;
-  const float bcls = table[(long long)(q == 0 ? nrd - 1 : nrd - 2) * H + h] * kLog2e;      // bias towards the cls key
+  const float bcls = table[(long long)(q == 0 ? nrd - 1 : nrd - 2) * H + h];      // bias towards the cls key
   const int nch = (Wh + G::RPC - 1) / G::RPC;
+#ifdef WIN_STAMP
+  unsigned long long st_acc[4] = {0, 0, 0, 0};
+#endif
   for (int b = blockIdx.z; b < B; b += gridDim.z) {
     const __bf16* s0 = qkv + (long long)b * T * ldq + h * HD;
     bf16x8 Qf[4];
@@ -131,132 +384,50 @@ __global__ __launch_bounds__(512) void attn_fwd_win_kernel(const __bf16* __restr
 #pragma unroll
       for (int i = 0; i < 16; ++i) o[db][i] = 0.f;
     for (int c = 0; c < nch; ++c) {
-      const int cur = c & 1;
-      const char* Ks = imgs + cur * 2 * IMG;
-      const char* Vs = Ks + IMG;
-      ATTN_DMA_WAIT();
-      __syncthreads();                         // chunk c landed; chunk c-1 fully consumed
-      if (c + 1 < nch) {
-        stage_chunk_win<WW>(imgs + (cur ^ 1) * 2 * IMG, s0 + D, ldq, c + 1, Wh);
-        stage_chunk_win<WW>(imgs + (cur ^ 1) * 2 * IMG + IMG, s0 + 2 * D, ldq, c + 1, Wh);
-      }
-      if (!active) continue;
       const unsigned base = base0 + (unsigned)c * cstep;
       const int rows_left = Wh - c * G::RPC;   // grid rows of this chunk that exist (wave-uniform)
-      // bias prefetch: the reads of two 32-slot blocks are in flight while the score MFMAs run; block kb + 2 is issued
-      // when block kb has been consumed (the loads depend on nothing but the lane's base)
-      float bz[2][16];
-      auto bias_issue = [&](int kb) {
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int s0i = kb * 32 + 8 * g;
-          if (!G::valid(s0i) && !G::valid(s0i + 4)) continue;
-          const auto* p = reinterpret_cast<const __attribute__((address_space(3))) F2u*>(base + 4u * (unsigned)G::imm(s0i));
-#if defined(WIN_EXP) && WIN_EXP == 2     // timing experiment (wrong results): no bias reads
-          (void)p;
-          bz[kb & 1][4 * g] = bz[kb & 1][4 * g + 1] = bz[kb & 1][4 * g + 2] = bz[kb & 1][4 * g + 3] = bcls;
-#else
-          bz[kb & 1][4 * g] = p[0].a; bz[kb & 1][4 * g + 1] = p[0].b; bz[kb & 1][4 * g + 2] = p[1].a; bz[kb & 1][4 * g + 3] = p[1].b;
-#endif
-        }
-      };
-      bias_issue(0);
-      bias_issue(1);
-      __builtin_amdgcn_sched_barrier(0);
       f32x16 s[CKB];
-#pragma unroll
-      for (int kb = 0; kb < CKB; ++kb) {
-#pragma unroll
-        for (int i = 0; i < 16; ++i) s[kb][i] = 0.f;
-#pragma unroll
-        for (int t = 0; t < 4; ++t) s[kb] = MFMA32(row_frag_o(Ks, lo, kb, t), Qf[t], s[kb]);
-      }
       float cmax = -INFINITY;
-      float cls_raw = s[G::CLS_KB][4 * G::CLS_G];
-      auto scores = [&](auto RAGGED) {
-#pragma unroll
-        for (int kb = 0; kb < CKB; ++kb) {
-#pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            const int s0i = kb * 32 + 8 * g;                   // slot of (hh = 0, e = 0); hh = 1: + 4
-            const bool v0 = G::valid(s0i), v1 = G::valid(s0i + 4);
-            if (!v0 && !v1) {
-#pragma unroll
-              for (int e = 0; e < 4; ++e) s[kb][4 * g + e] = -INFINITY;
-              continue;
-            }
-            bfr2(s[kb], 4 * g);
-            bfr2(s[kb], 4 * g + 2);
-            const bool rowdead = decltype(RAGGED)::value && G::row(s0i) >= rows_left;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              float v = fmaf(s[kb][4 * g + e], kLog2e, bz[kb & 1][4 * g + e]);
-              if (v0 != v1) v = (hh ? v1 : v0) ? v : -INFINITY;
-              if (rowdead) v = -INFINITY;
-              s[kb][4 * g + e] = v;
-              cmax = fmaxf(cmax, v);
-            }
-          }
-          __builtin_amdgcn_sched_barrier(0);
-          if (kb + 2 < CKB) bias_issue(kb + 2);
-          __builtin_amdgcn_sched_barrier(0);
+      if constexpr (NW == 8) {
+        const int cur = c & 1;
+        const char* Ks = imgs + cur * 2 * IMG;
+        const char* Vs = Ks + IMG;
+        unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+        (void)t0; (void)t1; (void)t2; (void)t3;
+        WIN_T(t0);
+#if !(defined(WIN_EXP) && WIN_EXP == 4)   // (4: timing experiment, wrong results: no staging, no barrier in the chunk loop)
+        ATTN_DMA_WAIT();
+        __syncthreads();                         // chunk c landed; chunk c-1 fully consumed
+        if (c + 1 < nch) {
+          stage_chunk_win<WW>(imgs + (cur ^ 1) * 2 * IMG, s0 + D, ldq, c + 1, Wh);
+          stage_chunk_win<WW>(imgs + (cur ^ 1) * 2 * IMG + IMG, s0 + 2 * D, ldq, c + 1, Wh);
         }
-      };
-      if (rows_left < G::RPC) scores(std::true_type{}); else scores(std::false_type{});
-      if (c == 0) {                            // the cls key: slot PAD0 = register (CLS_KB, CLS_G, e = 0) of the hh = 0 lanes
-        const float v = hh == 0 ? fmaf(bfr(cls_raw), kLog2e, bcls) : -INFINITY;
-        s[G::CLS_KB][4 * G::CLS_G] = v;
-        cmax = fmaxf(cmax, v);
-      }
-      cmax = fmaxf(cmax, __shfl_xor(cmax, 32));
-      const float mn = fmaxf(m, cmax);         // finite from the first chunk on
-      const float alpha = fexp2(m - mn);
-      float sum = 0.f;
-#pragma unroll
-      for (int kb = 0; kb < CKB; ++kb)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-#if defined(WIN_EXP) && WIN_EXP == 1     // timing experiment (wrong results): no exp / sub / add per element
-          const float p = s[kb][i];
-#else
-          const float p = fexp2(s[kb][i] - mn);
 #endif
-          s[kb][i] = p;
-#if !(defined(WIN_EXP) && WIN_EXP == 1)
-          sum += p;
+        if (!active) continue;
+        WIN_T(t1);
+        fwd_phase_a<WW>(Ks, lo, Qf, base, rows_left, c, hh, bcls, s, cmax);
+        WIN_T(t2);
+        fwd_phase_b<WW>(Vs, lo, s, cmax, m, l, o);
+        WIN_T(t3);
+#ifdef WIN_STAMP
+        st_acc[0] += t1 - t0; st_acc[1] += t2 - t1; st_acc[2] += t3 - t2; st_acc[3] += 1;
 #endif
-        }
-      sum += __shfl_xor(sum, 32);
-      l = fmaf(l, alpha, sum);
-      m = mn;
-#pragma unroll
-      for (int db = 0; db < 2; ++db)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) o[db][i] *= alpha;
-#pragma unroll
-      for (int kb = 0; kb < CKB; ++kb) {
-        bf16x8 vf[2][2];
-#pragma unroll
-        for (int ss = 0; ss < 2; ++ss)
-#pragma unroll
-          for (int db = 0; db < 2; ++db) vf[ss][db] = col_frag_o(Vs, lo, kb, ss, db);
-        bf16x8 pf[2];
-#pragma unroll
-        for (int ss = 0; ss < 2; ++ss) pf[ss] = acc_frag(s[kb], ss, 1.0f);
-        LDS_TR_WAIT();
-#if defined(WIN_EXP) && WIN_EXP == 3     // timing experiment (wrong results): no PV MFMAs
-        o[0][0] += (float)vf[0][0][0] + (float)vf[1][1][0] + (float)vf[0][1][0] + (float)vf[1][0][0] + (float)pf[0][0] + (float)pf[1][0];
-#else
-#pragma unroll
-        for (int ss = 0; ss < 2; ++ss)
-#pragma unroll
-          for (int db = 0; db < 2; ++db) o[db] = MFMA32(vf[ss][db], pf[ss], o[db]);
-#endif
+      } else {
+        const char* Ks = imgs;
+        const char* Vs = imgs + IMG;
+        ATTN_DMA_WAIT();                         // K(c) (and V(0) of the sample's first chunk)
+        __syncthreads();                         // K(c) visible; everybody is done with V(c-1)
+        if (c > 0) stage_chunk_win<WW>(imgs + IMG, s0 + 2 * D, ldq, c, Wh);          // V(c) lands under phase A
+        if (active) fwd_phase_a<WW>(Ks, lo, Qf, base, rows_left, c, hh, bcls, s, cmax);
+        ATTN_DMA_WAIT();                         // V(c)
+        __syncthreads();                         // V(c) visible; everybody is done with K(c)
+        if (c + 1 < nch) stage_chunk_win<WW>(imgs, s0 + D, ldq, c + 1, Wh);          // K(c+1) lands under phase B
+        if (active) fwd_phase_b<WW>(Vs, lo, s, cmax, m, l, o);
       }
     }
     if (active) {
       const float inv = 1.0f / l;
-      if (hh == 0 && q < T) lse[((long long)b * H + h) * TP + q] = (m + flog2(l)) * kLn2;
+      if (hh == 0 && q < T) lse[((long long)b * H + h) * TP + q] = m + flog2(l) * kLn2;
       if (q < T) {
         __bf16* orow = out + ((long long)b * T + q) * ldo + h * HD;
 #pragma unroll
@@ -271,6 +442,13 @@ __global__ __launch_bounds__(512) void attn_fwd_win_kernel(const __bf16* __restr
       }
     }
   }
+#ifdef WIN_STAMP
+  if (NW == 8 && (wave == 0 || wave == 4) && lane == 0) {
+    const int wg = (int)((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) & 1023;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) g_win_stamps[wg * 8 + (wave >> 2) * 4 + i] = st_acc[i];
+  }
+#endif
 }
 
 template <typename K>
@@ -283,33 +461,39 @@ int set_lds_attr(K kernel, bool* done) {
 }
 
 template <int WW>
-size_t win_lds_fwd(int Wh) {
+size_t win_lds_fwd(int Wh, int nw) {
   using G = WinGeo<WW>;
   const int NB = (2 * Wh - 1) * G::P;
-  return (size_t)(((NB + 3) & ~3) + G::CQ) * 4 + (size_t)4 * G::CT * 128;
+  return (size_t)(((NB + 3) & ~3) + G::CQ) * 4 + (size_t)(nw == 4 ? 2 : 4) * G::CT * 128;
 }
 
-template <int WW>
+template <int WW, int NW>
 int launch_fwd(const void* qkv, int64_t ldqkv, int B, int T, int D, int heads, const float* table, int Wh, void* out,
                int64_t ldo, float* lse, hipStream_t s) {
   const int TP = ((T + 31) / 32) * 32;
   const int nrd = (2 * Wh - 1) * (2 * WW - 1) + 3;
-  const size_t sm = win_lds_fwd<WW>(Wh);
-  if (sm > (size_t)kMaxLds) return MEMHIP_EUNSUPPORTED;
+  const size_t sm = win_lds_fwd<WW>(Wh, NW);
+  if (sm > (size_t)(NW == 4 ? kMaxLds / 2 : kMaxLds)) return MEMHIP_EUNSUPPORTED;
   static bool done = false;
-  if (int rc = set_lds_attr(attn_fwd_win_kernel<WW>, &done)) return rc;
-  const int groups = (TP / 32 + 7) / 8;
+  if (int rc = set_lds_attr(attn_fwd_win_kernel<WW, NW>, &done)) return rc;
+  const int groups = (TP / 32 + NW - 1) / NW;
   // samples per workgroup: the table set-up is paid once per workgroup; keep the grid a few rounds of the chip deep
   int nbz = B;
   const long long per = (long long)groups * heads;
   const int cus = usable_cus(s);
-  while (nbz > 1 && per * nbz > 6LL * cus) nbz = (nbz + 1) / 2;
-  hipLaunchKernelGGL(attn_fwd_win_kernel<WW>, dim3(groups, heads, nbz), dim3(512), sm, s, (const __bf16*)qkv, (long long)ldqkv,
+  while (nbz > 1 && per * nbz > (NW == 4 ? 12LL : 6LL) * cus) nbz = (nbz + 1) / 2;
+  hipLaunchKernelGGL((attn_fwd_win_kernel<WW, NW>), dim3(groups, heads, nbz), dim3(NW * 64), sm, s, (const __bf16*)qkv, (long long)ldqkv,
                      B, T, TP, D, heads, table, nrd, Wh, (__bf16*)out, (long long)ldo, lse);
   return check_launch("attn_fwd(win)");
 }
 
 }  // namespace
+
+#ifdef WIN_STAMP
+extern "C" int memhip_debug_win_stamps(unsigned long long* host_out) {
+  return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_win_stamps), sizeof(unsigned long long) * 1024 * 8) == hipSuccess ? 0 : -1;
+}
+#endif
 
 namespace memhip {
 
@@ -319,8 +503,13 @@ bool attn_win_fits(int T, int window_h, int window_w) {
 
 int attn_fwd_win(const void* qkv, int64_t ldqkv, int B, int T, int D, int heads, const float* table, int window_h, int window_w,
                  void* out, int64_t ldo, float* lse, hipStream_t s) {
-  if (window_w == 40) return launch_fwd<40>(qkv, ldqkv, B, T, D, heads, table, window_h, out, ldo, lse, s);
-  if (window_w == 20) return launch_fwd<20>(qkv, ldqkv, B, T, D, heads, table, window_h, out, ldo, lse, s);
+  const bool w4 = opt(OPT_ATTN_WIN) == 2;      // A/B: 2 = two 4-wave workgroups per CU, single-buffered chunks
+  if (window_w == 40)
+    return w4 ? launch_fwd<40, 4>(qkv, ldqkv, B, T, D, heads, table, window_h, out, ldo, lse, s)
+              : launch_fwd<40, 8>(qkv, ldqkv, B, T, D, heads, table, window_h, out, ldo, lse, s);
+  if (window_w == 20)
+    return w4 ? launch_fwd<20, 4>(qkv, ldqkv, B, T, D, heads, table, window_h, out, ldo, lse, s)
+              : launch_fwd<20, 8>(qkv, ldqkv, B, T, D, heads, table, window_h, out, ldo, lse, s);
   return MEMHIP_EUNSUPPORTED;
 }
 

@@ -8,12 +8,14 @@ from oracle.vit_ref import rel_pos_index
 
 what = sys.argv[1] if len(sys.argv) > 1 else "all"
 do_time = len(sys.argv) > 2
+MODES = tuple(int(x) for x in os.environ.get('WIN_MODES', '0,1,2').split(','))
 
 def setopt(v):
     assert _lib.lib.memhip_set_option(b"attn_win", v) == 0
 
-def tm(f, n=5):
-    f(); torch.cuda.synchronize(); t0 = time.perf_counter()
+def tm(f, n=10):
+    for _ in range(3): f()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(n): f()
     torch.cuda.synchronize(); return (time.perf_counter() - t0) / n * 1e6
 
@@ -28,7 +30,7 @@ def run(B, H, win, seed=0, time_it=False, ref64=False):
     table = torch.randn(nrd, H, generator=g, device="cuda") * 0.5
     dout = torch.randn(B * T, D, generator=g, device="cuda").bfloat16()
     res = {}
-    for mode in (0, 1):
+    for mode in MODES:
         setopt(mode)
         out = torch.zeros(B * T, D, dtype=torch.bfloat16, device="cuda"); lse = torch.zeros(B, H, TP, device="cuda")
         dqkv = torch.full((B * T, 3 * D), 3.0, dtype=torch.bfloat16, device="cuda"); dtable = torch.zeros(nrd, H, device="cuda")
@@ -39,16 +41,17 @@ def run(B, H, win, seed=0, time_it=False, ref64=False):
             ops.attn_bwd(qkv, dout, lse, delta, table, win, B, T, D, H, 0.125, dqkv, dtable, dqb, None)
         torch.cuda.synchronize()
         res[mode] = (out.float(), lse[:, :, :T].clone(), dqkv.float(), dtable.clone(), dqb.clone())
-        if time_it:
+        for rep in range(2 if time_it else 0):
             msg = f"mode {mode}: fwd {tm(lambda: ops.attn_fwd(qkv, B, T, D, H, table, win, out, lse)):.1f} us"
             if what == "all":
                 msg += f"  bwd {tm(lambda: ops.attn_bwd(qkv, dout, lse, delta, table, win, B, T, D, H, 0.125, dqkv, dtable, dqb, None)):.1f} us"
                 msg += f"  bwd(no dtable) {tm(lambda: ops.attn_bwd(qkv, dout, lse, delta, table, win, B, T, D, H, 0.125, dqkv, None, dqb, None)):.1f} us"
             print(msg, flush=True)
     names = ("out", "lse", "dqkv", "dtable", "dq_bias")
-    for n, a, b in list(zip(names, res[0], res[1]))[: (5 if what == "all" else 2)]:
-        d = (a - b).abs().max().item(); rel = ((a - b).norm() / (a.norm() + 1e-30)).item()
-        print(f"B={B} H={H} win={win} {n}: max|old-new| {d:.3e}  rel-L2 {rel:.3e}  max|old| {a.abs().max().item():.3e}  finite {bool(torch.isfinite(b).all())}", flush=True)
+    for mode in MODES[1:]:
+        for n, a, b in list(zip(names, res[0], res[mode]))[: (5 if what == "all" else 2)]:
+            d = (a - b).abs().max().item(); rel = ((a - b).norm() / (a.norm() + 1e-30)).item()
+            print(f"B={B} H={H} win={win} mode {mode} {n}: max|old-new| {d:.3e}  rel-L2 {rel:.3e}  max|old| {a.abs().max().item():.3e}  finite {bool(torch.isfinite(b).all())}", flush=True)
     if ref64:
         q = qkv.view(B, T, 3, H, 64).double()
         qq, kk, vv = q[:, :, 0].permute(0, 2, 1, 3), q[:, :, 1].permute(0, 2, 1, 3), q[:, :, 2].permute(0, 2, 1, 3)
@@ -57,7 +60,7 @@ def run(B, H, win, seed=0, time_it=False, ref64=False):
         p = torch.softmax(s, -1)
         ref = (p.bfloat16().double() @ vv).permute(0, 2, 1, 3).reshape(B * T, D)
         lse_ref = torch.logsumexp(s, -1)
-        for mode in (0, 1):
+        for mode in MODES:
             a = res[mode][0].double()
             print(f"   vs float64 formula, mode {mode}: out rel-L2 {((a - ref).norm() / ref.norm()).item():.3e}  "
                   f"lse max {(res[mode][1].double() - lse_ref).abs().max().item():.3e}", flush=True)
