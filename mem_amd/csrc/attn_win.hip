@@ -451,6 +451,144 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_fwd_win_kernel(
 #endif
 }
 
+// ---- the forward with the two waves of a SIMD HALF A CHUNK APART (round 5).  Section stamps of the kernel above (-DWIN_STAMP,
+// tools/attn_win_stamps.py): a chunk takes ~9 000 cycles of which phase A -- 150 vector instructions, 16 MFMAs -- takes
+// 3 100 (waves 0-3) to 5 250 (waves 4-7): all eight waves leave the chunk's barrier together and issue their 24 K-fragment
+// and bias reads into the same LDS queue, then wait.  Here an INTERVAL is half a chunk; waves 0-3 run phase A of chunk g in
+// interval 2g and phase B in 2g + 1, waves 4-7 one interval later (one extra s_barrier up front), so one wave's LDS-latency
+// phase meets its SIMD partner's exponentials.  The chunks of all samples of the workgroup form one stream (image index
+// 2g = K(g), 2g + 1 = V(g); K and V double-buffered separately): image i + 2 is issued at the top of interval i (its buffer
+// was last read in interval i - 1), s_waitcnt vmcnt(2) -- all but the newest image -- closes every interval.
+template <int WW>
+__global__ __launch_bounds__(512) void attn_fwd_win_stag_kernel(
+    const __bf16* __restrict__ qkv, long long ldq, int B, int T, int TP, int D, int H, const float* __restrict__ table, int nrd,
+    int Wh, __bf16* __restrict__ out, long long ldo, float* __restrict__ lse) {
+  using G = WinGeo<WW>;
+  constexpr int CT = G::CT, IMG = CT * 128, CKB = CT / 32;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int NB = (2 * Wh - 1) * G::P;
+  float* R = reinterpret_cast<float*>(smem);
+  float* Cq = R + ((NB + 3) & ~3);
+  char* imgs = reinterpret_cast<char*>(Cq + G::CQ);        // K0 V0 K1 V1
+  const int h = blockIdx.y;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wr = wave >> 2;
+  const int r = lane & 31, hh = lane >> 5;
+  const LaneOffs lo = lane_offs(lane);
+  win_setup<WW>(R, Cq, table, nrd, H, h, Wh, 1.0f, true, nrd - 3);
+  const int qb = blockIdx.x * 8 + wave;
+  const bool active = qb * 32 < T;
+  const int q = qb * 32 + r;
+  const int qc = q < T ? q : T - 1;
+  unsigned base0, cstep;
+  if (q == 0 || q >= T) {
+    base0 = lds_addr_of(reinterpret_cast<const char*>(Cq));
+    cstep = 0;
+  } else {
+    const int u = q - 1, qy = u / WW, qx = u - qy * WW;
+    base0 = lds_addr_of(reinterpret_cast<const char*>(R)) + 4u * (unsigned)(NB - 1 - (qy + Wh - 1) * G::P - (qx + WW - 1));
+    cstep = 4u * G::RPC * G::P;
+  }
+  base0 += 16u * hh;
+  const float bcls = table[(long long)(q == 0 ? nrd - 1 : nrd - 2) * H + h];
+  const int nch = (Wh + G::RPC - 1) / G::RPC;
+  const int nsamp = ((int)B - (int)blockIdx.z + (int)gridDim.z - 1) / (int)gridDim.z;
+  const int N = nsamp * nch;                   // chunks of this workgroup's stream
+  const int NI = 2 * N;                        // images
+  // image i of the stream -> LDS-DMA (every wave moves its 2 pieces)
+  auto issue = [&](int i) {
+    if (i >= NI) return;
+    const int g = i >> 1, isv = i & 1;
+    const int si = g / nch, c = g - si * nch;
+    const int b = (int)blockIdx.z + si * (int)gridDim.z;
+    const __bf16* src = qkv + (long long)b * T * ldq + h * HD + (isv ? 2 * D : D);
+    stage_chunk_win<WW>(imgs + ((g & 1) * 2 + isv) * IMG, src, ldq, c, Wh);
+  };
+  // closes interval i: images <= i + 1 have landed (issued so far: up to max(3, i + 2), below NI), then the barrier
+  auto close = [&](int i) {
+    int newest = i + 2 > 3 ? i + 2 : 3;
+    newest = newest < NI - 1 ? newest : NI - 1;
+    const int fly = newest - (i + 1);          // images that may stay in flight
+    if (fly >= 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if (fly == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  };
+  __syncthreads();                             // the table is set up
+  issue(0); issue(1); issue(2); issue(3);
+  {
+    const int fly = (NI < 4 ? NI : 4) - 1;     // image 0 has landed
+    if (fly >= 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if (fly == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if (fly == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
+  if (wr) close(0);                            // waves 4-7 sit out interval 0
+  float m = -INFINITY, l = 0.f;
+  f32x16 o[2];
+#pragma unroll
+  for (int db = 0; db < 2; ++db)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) o[db][i] = 0.f;
+  int b = blockIdx.z, c = 0;
+  bf16x8 Qf[4];
+  {
+    const __bf16* s0 = qkv + (long long)b * T * ldq + h * HD;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) Qf[t] = ld16(s0 + (long long)qc * ldq + 16 * t + 8 * hh);
+  }
+  for (int g = 0; g < N; ++g) {
+    const int iA = 2 * g + wr;
+    const char* Ks = imgs + (g & 1) * 2 * IMG;
+    const char* Vs = Ks + IMG;
+    const unsigned base = base0 + (unsigned)c * cstep;
+    const int rows_left = Wh - c * G::RPC;
+    f32x16 s[CKB];
+    float cmax = -INFINITY;
+    // ---- phase A (interval iA)
+    if (iA >= 2) issue(iA + 2);
+    if (active) fwd_phase_a<WW>(Ks, lo, Qf, base, rows_left, c, hh, bcls, s, cmax);
+    close(iA);
+    // ---- phase B (interval iA + 1)
+    issue(iA + 3);
+    if (active) fwd_phase_b<WW>(Vs, lo, s, cmax, m, l, o);
+    close(iA + 1);
+    if (++c == nch) {                          // the sample is complete: normalise, store, next sample's queries
+      if (active) {
+        const float inv = 1.0f / l;
+        if (hh == 0 && q < T) lse[((long long)b * H + h) * TP + q] = m + flog2(l) * kLn2;
+        if (q < T) {
+          __bf16* orow = out + ((long long)b * T + q) * ldo + h * HD;
+#pragma unroll
+          for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int gg = 0; gg < 4; ++gg) {
+              bf16x4 w;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) w[e] = (__bf16)(o[db][4 * gg + e] * inv);
+              *reinterpret_cast<bf16x4*>(orow + db * 32 + 8 * gg + 4 * hh) = w;
+            }
+        }
+      }
+      c = 0;
+      b += gridDim.z;
+      m = -INFINITY; l = 0.f;
+#pragma unroll
+      for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) o[db][i] = 0.f;
+      if (b < B) {
+        const __bf16* s0 = qkv + (long long)b * T * ldq + h * HD;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) Qf[t] = ld16(s0 + (long long)qc * ldq + 16 * t + 8 * hh);
+      }
+    }
+  }
+  if (!wr) __builtin_amdgcn_s_barrier();       // balances the interval waves 4-7 started late
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
 template <typename K>
 int set_lds_attr(K kernel, bool* done) {
   if (!*done) {
@@ -487,6 +625,25 @@ int launch_fwd(const void* qkv, int64_t ldqkv, int B, int T, int D, int heads, c
   return check_launch("attn_fwd(win)");
 }
 
+template <int WW>
+int launch_fwd_stag(const void* qkv, int64_t ldqkv, int B, int T, int D, int heads, const float* table, int Wh, void* out,
+                    int64_t ldo, float* lse, hipStream_t s) {
+  const int TP = ((T + 31) / 32) * 32;
+  const int nrd = (2 * Wh - 1) * (2 * WW - 1) + 3;
+  const size_t sm = win_lds_fwd<WW>(Wh, 8);
+  if (sm > (size_t)kMaxLds) return MEMHIP_EUNSUPPORTED;
+  static bool done = false;
+  if (int rc = set_lds_attr(attn_fwd_win_stag_kernel<WW>, &done)) return rc;
+  const int groups = (TP / 32 + 7) / 8;
+  int nbz = B;
+  const long long per = (long long)groups * heads;
+  const int cus = usable_cus(s);
+  while (nbz > 1 && per * nbz > 6LL * cus) nbz = (nbz + 1) / 2;
+  hipLaunchKernelGGL((attn_fwd_win_stag_kernel<WW>), dim3(groups, heads, nbz), dim3(512), sm, s, (const __bf16*)qkv,
+                     (long long)ldqkv, B, T, TP, D, heads, table, nrd, Wh, (__bf16*)out, (long long)ldo, lse);
+  return check_launch("attn_fwd(win, staggered)");
+}
+
 }  // namespace
 
 #ifdef WIN_STAMP
@@ -503,6 +660,10 @@ bool attn_win_fits(int T, int window_h, int window_w) {
 
 int attn_fwd_win(const void* qkv, int64_t ldqkv, int B, int T, int D, int heads, const float* table, int window_h, int window_w,
                  void* out, int64_t ldo, float* lse, hipStream_t s) {
+  if (opt(OPT_ATTN_WIN) == 3) {                // A/B: 3 = the staggered 8-wave form
+    if (window_w == 40) return launch_fwd_stag<40>(qkv, ldqkv, B, T, D, heads, table, window_h, out, ldo, lse, s);
+    if (window_w == 20) return launch_fwd_stag<20>(qkv, ldqkv, B, T, D, heads, table, window_h, out, ldo, lse, s);
+  }
   const bool w4 = opt(OPT_ATTN_WIN) == 2;      // A/B: 2 = two 4-wave workgroups per CU, single-buffered chunks
   if (window_w == 40)
     return w4 ? launch_fwd<40, 4>(qkv, ldqkv, B, T, D, heads, table, window_h, out, ldo, lse, s)
