@@ -600,6 +600,9 @@ int attn_bwd_stream(const void* qkv, int64_t ldqkv, const void* dout, int64_t ld
 bool attn_win_fits(int T, int window_h, int window_w);
 int attn_fwd_win(const void* qkv, int64_t ldqkv, int B, int T, int D, int heads, const float* table, int window_h, int window_w,
                  void* out, int64_t ldo, float* lse, hipStream_t s);
+int attn_bwd_win(const void* qkv, int64_t ldqkv, const void* dout, int64_t ldo, const float* lse, float* delta, float* stats,
+                 const float* table, int window_h, int window_w, int B, int T, int D, int heads, float scale, void* dqkv,
+                 int64_t lddqkv, float* dtable, float* dq_bias, float* dv_bias, hipStream_t s);
 // attn16.hip: the 14 x 14 window (197 tokens) -- key-slot layout, fused backward
 bool attn16_fits(int T, int window_h, int window_w);
 int attn16_fwd(const void* qkv, int64_t ldqkv, int B, int D, int heads, const float* table, void* out, int64_t ldo,
@@ -712,9 +715,15 @@ extern "C" int memhip_attn_bwd(const void* qkv, int64_t ldqkv, const void* dout,
   const int glen = rel_geom(window_h, window_w).len;
   float* stats = delta + 2LL * B * T * heads;             // per-head bounds, written by the kv kernel for the q kernel
   if (dtable) hipLaunchKernelGGL(attn_stats_zero_kernel, dim3(1), dim3(64), 0, s, stats, 4 * heads);
-  if (nkb > 8)
+  if (nkb > 8) {
+    if (opt(OPT_ATTN_WIN) && memhip::attn_win_fits(T, window_h, window_w)) {
+      const int rc = memhip::attn_bwd_win(qkv, ldqkv, dout, ldo, lse, delta, stats, table, window_h, window_w, B, T, D, heads,
+                                          scale, dqkv, lddqkv, dtable, dq_bias, dv_bias, s);
+      if (rc != MEMHIP_EUNSUPPORTED) return rc;
+    }
     return memhip::attn_bwd_stream(qkv, ldqkv, dout, ldo, lse, delta, stats, table, window_h, window_w, B, T, D, heads,
                                    scale, dqkv, lddqkv, dtable, dq_bias, dv_bias, s);
+  }
 #define BWD(N)                                                                                          \
   {                                                                                                     \
     static bool attr_done = false;                                                                      \

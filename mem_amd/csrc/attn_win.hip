@@ -589,6 +589,439 @@ __global__ __launch_bounds__(512) void attn_fwd_win_stag_kernel(
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
+// ------------------------------------------------------------------------------- backward (dK, dV)
+// A wave owns 32 resident keys (token order; K, V fragments in registers), the workgroup streams Q' / dO chunks in the SLOT
+// layout over queries: lane = key, registers = query slots, bucket(q, k) at Kp(k) + qy P + qx with the table in forward order.
+// Per-query scalars travel by slot as well: -lse log2(e) (= -inf for padding slots: their probabilities are exactly 0, no
+// compare anywhere) and -delta.  Same outputs and rounding points as attn_bwd_kv_stream_kernel.
+template <int WW, bool VB>
+__global__ __launch_bounds__(512) void attn_bwd_kv_win_kernel(
+    const __bf16* __restrict__ qkv, long long ldq, const __bf16* __restrict__ dout, long long ldo,
+    const float* __restrict__ lse, const float* __restrict__ delta, float* __restrict__ stats,
+    const float* __restrict__ table, int nrd, int Wh, __bf16* __restrict__ dqkv, long long lddq,
+    float* __restrict__ dvbias, int B, int T, int TP, int D, int H) {
+  using G = WinGeo<WW>;
+  constexpr int CT = G::CT, IMG = CT * 128, CKB = CT / 32;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int NB = (2 * Wh - 1) * G::P;
+  float* R = reinterpret_cast<float*>(smem);
+  float* Cq = R + ((NB + 3) & ~3);
+  float* nlS = Cq + G::CQ;                                   // [2][CT]  -lse * log2(e) by slot
+  float* ndS = nlS + 2 * CT;                                 // [2][CT]  -delta by slot
+  float* vsum = ndS + 2 * CT;                                // [64]
+  char* imgs = reinterpret_cast<char*>(vsum + HD);
+  const int h = blockIdx.y;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 31, hh = lane >> 5;
+  const LaneOffs lo = lane_offs(lane);
+  win_setup<WW>(R, Cq, table, nrd, H, h, Wh, 1.0f, false, nrd - 2);
+  if (threadIdx.x < HD) vsum[threadIdx.x] = 0.f;
+  const unsigned sel_lo = sel_lo_reg();
+  const int kbg = blockIdx.x * 8 + wave;
+  const bool active = kbg * 32 < T;
+  const int key = kbg * 32 + r;
+  const int kc_tok = key < T ? key : T - 1;
+  unsigned base0, cstep;
+  if (key == 0 || key >= T) {
+    base0 = lds_addr_of(reinterpret_cast<const char*>(Cq));
+    cstep = 0;
+  } else {
+    const int u = key - 1, ky = u / WW, kx = u - ky * WW;
+    base0 = lds_addr_of(reinterpret_cast<const char*>(R)) + 4u * (unsigned)((Wh - 1 - ky) * G::P + (WW - 1 - kx));
+    cstep = 4u * G::RPC * G::P;
+  }
+  base0 += 16u * hh;
+  const float bcls = table[(long long)(key == 0 ? nrd - 1 : nrd - 3) * H + h];       // bias from the cls query
+  const float kmask = key < T ? 1.f : 0.f;
+  const bool kpad = __builtin_amdgcn_readfirstlane(kbg) * 32 + 32 > T;               // this wave holds keys >= T
+  const int nch = (Wh + G::RPC - 1) / G::RPC;
+  float vmax = 0.f, dmax = 0.f, nmax = 0.f;
+  float bsum[VB ? 32 : 1];
+  if (VB) {
+#pragma unroll
+    for (int i = 0; i < (VB ? 32 : 1); ++i) bsum[i] = 0.f;
+  }
+  for (int b = blockIdx.z; b < B; b += gridDim.z) {
+    const __bf16* s0 = qkv + (long long)b * T * ldq + h * HD;
+    const __bf16* d0 = dout + (long long)b * T * ldo + h * HD;
+    bf16x8 Kf[4], Vf[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      Kf[t] = ld16(s0 + (long long)kc_tok * ldq + D + 16 * t + 8 * hh);
+      Vf[t] = ld16(s0 + (long long)kc_tok * ldq + 2 * D + 16 * t + 8 * hh);
+    }
+    if (stats) {
+      float vn = 0.f;
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) vn = fmaf((float)Vf[t][i], (float)Vf[t][i], vn);
+      vn += __shfl_xor(vn, 32);
+      vmax = fmaxf(vmax, vn);
+    }
+    float nln = 0.f, ndn = 0.f;
+    auto load_next = [&](int c) {                            // this thread's slot of chunk c
+      const int t = (int)threadIdx.x;
+      if (t >= CT) return;
+      const int j = t / G::WS, qx = t - j * G::WS, qy = c * G::RPC + j;
+      bool ok = t < G::PAD0 && qx < WW && qy < Wh;
+      int tok = 1 + qy * WW + qx;
+      if (c == 0 && t == G::PAD0) { ok = true; tok = 0; }
+      nln = ok ? -lse[((long long)b * H + h) * TP + tok] * kLog2e : -INFINITY;
+      ndn = ok ? -delta[((long long)b * T + tok) * H + h] : 0.f;
+      if (stats && ok) nmax = fmaxf(nmax, delta[((long long)B * T + (long long)b * T + tok) * H + h]);   // |dO_q|^2
+    };
+    load_next(0);
+    __syncthreads();                                         // the previous sample's last chunk is consumed (and the setup done)
+    stage_chunk_win<WW>(imgs, s0, ldq, 0, Wh);               // Q'
+    stage_chunk_win<WW>(imgs + IMG, d0, ldo, 0, Wh);         // dO
+    f32x16 dVt[2], dKt[2];
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { dVt[db][i] = 0.f; dKt[db][i] = 0.f; }
+    for (int c = 0; c < nch; ++c) {
+      const int cur = c & 1;
+      const char* Qs = imgs + cur * 2 * IMG;
+      const char* dOs = Qs + IMG;
+      if (stats) dmax = fmaxf(dmax, fabsf(ndn));
+      if ((int)threadIdx.x < CT) { nlS[cur * CT + threadIdx.x] = nln; ndS[cur * CT + threadIdx.x] = ndn; }
+      ATTN_DMA_WAIT();
+      __syncthreads();
+      if (c + 1 < nch) {
+        load_next(c + 1);
+        stage_chunk_win<WW>(imgs + (cur ^ 1) * 2 * IMG, s0, ldq, c + 1, Wh);
+        stage_chunk_win<WW>(imgs + (cur ^ 1) * 2 * IMG + IMG, d0, ldo, c + 1, Wh);
+      }
+      if (!active) continue;
+      const unsigned base = base0 + (unsigned)c * cstep;
+      const float* nlC = nlS + cur * CT;
+      const float* ndC = ndS + cur * CT;
+      const ColAddr qa = col_addr(Qs, lo), da = col_addr(dOs, lo);
+      auto block = [&](auto QB) {
+        constexpr int qb = decltype(QB)::value;
+        f32x16 S, dP;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { S[i] = 0.f; dP[i] = 0.f; }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          S = MFMA32(row_frag_o(Qs, lo, qb, t), Kf[t], S);
+          dP = MFMA32(row_frag_o(dOs, lo, qb, t), Vf[t], dP);
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int s0i = qb * 32 + 8 * g;                   // slot of (hh = 0, e = 0); hh = 1: + 4
+          const int ql = s0i + 4 * hh;
+          const float4 lv = *reinterpret_cast<const float4*>(nlC + ql);
+          const float4 dv = *reinterpret_cast<const float4*>(ndC + ql);
+          const float ll[4] = {lv.x, lv.y, lv.z, lv.w}, dd[4] = {dv.x, dv.y, dv.z, dv.w};
+          float bz[4];
+          if (G::valid(s0i) || G::valid(s0i + 4)) {
+            const auto* p = reinterpret_cast<const __attribute__((address_space(3))) F2u*>(base + 4u * (unsigned)G::imm(s0i));
+            bz[0] = p[0].a; bz[1] = p[0].b; bz[2] = p[1].a; bz[3] = p[1].b;
+          } else {
+            bz[0] = bz[1] = bz[2] = bz[3] = 0.f;
+          }
+          if (qb == G::CLS_KB && g == G::CLS_G && c == 0 && hh == 0) bz[0] = bcls;      // the cls query's slot
+          const unsigned s01 = pk_bf16(S[4 * g], S[4 * g + 1]), s23 = pk_bf16(S[4 * g + 2], S[4 * g + 3]);
+          const unsigned d01 = pk_bf16(dP[4 * g], dP[4 * g + 1]), d23 = pk_bf16(dP[4 * g + 2], dP[4 * g + 3]);
+          float sv[4], dq[4];
+          sv[0] = add_lo(s01, bz[0], sel_lo); sv[1] = add_hi(s01, bz[1]); sv[2] = add_lo(s23, bz[2], sel_lo); sv[3] = add_hi(s23, bz[3]);
+          dq[0] = add_lo(d01, dd[0], sel_lo); dq[1] = add_hi(d01, dd[1]); dq[2] = add_lo(d23, dd[2], sel_lo); dq[3] = add_hi(d23, dd[3]);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float p = fexp2(fmaf(sv[e], kLog2e, ll[e]));      // ll = -lse log2(e); -inf for padding slots: p = 0
+            if (kpad) p *= kmask;                             // (wave-uniform: only the wave that holds padding keys)
+            S[4 * g + e] = p;
+            dP[4 * g + e] = p * dq[e];
+          }
+        }
+#pragma unroll
+        for (int ss = 0; ss < 2; ++ss) {
+          bf16x8 cdo[2], cq[2];
+#pragma unroll
+          for (int db = 0; db < 2; ++db) {
+            cdo[db] = col_frag_i<qb * 4096>(da, ss, db);
+            cq[db] = col_frag_i<qb * 4096>(qa, ss, db);
+          }
+          const bf16x8 pf = acc_frag(S, ss, 1.0f), dsf = acc_frag(dP, ss, 1.0f);
+          LDS_TR_WAIT();
+#pragma unroll
+          for (int db = 0; db < 2; ++db) {
+            dVt[db] = MFMA32(cdo[db], pf, dVt[db]);
+            dKt[db] = MFMA32(cq[db], dsf, dKt[db]);
+          }
+        }
+      };
+      static_assert(CKB == 4, "four 32-slot blocks per chunk");
+      block(std::integral_constant<int, 0>{});
+      block(std::integral_constant<int, 1>{});
+      block(std::integral_constant<int, 2>{});
+      block(std::integral_constant<int, 3>{});
+    }
+    if (active) {
+#pragma unroll
+      for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          bf16x4 wv, wk;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { wv[e] = (__bf16)dVt[db][4 * g + e]; wk[e] = (__bf16)dKt[db][4 * g + e]; }
+          if (key < T) {
+            __bf16* drow = dqkv + ((long long)b * T + key) * lddq + h * HD;
+            *reinterpret_cast<bf16x4*>(drow + 2 * D + db * 32 + 8 * g + 4 * hh) = wv;
+            *reinterpret_cast<bf16x4*>(drow + D + db * 32 + 8 * g + 4 * hh) = wk;
+          }
+          if constexpr (VB) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) bsum[db * 16 + 4 * g + e] += (float)wv[e] * kmask;
+          }
+        }
+    }
+  }
+  if (stats) {
+    for (int o = 32; o > 0; o >>= 1) {
+      vmax = fmaxf(vmax, __shfl_xor(vmax, o));
+      dmax = fmaxf(dmax, __shfl_xor(dmax, o));
+      nmax = fmaxf(nmax, __shfl_xor(nmax, o));
+    }
+    if (lane == 0) {
+      atomicMax(reinterpret_cast<int*>(stats) + h * 4 + 0, __float_as_int(nmax));
+      atomicMax(reinterpret_cast<int*>(stats) + h * 4 + 1, __float_as_int(dmax));
+      atomicMax(reinterpret_cast<int*>(stats) + h * 4 + 2, __float_as_int(vmax));
+    }
+  }
+  if (VB) {
+    __syncthreads();
+    if (active) {
+#pragma unroll
+      for (int i = 0; i < 32; ++i) {
+        float v = bsum[i];
+        for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        if (r == 0) atomicAdd(vsum + (i >> 4) * 32 + 8 * ((i >> 2) & 3) + 4 * hh + (i & 3), v);
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x < HD) atomicAdd(dvbias + h * HD + threadIdx.x, vsum[threadIdx.x]);
+  }
+}
+
+// ------------------------------------------------------------------------------- backward (dQ, dBias)
+// A wave owns 32 resident queries (Q', dO fragments, lse, delta in registers), the workgroup streams K / V slot chunks (the
+// forward's orientation: reversed table, bucket at A(q) + ky P + kx) and is persistent over its samples, so the fixed-point
+// gradient buckets -- an integer image of [R | Cq] -- are flushed once.  A bucket collects at most one term per resident
+// query and sample (the bucket index is injective in the key): <= 256 * samples terms of magnitude <= 2^18.
+// The cls KEY column is one static register of chunk 0: its gradient is summed in a lane register.
+template <int WW, bool DT>
+__global__ __launch_bounds__(512) void attn_bwd_q_win_kernel(
+    const __bf16* __restrict__ qkv, long long ldq, const __bf16* __restrict__ dout, long long ldo,
+    const float* __restrict__ lse, const float* __restrict__ delta, const float* __restrict__ stats,
+    const float* __restrict__ table, int nrd, int Wh, __bf16* __restrict__ dqkv, long long lddq,
+    float* __restrict__ dtable, float* __restrict__ dqbias, int B, int T, int TP, int D, int H, float scale) {
+  using G = WinGeo<WW>;
+  constexpr int CT = G::CT, IMG = CT * 128, CKB = CT / 32;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int NB = (2 * Wh - 1) * G::P, NBP = (NB + 3) & ~3;
+  float* R = reinterpret_cast<float*>(smem);
+  float* Cq = R + NBP;
+  int* binsR = reinterpret_cast<int*>(Cq + G::CQ);           // fixed-point buckets: image of [R | Cq]
+  float* qsum = reinterpret_cast<float*>(binsR + NBP + G::CQ);
+  char* imgs = reinterpret_cast<char*>(qsum + HD);
+  const int h = blockIdx.y;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 31, hh = lane >> 5;
+  const LaneOffs lo = lane_offs(lane);
+  win_setup<WW>(R, Cq, table, nrd, H, h, Wh, 1.0f, true, nrd - 3);
+  for (int i = threadIdx.x; i < NBP + G::CQ + HD; i += blockDim.x) binsR[i] = 0;     // buckets, qsum
+  const unsigned sel_lo = sel_lo_reg();
+  const unsigned bins_delta = (unsigned)(NBP + G::CQ) * 4u;
+  const int qb = blockIdx.x * 8 + wave;
+  const bool active = qb * 32 < T;
+  const int q = qb * 32 + r;
+  const int qc = q < T ? q : T - 1;
+  unsigned base0, cstep;
+  if (q == 0 || q >= T) {
+    base0 = lds_addr_of(reinterpret_cast<const char*>(Cq));
+    cstep = 0;
+  } else {
+    const int u = q - 1, qy = u / WW, qx = u - qy * WW;
+    base0 = lds_addr_of(reinterpret_cast<const char*>(R)) + 4u * (unsigned)(NB - 1 - (qy + Wh - 1) * G::P - (qx + WW - 1));
+    cstep = 4u * G::RPC * G::P;
+  }
+  base0 += 16u * hh;
+  const float bcls = table[(long long)(q == 0 ? nrd - 1 : nrd - 2) * H + h];      // bias towards the cls key
+  float fx = 0.f;
+  if (DT) {
+    const float bound = sqrtf(stats[h * 4 + 0]) * sqrtf(stats[h * 4 + 2]) + stats[h * 4 + 1];
+    fx = bound > 0.f ? 262144.0f / bound : 0.f;
+  }
+  float gcls = 0.f;                                          // gradient of the cls-key bucket of this lane's query
+  float bsum[32];
+#pragma unroll
+  for (int i = 0; i < 32; ++i) bsum[i] = 0.f;
+  const float qmask = q < T ? 1.f : 0.f;
+  const bool qpadw = __builtin_amdgcn_readfirstlane(qb) * 32 + 32 > T;            // this wave holds queries >= T
+  const int nch = (Wh + G::RPC - 1) / G::RPC;
+  for (int b = blockIdx.z; b < B; b += gridDim.z) {
+    const long long row = (long long)b * T + qc;
+    const __bf16* s0 = qkv + (long long)b * T * ldq + h * HD;
+    bf16x8 Qf[4], dOf[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      Qf[t] = ld16(qkv + row * ldq + h * HD + 16 * t + 8 * hh);
+      dOf[t] = ld16(dout + row * ldo + h * HD + 16 * t + 8 * hh);
+    }
+    const float nlq = -lse[((long long)b * H + h) * TP + qc] * kLog2e;
+    const float ndq = -delta[row * H + h];
+    __syncthreads();                       // previous sample's last chunk fully consumed (and the setup done)
+    stage_chunk_win<WW>(imgs, s0 + D, ldq, 0, Wh);
+    stage_chunk_win<WW>(imgs + IMG, s0 + 2 * D, ldq, 0, Wh);
+    f32x16 dQt[2];
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) dQt[db][i] = 0.f;
+    for (int c = 0; c < nch; ++c) {
+      const int cur = c & 1;
+      const char* Ks = imgs + cur * 2 * IMG;
+      const char* Vs = Ks + IMG;
+      ATTN_DMA_WAIT();
+      __syncthreads();
+      if (c + 1 < nch) {
+        stage_chunk_win<WW>(imgs + (cur ^ 1) * 2 * IMG, s0 + D, ldq, c + 1, Wh);
+        stage_chunk_win<WW>(imgs + (cur ^ 1) * 2 * IMG + IMG, s0 + 2 * D, ldq, c + 1, Wh);
+      }
+      if (!active) continue;
+      const unsigned base = base0 + (unsigned)c * cstep;
+      const int rows_left = Wh - c * G::RPC;
+      const ColAddr ka = col_addr(Ks, lo);
+      auto block = [&](auto KB, auto RAGGED) {
+        constexpr int kb = decltype(KB)::value;
+        f32x16 St, dPt;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { St[i] = 0.f; dPt[i] = 0.f; }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          St = MFMA32(row_frag_o(Ks, lo, kb, t), Qf[t], St);
+          dPt = MFMA32(row_frag_o(Vs, lo, kb, t), dOf[t], dPt);
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int s0i = kb * 32 + 8 * g;                   // slot of (hh = 0, e = 0); hh = 1: + 4
+          const bool v0 = G::valid(s0i), v1 = G::valid(s0i + 4);
+          const bool clsg = kb == G::CLS_KB && g == G::CLS_G;           // the group that holds the cls key's slot (chunk 0)
+          if (!v0 && !v1 && !clsg) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dPt[4 * g + e] = 0.f;
+            continue;
+          }
+          float bz[4] = {0.f, 0.f, 0.f, 0.f};
+          const unsigned a = base + 4u * (unsigned)G::imm(s0i);
+          if (v0 || v1) {
+            const auto* p = reinterpret_cast<const __attribute__((address_space(3))) F2u*>(a);
+            bz[0] = p[0].a; bz[1] = p[0].b; bz[2] = p[1].a; bz[3] = p[1].b;
+          }
+          if (clsg) bz[0] = bcls;
+          const unsigned s01 = pk_bf16(St[4 * g], St[4 * g + 1]), s23 = pk_bf16(St[4 * g + 2], St[4 * g + 3]);
+          const unsigned d01 = pk_bf16(dPt[4 * g], dPt[4 * g + 1]), d23 = pk_bf16(dPt[4 * g + 2], dPt[4 * g + 3]);
+          float sv[4], dq[4];
+          sv[0] = add_lo(s01, bz[0], sel_lo); sv[1] = add_hi(s01, bz[1]); sv[2] = add_lo(s23, bz[2], sel_lo); sv[3] = add_hi(s23, bz[3]);
+          dq[0] = add_lo(d01, ndq, sel_lo); dq[1] = add_hi(d01, ndq); dq[2] = add_lo(d23, ndq, sel_lo); dq[3] = add_hi(d23, ndq);
+          const bool rowdead = decltype(RAGGED)::value && G::row(s0i) >= rows_left;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float pe = fexp2(fmaf(sv[e], kLog2e, nlq));
+            if (qpadw) pe *= qmask;                          // (wave-uniform: only the wave that holds padding queries)
+            bool live = hh ? v1 : v0;                        // compile-time per half unless the two halves differ
+            if (clsg) live = (e == 0) && (c == 0) && (hh == 0);
+            if (rowdead) live = false;
+            const float ds = live ? pe * dq[e] : 0.f;
+            dPt[4 * g + e] = ds;
+            if (DT) {
+              if (clsg) {
+                if (e == 0) gcls += ds;
+              } else if (v0 || v1) {
+                __hip_atomic_fetch_add(reinterpret_cast<__attribute__((address_space(3))) int*>(a + bins_delta + 4u * e),
+                                       fx_round(ds, fx), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+              }
+            }
+          }
+        }
+        bf16x8 ckf[2][2];
+#pragma unroll
+        for (int ss = 0; ss < 2; ++ss)
+#pragma unroll
+          for (int db = 0; db < 2; ++db) ckf[ss][db] = col_frag_i<kb * 4096>(ka, ss, db);
+        bf16x8 dsf[2];
+#pragma unroll
+        for (int ss = 0; ss < 2; ++ss) dsf[ss] = acc_frag(dPt, ss, 1.0f);
+        LDS_TR_WAIT();
+#pragma unroll
+        for (int ss = 0; ss < 2; ++ss)
+#pragma unroll
+          for (int db = 0; db < 2; ++db) dQt[db] = MFMA32(ckf[ss][db], dsf[ss], dQt[db]);
+      };
+      auto chunk = [&](auto RAGGED) {
+        block(std::integral_constant<int, 0>{}, RAGGED);
+        block(std::integral_constant<int, 1>{}, RAGGED);
+        block(std::integral_constant<int, 2>{}, RAGGED);
+        block(std::integral_constant<int, 3>{}, RAGGED);
+      };
+      static_assert(CKB == 4, "four 32-slot blocks per chunk");
+      if (rows_left < G::RPC) chunk(std::true_type{}); else chunk(std::false_type{});
+    }
+    if (active) {
+#pragma unroll
+      for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          bf16x4 w;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) w[e] = (__bf16)(bfr(dQt[db][4 * g + e]) * scale);
+          if (q < T)
+            *reinterpret_cast<bf16x4*>(dqkv + ((long long)b * T + q) * lddq + h * HD + db * 32 + 8 * g + 4 * hh) = w;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) bsum[db * 16 + 4 * g + e] += (float)w[e] * qmask;   // q_bias gradient
+        }
+    }
+  }
+  __syncthreads();
+  if (DT) {
+    const float inv = fx > 0.f ? 1.0f / fx : 0.f;
+    for (int i = threadIdx.x; i < NB; i += blockDim.x) {
+      const int v = binsR[i];
+      if (v != 0) atomicAdd(dtable + (long long)(NB - 1 - i) * H + h, (float)v * inv);
+    }
+    if (wave == 0) {                                         // the cls ROW: the strip behind the buckets
+      float v = 0.f;
+      for (int i = lane; i < G::CQ; i += 64) v += (float)binsR[NBP + i] * inv;
+      for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+      if (lane == 0 && v != 0.f) atomicAdd(dtable + (long long)(nrd - 3) * H + h, v);
+    }
+    // the cls COLUMN: lane sums (the cls query's own term is the (cls, cls) bucket)
+    if (active) {
+      float colv = (q != 0 && q < T) ? gcls : 0.f;
+      const float both = q == 0 ? gcls : 0.f;
+      colv += __shfl_xor(colv, 32);                         // (only hh = 0 lanes hold terms)
+      for (int o = 16; o > 0; o >>= 1) colv += __shfl_xor(colv, o);
+      if (lane == 0 && colv != 0.f) atomicAdd(dtable + (long long)(nrd - 2) * H + h, colv);
+      if (q == 0 && hh == 0 && both != 0.f) atomicAdd(dtable + (long long)(nrd - 1) * H + h, both);
+    }
+  }
+  if (dqbias) {
+    if (active) {
+#pragma unroll
+      for (int i = 0; i < 32; ++i) {
+        float v = bsum[i];
+        for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        if (r == 0) atomicAdd(qsum + (i >> 4) * 32 + 8 * ((i >> 2) & 3) + 4 * hh + (i & 3), v);
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x < HD) atomicAdd(dqbias + h * HD + threadIdx.x, qsum[threadIdx.x]);
+  }
+}
+
 template <typename K>
 int set_lds_attr(K kernel, bool* done) {
   if (!*done) {
@@ -644,9 +1077,55 @@ int launch_fwd_stag(const void* qkv, int64_t ldqkv, int B, int T, int D, int hea
   return check_launch("attn_fwd(win, staggered)");
 }
 
+template <int WW>
+int launch_bwd(const void* qkv, int64_t ldqkv, const void* dout, int64_t ldo, const float* lse, float* delta, float* stats,
+               const float* table, int Wh, int B, int T, int D, int heads, float scale, void* dqkv, int64_t lddqkv, float* dtable,
+               float* dq_bias, float* dv_bias, hipStream_t s) {
+  using G = WinGeo<WW>;
+  const int TP = ((T + 31) / 32) * 32;
+  const int nrd = (2 * Wh - 1) * (2 * WW - 1) + 3;
+  const int NBP = ((2 * Wh - 1) * G::P + 3) & ~3;
+  const size_t sm_kv = (size_t)(NBP + G::CQ + 4 * G::CT + HD) * 4 + (size_t)4 * G::CT * 128;
+  const size_t sm_q = (size_t)(2 * (NBP + G::CQ) + HD) * 4 + (size_t)4 * G::CT * 128;
+  if (sm_kv > (size_t)kMaxLds || sm_q > (size_t)kMaxLds) return MEMHIP_EUNSUPPORTED;
+  static bool d0 = false, d1 = false, d2 = false, d3 = false;
+  if (int rc = set_lds_attr(attn_bwd_kv_win_kernel<WW, true>, &d0)) return rc;
+  if (int rc = set_lds_attr(attn_bwd_kv_win_kernel<WW, false>, &d1)) return rc;
+  if (int rc = set_lds_attr(attn_bwd_q_win_kernel<WW, true>, &d2)) return rc;
+  if (int rc = set_lds_attr(attn_bwd_q_win_kernel<WW, false>, &d3)) return rc;
+  const int groups = (TP / 32 + 7) / 8;
+  int nbz = B;
+  const long long per = (long long)groups * heads;
+  const int cus = usable_cus(s);
+  while (nbz > 1 && per * nbz > 6LL * cus) nbz = (nbz + 1) / 2;
+  const dim3 grid(groups, heads, nbz);
+  if (dv_bias)
+    hipLaunchKernelGGL((attn_bwd_kv_win_kernel<WW, true>), grid, dim3(512), sm_kv, s, (const __bf16*)qkv, (long long)ldqkv,
+                       (const __bf16*)dout, (long long)ldo, lse, delta, dtable ? stats : (float*)nullptr, table, nrd, Wh,
+                       (__bf16*)dqkv, (long long)lddqkv, dv_bias, B, T, TP, D, heads);
+  else
+    hipLaunchKernelGGL((attn_bwd_kv_win_kernel<WW, false>), grid, dim3(512), sm_kv, s, (const __bf16*)qkv, (long long)ldqkv,
+                       (const __bf16*)dout, (long long)ldo, lse, delta, dtable ? stats : (float*)nullptr, table, nrd, Wh,
+                       (__bf16*)dqkv, (long long)lddqkv, dv_bias, B, T, TP, D, heads);
+  // the dQ kernel is persistent over at most 16 samples per workgroup (the fixed-point bound of the buckets)
+  int nbq = nbz;
+  while ((B + nbq - 1) / nbq > 16) ++nbq;
+  const dim3 gq(groups, heads, nbq);
+  if (dtable)
+    hipLaunchKernelGGL((attn_bwd_q_win_kernel<WW, true>), gq, dim3(512), sm_q, s, (const __bf16*)qkv, (long long)ldqkv,
+                       (const __bf16*)dout, (long long)ldo, lse, delta, stats, table, nrd, Wh, (__bf16*)dqkv, (long long)lddqkv,
+                       dtable, dq_bias, B, T, TP, D, heads, scale);
+  else
+    hipLaunchKernelGGL((attn_bwd_q_win_kernel<WW, false>), gq, dim3(512), sm_q, s, (const __bf16*)qkv, (long long)ldqkv,
+                       (const __bf16*)dout, (long long)ldo, lse, delta, stats, table, nrd, Wh, (__bf16*)dqkv, (long long)lddqkv,
+                       dtable, dq_bias, B, T, TP, D, heads, scale);
+  return check_launch("attn_bwd(win)");
+}
+
 }  // namespace
 
 #ifdef WIN_STAMP
+
 extern "C" int memhip_debug_win_stamps(unsigned long long* host_out) {
   return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_win_stamps), sizeof(unsigned long long) * 1024 * 8) == hipSuccess ? 0 : -1;
 }
@@ -671,6 +1150,19 @@ int attn_fwd_win(const void* qkv, int64_t ldqkv, int B, int T, int D, int heads,
   if (window_w == 20)
     return w4 ? launch_fwd<20, 4>(qkv, ldqkv, B, T, D, heads, table, window_h, out, ldo, lse, s)
               : launch_fwd<20, 8>(qkv, ldqkv, B, T, D, heads, table, window_h, out, ldo, lse, s);
+  return MEMHIP_EUNSUPPORTED;
+}
+
+
+int attn_bwd_win(const void* qkv, int64_t ldqkv, const void* dout, int64_t ldo, const float* lse, float* delta, float* stats,
+                 const float* table, int window_h, int window_w, int B, int T, int D, int heads, float scale, void* dqkv,
+                 int64_t lddqkv, float* dtable, float* dq_bias, float* dv_bias, hipStream_t s) {
+  if (window_w == 40)
+    return launch_bwd<40>(qkv, ldqkv, dout, ldo, lse, delta, stats, table, window_h, B, T, D, heads, scale, dqkv, lddqkv, dtable,
+                          dq_bias, dv_bias, s);
+  if (window_w == 20)
+    return launch_bwd<20>(qkv, ldqkv, dout, ldo, lse, delta, stats, table, window_h, B, T, D, heads, scale, dqkv, lddqkv, dtable,
+                          dq_bias, dv_bias, s);
   return MEMHIP_EUNSUPPORTED;
 }
 

@@ -158,3 +158,47 @@ def test_gemm_p8_residual_epilogue_counted_waits(tmp_path):
     for r, (issued, n) in enumerate(waits):
         assert row_last_load[r] <= issued - n, (r, row_last_load[r], issued, n)     # row r's loads are not among the n youngest
         assert n <= 10
+
+
+def test_asm_lds_dma_owns_its_m0(tmp_path):
+    """The kernels issue LDS-DMA (`global_load_lds_dwordx4`) from inline asm that writes the destination into M0 itself
+    (`s_mov_b32 m0, <sgpr>; s_nop 0; global_load_lds ...`, "m0" on the clobber list) next to compiler-issued LDS-DMA through the
+    builtin, for which hipcc manages M0 on its own.  The two must never be interleaved: on the compiler's output, every LDS-DMA
+    instruction must be preceded -- within a few instructions and with no other M0 write, no other LDS-DMA and no branch target
+    in between -- by exactly one write of M0."""
+    import re, shutil, subprocess
+    from concurrent.futures import ThreadPoolExecutor
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        import pytest
+        pytest.skip("no hipcc")
+    files = ["gemm_p8.hip", "gemm_tn_p8.hip", "attn16.hip", "attn.hip", "attn_stream.hip", "attn_win.hip"]
+
+    def build(f):
+        out = str(tmp_path / (f + ".s"))
+        subprocess.run([hipcc, "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-fno-fast-math", "-w", "-S",
+                        "--cuda-device-only", "-o", out, os.path.join(ROOT, "mem_amd", "csrc", f)], check=True, capture_output=True)
+        return out
+    with ThreadPoolExecutor(max_workers=6) as ex:
+        outs = list(ex.map(build, files))
+    total = 0
+    for f, out in zip(files, outs):
+        lines = [l for l in open(out).read().split("\n")]
+        code = [(i, l.strip()) for i, l in enumerate(lines) if l.startswith("\t") and not l.strip().startswith((";", "."))
+                or re.match(r"^\.LBB\d+_\d+:", l)]
+        for k, (i, l) in enumerate(code):
+            if not re.match(r"(global_load_lds_|buffer_load_.*\blds\b)", l):
+                continue
+            total += 1
+            # walk back to the M0 write that feeds this instruction
+            j, found = k - 1, None
+            while j >= 0 and k - j <= 8:
+                prev = code[j][1]
+                assert not re.match(r"^\.LBB", prev), (f, i, "a branch target between the m0 write and its LDS-DMA")
+                assert not re.match(r"(global_load_lds_|buffer_load_.*\blds\b)", prev), (f, i, "two LDS-DMA behind one m0 write")
+                if re.match(r"s_\w+\s+m0\b", prev):
+                    found = j
+                    break
+                j -= 1
+            assert found is not None, (f, i, l, "no m0 write within 8 instructions in front of the LDS-DMA")
+    assert total >= 100, total
