@@ -151,9 +151,49 @@ def _attn_ref(qkv, bias, B, T, D, H, scale):
                                        (1, 256, 2, (15, 17)), (40, 37, 3, (4, 9)),
                                        # > 256 tokens: the streaming kernels (attn_stream.hip); 30x40 = ViT-L @ 480x640
                                        (1, 257, 2, (16, 16)), (3, 324, 3, (17, 19)), (2, 1201, 2, (30, 40)),
-                                       (64, 290, 16, (17, 17))])
+                                       (64, 290, 16, (17, 17)),
+                                       # windows 40 / 20 wide: the slot-layout kernels (attn_win.hip, round 5); ragged last chunks
+                                       # (7 = 2 x 3 + 1 grid rows, 13 = 2 x 5 + 3), workgroups persistent over several samples
+                                       (2, 321, 2, (16, 20)), (3, 261, 3, (13, 20)), (4, 281, 3, (7, 40)), (40, 1201, 16, (30, 40))])
 def test_attention_fwd_bwd(B, T, H, win):
     _attention_case(B, T, H, win)
+
+
+def test_attn_win_equals_stream_kernels():
+    """The slot-layout kernels (attn_win.hip) against the token-order streaming kernels (attn_stream.hip, option attn_win = 0)
+    on the same inputs: equal to the rounding of the bf16 outputs (the two differ in fp32 summation order and in the
+    truncating v_dot2c bias add), table gradient to its fixed-point step."""
+    from mem_amd import _lib, ops
+    from oracle.vit_ref import rel_pos_index
+    for B, H, win in ((3, 2, (30, 40)), (5, 3, (7, 40)), (4, 3, (13, 20)), (24, 16, (30, 40))):
+        T, D = win[0] * win[1] + 1, 64 * H
+        TP = ops.attn_tokens_padded(T)
+        g = torch.Generator(device="cuda").manual_seed(B)
+        qkv = (torch.randn(B * T, 3 * D, generator=g, device="cuda") * 0.7)
+        qkv[:, :D] *= 0.5
+        qkv = qkv.bfloat16()
+        _, nrd = rel_pos_index(win)
+        table = torch.randn(nrd, H, generator=g, device="cuda") * 0.5
+        dout = torch.randn(B * T, D, generator=g, device="cuda").bfloat16()
+        res = {}
+        try:
+            for mode in (0, 1):
+                _lib.set_option("attn_win", mode)
+                out = torch.zeros(B * T, D, dtype=torch.bfloat16, device="cuda"); lse = torch.zeros(B, H, TP, device="cuda")
+                dqkv = torch.full((B * T, 3 * D), 3.0, dtype=torch.bfloat16, device="cuda")
+                dtable = torch.zeros(nrd, H, device="cuda"); dqb = torch.zeros(D, device="cuda"); dvb = torch.zeros(D, device="cuda")
+                delta = torch.zeros(2 * B * T + 4, H, device="cuda")
+                ops.attn_fwd(qkv, B, T, D, H, table, win, out, lse)
+                ops.attn_delta(dout, out, B * T, H, delta)
+                ops.attn_bwd(qkv, dout, lse, delta, table, win, B, T, D, H, 0.125, dqkv, dtable, dqb, dvb)
+                torch.cuda.synchronize()
+                res[mode] = (out.float(), lse[:, :, :T].clone(), dqkv.float(), dtable.clone(), dqb.clone(), dvb.clone())
+        finally:
+            _lib.set_option("attn_win", 1)
+        for name, a, b, tol in zip(("out", "lse", "dqkv", "dtable", "dq_bias", "dv_bias"), res[0], res[1],
+                                   (2e-3, 1e-6, 3e-3, 2e-3, 4e-3, 4e-3)):
+            rel = ((a - b).norm() / (a.norm() + 1e-30)).item()
+            assert torch.isfinite(b).all() and rel <= tol, (B, H, win, name, rel)
 
 
 def test_attention_general_kernels_at_14x14():

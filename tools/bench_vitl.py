@@ -8,6 +8,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mem_amd.masking_generator import MaskingGenerator
 from mem_amd.modeling_pretrain import pt_vit
 from mem_amd.optim_factory import FlatAdamW, get_parameter_groups
+from mem_amd import _lib
+for kv in filter(None, os.environ.get("MEMHIP_OPTS", "").split(",")):      # A/B: MEMHIP_OPTS=attn_win=0
+    _lib.set_option(kv.split("=")[0], int(kv.split("=")[1]))
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 H, W = 480, 640
