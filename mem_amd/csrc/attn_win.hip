@@ -123,9 +123,31 @@ __device__ __forceinline__ void win_setup(float* R, float* Cq, const float* tabl
 // ------------------------------------------------------------------------------- forward
 // Phase A of a chunk: S^T = K_chunk Q^T (lane = resident query, registers = streamed slots), bf16 rounding, + bias (log2 domain),
 // static / ragged masks, the cls key of chunk 0; returns the lane's maximum over the chunk's scores.
+// the K fragments and bias words of the first two 32-slot blocks of a chunk (read ahead of phase A: fwd_prefetch)
+struct FwdPre {
+  bf16x8 kf[2][4];
+  float bz[2][16];
+};
 template <int WW>
+__device__ __forceinline__ void fwd_prefetch(const char* Ks, const LaneOffs& lo, unsigned base, FwdPre& pre) {
+  using G = WinGeo<WW>;
+#pragma unroll
+  for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) pre.kf[kb][t] = row_frag_o(Ks, lo, kb, t);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int s0i = kb * 32 + 8 * g;
+      if (!G::valid(s0i) && !G::valid(s0i + 4)) continue;
+      const auto* p = reinterpret_cast<const __attribute__((address_space(3))) F2u*>(base + 4u * (unsigned)G::imm(s0i));
+      pre.bz[kb][4 * g] = p[0].a; pre.bz[kb][4 * g + 1] = p[0].b; pre.bz[kb][4 * g + 2] = p[1].a; pre.bz[kb][4 * g + 3] = p[1].b;
+    }
+  }
+}
+
+template <int WW, bool PRE = false>
 __device__ __forceinline__ void fwd_phase_a(const char* Ks, const LaneOffs& lo, const bf16x8 (&Qf)[4], unsigned base, int rows_left,
-                                            int c, int hh, float bcls, f32x16 (&s)[4], float& cmax_out) {
+                                            int c, int hh, float bcls, f32x16 (&s)[4], float& cmax_out, FwdPre* pre = nullptr) {
   using G = WinGeo<WW>;
   constexpr int CKB = G::CT / 32;
   const unsigned sel_lo = sel_lo_reg();
@@ -140,7 +162,7 @@ __device__ __forceinline__ void fwd_phase_a(const char* Ks, const LaneOffs& lo, 
       const int s0i = kb * 32 + 8 * g;
       if (!G::valid(s0i) && !G::valid(s0i + 4)) continue;
       const auto* p = reinterpret_cast<const __attribute__((address_space(3))) F2u*>(base + 4u * (unsigned)G::imm(s0i));
-#if defined(WIN_EXP) && WIN_EXP == 2     // timing experiment (wrong results): no bias reads
+#if defined(WIN_EXP) && (WIN_EXP == 2 || WIN_EXP == 6)     // timing experiment (wrong results): no bias reads
       (void)p;
       bz[kb & 1][4 * g] = bz[kb & 1][4 * g + 1] = bz[kb & 1][4 * g + 2] = bz[kb & 1][4 * g + 3] = bcls;
 #else
@@ -151,13 +173,24 @@ __device__ __forceinline__ void fwd_phase_a(const char* Ks, const LaneOffs& lo, 
   bf16x8 kf[2][4];
   auto kread = [&](int kb) {
 #pragma unroll
-    for (int t = 0; t < 4; ++t) kf[kb & 1][t] = row_frag_o(Ks, lo, kb, t);
+    for (int t = 0; t < 4; ++t) {
+#if defined(WIN_EXP) && (WIN_EXP == 5 || WIN_EXP == 6)     // timing experiment (wrong results): no K fragment reads
+      kf[kb & 1][t] = Qf[t];
+#else
+      kf[kb & 1][t] = row_frag_o(Ks, lo, kb, t);
+#endif
+    }
   };
   auto chain = [&](int kb) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) s[kb][i] = 0.f;
+#if defined(WIN_EXP) && WIN_EXP == 7       // timing experiment (wrong results): no score MFMAs
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s[kb][i] = (float)kf[kb & 1][i & 3][i >> 2];
+#else
 #pragma unroll
     for (int t = 0; t < 4; ++t) s[kb] = MFMA32(kf[kb & 1][t], Qf[t], s[kb]);
+#endif
   };
   float cmax = -INFINITY;
   float cls_raw = 0.f;
@@ -190,10 +223,20 @@ __device__ __forceinline__ void fwd_phase_a(const char* Ks, const LaneOffs& lo, 
     }
   };
   auto run = [&](auto RAGGED) {
-    kread(0);
-    kread(1);
-    bias_issue(0);
-    bias_issue(1);
+    if constexpr (PRE) {                        // blocks 0 and 1 were read during the previous chunk's phase B
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) kf[kb][t] = pre->kf[kb][t];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) bz[kb][i] = pre->bz[kb][i];
+      }
+    } else {
+      kread(0);
+      kread(1);
+      bias_issue(0);
+      bias_issue(1);
+    }
     chain(0);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -205,6 +248,9 @@ __device__ __forceinline__ void fwd_phase_a(const char* Ks, const LaneOffs& lo, 
         bias_issue(kb + 2);
       }
       if (kb + 1 < CKB) {
+        // the LDS reads of block kb + 2 go FIRST (left to the scheduler they end up behind the region's last MFMA and the
+        // next region opens with a wait for them: ~90 cycles per read exposed, 16 % of the kernel by removal)
+        if (kb + 2 < CKB) __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     // one MFMA
@@ -451,16 +497,18 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_fwd_win_kernel(
 #endif
 }
 
-// ---- the forward with the two waves of a SIMD HALF A CHUNK APART (round 5).  Section stamps of the kernel above (-DWIN_STAMP,
-// tools/attn_win_stamps.py): a chunk takes ~9 000 cycles of which phase A -- 150 vector instructions, 16 MFMAs -- takes
-// 3 100 (waves 0-3) to 5 250 (waves 4-7): all eight waves leave the chunk's barrier together and issue their 24 K-fragment
-// and bias reads into the same LDS queue, then wait.  Here an INTERVAL is half a chunk; waves 0-3 run phase A of chunk g in
-// interval 2g and phase B in 2g + 1, waves 4-7 one interval later (one extra s_barrier up front), so one wave's LDS-latency
-// phase meets its SIMD partner's exponentials.  The chunks of all samples of the workgroup form one stream (image index
-// 2g = K(g), 2g + 1 = V(g); K and V double-buffered separately): image i + 2 is issued at the top of interval i (its buffer
-// was last read in interval i - 1), s_waitcnt vmcnt(2) -- all but the newest image -- closes every interval.
+// ---- the forward with ONE barrier per chunk in the MIDDLE of the chunk and the next chunk's first fragments read ahead
+// (round 5).  Removal experiments on the kernel above (profiles/r05_attn_win_fwd_exp.txt): without the LDS reads of phase A
+// -- 16 K-fragment reads and 30 bias reads per chunk and wave -- the kernel runs 28 % faster, without the score MFMAs 14 %:
+// the reads are few, but all eight waves leave the chunk's barrier together, issue them into one queue and wait with nothing
+// else to do.  Here the chunks of all samples of a workgroup form one stream; K and V are double-buffered separately:
+//     A(g) | s_waitcnt vmcnt(0), s_barrier | issue K(g+2), V(g+1) | read ahead for A(g+1) | B(g) | (sample epilogue)
+// The barrier publishes K(g+1) and V(g) (both issued one chunk earlier) and tells that A(g) and B(g-1) are done everywhere,
+// i.e. that K(g)'s and V(g-1)'s buffers are free; the fragment and bias reads of chunk g+1's first two blocks are issued
+// before phase B(g) -- their latency runs under its exponentials.  (A two-waves-half-a-chunk-apart form was measured 13 %
+// SLOWER than the plain kernel, 921 vs 815 us: two barriers per chunk and no fewer exposed reads.)
 template <int WW>
-__global__ __launch_bounds__(512) void attn_fwd_win_stag_kernel(
+__global__ __launch_bounds__(512) void attn_fwd_win_mid_kernel(
     const __bf16* __restrict__ qkv, long long ldq, int B, int T, int TP, int D, int H, const float* __restrict__ table, int nrd,
     int Wh, __bf16* __restrict__ out, long long ldo, float* __restrict__ lse) {
   using G = WinGeo<WW>;
@@ -469,10 +517,9 @@ __global__ __launch_bounds__(512) void attn_fwd_win_stag_kernel(
   const int NB = (2 * Wh - 1) * G::P;
   float* R = reinterpret_cast<float*>(smem);
   float* Cq = R + ((NB + 3) & ~3);
-  char* imgs = reinterpret_cast<char*>(Cq + G::CQ);        // K0 V0 K1 V1
+  char* imgs = reinterpret_cast<char*>(Cq + G::CQ);        // K0 K1 V0 V1
   const int h = blockIdx.y;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int wr = wave >> 2;
   const int r = lane & 31, hh = lane >> 5;
   const LaneOffs lo = lane_offs(lane);
   win_setup<WW>(R, Cq, table, nrd, H, h, Wh, 1.0f, true, nrd - 3);
@@ -494,37 +541,20 @@ __global__ __launch_bounds__(512) void attn_fwd_win_stag_kernel(
   const int nch = (Wh + G::RPC - 1) / G::RPC;
   const int nsamp = ((int)B - (int)blockIdx.z + (int)gridDim.z - 1) / (int)gridDim.z;
   const int N = nsamp * nch;                   // chunks of this workgroup's stream
-  const int NI = 2 * N;                        // images
-  // image i of the stream -> LDS-DMA (every wave moves its 2 pieces)
-  auto issue = [&](int i) {
-    if (i >= NI) return;
-    const int g = i >> 1, isv = i & 1;
+  // K (isv = 0) or V (isv = 1) of stream chunk g -> LDS-DMA (every wave moves its 2 pieces)
+  auto issue = [&](int g, int isv) {
+    if (g >= N) return;
     const int si = g / nch, c = g - si * nch;
     const int b = (int)blockIdx.z + si * (int)gridDim.z;
     const __bf16* src = qkv + (long long)b * T * ldq + h * HD + (isv ? 2 * D : D);
-    stage_chunk_win<WW>(imgs + ((g & 1) * 2 + isv) * IMG, src, ldq, c, Wh);
-  };
-  // closes interval i: images <= i + 1 have landed (issued so far: up to max(3, i + 2), below NI), then the barrier
-  auto close = [&](int i) {
-    int newest = i + 2 > 3 ? i + 2 : 3;
-    newest = newest < NI - 1 ? newest : NI - 1;
-    const int fly = newest - (i + 1);          // images that may stay in flight
-    if (fly >= 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else if (fly == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
+    stage_chunk_win<WW>(imgs + (isv * 2 + (g & 1)) * IMG, src, ldq, c, Wh);
   };
   __syncthreads();                             // the table is set up
-  issue(0); issue(1); issue(2); issue(3);
-  {
-    const int fly = (NI < 4 ? NI : 4) - 1;     // image 0 has landed
-    if (fly >= 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    else if (fly == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else if (fly == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-  }
-  if (wr) close(0);                            // waves 4-7 sit out interval 0
+  issue(0, 0);
+  issue(1, 0);
+  issue(0, 1);
+  asm volatile("s_waitcnt vmcnt(4)" ::: "memory");           // K(0) has landed (K(1), V(0) may be in flight)
+  __builtin_amdgcn_s_barrier();
   float m = -INFINITY, l = 0.f;
   f32x16 o[2];
 #pragma unroll
@@ -538,23 +568,25 @@ __global__ __launch_bounds__(512) void attn_fwd_win_stag_kernel(
 #pragma unroll
     for (int t = 0; t < 4; ++t) Qf[t] = ld16(s0 + (long long)qc * ldq + 16 * t + 8 * hh);
   }
+  FwdPre pre;
+  if (active) fwd_prefetch<WW>(imgs, lo, base0, pre);
   for (int g = 0; g < N; ++g) {
-    const int iA = 2 * g + wr;
-    const char* Ks = imgs + (g & 1) * 2 * IMG;
-    const char* Vs = Ks + IMG;
+    const char* Ks = imgs + (g & 1) * IMG;
+    const char* Vs = imgs + (2 + (g & 1)) * IMG;
     const unsigned base = base0 + (unsigned)c * cstep;
     const int rows_left = Wh - c * G::RPC;
     f32x16 s[CKB];
     float cmax = -INFINITY;
-    // ---- phase A (interval iA)
-    if (iA >= 2) issue(iA + 2);
-    if (active) fwd_phase_a<WW>(Ks, lo, Qf, base, rows_left, c, hh, bcls, s, cmax);
-    close(iA);
-    // ---- phase B (interval iA + 1)
-    issue(iA + 3);
+    if (active) fwd_phase_a<WW, true>(Ks, lo, Qf, base, rows_left, c, hh, bcls, s, cmax, &pre);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // K(g+1), V(g) (issued one chunk ago)
+    __builtin_amdgcn_s_barrier();
+    issue(g + 2, 0);
+    issue(g + 1, 1);
+    const int cn = c + 1 == nch ? 0 : c + 1;                 // chunk index of stream chunk g + 1 inside its sample
+    if (active && g + 1 < N) fwd_prefetch<WW>(imgs + ((g + 1) & 1) * IMG, lo, base0 + (unsigned)cn * cstep, pre);
     if (active) fwd_phase_b<WW>(Vs, lo, s, cmax, m, l, o);
-    close(iA + 1);
-    if (++c == nch) {                          // the sample is complete: normalise, store, next sample's queries
+    c = cn;
+    if (c == 0) {                              // the sample is complete: normalise, store, next sample's queries
       if (active) {
         const float inv = 1.0f / l;
         if (hh == 0 && q < T) lse[((long long)b * H + h) * TP + q] = m + flog2(l) * kLn2;
@@ -571,7 +603,6 @@ __global__ __launch_bounds__(512) void attn_fwd_win_stag_kernel(
             }
         }
       }
-      c = 0;
       b += gridDim.z;
       m = -INFINITY; l = 0.f;
 #pragma unroll
@@ -585,7 +616,6 @@ __global__ __launch_bounds__(512) void attn_fwd_win_stag_kernel(
       }
     }
   }
-  if (!wr) __builtin_amdgcn_s_barrier();       // balances the interval waves 4-7 started late
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
@@ -1059,22 +1089,22 @@ int launch_fwd(const void* qkv, int64_t ldqkv, int B, int T, int D, int heads, c
 }
 
 template <int WW>
-int launch_fwd_stag(const void* qkv, int64_t ldqkv, int B, int T, int D, int heads, const float* table, int Wh, void* out,
+int launch_fwd_mid(const void* qkv, int64_t ldqkv, int B, int T, int D, int heads, const float* table, int Wh, void* out,
                     int64_t ldo, float* lse, hipStream_t s) {
   const int TP = ((T + 31) / 32) * 32;
   const int nrd = (2 * Wh - 1) * (2 * WW - 1) + 3;
   const size_t sm = win_lds_fwd<WW>(Wh, 8);
   if (sm > (size_t)kMaxLds) return MEMHIP_EUNSUPPORTED;
   static bool done = false;
-  if (int rc = set_lds_attr(attn_fwd_win_stag_kernel<WW>, &done)) return rc;
+  if (int rc = set_lds_attr(attn_fwd_win_mid_kernel<WW>, &done)) return rc;
   const int groups = (TP / 32 + 7) / 8;
   int nbz = B;
   const long long per = (long long)groups * heads;
   const int cus = usable_cus(s);
   while (nbz > 1 && per * nbz > 6LL * cus) nbz = (nbz + 1) / 2;
-  hipLaunchKernelGGL((attn_fwd_win_stag_kernel<WW>), dim3(groups, heads, nbz), dim3(512), sm, s, (const __bf16*)qkv,
+  hipLaunchKernelGGL((attn_fwd_win_mid_kernel<WW>), dim3(groups, heads, nbz), dim3(512), sm, s, (const __bf16*)qkv,
                      (long long)ldqkv, B, T, TP, D, heads, table, nrd, Wh, (__bf16*)out, (long long)ldo, lse);
-  return check_launch("attn_fwd(win, staggered)");
+  return check_launch("attn_fwd(win, mid barrier)");
 }
 
 template <int WW>
@@ -1139,9 +1169,9 @@ bool attn_win_fits(int T, int window_h, int window_w) {
 
 int attn_fwd_win(const void* qkv, int64_t ldqkv, int B, int T, int D, int heads, const float* table, int window_h, int window_w,
                  void* out, int64_t ldo, float* lse, hipStream_t s) {
-  if (opt(OPT_ATTN_WIN) == 3) {                // A/B: 3 = the staggered 8-wave form
-    if (window_w == 40) return launch_fwd_stag<40>(qkv, ldqkv, B, T, D, heads, table, window_h, out, ldo, lse, s);
-    if (window_w == 20) return launch_fwd_stag<20>(qkv, ldqkv, B, T, D, heads, table, window_h, out, ldo, lse, s);
+  if (opt(OPT_ATTN_WIN) == 3) {                // A/B: 3 = barrier in the middle of the chunk, next chunk's first fragments read ahead
+    if (window_w == 40) return launch_fwd_mid<40>(qkv, ldqkv, B, T, D, heads, table, window_h, out, ldo, lse, s);
+    if (window_w == 20) return launch_fwd_mid<20>(qkv, ldqkv, B, T, D, heads, table, window_h, out, ldo, lse, s);
   }
   const bool w4 = opt(OPT_ATTN_WIN) == 2;      // A/B: 2 = two 4-wave workgroups per CU, single-buffered chunks
   if (window_w == 40)
