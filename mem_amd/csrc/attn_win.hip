@@ -123,31 +123,9 @@ __device__ __forceinline__ void win_setup(float* R, float* Cq, const float* tabl
 // ------------------------------------------------------------------------------- forward
 // Phase A of a chunk: S^T = K_chunk Q^T (lane = resident query, registers = streamed slots), bf16 rounding, + bias (log2 domain),
 // static / ragged masks, the cls key of chunk 0; returns the lane's maximum over the chunk's scores.
-// the K fragments and bias words of the first two 32-slot blocks of a chunk (read ahead of phase A: fwd_prefetch)
-struct FwdPre {
-  bf16x8 kf[2][4];
-  float bz[2][16];
-};
 template <int WW>
-__device__ __forceinline__ void fwd_prefetch(const char* Ks, const LaneOffs& lo, unsigned base, FwdPre& pre) {
-  using G = WinGeo<WW>;
-#pragma unroll
-  for (int kb = 0; kb < 2; ++kb) {
-#pragma unroll
-    for (int t = 0; t < 4; ++t) pre.kf[kb][t] = row_frag_o(Ks, lo, kb, t);
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const int s0i = kb * 32 + 8 * g;
-      if (!G::valid(s0i) && !G::valid(s0i + 4)) continue;
-      const auto* p = reinterpret_cast<const __attribute__((address_space(3))) F2u*>(base + 4u * (unsigned)G::imm(s0i));
-      pre.bz[kb][4 * g] = p[0].a; pre.bz[kb][4 * g + 1] = p[0].b; pre.bz[kb][4 * g + 2] = p[1].a; pre.bz[kb][4 * g + 3] = p[1].b;
-    }
-  }
-}
-
-template <int WW, bool PRE = false>
 __device__ __forceinline__ void fwd_phase_a(const char* Ks, const LaneOffs& lo, const bf16x8 (&Qf)[4], unsigned base, int rows_left,
-                                            int c, int hh, float bcls, f32x16 (&s)[4], float& cmax_out, FwdPre* pre = nullptr) {
+                                            int c, int hh, float bcls, f32x16 (&s)[4], float& cmax_out) {
   using G = WinGeo<WW>;
   constexpr int CKB = G::CT / 32;
   const unsigned sel_lo = sel_lo_reg();
@@ -223,20 +201,10 @@ __device__ __forceinline__ void fwd_phase_a(const char* Ks, const LaneOffs& lo, 
     }
   };
   auto run = [&](auto RAGGED) {
-    if constexpr (PRE) {                        // blocks 0 and 1 were read during the previous chunk's phase B
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb) {
-#pragma unroll
-        for (int t = 0; t < 4; ++t) kf[kb][t] = pre->kf[kb][t];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) bz[kb][i] = pre->bz[kb][i];
-      }
-    } else {
-      kread(0);
-      kread(1);
-      bias_issue(0);
-      bias_issue(1);
-    }
+    kread(0);
+    kread(1);
+    bias_issue(0);
+    bias_issue(1);
     chain(0);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -365,12 +333,18 @@ __device__ __forceinline__ void fwd_phase_b(const char* Vs, const LaneOffs& lo, 
   l = fmaf(l, alpha, sum);
 }
 
-// A wave owns 32 resident queries (token order), the workgroup streams K / V slot chunks and is persistent over the samples
-// b = blockIdx.z, + gridDim.z, ...  Two shapes (NW = waves per workgroup):
-//   NW = 8: one workgroup per CU, K / V chunks double-buffered, one barrier per chunk;
-//   NW = 4: TWO independent workgroups per CU (51.5 KB of LDS each): K and V single-buffered -- K(c+1) is staged while phase B
-//           of chunk c runs, V(c+1) while phase A of chunk c+1 runs, two barriers per chunk.  The two workgroups of a CU are
-//           not synchronised with each other, so on every SIMD one wave's MFMA phases meet the other's VALU phases.
+// A wave owns 32 resident queries (token order), the workgroup (8 waves, one per CU) streams K / V slot chunks, double-buffered,
+// one barrier per chunk, and is persistent over the samples b = blockIdx.z, + gridDim.z, ...
+// Measured and dropped (round 5, B = 64 x 16 heads x 1201 tokens; this kernel 815 us, attn_stream.hip 950-1070):
+//   * two 4-wave workgroups per CU with single-buffered chunks (two barriers per chunk): 860 us;
+//   * waves 4-7 half a chunk behind waves 0-3 (the gemm_p8 stagger; two barriers per chunk): 921 us;
+//   * one barrier in the MIDDLE of the chunk + the next chunk's first K fragments / bias words read ahead of phase B: 885-908 us
+//     (10 spilled registers);
+//   * the LDS reads of block kb + 2 forced to the front of region kb: no change.
+// Removal experiments (-DWIN_EXP, profiles/r05_attn_win_fwd_removals.txt): without the LDS reads of phase A (16 K-fragment and
+// 30 bias reads per chunk and wave) -28 %, without the score MFMAs -14 %, without the exponentials -12 %, without barrier and
+// staging -15 %; counters (profiles/r05_attn_win_fwd_pmc.txt): a wave issues 34 % of its cycles, is parked at a wait or the
+// barrier 33 % and is issue-stalled 33 %; the SIMD's vector unit is busy ~53 %, the matrix pipe 21 %.
 #ifdef WIN_STAMP
 // diagnostic build (tools/build_variant_fast.sh ... -DWIN_STAMP): waves 0 and 4 of every workgroup accumulate shader cycles
 // (s_memtime) per section of the chunk loop: [0] DMA wait + barrier + staging issue, [1] phase A, [2] phase B, [3] chunks
@@ -379,8 +353,8 @@ __device__ unsigned long long g_win_stamps[1024 * 8];
 #else
 #define WIN_T(var) do { } while (0)
 #endif
-template <int WW, int NW>
-__global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_fwd_win_kernel(
+template <int WW>
+__global__ __launch_bounds__(512) void attn_fwd_win_kernel(
     const __bf16* __restrict__ qkv, long long ldq, int B, int T, int TP, int D, int H, const float* __restrict__ table, int nrd,
     int Wh, __bf16* __restrict__ out, long long ldo, float* __restrict__ lse) {
   using G = WinGeo<WW>;
@@ -395,7 +369,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_fwd_win_kernel(
   const int r = lane & 31, hh = lane >> 5;
   const LaneOffs lo = lane_offs(lane);
   win_setup<WW>(R, Cq, table, nrd, H, h, Wh, 1.0f, true, nrd - 3);
-  const int qb = blockIdx.x * NW + wave;
+  const int qb = blockIdx.x * 8 + wave;
   const bool active = qb * 32 < T;
   const int q = qb * 32 + r;
   const int qc = q < T ? q : T - 1;
@@ -434,42 +408,29 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_fwd_win_kernel(
       const int rows_left = Wh - c * G::RPC;   // grid rows of this chunk that exist (wave-uniform)
       f32x16 s[CKB];
       float cmax = -INFINITY;
-      if constexpr (NW == 8) {
-        const int cur = c & 1;
-        const char* Ks = imgs + cur * 2 * IMG;
-        const char* Vs = Ks + IMG;
-        unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0;
-        (void)t0; (void)t1; (void)t2; (void)t3;
-        WIN_T(t0);
+      const int cur = c & 1;
+      const char* Ks = imgs + cur * 2 * IMG;
+      const char* Vs = Ks + IMG;
+      unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+      (void)t0; (void)t1; (void)t2; (void)t3;
+      WIN_T(t0);
 #if !(defined(WIN_EXP) && WIN_EXP == 4)   // (4: timing experiment, wrong results: no staging, no barrier in the chunk loop)
-        ATTN_DMA_WAIT();
-        __syncthreads();                         // chunk c landed; chunk c-1 fully consumed
-        if (c + 1 < nch) {
-          stage_chunk_win<WW>(imgs + (cur ^ 1) * 2 * IMG, s0 + D, ldq, c + 1, Wh);
-          stage_chunk_win<WW>(imgs + (cur ^ 1) * 2 * IMG + IMG, s0 + 2 * D, ldq, c + 1, Wh);
-        }
-#endif
-        if (!active) continue;
-        WIN_T(t1);
-        fwd_phase_a<WW>(Ks, lo, Qf, base, rows_left, c, hh, bcls, s, cmax);
-        WIN_T(t2);
-        fwd_phase_b<WW>(Vs, lo, s, cmax, m, l, o);
-        WIN_T(t3);
-#ifdef WIN_STAMP
-        st_acc[0] += t1 - t0; st_acc[1] += t2 - t1; st_acc[2] += t3 - t2; st_acc[3] += 1;
-#endif
-      } else {
-        const char* Ks = imgs;
-        const char* Vs = imgs + IMG;
-        ATTN_DMA_WAIT();                         // K(c) (and V(0) of the sample's first chunk)
-        __syncthreads();                         // K(c) visible; everybody is done with V(c-1)
-        if (c > 0) stage_chunk_win<WW>(imgs + IMG, s0 + 2 * D, ldq, c, Wh);          // V(c) lands under phase A
-        if (active) fwd_phase_a<WW>(Ks, lo, Qf, base, rows_left, c, hh, bcls, s, cmax);
-        ATTN_DMA_WAIT();                         // V(c)
-        __syncthreads();                         // V(c) visible; everybody is done with K(c)
-        if (c + 1 < nch) stage_chunk_win<WW>(imgs, s0 + D, ldq, c + 1, Wh);          // K(c+1) lands under phase B
-        if (active) fwd_phase_b<WW>(Vs, lo, s, cmax, m, l, o);
+      ATTN_DMA_WAIT();
+      __syncthreads();                         // chunk c landed; chunk c-1 fully consumed
+      if (c + 1 < nch) {
+        stage_chunk_win<WW>(imgs + (cur ^ 1) * 2 * IMG, s0 + D, ldq, c + 1, Wh);
+        stage_chunk_win<WW>(imgs + (cur ^ 1) * 2 * IMG + IMG, s0 + 2 * D, ldq, c + 1, Wh);
       }
+#endif
+      if (!active) continue;
+      WIN_T(t1);
+      fwd_phase_a<WW>(Ks, lo, Qf, base, rows_left, c, hh, bcls, s, cmax);
+      WIN_T(t2);
+      fwd_phase_b<WW>(Vs, lo, s, cmax, m, l, o);
+      WIN_T(t3);
+#ifdef WIN_STAMP
+      st_acc[0] += t1 - t0; st_acc[1] += t2 - t1; st_acc[2] += t3 - t2; st_acc[3] += 1;
+#endif
     }
     if (active) {
       const float inv = 1.0f / l;
@@ -489,134 +450,12 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_fwd_win_kernel(
     }
   }
 #ifdef WIN_STAMP
-  if (NW == 8 && (wave == 0 || wave == 4) && lane == 0) {
+  if ((wave == 0 || wave == 4) && lane == 0) {
     const int wg = (int)((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) & 1023;
 #pragma unroll
     for (int i = 0; i < 4; ++i) g_win_stamps[wg * 8 + (wave >> 2) * 4 + i] = st_acc[i];
   }
 #endif
-}
-
-// ---- the forward with ONE barrier per chunk in the MIDDLE of the chunk and the next chunk's first fragments read ahead
-// (round 5).  Removal experiments on the kernel above (profiles/r05_attn_win_fwd_exp.txt): without the LDS reads of phase A
-// -- 16 K-fragment reads and 30 bias reads per chunk and wave -- the kernel runs 28 % faster, without the score MFMAs 14 %:
-// the reads are few, but all eight waves leave the chunk's barrier together, issue them into one queue and wait with nothing
-// else to do.  Here the chunks of all samples of a workgroup form one stream; K and V are double-buffered separately:
-//     A(g) | s_waitcnt vmcnt(0), s_barrier | issue K(g+2), V(g+1) | read ahead for A(g+1) | B(g) | (sample epilogue)
-// The barrier publishes K(g+1) and V(g) (both issued one chunk earlier) and tells that A(g) and B(g-1) are done everywhere,
-// i.e. that K(g)'s and V(g-1)'s buffers are free; the fragment and bias reads of chunk g+1's first two blocks are issued
-// before phase B(g) -- their latency runs under its exponentials.  (A two-waves-half-a-chunk-apart form was measured 13 %
-// SLOWER than the plain kernel, 921 vs 815 us: two barriers per chunk and no fewer exposed reads.)
-template <int WW>
-__global__ __launch_bounds__(512) void attn_fwd_win_mid_kernel(
-    const __bf16* __restrict__ qkv, long long ldq, int B, int T, int TP, int D, int H, const float* __restrict__ table, int nrd,
-    int Wh, __bf16* __restrict__ out, long long ldo, float* __restrict__ lse) {
-  using G = WinGeo<WW>;
-  constexpr int CT = G::CT, IMG = CT * 128, CKB = CT / 32;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int NB = (2 * Wh - 1) * G::P;
-  float* R = reinterpret_cast<float*>(smem);
-  float* Cq = R + ((NB + 3) & ~3);
-  char* imgs = reinterpret_cast<char*>(Cq + G::CQ);        // K0 K1 V0 V1
-  const int h = blockIdx.y;
-  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int r = lane & 31, hh = lane >> 5;
-  const LaneOffs lo = lane_offs(lane);
-  win_setup<WW>(R, Cq, table, nrd, H, h, Wh, 1.0f, true, nrd - 3);
-  const int qb = blockIdx.x * 8 + wave;
-  const bool active = qb * 32 < T;
-  const int q = qb * 32 + r;
-  const int qc = q < T ? q : T - 1;
-  unsigned base0, cstep;
-  if (q == 0 || q >= T) {
-    base0 = lds_addr_of(reinterpret_cast<const char*>(Cq));
-    cstep = 0;
-  } else {
-    const int u = q - 1, qy = u / WW, qx = u - qy * WW;
-    base0 = lds_addr_of(reinterpret_cast<const char*>(R)) + 4u * (unsigned)(NB - 1 - (qy + Wh - 1) * G::P - (qx + WW - 1));
-    cstep = 4u * G::RPC * G::P;
-  }
-  base0 += 16u * hh;
-  const float bcls = table[(long long)(q == 0 ? nrd - 1 : nrd - 2) * H + h];
-  const int nch = (Wh + G::RPC - 1) / G::RPC;
-  const int nsamp = ((int)B - (int)blockIdx.z + (int)gridDim.z - 1) / (int)gridDim.z;
-  const int N = nsamp * nch;                   // chunks of this workgroup's stream
-  // K (isv = 0) or V (isv = 1) of stream chunk g -> LDS-DMA (every wave moves its 2 pieces)
-  auto issue = [&](int g, int isv) {
-    if (g >= N) return;
-    const int si = g / nch, c = g - si * nch;
-    const int b = (int)blockIdx.z + si * (int)gridDim.z;
-    const __bf16* src = qkv + (long long)b * T * ldq + h * HD + (isv ? 2 * D : D);
-    stage_chunk_win<WW>(imgs + (isv * 2 + (g & 1)) * IMG, src, ldq, c, Wh);
-  };
-  __syncthreads();                             // the table is set up
-  issue(0, 0);
-  issue(1, 0);
-  issue(0, 1);
-  asm volatile("s_waitcnt vmcnt(4)" ::: "memory");           // K(0) has landed (K(1), V(0) may be in flight)
-  __builtin_amdgcn_s_barrier();
-  float m = -INFINITY, l = 0.f;
-  f32x16 o[2];
-#pragma unroll
-  for (int db = 0; db < 2; ++db)
-#pragma unroll
-    for (int i = 0; i < 16; ++i) o[db][i] = 0.f;
-  int b = blockIdx.z, c = 0;
-  bf16x8 Qf[4];
-  {
-    const __bf16* s0 = qkv + (long long)b * T * ldq + h * HD;
-#pragma unroll
-    for (int t = 0; t < 4; ++t) Qf[t] = ld16(s0 + (long long)qc * ldq + 16 * t + 8 * hh);
-  }
-  FwdPre pre;
-  if (active) fwd_prefetch<WW>(imgs, lo, base0, pre);
-  for (int g = 0; g < N; ++g) {
-    const char* Ks = imgs + (g & 1) * IMG;
-    const char* Vs = imgs + (2 + (g & 1)) * IMG;
-    const unsigned base = base0 + (unsigned)c * cstep;
-    const int rows_left = Wh - c * G::RPC;
-    f32x16 s[CKB];
-    float cmax = -INFINITY;
-    if (active) fwd_phase_a<WW, true>(Ks, lo, Qf, base, rows_left, c, hh, bcls, s, cmax, &pre);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // K(g+1), V(g) (issued one chunk ago)
-    __builtin_amdgcn_s_barrier();
-    issue(g + 2, 0);
-    issue(g + 1, 1);
-    const int cn = c + 1 == nch ? 0 : c + 1;                 // chunk index of stream chunk g + 1 inside its sample
-    if (active && g + 1 < N) fwd_prefetch<WW>(imgs + ((g + 1) & 1) * IMG, lo, base0 + (unsigned)cn * cstep, pre);
-    if (active) fwd_phase_b<WW>(Vs, lo, s, cmax, m, l, o);
-    c = cn;
-    if (c == 0) {                              // the sample is complete: normalise, store, next sample's queries
-      if (active) {
-        const float inv = 1.0f / l;
-        if (hh == 0 && q < T) lse[((long long)b * H + h) * TP + q] = m + flog2(l) * kLn2;
-        if (q < T) {
-          __bf16* orow = out + ((long long)b * T + q) * ldo + h * HD;
-#pragma unroll
-          for (int db = 0; db < 2; ++db)
-#pragma unroll
-            for (int gg = 0; gg < 4; ++gg) {
-              bf16x4 w;
-#pragma unroll
-              for (int e = 0; e < 4; ++e) w[e] = (__bf16)(o[db][4 * gg + e] * inv);
-              *reinterpret_cast<bf16x4*>(orow + db * 32 + 8 * gg + 4 * hh) = w;
-            }
-        }
-      }
-      b += gridDim.z;
-      m = -INFINITY; l = 0.f;
-#pragma unroll
-      for (int db = 0; db < 2; ++db)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) o[db][i] = 0.f;
-      if (b < B) {
-        const __bf16* s0 = qkv + (long long)b * T * ldq + h * HD;
-#pragma unroll
-        for (int t = 0; t < 4; ++t) Qf[t] = ld16(s0 + (long long)qc * ldq + 16 * t + 8 * hh);
-      }
-    }
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
 // ------------------------------------------------------------------------------- backward (dK, dV)
@@ -1062,49 +901,30 @@ int set_lds_attr(K kernel, bool* done) {
 }
 
 template <int WW>
-size_t win_lds_fwd(int Wh, int nw) {
+size_t win_lds_fwd(int Wh) {
   using G = WinGeo<WW>;
   const int NB = (2 * Wh - 1) * G::P;
-  return (size_t)(((NB + 3) & ~3) + G::CQ) * 4 + (size_t)(nw == 4 ? 2 : 4) * G::CT * 128;
+  return (size_t)(((NB + 3) & ~3) + G::CQ) * 4 + (size_t)4 * G::CT * 128;
 }
 
-template <int WW, int NW>
+template <int WW>
 int launch_fwd(const void* qkv, int64_t ldqkv, int B, int T, int D, int heads, const float* table, int Wh, void* out,
                int64_t ldo, float* lse, hipStream_t s) {
   const int TP = ((T + 31) / 32) * 32;
   const int nrd = (2 * Wh - 1) * (2 * WW - 1) + 3;
-  const size_t sm = win_lds_fwd<WW>(Wh, NW);
-  if (sm > (size_t)(NW == 4 ? kMaxLds / 2 : kMaxLds)) return MEMHIP_EUNSUPPORTED;
+  const size_t sm = win_lds_fwd<WW>(Wh);
+  if (sm > (size_t)kMaxLds) return MEMHIP_EUNSUPPORTED;
   static bool done = false;
-  if (int rc = set_lds_attr(attn_fwd_win_kernel<WW, NW>, &done)) return rc;
-  const int groups = (TP / 32 + NW - 1) / NW;
+  if (int rc = set_lds_attr(attn_fwd_win_kernel<WW>, &done)) return rc;
+  const int groups = (TP / 32 + 7) / 8;
   // samples per workgroup: the table set-up is paid once per workgroup; keep the grid a few rounds of the chip deep
   int nbz = B;
   const long long per = (long long)groups * heads;
   const int cus = usable_cus(s);
-  while (nbz > 1 && per * nbz > (NW == 4 ? 12LL : 6LL) * cus) nbz = (nbz + 1) / 2;
-  hipLaunchKernelGGL((attn_fwd_win_kernel<WW, NW>), dim3(groups, heads, nbz), dim3(NW * 64), sm, s, (const __bf16*)qkv, (long long)ldqkv,
+  while (nbz > 1 && per * nbz > 6LL * cus) nbz = (nbz + 1) / 2;
+  hipLaunchKernelGGL((attn_fwd_win_kernel<WW>), dim3(groups, heads, nbz), dim3(512), sm, s, (const __bf16*)qkv, (long long)ldqkv,
                      B, T, TP, D, heads, table, nrd, Wh, (__bf16*)out, (long long)ldo, lse);
   return check_launch("attn_fwd(win)");
-}
-
-template <int WW>
-int launch_fwd_mid(const void* qkv, int64_t ldqkv, int B, int T, int D, int heads, const float* table, int Wh, void* out,
-                    int64_t ldo, float* lse, hipStream_t s) {
-  const int TP = ((T + 31) / 32) * 32;
-  const int nrd = (2 * Wh - 1) * (2 * WW - 1) + 3;
-  const size_t sm = win_lds_fwd<WW>(Wh, 8);
-  if (sm > (size_t)kMaxLds) return MEMHIP_EUNSUPPORTED;
-  static bool done = false;
-  if (int rc = set_lds_attr(attn_fwd_win_mid_kernel<WW>, &done)) return rc;
-  const int groups = (TP / 32 + 7) / 8;
-  int nbz = B;
-  const long long per = (long long)groups * heads;
-  const int cus = usable_cus(s);
-  while (nbz > 1 && per * nbz > 6LL * cus) nbz = (nbz + 1) / 2;
-  hipLaunchKernelGGL((attn_fwd_win_mid_kernel<WW>), dim3(groups, heads, nbz), dim3(512), sm, s, (const __bf16*)qkv,
-                     (long long)ldqkv, B, T, TP, D, heads, table, nrd, Wh, (__bf16*)out, (long long)ldo, lse);
-  return check_launch("attn_fwd(win, mid barrier)");
 }
 
 template <int WW>
@@ -1169,17 +989,8 @@ bool attn_win_fits(int T, int window_h, int window_w) {
 
 int attn_fwd_win(const void* qkv, int64_t ldqkv, int B, int T, int D, int heads, const float* table, int window_h, int window_w,
                  void* out, int64_t ldo, float* lse, hipStream_t s) {
-  if (opt(OPT_ATTN_WIN) == 3) {                // A/B: 3 = barrier in the middle of the chunk, next chunk's first fragments read ahead
-    if (window_w == 40) return launch_fwd_mid<40>(qkv, ldqkv, B, T, D, heads, table, window_h, out, ldo, lse, s);
-    if (window_w == 20) return launch_fwd_mid<20>(qkv, ldqkv, B, T, D, heads, table, window_h, out, ldo, lse, s);
-  }
-  const bool w4 = opt(OPT_ATTN_WIN) == 2;      // A/B: 2 = two 4-wave workgroups per CU, single-buffered chunks
-  if (window_w == 40)
-    return w4 ? launch_fwd<40, 4>(qkv, ldqkv, B, T, D, heads, table, window_h, out, ldo, lse, s)
-              : launch_fwd<40, 8>(qkv, ldqkv, B, T, D, heads, table, window_h, out, ldo, lse, s);
-  if (window_w == 20)
-    return w4 ? launch_fwd<20, 4>(qkv, ldqkv, B, T, D, heads, table, window_h, out, ldo, lse, s)
-              : launch_fwd<20, 8>(qkv, ldqkv, B, T, D, heads, table, window_h, out, ldo, lse, s);
+  if (window_w == 40) return launch_fwd<40>(qkv, ldqkv, B, T, D, heads, table, window_h, out, ldo, lse, s);
+  if (window_w == 20) return launch_fwd<20>(qkv, ldqkv, B, T, D, heads, table, window_h, out, ldo, lse, s);
   return MEMHIP_EUNSUPPORTED;
 }
 

@@ -33,6 +33,7 @@ int opt(int id);
 // reducer sets the option while gradient buckets are in flight: RCCL's channel kernels need CUs of their own -- a
 // persistent grid that covers every CU would otherwise finish its last workgroups one full workgroup-duration late.
 int usable_cus(hipStream_t s = nullptr);
+int max_cus();     // all CUs, reservations ignored (workspace sizing)
 
 inline hipStream_t as_stream(memhip_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 

@@ -46,15 +46,19 @@ __global__ __launch_bounds__(kThreads, 2) void conv_gemm_f32_kernel(ConvArgsF32 
     nb = na < nb ? (na > 0 ? na : 0) : nb;
   }
   const int M = nb * p.Ho * p.Wo;
-  const int nwg = gridDim.x;
-  int pid = blockIdx.x;
-  {                                                  // XCD-aware bijective remap, n fastest
+  const int ntn = (p.Cout + BN - 1) / BN;
+  // Static batch: one tile per workgroup (XCD-aware bijective remap, n fastest).  Dynamic batch (n_active): the grid is a
+  // fixed number of workgroups that walk the LIVE tiles -- a grid that covered the capacity cost ~1 us per empty workgroup
+  // (37 000 of them per layer at a capacity of 128 samples: 20-30 ms per call, tools/tok_cert_probe.py).
+  const int ntiles = ((M + BM - 1) / BM) * ntn;
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  int pid = tile;
+  if (!p.n_active) {
+    const int nwg = gridDim.x;
     const int q = nwg >> 3, r = nwg & 7, xcd = pid & 7, idx = pid >> 3;
     pid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
-  const int ntn = (p.Cout + BN - 1) / BN;
   const int m0 = (pid / ntn) * BM, n0 = (pid % ntn) * BN;
-  if (m0 >= M) return;
 
   // global -> register staging: load j of this thread covers row (wave*4 + j)*8 + lane/8, chunk lane%8 (4 floats)
   long long abase[4], bbase[4];
@@ -176,6 +180,8 @@ __global__ __launch_bounds__(kThreads, 2) void conv_gemm_f32_kernel(ConvArgsF32 
       *reinterpret_cast<float4*>(p.out + mo * p.Cout + n) = make_float4(v[0], v[1], v[2], v[3]);
     }
   }
+  __syncthreads();                                   // the epilogue's LDS slots are free before the next tile is staged
+  }
 }
 
 // images f32 NCHW [B, C<=4, H, W] -> fp32 padded NHWC4 interior, optional (x - mean) / std
@@ -214,12 +220,11 @@ __global__ __launch_bounds__(256) void argmax_rows_f32_kernel(const float* __res
                                                               float* __restrict__ rms, const int* __restrict__ samples_dyn,
                                                               int rows_per_sample) {
   const int lane = threadIdx.x & 63;
-  const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (samples_dyn) {
     const long long live = (long long)(*samples_dyn) * rows_per_sample;
-    if (m >= live) return;
+    M = live < M ? (int)live : M;
   }
-  if (m >= M) return;
+  for (int m = blockIdx.x * 4 + (threadIdx.x >> 6); m < M; m += gridDim.x * 4) {
   float best = -INFINITY, second = -INFINITY;
   float sq = 0.f;
   int bi = 0x7fffffff;
@@ -250,6 +255,7 @@ __global__ __launch_bounds__(256) void argmax_rows_f32_kernel(const float* __res
     ids[m] = bi;
     if (gap) gap[m] = best - second;
     if (rms) rms[m] = sqrtf(sq / (float)N);
+  }
   }
 }
 
@@ -309,20 +315,21 @@ __global__ __launch_bounds__(256) void gather_nchw_to_padded_nhwc4_f32_kernel(co
   int live = *count - off;
   live = live < 0 ? 0 : (live > R ? R : live);
   if (blockIdx.x == 0 && threadIdx.x == 0) *n_round = live;
-  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (i >= (long long)live * H * W) return;
-  const int xw = (int)(i % W);
-  const long long t = i / W;
-  const int y = (int)(t % H), j = (int)(t / H);
-  const int b = list[off + j];
-  float v[4] = {0.f, 0.f, 0.f, 0.f};
-  for (int c = 0; c < C; ++c) {
-    float u = x[(((long long)b * C + c) * H + y) * W + xw];
-    if (mean) u = (u - mean[c]) / stdv[c];
-    v[c] = u;
+  const long long total = (long long)live * H * W;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {   // live pixels only
+    const int xw = (int)(i % W);
+    const long long t = i / W;
+    const int y = (int)(t % H), j = (int)(t / H);
+    const int b = list[off + j];
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int c = 0; c < C; ++c) {
+      float u = x[(((long long)b * C + c) * H + y) * W + xw];
+      if (mean) u = (u - mean[c]) / stdv[c];
+      v[c] = u;
+    }
+    *reinterpret_cast<float4*>(out + (((long long)j * (H + 2) + y + 1) * (W + 2) + xw + 1) * 4) =
+        make_float4(v[0], v[1], v[2], v[3]);
   }
-  *reinterpret_cast<float4*>(out + (((long long)j * (H + 2) + y + 1) * (W + 2) + xw + 1) * 4) =
-      make_float4(v[0], v[1], v[2], v[3]);
 }
 
 // ids_out[list[off + j] * hw + t] = ids_in[j * hw + t] for the live slots of the round
@@ -356,7 +363,8 @@ static int conv2d_nhwc_f32_impl(const float* in, const float* weight, const floa
   MEMHIP_REQUIRE(p.K % BK == 0, "conv2d_f32: K = %d must be a multiple of %d", p.K, BK);
   const long long M = (long long)B * p.Ho * p.Wo;
   MEMHIP_REQUIRE(M < (1LL << 31), "conv2d_f32: too many output pixels");
-  const int grid = cdiv(M, BM) * cdiv(Cout, BN);
+  int grid = cdiv(M, BM) * cdiv(Cout, BN);
+  if (n_active && grid > 1024) grid = 1024;          // dynamic batch: persistent workgroups over the live tiles
   const size_t lds = 2 * kStageFloats * sizeof(float);
   static bool attr_done = false;
   if (!attr_done) {
@@ -409,8 +417,9 @@ extern "C" int memhip_argmax_rows_f32_ex(const float* logits, int64_t ld, int M,
   MEMHIP_REQUIRE(!n_samples || rows_per_sample > 0, "argmax_rows_f32_ex: rows_per_sample");
   if (M == 0) return MEMHIP_OK;
   MEMHIP_REQUIRE(logits && ids, "argmax_rows_f32_ex: null pointer");
-  hipLaunchKernelGGL(argmax_rows_f32_kernel, dim3((M + 3) / 4), dim3(256), 0, as_stream(stream), logits, (long long)ld, M, N,
-                     (long long*)ids, top2_gap, row_rms, (const int*)n_samples, rows_per_sample);
+  const int blocks = (M + 3) / 4;
+  hipLaunchKernelGGL(argmax_rows_f32_kernel, dim3(n_samples && blocks > 2048 ? 2048 : blocks), dim3(256), 0, as_stream(stream),
+                     logits, (long long)ld, M, N, (long long*)ids, top2_gap, row_rms, (const int*)n_samples, rows_per_sample);
   return check_launch("argmax_rows_f32_ex");
 }
 
@@ -429,7 +438,8 @@ extern "C" int memhip_tok_gather_images_f32(const float* x, int C, int H, int W,
   MEMHIP_REQUIRE(C >= 1 && C <= 4 && H > 0 && W > 0 && offset >= 0 && R > 0, "tok_gather_images_f32: bad shape");
   MEMHIP_REQUIRE(x && out && list && count && n_round && (!mean == !stdv), "tok_gather_images_f32: null pointer");
   const long long n = (long long)R * H * W;
-  hipLaunchKernelGGL(gather_nchw_to_padded_nhwc4_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream),
+  const long long blocks = (n + 255) / 256;
+  hipLaunchKernelGGL(gather_nchw_to_padded_nhwc4_f32_kernel, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, as_stream(stream),
                      x, C, H, W, mean, stdv, (const int*)list, (const int*)count, offset, R, out, (int*)n_round);
   return check_launch("tok_gather_images_f32");
 }

@@ -28,7 +28,7 @@ static int stream_reserved(hipStream_t s) {
   return 0;
 }
 
-int usable_cus(hipStream_t s) {
+static int device_cu_count() {
   static std::atomic<int> device_cus{0};
   int n = device_cus.load(std::memory_order_relaxed);
   if (!n) {
@@ -38,6 +38,15 @@ int usable_cus(hipStream_t s) {
     n = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     device_cus.store(n, std::memory_order_relaxed);
   }
+  return n;
+}
+
+// every CU of the device, no reservation applied: workspace queries size for this (the largest grid any stream can plan)
+int max_cus() { return device_cu_count(); }
+
+int usable_cus(hipStream_t s) {
+  const int n = device_cu_count();
+  if (!n) return 0;
   int r = opt(OPT_RESERVE_CUS);                       // A/B tools: every stream
   const int rs = stream_reserved(s);                   // the caller's reservation for launches on THIS stream
   r = r > rs ? r : rs;

@@ -366,13 +366,19 @@ static void tn_p8_plan(int R, int N, int K, int num_cu, int& tiles, int& splits,
 static int tn_p8_num_cu(hipStream_t s = nullptr) { return usable_cus(s); }
 
 // bytes of workspace with which the partial tiles go through plain stores + a reduction pass
+// (sized for EVERY CU: a launch stream without a reservation plans the most splits, whatever another stream reserved)
 size_t gemm_tn_p8_workspace(int R, int N, int K) {
   if (N % BM != 0 || K % BN != 0 || R < 2048) return 0;
-  const int num_cu = tn_p8_num_cu();
+  const int num_cu = max_cus();
   if (!num_cu) return 0;
-  int tiles, splits, rps;
-  tn_p8_plan(R, N, K, num_cu, tiles, splits, rps);
-  return splits > 1 ? (size_t)splits * N * K * sizeof(float) : 0;
+  size_t need = 0;
+  for (int cu = num_cu; cu >= 8; cu -= 8) {                   // the split count is not monotone in the CU count: take the maximum
+    int tiles, splits, rps;
+    tn_p8_plan(R, N, K, cu, tiles, splits, rps);
+    const size_t b = splits > 1 ? (size_t)splits * N * K * sizeof(float) : 0;
+    need = b > need ? b : need;
+  }
+  return need;
 }
 
 // MEMHIP_EUNSUPPORTED when the shape does not fit (caller falls back to the other TN kernels).

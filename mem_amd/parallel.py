@@ -91,6 +91,14 @@ class GradReducer:
             h = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
             self.handles.append((h, view))
 
+    def sync_flag(self, flag):
+        """MAX of a small integer / float flag tensor over the ranks, in place (the bad-sample counter of the training loop:
+        every rank must take the SAME skip-this-update decision and every rank must raise at the next check -- a rank-local
+        flag would let the replicas diverge).  No-op outside a multi-rank group."""
+        if self.active and self.world > 1:
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=self.group)
+        return flag
+
     def finish(self):
         for h, view in self.handles:
             h.wait()

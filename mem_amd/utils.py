@@ -232,6 +232,8 @@ class NativeScalerWithGradNormCount:
         if not update_grad:
             return None
         if reducer is not None:
+            if poison is not None and hasattr(reducer, "sync_flag"):
+                reducer.sync_flag(poison)          # the flag is GLOBAL before it gates the update (every rank skips, every rank raises)
             reducer.finish()
         norm = optimizer.engine.grad_norm()
         if poison is not None:

@@ -35,6 +35,14 @@ def _worker(rank, world, port, q):
     ml.synchronize_between_processes()
     ok = ok and abs(ml.loss.global_avg - (1 + 3 + 2 + 4) / 4) < 1e-12 and ml.loss.count == 4
     ok = ok and abs(ml.acc.global_avg - (0.5 + 1.0) / 2) < 1e-12
+    # the bad-sample flag is made global before it gates the update (NativeScalerWithGradNormCount): only rank 1 saw a bad
+    # sample, both ranks hold the flag afterwards; a reducer that was released forgets its pending handles
+    flag = torch.tensor([3 if rank == 1 else 0], dtype=torch.int64)
+    red.sync_flag(flag)
+    ok = ok and int(flag) == 3
+    red(0)
+    red.release()
+    ok = ok and red.handles == []
     q.put((rank, bool(ok)))
     dist.destroy_process_group()
 
