@@ -286,6 +286,21 @@ __global__ __launch_bounds__(kThreads) void gemm_tn_p8_kernel(const __bf16* __re
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the idle tail of the prefetch stream has landed
   TP_BARRIER();                                            // every wave is done with the ring
 
+#ifdef TN_EXP_NOSTORE     // timing experiment (wrong results): the partial tile is neither staged nor stored -- what the slab write-out costs
+  {
+    float t = 0.f;                                    // (every accumulator stays live: 128 adds instead of the write-out)
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int nf = 0; nf < 4; ++nf)
+#pragma unroll
+        for (int kf = 0; kf < 2; ++kf)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) t += TP_ACC_EL(q, nf, kf, r);
+    if (t == 12345.678f) out[0] = t;
+  }
+  return;
+#endif
   // ---- epilogue: fp32 atomics.  C layout of a 16x16 tile: col (k) = lane & 15, row (n) =
   // 4 * (lane >> 4) + reg.  A pass moves 16 n-rows x 64 k (the wave's 32 columns in each B half)
   // through this wave's 4 KiB, then adds row by row: one wave-instruction = two 128-byte runs.
