@@ -191,6 +191,7 @@ int gemm256_dispatch(const GemmArgs& p, hipStream_t s);
 int gemm_p8_dispatch(const GemmArgs& p, hipStream_t s);
 int gemm_p8_split_rows(const GemmArgs& p, hipStream_t s);
 int gemm_p8_half_dispatch(const GemmArgs& p, hipStream_t s);
+int gemm_p8_pair_dispatch(const GemmArgs& head, const GemmArgs& tail, hipStream_t s);
 }
 
 extern "C" int memhip_gemm_bf16_nt(const memhip_gemm_args_t* a, memhip_stream_t stream) {
@@ -233,10 +234,10 @@ extern "C" int memhip_gemm_bf16_nt(const memhip_gemm_args_t* a, memhip_stream_t 
     const bool split_on = opt(OPT_GEMM_SPLIT) != 0;
     const int split = split_on ? gemm_p8_split_rows(p, s) : 0;
     if (split > 0 && split < p.M && p.epilogue != MEMHIP_EPI_PATCH_EMBED) {
+      const GemmArgs whole = p;
       GemmArgs head = p;
       head.M = split;
-      const int rc = gemm_p8_dispatch(head, s);
-      if (rc == MEMHIP_OK) {
+      {
         const long long r = split;
         p.A += r * p.lda;
         if (p.out0) p.out0 = (char*)p.out0 + r * p.ldo0 * (p.epilogue == MEMHIP_EPI_F32 ? 4 : 2);
@@ -247,6 +248,14 @@ extern "C" int memhip_gemm_bf16_nt(const memhip_gemm_args_t* a, memhip_stream_t 
           p.aux = (const char*)p.aux + r * p.ldaux * (p.epilogue == MEMHIP_EPI_RESIDUAL ? 4 : 2);
         p.M -= split;
         p.m_base = split;
+      }
+      // one launch for both row ranges (gemm_p8.hip: gemm_p8_pair_kernel) when the epilogue has a paired form
+      if (opt(OPT_GEMM_P8_HALF) != 0 && opt(OPT_GEMM_P8_PAIR) != 0) {
+        const int rcp = gemm_p8_pair_dispatch(head, p, s);
+        if (rcp != MEMHIP_EUNSUPPORTED) return rcp;
+      }
+      const int rc = gemm_p8_dispatch(head, s);
+      if (rc == MEMHIP_OK) {
         // the left-over rows: the same phase structure on 128-row tiles (MEMHIP_GEMM_P8_HALF=0: 128x128 kernel)
         const bool half_on = opt(OPT_GEMM_P8_HALF) != 0;
         if (half_on) {
@@ -264,6 +273,7 @@ extern "C" int memhip_gemm_bf16_nt(const memhip_gemm_args_t* a, memhip_stream_t 
         }
       }
       if (rc != MEMHIP_EUNSUPPORTED) return rc;
+      p = whole;                                   // no persistent form for this call: the paths below take all rows
     } else {
       const int rc = gemm_p8_dispatch(p, s);
       if (rc != MEMHIP_EUNSUPPORTED) return rc;

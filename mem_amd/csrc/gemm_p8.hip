@@ -170,8 +170,10 @@ __device__ __forceinline__ int key_b(int r) { return ((r >> 1) & 1) | (((r >> 3)
 // instantiated without it; the 128-row kernel in both forms (the rows it is handed are usually whole tiles too).
 // COPY (residual epilogue only): the bf16 copy of the branch output (out0) is wanted.  Without it the epilogue has no
 // such store at all (it used to go to a 1 KiB scratch line shared by the whole chip: 77 MB of stores per launch).
+// (the kernel body as a device function of (block id, block count): gemm_p8_kernel runs it over the whole grid, gemm_p8_pair_kernel
+// runs the 256-row form on the first workgroups of a launch and the 128-row form on the rest)
 template <int EPI, int BMT, bool GUARD, bool COPY>
-__global__ __launch_bounds__(kThreads) void gemm_p8_kernel(GemmArgs p, int ntm, int ntn, int stagger, int prefetch) {
+__device__ __forceinline__ void p8_body(const GemmArgs& p, int ntm, int ntn, int stagger, int prefetch, const int bid, const int nblk) {
   using G = P8Geo<BMT>;
   constexpr int kBuf = G::kBuf, MF = G::MF, AP = G::kAPieces, kAHalf = G::kAHalf;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -181,9 +183,9 @@ __global__ __launch_bounds__(kThreads) void gemm_p8_kernel(GemmArgs p, int ntm, 
   const int nk = p.K / BK;
   const int ntiles = ntm * ntn;
   // every XCD (workgroups b, b+8, ...) takes a contiguous run of tile ids per round
-  const int per_xcd = (gridDim.x + 7) / 8;
-  const int first = (gridDim.x % 8 == 0) ? ((int)blockIdx.x % 8) * per_xcd + (int)blockIdx.x / 8 : (int)blockIdx.x;
-  const int my_tiles = (ntiles - first + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int per_xcd = (nblk + 7) / 8;
+  const int first = (nblk % 8 == 0) ? (bid % 8) * per_xcd + bid / 8 : bid;
+  const int my_tiles = (ntiles - first + nblk - 1) / nblk;
   const int total = my_tiles * nk;
   if (total <= 0) return;
   // Phase stagger.  Every workgroup runs the same number of K-tiles per output tile, so all CUs reach their epilogues
@@ -192,9 +194,9 @@ __global__ __launch_bounds__(kThreads) void gemm_p8_kernel(GemmArgs p, int ntm, 
   // fullest have a tile time of slack: they start late by a per-workgroup fraction of `stagger` cycles per K-tile of a
   // tile (stagger < 0: every workgroup is delayed, |stagger| cycles per K-tile).
   if (stagger != 0) {
-    const int max_tiles = (ntiles + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int max_tiles = (ntiles + nblk - 1) / nblk;
     if (stagger < 0 || my_tiles < max_tiles) {
-      const unsigned frac = (((unsigned)blockIdx.x * 2654435761u) >> 22) & 1023u;
+      const unsigned frac = (((unsigned)bid * 2654435761u) >> 22) & 1023u;
       const unsigned long long wait = ((unsigned long long)(stagger < 0 ? -stagger : stagger) * (unsigned)nk * frac) >> 10;
       const unsigned long long t0 = __builtin_readcyclecounter();
       while (__builtin_readcyclecounter() - t0 < wait) __builtin_amdgcn_s_sleep(16);
@@ -278,7 +280,7 @@ __global__ __launch_bounds__(kThreads) void gemm_p8_kernel(GemmArgs p, int ntm, 
   auto advance2 = [&]() {
     if (g2 + 1 < total) {
       ++g2;
-      if (++k2 == nk) { k2 = 0; id2 += gridDim.x; decode(id2, tm2, tn2); }
+      if (++k2 == nk) { k2 = 0; id2 += nblk; decode(id2, tm2, tn2); }
     }
   };
   // prologue: K-tile 0 entirely, B0 A0 B1 of K-tile 1
@@ -878,7 +880,7 @@ __global__ __launch_bounds__(kThreads) void gemm_p8_kernel(GemmArgs p, int ntm, 
       ++stamp_tile;
 #endif
       c_k = 0;
-      c_tile += gridDim.x;
+      c_tile += nblk;
       if (c_tile < ntiles) decode(c_tile, ctm, ctn);
       tile_par ^= 1;
       if (P8_REALIGN && wr == 1) P8_BARRIER();
@@ -888,6 +890,25 @@ __global__ __launch_bounds__(kThreads) void gemm_p8_kernel(GemmArgs p, int ntm, 
   }
   if (wr == 0) P8_BARRIER();                               // balances the last stagger barrier of waves 4-7
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // no LDS-DMA may outlive the workgroup
+}
+
+template <int EPI, int BMT, bool GUARD, bool COPY>
+__global__ __launch_bounds__(kThreads) void gemm_p8_kernel(GemmArgs p, int ntm, int ntn, int stagger, int prefetch) {
+  p8_body<EPI, BMT, GUARD, COPY>(p, ntm, ntn, stagger, prefetch, (int)blockIdx.x, (int)gridDim.x);
+}
+
+// ONE launch for a product whose last round of 256-row tiles would be poorly filled (N = 768: 591 tiles on 256 CUs): workgroups
+// 0 .. nmain-1 are the persistent 256-row workgroups over the rows of the full rounds (`head`), the remaining workgroups run the
+// 128-row form over the left-over rows (`tail`).  Both kinds ask for the same LDS (one workgroup per CU), so the dispatcher
+// starts a tail workgroup on every CU the moment its 256-row workgroup retires: no second launch, no chip-wide drain between
+// the full rounds and the ragged one (round 5; the two-launch form stays behind MEMHIP option gemm_p8_pair = 0).
+template <int EPI, bool GUARD_T, bool COPY>
+__global__ __launch_bounds__(kThreads) void gemm_p8_pair_kernel(GemmArgs head, GemmArgs tail, int ntm_h, int ntm_t, int ntn, int nmain,
+                                                                int stagger, int prefetch) {
+  if ((int)blockIdx.x < nmain)
+    p8_body<EPI, 256, false, COPY>(head, ntm_h, ntn, stagger, prefetch, (int)blockIdx.x, nmain);
+  else
+    p8_body<EPI, 128, GUARD_T, COPY>(tail, ntm_t, ntn, 0, prefetch, (int)blockIdx.x - nmain, (int)gridDim.x - nmain);
 }
 
 template <int EPI, int BMT, bool GUARD, bool COPY>
@@ -1005,6 +1026,44 @@ int gemm_p8_half_dispatch(const GemmArgs& p, hipStream_t s) {
     case MEMHIP_EPI_F32: return launch_p8<MEMHIP_EPI_F32, 128>(p, s, num_cu);
     default: return MEMHIP_EUNSUPPORTED;
   }
+}
+
+
+template <int EPI, bool GUARD_T>
+static int launch_pair(const GemmArgs& head, const GemmArgs& tail, hipStream_t s, int num_cu) {
+  constexpr bool COPY = EPI != MEMHIP_EPI_RESIDUAL;
+  const int ntn = head.N / BN, ntm_h = head.M / BM, ntm_t = (tail.M + 127) / 128;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_p8_pair_kernel<EPI, GUARD_T, COPY>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, P8Geo<256>::kLdsAll);
+    if (e != hipSuccess) return fail(MEMHIP_ELAUNCH, "gemm_p8(pair): set smem attr: %s", hipGetErrorString(e));
+    attr_done = true;
+  }
+  const int nmain = ntm_h * ntn < num_cu ? ntm_h * ntn : num_cu;
+  const int ntail = ntm_t * ntn < num_cu ? ntm_t * ntn : num_cu;
+  hipLaunchKernelGGL((gemm_p8_pair_kernel<EPI, GUARD_T, COPY>), dim3(nmain + ntail), dim3(kThreads), P8Geo<256>::kLdsAll, s, head, tail,
+                     ntm_h, ntm_t, ntn, nmain, opt(OPT_GEMM_STAGGER), opt(OPT_GEMM_PREFETCH));
+  return check_launch("gemm_bf16_nt(p8 pair)");
+}
+
+// head: whole 256-row tiles of the full rounds; tail: the left-over rows (any count >= 128).  MEMHIP_EUNSUPPORTED when this
+// epilogue / shape has no paired form (the caller launches the two kernels one after the other).
+int gemm_p8_pair_dispatch(const GemmArgs& head, const GemmArgs& tail, hipStream_t s) {
+  if (!p8_fits(head) || head.M % BM != 0 || tail.M < 128) return MEMHIP_EUNSUPPORTED;
+  if (head.epilogue == MEMHIP_EPI_RESIDUAL && head.out0) return MEMHIP_EUNSUPPORTED;     // (the COPY form lives on the 128-row kernel only)
+  const int num_cu = p8_num_cu(s);
+  if (!num_cu || num_cu % 8 != 0) return MEMHIP_EUNSUPPORTED;
+  const bool g = tail.M % 128 != 0;
+#define P8_PAIR(E) return g ? launch_pair<E, true>(head, tail, s, num_cu) : launch_pair<E, false>(head, tail, s, num_cu)
+  switch (head.epilogue) {
+    case MEMHIP_EPI_BIAS_BF16: P8_PAIR(MEMHIP_EPI_BIAS_BF16);
+    case MEMHIP_EPI_RESIDUAL: P8_PAIR(MEMHIP_EPI_RESIDUAL);
+    case MEMHIP_EPI_BIAS_GELU_DG: P8_PAIR(MEMHIP_EPI_BIAS_GELU_DG);
+    case MEMHIP_EPI_MUL_AUX: P8_PAIR(MEMHIP_EPI_MUL_AUX);
+    default: return MEMHIP_EUNSUPPORTED;
+  }
+#undef P8_PAIR
 }
 
 }  // namespace memhip
