@@ -345,6 +345,9 @@ __device__ __forceinline__ void fwd_phase_b(const char* Vs, const LaneOffs& lo, 
 // 30 bias reads per chunk and wave) -28 %, without the score MFMAs -14 %, without the exponentials -12 %, without barrier and
 // staging -15 %; counters (profiles/r05_attn_win_fwd_pmc.txt): a wave issues 34 % of its cycles, is parked at a wait or the
 // barrier 33 % and is issue-stalled 33 %; the SIMD's vector unit is busy ~53 %, the matrix pipe 21 %.
+#ifndef WIN_PRIO
+#define WIN_PRIO 0     // 1: waves 4-7 (the second-dispatched, arbitration-losing half of the workgroup) run at priority 1 (measured: forward 834 vs 812 us, backward unchanged)
+#endif
 #ifdef WIN_STAMP
 // diagnostic build (tools/build_variant_fast.sh ... -DWIN_STAMP): waves 0 and 4 of every workgroup accumulate shader cycles
 // (s_memtime) per section of the chunk loop: [0] DMA wait + barrier + staging issue, [1] phase A, [2] phase B, [3] chunks
@@ -385,6 +388,9 @@ __global__ __launch_bounds__(512) void attn_fwd_win_kernel(
   }
   base0 += 16u * hh;
   const float bcls = table[(long long)(q == 0 ? nrd - 1 : nrd - 2) * H + h];      // bias towards the cls key
+#if WIN_PRIO
+  if (wave >= 4) __builtin_amdgcn_s_setprio(1);
+#endif
   const int nch = (Wh + G::RPC - 1) / G::RPC;
 #ifdef WIN_STAMP
   unsigned long long st_acc[4] = {0, 0, 0, 0};
@@ -503,6 +509,9 @@ __global__ __launch_bounds__(512) void attn_bwd_kv_win_kernel(
   const float bcls = table[(long long)(key == 0 ? nrd - 1 : nrd - 3) * H + h];       // bias from the cls query
   const float kmask = key < T ? 1.f : 0.f;
   const bool kpad = __builtin_amdgcn_readfirstlane(kbg) * 32 + 32 > T;               // this wave holds keys >= T
+#if WIN_PRIO
+  if (wave >= 4) __builtin_amdgcn_s_setprio(1);
+#endif
   const int nch = (Wh + G::RPC - 1) / G::RPC;
   float vmax = 0.f, dmax = 0.f, nmax = 0.f;
   float bsum[VB ? 32 : 1];
@@ -730,6 +739,9 @@ __global__ __launch_bounds__(512) void attn_bwd_q_win_kernel(
   for (int i = 0; i < 32; ++i) bsum[i] = 0.f;
   const float qmask = q < T ? 1.f : 0.f;
   const bool qpadw = __builtin_amdgcn_readfirstlane(qb) * 32 + 32 > T;            // this wave holds queries >= T
+#if WIN_PRIO
+  if (wave >= 4) __builtin_amdgcn_s_setprio(1);
+#endif
   const int nch = (Wh + G::RPC - 1) / G::RPC;
   for (int b = blockIdx.z; b < B; b += gridDim.z) {
     const long long row = (long long)b * T + qc;
