@@ -184,6 +184,144 @@ __global__ __launch_bounds__(kThreads, 2) void conv_gemm_f32_kernel(ConvArgsF32 
   }
 }
 
+// The same convolution on 32 x 128 tiles for the DYNAMIC-batch calls of the certified tokenizer (a handful of live samples):
+// a 128-row tile is a whole K loop on one CU (0.65 ms at K = 6144 on the fp32 matrix pipe) however few tiles the layer has,
+// so four samples cost as much as sixty-four.  Identical arithmetic per output element -- the same BK = 32 steps, the same
+// v_mfma_f32_16x16x4_f32 chain in the same order, the same epilogue -- so the results equal conv_gemm_f32_kernel's bit for bit
+// (tests/test_tokenizer_gpu.py: certified ids == fp32 ids with samples recomputed here).  4 waves side by side along N,
+// each 32 rows x 32 columns; persistent over the live tiles.
+constexpr int SBM = 32;
+__global__ __launch_bounds__(kThreads, 4) void conv_gemm_f32_m32_kernel(ConvArgsF32 p) {
+  extern __shared__ __attribute__((aligned(16))) float smem_f[];
+  constexpr int kATile = SBM * PITCH, kStage = kATile + kTileFloats;       // A tile (32 rows) + B tile (128 rows)
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  int nb = p.B;
+  if (p.n_active) {
+    const int na = *p.n_active;
+    nb = na < nb ? (na > 0 ? na : 0) : nb;
+  }
+  const int M = nb * p.Ho * p.Wo;
+  const int ntn = (p.Cout + BN - 1) / BN;
+  const int ntiles = ((M + SBM - 1) / SBM) * ntn;
+  const int chunk = lane & 7;
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int m0 = (tile / ntn) * SBM, n0 = (tile % ntn) * BN;
+    long long abase, bbase[4];
+    {
+      const int row = wave * 8 + (lane >> 3);
+      int m = m0 + row;
+      m = m < M ? m : M - 1;
+      const int hw = p.Ho * p.Wo;
+      const int b = m / hw, r = m - b * hw;
+      const int oy = r / p.Wo, ox = r - oy * p.Wo;
+      abase = (((long long)b * p.Hp + oy * p.stride + p.off) * p.Wp + ox * p.stride + p.off) * p.Cin;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      int n = n0 + (wave * 4 + j) * 8 + (lane >> 3);
+      n = n < p.Cout ? n : p.Cout - 1;
+      bbase[j] = (long long)n * p.K;
+    }
+    float4 ra, rb[4];
+    auto fetch = [&](int t) {
+      const int k = t * BK + chunk * 4;
+      const int tap = k / p.Cin, c0 = k - tap * p.Cin;
+      const int ky = tap / p.kw, kx = tap - ky * p.kw;
+      const long long koff = ((long long)ky * p.Wp + kx) * p.Cin + c0;
+      ra = *reinterpret_cast<const float4*>(p.in + abase + koff);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) rb[j] = *reinterpret_cast<const float4*>(p.w + bbase[j] + k);
+    };
+    auto commit = [&](float* dst) {
+      {
+        float2* a = reinterpret_cast<float2*>(dst + (wave * 8 + (lane >> 3)) * PITCH + chunk * 4);
+        a[0] = make_float2(ra.x, ra.y);
+        a[1] = make_float2(ra.z, ra.w);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int row = (wave * 4 + j) * 8 + (lane >> 3);
+        float2* b = reinterpret_cast<float2*>(dst + kATile + row * PITCH + chunk * 4);
+        b[0] = make_float2(rb[j].x, rb[j].y);
+        b[1] = make_float2(rb[j].z, rb[j].w);
+      }
+    };
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int nk = p.K / BK;
+    fetch(0);
+    commit(smem_f);
+    __syncthreads();
+    int cur = 0;
+    const int frow = lane & 15, fk = lane >> 4;
+    for (int t = 0; t < nk; ++t) {
+      if (t + 1 < nk) fetch(t + 1);
+      const float* At = smem_f + cur * kStage + frow * PITCH + fk;
+      const float* Bt = smem_f + cur * kStage + kATile + (wave * 32 + frow) * PITCH + fk;
+#pragma unroll
+      for (int kk = 0; kk < BK / 4; ++kk) {
+        float af[2], bf[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) af[i] = At[i * 16 * PITCH + kk * 4];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) bf[j] = Bt[j * 16 * PITCH + kk * 4];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+      }
+      if (t + 1 < nk) commit(smem_f + (cur ^ 1) * kStage);
+      __syncthreads();
+      cur ^= 1;
+    }
+    // ---- epilogue: the wave's 32 x 32 sub-tile through LDS; lane -> (row, 4 columns), 8 lanes per row
+    constexpr int LS = 36;
+    float* wreg = smem_f + wave * (32 * LS);
+    const int nw = n0 + wave * 32;
+    const int c4 = (lane & 7) * 4;
+    const int n = nw + c4;
+    float bias[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) bias[k] = (p.bias && n + k < p.Cout) ? p.bias[n + k] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) wreg[(i * 16 + (lane >> 4) * 4 + r) * LS + j * 16 + (lane & 15)] = acc[i][j][r];
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int row = it * 8 + (lane >> 3);
+      const int m = m0 + row;
+      if (m >= M || n >= p.Cout) continue;
+      long long mo = m;
+      if (p.out_padded) {
+        const int hw = p.Ho * p.Wo;
+        const int b = m / hw, r = m - b * hw;
+        const int oy = r / p.Wo, ox = r - oy * p.Wo;
+        mo = ((long long)b * (p.Ho + 2) + oy + 1) * (p.Wo + 2) + ox + 1;
+      }
+      const float4 v0 = *reinterpret_cast<const float4*>(wreg + row * LS + c4);
+      float v[4] = {v0.x + bias[0], v0.y + bias[1], v0.z + bias[2], v0.w + bias[3]};
+      if (p.relu) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k], 0.f);
+      }
+      if (p.add) {
+        const float4 xv = *reinterpret_cast<const float4*>(p.add + mo * p.Cout + n);
+        v[0] += xv.x; v[1] += xv.y; v[2] += xv.z; v[3] += xv.w;
+      }
+      *reinterpret_cast<float4*>(p.out + mo * p.Cout + n) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+    __syncthreads();
+  }
+}
+
 // images f32 NCHW [B, C<=4, H, W] -> fp32 padded NHWC4 interior, optional (x - mean) / std
 __global__ __launch_bounds__(256) void nchw_to_padded_nhwc4_f32_kernel(const float* __restrict__ x, int B, int C, int H,
                                                                        int W, const float* __restrict__ mean,
@@ -363,8 +501,20 @@ static int conv2d_nhwc_f32_impl(const float* in, const float* weight, const floa
   MEMHIP_REQUIRE(p.K % BK == 0, "conv2d_f32: K = %d must be a multiple of %d", p.K, BK);
   const long long M = (long long)B * p.Ho * p.Wo;
   MEMHIP_REQUIRE(M < (1LL << 31), "conv2d_f32: too many output pixels");
-  int grid = cdiv(M, BM) * cdiv(Cout, BN);
-  if (n_active && grid > 1024) grid = 1024;          // dynamic batch: persistent workgroups over the live tiles
+  if (n_active) {                                    // dynamic batch: 32-row tiles, persistent workgroups over the live tiles
+    const size_t lds_s = (size_t)2 * (SBM * PITCH + kTileFloats) * sizeof(float);
+    int grid_s = cdiv(M, SBM) * cdiv(Cout, BN);
+    grid_s = grid_s > 2048 ? 2048 : grid_s;
+    static bool attr_s = false;
+    if (!attr_s) {
+      MEMHIP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_gemm_f32_m32_kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s));
+      attr_s = true;
+    }
+    hipLaunchKernelGGL(conv_gemm_f32_m32_kernel, dim3(grid_s), dim3(kThreads), lds_s, as_stream(stream), p);
+    return check_launch("conv2d_nhwc_f32(dyn)");
+  }
+  const int grid = cdiv(M, BM) * cdiv(Cout, BN);
   const size_t lds = 2 * kStageFloats * sizeof(float);
   static bool attr_done = false;
   if (!attr_done) {
