@@ -97,10 +97,15 @@ def mfma_util_by_kernel(uj=None):
 
 
 def kernel_clock(cj=None):
-    """In-kernel shader clock of the GEMM main loops from profiles/r04_clock.json (tools/clock_probe.py: stamp build,
+    """In-kernel shader clock of the GEMM main loops from profiles/r05_clock.json (tools/clock_probe.py: stamp build,
     d(s_memtime) / d(s_memrealtime) x 100 MHz after 2 s of back-to-back launches): {"gemm_p8_ghz", "gemm_tn_p8_ghz",
     "at_clock_peak_tflops", ...} or None.  The dense bf16 peak the chip can issue at that clock is 2.5 PFLOP/s x clock / 2.4."""
-    cj = _load_profile("r04_clock.json") if cj is None else cj
+    src = "r05_clock.json"
+    if cj is None:
+        cj = _load_profile(src)
+        if cj is None:
+            src = "r04_clock.json"
+            cj = _load_profile(src)
     if not cj or "kernels" not in cj:
         return None
     nt = [v["clock_ghz"] for k, v in cj["kernels"].items() if k.startswith("gemm_p8 ")]
@@ -110,7 +115,7 @@ def kernel_clock(cj=None):
     nt_g, tn_g = sum(nt) / len(nt), sum(tn) / len(tn)
     return {"gemm_p8_ghz": round(nt_g, 3), "gemm_tn_p8_ghz": round(tn_g, 3), "spec_clock_ghz": cj.get("spec_clock_ghz", 2.4),
             "at_clock_peak_tflops": round(PEAK_BF16_TFLOPS * min(nt_g, tn_g) / cj.get("spec_clock_ghz", 2.4), 1),
-            "spec_peak_tflops": PEAK_BF16_TFLOPS, "source": "profiles/r04_clock.json (tools/clock_probe.py; " + cj.get("method", "") + ")"}
+            "spec_peak_tflops": PEAK_BF16_TFLOPS, "source": "profiles/" + src + " (tools/clock_probe.py; " + cj.get("method", "") + ")"}
 
 
 class _CachedEvents:
@@ -129,7 +134,7 @@ def config5_figure(B=64, steps=5, warmup=2):
     mem/modeling_pretrain.py:22-140 with the reference's `pt_vit_large`-style arguments) on 480 x 640 2-bin voxels = 30 x 40 + 1
     = 1201 tokens (streaming attention, 4664-entry bias table), 600 masked patches per sample, bf16, stochastic depth 0.1,
     AdamW; a step = masks + forward + CE + backward + clip + AdamW on a batch resident in HBM.  B = 64 per GPU (the
-    reference's global 512 over 8 GPUs; profiles/r04_vitl_batch.log: B 16: 222, B 32: 248, B 48: 259, B 64: 267 samples/s,
+    reference's global 512 over 8 GPUs; profiles/r04_vitl_batch.log: B 16: 222, B 32: 248, B 48: 259, B 64: 267 samples/s with the round-4 attention kernels,
     73.5 GB of the 288 GB).  FLOPs: 2 635.5 GFLOP per sample fwd + bwd (GEMMs only)."""
     import contextlib
     import io
@@ -201,7 +206,8 @@ def config5_figure(B=64, steps=5, warmup=2):
            "instrumented_step_ms": round(inst_ms, 2),
            "note": "family split: HIP events around every launch of one extra step run on ONE stream (the default step overlaps the "
                    "weight gradients with the dgrad chain on a second stream); rocprofv3 summary of the same workload: "
-                   "profiles/r04_vitl_kernel_stats.csv"}
+                   "profiles/r05_final_vitl_kernel_stats.csv (counters: r05_final_vitl_mfma_util.json, r05_final_vitl_traffic.json); "
+                   "attention = the slot-layout kernels of csrc/attn_win.hip (round 5; attn_stream.hip: MEMHIP option attn_win = 0)"}
     del model, opt, eng, x
     torch.cuda.empty_cache()
     return out
@@ -212,7 +218,7 @@ def entrypoint_figure(model, opt, B, steps, warmup, workers, lr_sched):
     train_one_epoch over torch DataLoader(num_workers, pin_memory) of RawEventDataset -- N-Caltech101 geometry (240 x 180
     sensor, per-sample extents, data-dependent canvases), SliceRandomMaxEvs 30 000, the ncaltech.conf augmentation chain
     (random shift / flips, Resize(antialias), EventRandAugment, ColorJitter) batched on the GPU, the CLI's default tokenizer
-    (fp16x2 since round 4; labels equal to the fp32 mode's, `with_tokenizer`) producing the labels, block-wise masks drawn per sample in the workers -- with the 246 MB of events of every batch
+    (fp16x2, CERTIFIED since round 5: labels equal to the fp32 mode's by construction, `with_tokenizer`) producing the labels, block-wise masks drawn per sample in the workers -- with the 246 MB of events of every batch
     crossing PCIe inside the timed region.  Returns samples/s over `steps` steps after `warmup`, and the stages timed alone."""
     import contextlib
     import io
@@ -233,7 +239,7 @@ def entrypoint_figure(model, opt, B, steps, warmup, workers, lr_sched):
         ds.source = _CachedEvents(ds.source, 512)
     vae = DiscreteVAE(input_H=224, input_W=224, num_tokens=8192, codebook_dim=512, num_layers=4, num_resnet_blocks=3,
                       hidden_dim=384, channels=3).cuda().eval()
-    # the tokenizer the CLI builds by default (run_mem_pretraining.py: --tokenizer_impl, round 4: hip_fp16x2)
+    # the tokenizer the CLI builds by default (run_mem_pretraining.py: --tokenizer_impl: hip_fp16x2, certified)
     tok_prec = {"hip": "fp32", "hip_fp16x2": "fp16x2", "hip_bf16": "bf16"}[args.tokenizer_impl]
     tok = HipTokenizer(vae, max_batch=B, precision=tok_prec)
     loader = torch.utils.data.DataLoader(ds, batch_size=B, shuffle=False, num_workers=workers, pin_memory=bool(args.pin_mem),
@@ -952,7 +958,7 @@ def main():
                         "instrumented_steps": n_inst,
                         "note": "HIP events around one weight-gradient product = gemm_tn_p8_kernel + its tn_reduce_kernel; the "
                                 "instrumented steps run on ONE stream (the events serialise the side stream), so compare with the "
-                                "sequential rocprofv3 summary (profiles/r04_final_seq_kernel_stats.csv: 136.1 + 11.8 us; the steady-state steps alone: r04_final_seq_step_kernels.txt), not with the "
+                                "sequential rocprofv3 summary (profiles/r05_final_seq_kernel_stats.csv; the steady-state steps alone: r05_final_seq_step_kernels.txt), not with the "
                                 "two-stream one, where concurrent launches stretch every kernel"}
             else:
                 roof = {"bound": "mfma", "kernel": "bf16 MFMA GEMM family", "achieved": round(ach, 1),
@@ -1034,7 +1040,9 @@ def main():
                 "ms_per_step": round(tok_f16x2_step_ms, 3), "tokenizer_ms_per_step": round(tok_f16x2_ms, 3),
                 **(tok_label_stat or {}),
                 "note": "--tokenizer_impl hip_fp16x2 (the entrypoint's default): two fp16 planes per value, three fp16 MFMAs per "
-                        "product; logits within ~3e-5 of the fp32 mode at a spread of 1.77"}
+                        "product; CERTIFIED (round 5): a label is kept only where its top-2 gap exceeds kappa x the row rms, every "
+                        "sample holding a token below that margin is recomputed on the fp32 kernels on the device (no host sync) "
+                        "-- labels equal the fp32 mode's by construction; `raw_fp16x2_tokenizer_ms` is the forward without that step"}
             # the primary figure is the mode the entrypoint runs by default -- the split-precision one, PROVIDED it reproduced
             # every label of the fp32 mode on the tokens compared in this very run; otherwise the fp32 mode
             exact = bool(f16_fig) and bool(tok_label_stat) and tok_label_stat["label_mismatches"] == 0
@@ -1049,8 +1057,9 @@ def main():
                                              "tokenizer forward producing the labels, MEASURED as the training loop runs it "
                                              "(tokenizer on its own HIP stream beside the ViT trunk; the loss waits for its "
                                              "ids); tokenizer forward (4 conv + 3 ResBlocks + 1x1 -> 8192, 24.4 GFLOP/sample, "
-                                             "random weights).  value = the entrypoint's default tokenizer mode if its labels equalled "
-                                             "the fp32 mode's on every token compared in this run, else the fp32 mode; the opt-in "
+                                             "random weights).  value = the entrypoint's default tokenizer mode (certified fp16x2: labels equal to "
+                                             "the fp32 mode's by construction, and compared with them on every token of this run), else "
+                                             "the fp32 mode; the opt-in "
                                              "bf16-operand mode (csrc/conv.hip, 1-3 % of labels differ) and the fp32 torch module "
                                              "on stock PyTorch-ROCm are timed beside it"}
         if rccl_info is not None:
