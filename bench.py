@@ -237,8 +237,11 @@ def entrypoint_figure(model, opt, B, steps, warmup, workers, lr_sched):
         args.window_size = (14, 14)
         ds = D.build_pretraining_dataset(args)
         ds.source = _CachedEvents(ds.source, 512)
-    vae = DiscreteVAE(input_H=224, input_W=224, num_tokens=8192, codebook_dim=512, num_layers=4, num_resnet_blocks=3,
-                      hidden_dim=384, channels=3).cuda().eval()
+    with torch.random.fork_rng(devices=[]):          # the same random tokenizer weights in every run and figure (the share of
+        torch.manual_seed(20251)                      # near-tie tokens, hence of certified recomputes, depends on them)
+        vae = DiscreteVAE(input_H=224, input_W=224, num_tokens=8192, codebook_dim=512, num_layers=4, num_resnet_blocks=3,
+                          hidden_dim=384, channels=3)
+    vae = vae.cuda().eval()
     # the tokenizer the CLI builds by default (run_mem_pretraining.py: --tokenizer_impl: hip_fp16x2, certified)
     tok_prec = {"hip": "fp32", "hip_fp16x2": "fp16x2", "hip_bf16": "bf16"}[args.tokenizer_impl]
     tok = HipTokenizer(vae, max_batch=B, precision=tok_prec)
@@ -262,6 +265,7 @@ def entrypoint_figure(model, opt, B, steps, warmup, workers, lr_sched):
                                   wd_schedule_values=None, args=args)
     torch.cuda.synchronize()
     dt = time.perf_counter() - marks["t0"]
+    cert = tok.certification_stats() if hasattr(tok, "certification_stats") else None
     # the stages alone, on one batch (device time by events; H2D from the pinned batch the loader hands over)
     batch, _ = next(iter(torch.utils.data.DataLoader(ds, batch_size=B, shuffle=False, num_workers=0, pin_memory=True,
                                                      collate_fn=ds.collate)))
@@ -291,6 +295,11 @@ def entrypoint_figure(model, opt, B, steps, warmup, workers, lr_sched):
             "events_bytes_per_step": int(batch["events"].numel() * 8), "last_loss": round(float(stats["loss"]), 4),
             "stages_alone_ms": {"h2d_events": round(h2d, 2), "augment_chain": round(aug, 2), "tokenizer_" + tok_prec: round(tok_ms, 2),
                                 "host_pack_draws": round(pack_ms, 2)},
+            "tokenizer_certification": (None if not cert else
+                                        {"flagged_samples_per_batch": round(cert["flagged_samples"] / max(1, cert["calls"]), 1),
+                                         "batches": cert["calls"], "kappa": cert["kappa"],
+                                         "note": "samples recomputed on the fp32 kernels because a token's fp16x2 top-2 gap was within "
+                                                 "kappa x the row rms (random tokenizer weights; sparse event images repeat near-ties)"}),
             "workload": "mem_amd.engine_for_pretraining.train_one_epoch over DataLoader(RawEventDataset): N-Caltech101 geometry "
                         "(data-dependent canvases), ncaltech.conf augmentations, " + tok_prec + " tokenizer labels (the CLI default), ViT-B/16 bf16, "
                         "events cross PCIe inside the timed region; event streams served from host memory"}
@@ -699,8 +708,11 @@ def main():
     if not a.no_tokenizer_figure and world == 1:                      # N=1 figures only: ranks must reach the teardown together
         try:
             from mem_amd.vae_model import DiscreteVAE, HipTokenizer
-            vae = DiscreteVAE(input_H=H, input_W=W, num_tokens=8192, codebook_dim=512, num_layers=4,
-                              num_resnet_blocks=3, hidden_dim=384, channels=3).cuda().eval()
+            with torch.random.fork_rng(devices=[]):
+                torch.manual_seed(20251)
+                vae = DiscreteVAE(input_H=H, input_W=W, num_tokens=8192, codebook_dim=512, num_layers=4,
+                                  num_resnet_blocks=3, hidden_dim=384, channels=3)
+            vae = vae.cuda().eval()
             img = torch.rand(B, 3, H, W, device="cuda")
 
             def _time(fn, n):

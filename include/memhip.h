@@ -53,7 +53,10 @@ const char* memhip_arch(void);
  * process-wide state is this explicit table.  Names: "gemm_p8", "gemm256", "gemm_split", "gemm_p8_half", "tn_p8",
  * "tn256", "raster_lds", "attn16" (0/1, default 1 = shipped dispatch), "gemm_p8_min_n" (768), "gemm256_min_n" (1024),
  * "attn16_stagger" (40000) / "attn16_stagger_fwd" (0): cycles by which the 14x14 attention workgroups with the smaller share
- * of samples start late at most, "gemm_stagger" (0): the same for the persistent GEMM workgroups, cycles per K-tile.
+ * of samples start late at most, "gemm_stagger" (0): the same for the persistent GEMM workgroups, cycles per K-tile;
+ * round 5: "attn_win" (1: windows 40 / 20 tokens wide and longer than 256 tokens run on the slot-layout kernels of
+ * attn_win.hip, 0: attn_stream.hip), "gemm_p8_pair" (1: the full rounds and the ragged round of an NT product are ONE
+ * launch, 0: two launches).
  * Unknown name: MEMHIP_EINVAL.  Results do not depend on any option (same contract, different kernel or timing). */
 int memhip_set_option(const char* name, int value);
 int memhip_get_option(const char* name, int* value);
