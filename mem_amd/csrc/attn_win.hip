@@ -343,7 +343,9 @@ __device__ __forceinline__ void fwd_phase_b(const char* Vs, const LaneOffs& lo, 
 //   * the LDS reads of block kb + 2 forced to the front of region kb: no change.
 // Removal experiments (-DWIN_EXP, profiles/r05_attn_win_fwd_removals.txt): without the LDS reads of phase A (16 K-fragment and
 // 30 bias reads per chunk and wave) -28 %, without the score MFMAs -14 %, without the exponentials -12 %, without barrier and
-// staging -15 %; counters (profiles/r05_attn_win_fwd_pmc.txt): a wave issues 34 % of its cycles, is parked at a wait or the
+// staging -15 %, with the barrier kept but no LDS-DMA in the chunk loop -17 % (a per-lane staging plan that cuts the ~30
+// vector instructions per piece to a multiply-add + a scalar-base load changed nothing: it is the transfer, not its issue);
+// counters (profiles/r05_attn_win_fwd_pmc.txt): a wave issues 34 % of its cycles, is parked at a wait or the
 // barrier 33 % and is issue-stalled 33 %; the SIMD's vector unit is busy ~53 %, the matrix pipe 21 %.
 #ifndef WIN_PRIO
 #define WIN_PRIO 0     // 1: waves 4-7 (the second-dispatched, arbitration-losing half of the workgroup) run at priority 1 (measured: forward 834 vs 812 us, backward unchanged)
@@ -423,7 +425,11 @@ __global__ __launch_bounds__(512) void attn_fwd_win_kernel(
 #if !(defined(WIN_EXP) && WIN_EXP == 4)   // (4: timing experiment, wrong results: no staging, no barrier in the chunk loop)
       ATTN_DMA_WAIT();
       __syncthreads();                         // chunk c landed; chunk c-1 fully consumed
+#if defined(WIN_EXP) && WIN_EXP == 8        // (8: timing experiment, wrong results: barrier kept, but no LDS-DMA in the chunk loop)
+      if (c + 1 < nch && T < 0) {
+#else
       if (c + 1 < nch) {
+#endif
         stage_chunk_win<WW>(imgs + (cur ^ 1) * 2 * IMG, s0 + D, ldq, c + 1, Wh);
         stage_chunk_win<WW>(imgs + (cur ^ 1) * 2 * IMG + IMG, s0 + 2 * D, ldq, c + 1, Wh);
       }
