@@ -114,8 +114,13 @@ template <int WW>
 __device__ __forceinline__ void win_setup(float* R, float* Cq, const float* table, int nrd, int H, int h, int Wh, float mul,
                                           bool reversed, int cls_bucket) {
   using G = WinGeo<WW>;
-  const int NB = (2 * Wh - 1) * G::P;
+  const int NB = (2 * Wh - 1) * G::P, NBP = (NB + 3) & ~3;
   for (int i = threadIdx.x; i < NB; i += blockDim.x) R[i] = table[(long long)(reversed ? NB - 1 - i : i) * H + h] * mul;
+  // the alignment pad behind the table is READ (never used): the rows behind a ragged last chunk address up to
+  // (RPC - 2) P + Ww + WS + 5 floats past the table, i.e. the pad and the strip.  The dK / dV kernel masks those slots through
+  // -lse = -inf, which only yields a probability of 0 if the bias it adds is finite -- found by tools/stress_attn_win.py as
+  // irreproducible NaNs in dK / dV of the three keys (ky = 0, kx = Ww - 3 ..) whose ragged-row buckets fall on the pad
+  if (threadIdx.x < NBP - NB) R[NB + threadIdx.x] = 0.f;
   const float cv = table[(long long)cls_bucket * H + h] * mul;
   for (int i = threadIdx.x; i < G::CQ; i += blockDim.x) Cq[i] = cv;
 }

@@ -37,3 +37,43 @@ def test_every_profile_json_parses():
     assert names
     for n in names:
         json.load(open(os.path.join(pdir, n)))
+
+
+def test_round5_evidence_set_is_consistent():
+    """profiles/r05_final_* come from ONE tools/r05_final.sh call: the per-kernel averages of the --stats summary, of the
+    per-step table cut from the SAME trace, and of the un-prefixed summaries bench.py reads must agree (a file regenerated on its own,
+    from another box or another build, shows up here)."""
+    import csv
+    import re
+    pdir = os.path.join(ROOT, "profiles")
+    stats = {}
+    for r in csv.DictReader(open(os.path.join(pdir, "r05_final_seq_kernel_stats.csv"))):
+        n = re.sub(r"^void ", "", r["Name"])
+        n = re.sub(r"\(anonymous namespace\)::", "", n)
+        n = re.sub(r"\(.*$", "", n)[:70]
+        stats[n] = (int(r["Calls"]), float(r["AverageNs"]) / 1e3)
+    step = {}
+    for l in open(os.path.join(pdir, "r05_final_seq_step_kernels.txt")):
+        m = re.match(r"^(\S.*?)\s+launches/step\s+([\d.]+)\s+avg\s+([\d.]+) us\s+per-step\s+([\d.]+) ms", l)
+        if m:
+            step[m.group(1).strip()] = (float(m.group(2)), float(m.group(3)), float(m.group(4)))
+    big = [k for k, v in step.items() if v[2] >= 0.5]                 # kernels with >= 0.5 ms per step
+    assert len(big) >= 10, big
+    for k in big:
+        assert k in stats, k
+        # the --stats average covers warm-up steps too: within 3 % of the steady-state window's
+        assert abs(stats[k][1] / step[k][1] - 1.0) <= 0.03, (k, stats[k][1], step[k][1])
+    # the files bench.py reads are the evidence set's
+    for a, b in (("gemm_traffic.json", "r05_final_traffic.json"), ("mfma_util.json", "r05_final_mfma_util.json"),
+                 ("raster_traffic.json", "r05_final_raster_traffic.json")):
+        assert json.load(open(os.path.join(pdir, a))) == json.load(open(os.path.join(pdir, b))), (a, b)
+    # the bench line of the set: its live HIP-event figure for the dominant kernel agrees with the rocprofv3 averages
+    bj = json.loads(open(os.path.join(pdir, "r05_final_bench.json")).read().strip().splitlines()[-1])
+    prof = stats["gemm_tn_p8_kernel<true>"][1] + stats["tn_reduce_kernel"][1]
+    assert abs(bj["roofline"]["avg_launch_us"] / prof - 1.0) <= 0.06, (bj["roofline"]["avg_launch_us"], prof)
+    assert abs(bj["roofline"]["frac"] - bj["roofline"]["achieved"] / bj["roofline"]["peak"]) < 1e-3
+    # config #5 has counters of its own since round 5
+    vu = json.load(open(os.path.join(pdir, "r05_final_vitl_mfma_util.json")))
+    vt = json.load(open(os.path.join(pdir, "r05_final_vitl_traffic.json")))
+    assert any(k.startswith("attn_fwd_win_kernel") for k in vu) and any(k.startswith("attn_bwd_q_win_kernel") for k in vt)
+    assert "raster_bin_keys" in json.load(open(os.path.join(pdir, "r05_final_raster_traffic.json")))
