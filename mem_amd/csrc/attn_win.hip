@@ -352,6 +352,9 @@ __device__ __forceinline__ void fwd_phase_b(const char* Vs, const LaneOffs& lo, 
 // vector instructions per piece to a multiply-add + a scalar-base load changed nothing: it is the transfer, not its issue);
 // counters (profiles/r05_attn_win_fwd_pmc.txt): a wave issues 34 % of its cycles, is parked at a wait or the
 // barrier 33 % and is issue-stalled 33 %; the SIMD's vector unit is busy ~53 %, the matrix pipe 21 %.
+#ifndef WIN_DMA_LATE
+#define WIN_DMA_LATE 0   // 1: forward: the LDS-DMA of chunk c + 1 is issued between phase A and phase B of chunk c
+#endif
 #ifndef WIN_PRIO
 #define WIN_PRIO 0     // 1: waves 4-7 (the second-dispatched, arbitration-losing half of the workgroup) run at priority 1 (measured: forward 834 vs 812 us, backward unchanged)
 #endif
@@ -433,16 +436,20 @@ __global__ __launch_bounds__(512) void attn_fwd_win_kernel(
 #if defined(WIN_EXP) && WIN_EXP == 8        // (8: timing experiment, wrong results: barrier kept, but no LDS-DMA in the chunk loop)
       if (c + 1 < nch && T < 0) {
 #else
-      if (c + 1 < nch) {
+      if (c + 1 < nch && !WIN_DMA_LATE) {
 #endif
         stage_chunk_win<WW>(imgs + (cur ^ 1) * 2 * IMG, s0 + D, ldq, c + 1, Wh);
         stage_chunk_win<WW>(imgs + (cur ^ 1) * 2 * IMG + IMG, s0 + 2 * D, ldq, c + 1, Wh);
       }
 #endif
-      if (!active) continue;
       WIN_T(t1);
-      fwd_phase_a<WW>(Ks, lo, Qf, base, rows_left, c, hh, bcls, s, cmax);
+      if (active) fwd_phase_a<WW>(Ks, lo, Qf, base, rows_left, c, hh, bcls, s, cmax);
       WIN_T(t2);
+      if (WIN_DMA_LATE && c + 1 < nch) {           // the next chunk's transfer starts under phase B (few LDS reads) instead of phase A
+        stage_chunk_win<WW>(imgs + (cur ^ 1) * 2 * IMG, s0 + D, ldq, c + 1, Wh);
+        stage_chunk_win<WW>(imgs + (cur ^ 1) * 2 * IMG + IMG, s0 + 2 * D, ldq, c + 1, Wh);
+      }
+      if (!active) continue;
       fwd_phase_b<WW>(Vs, lo, s, cmax, m, l, o);
       WIN_T(t3);
 #ifdef WIN_STAMP
