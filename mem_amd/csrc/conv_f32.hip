@@ -33,6 +33,8 @@ struct ConvArgsF32 {
   int B, Hp, Wp, Cin, Ho, Wo, Cout, kw, stride, off, K;
   int out_padded, relu;
   const int* n_active;  // device: samples actually present (<= B), or null = B (certified tokenizer: the count is made on the device)
+  int dyn_lo, dyn_hi;   // dynamic batch: this launch works only when dyn_lo <= *n_active < dyn_hi (the 32-row and the 128-row form
+                        // are both launched; the count picks one on the device)
 };
 
 __global__ __launch_bounds__(kThreads, 2) void conv_gemm_f32_kernel(ConvArgsF32 p) {
@@ -43,6 +45,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_gemm_f32_kernel(ConvArgsF32 
   int nb = p.B;
   if (p.n_active) {                                  // the grid covers the capacity B; tiles behind the live samples leave at once
     const int na = *p.n_active;
+    if (na < p.dyn_lo || na >= p.dyn_hi) return;
     nb = na < nb ? (na > 0 ? na : 0) : nb;
   }
   const int M = nb * p.Ho * p.Wo;
@@ -199,6 +202,7 @@ __global__ __launch_bounds__(kThreads, 4) void conv_gemm_f32_m32_kernel(ConvArgs
   int nb = p.B;
   if (p.n_active) {
     const int na = *p.n_active;
+    if (na < p.dyn_lo || na >= p.dyn_hi) return;
     nb = na < nb ? (na > 0 ? na : 0) : nb;
   }
   const int M = nb * p.Ho * p.Wo;
@@ -497,11 +501,27 @@ static int conv2d_nhwc_f32_impl(const float* in, const float* weight, const floa
   p.Ho = (H + 2 * pad - ksize) / stride + 1; p.Wo = (W + 2 * pad - ksize) / stride + 1;
   p.Cout = Cout; p.kw = ksize; p.stride = stride; p.off = 1 - pad; p.K = ksize * ksize * Cin;
   p.out_padded = out_padded; p.relu = relu; p.n_active = n_active;
+  p.dyn_lo = 0; p.dyn_hi = 1 << 30;
   MEMHIP_REQUIRE(p.Ho > 0 && p.Wo > 0, "conv2d_f32: empty output");
   MEMHIP_REQUIRE(p.K % BK == 0, "conv2d_f32: K = %d must be a multiple of %d", p.K, BK);
   const long long M = (long long)B * p.Ho * p.Wo;
   MEMHIP_REQUIRE(M < (1LL << 31), "conv2d_f32: too many output pixels");
-  if (n_active) {                                    // dynamic batch: 32-row tiles, persistent workgroups over the live tiles
+  const size_t lds = 2 * kStageFloats * sizeof(float);
+  static bool attr_done = false;
+  if (!attr_done) {
+    MEMHIP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_gemm_f32_kernel),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_done = true;
+  }
+  if (n_active) {
+    // dynamic batch: BOTH tile forms are launched with fixed grids of persistent workgroups; the device-side count selects
+    // one (fewer than kDynSwitch live samples: 32-row tiles, a layer is otherwise one under-filled round of 128-row tiles;
+    // from kDynSwitch on: the 128-row tiles at their better rate per FLOP).  The other launch returns at its first instruction.
+    // (per layer: the 128-row form pays once its live tiles fill the chip's 2 x 256 workgroup slots -- 7 samples at the 56 x 56
+    // level, 111 at the 14 x 14 level with 384 output channels)
+    const int ntn_ = cdiv(Cout, BN), hw_ = p.Ho * p.Wo;
+    int kDynSwitch = (int)((512LL * BM + (long long)hw_ * ntn_ - 1) / ((long long)hw_ * ntn_));
+    kDynSwitch = kDynSwitch < 1 ? 1 : kDynSwitch;
     const size_t lds_s = (size_t)2 * (SBM * PITCH + kTileFloats) * sizeof(float);
     int grid_s = cdiv(M, SBM) * cdiv(Cout, BN);
     grid_s = grid_s > 2048 ? 2048 : grid_s;
@@ -511,17 +531,15 @@ static int conv2d_nhwc_f32_impl(const float* in, const float* weight, const floa
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s));
       attr_s = true;
     }
+    p.dyn_lo = 0; p.dyn_hi = kDynSwitch;
     hipLaunchKernelGGL(conv_gemm_f32_m32_kernel, dim3(grid_s), dim3(kThreads), lds_s, as_stream(stream), p);
+    int grid_b = cdiv(M, BM) * cdiv(Cout, BN);
+    grid_b = grid_b > 1024 ? 1024 : grid_b;
+    p.dyn_lo = kDynSwitch; p.dyn_hi = 1 << 30;
+    hipLaunchKernelGGL(conv_gemm_f32_kernel, dim3(grid_b), dim3(kThreads), lds, as_stream(stream), p);
     return check_launch("conv2d_nhwc_f32(dyn)");
   }
   const int grid = cdiv(M, BM) * cdiv(Cout, BN);
-  const size_t lds = 2 * kStageFloats * sizeof(float);
-  static bool attr_done = false;
-  if (!attr_done) {
-    MEMHIP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_gemm_f32_kernel),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_done = true;
-  }
   hipLaunchKernelGGL(conv_gemm_f32_kernel, dim3(grid), dim3(kThreads), lds, as_stream(stream), p);
   return check_launch("conv2d_nhwc_f32");
 }

@@ -61,8 +61,11 @@ def test_round5_evidence_set_is_consistent():
     assert len(big) >= 10, big
     for k in big:
         assert k in stats, k
-        # the --stats average covers warm-up steps too: within 3 % of the steady-state window's
-        assert abs(stats[k][1] / step[k][1] - 1.0) <= 0.03, (k, stats[k][1], step[k][1])
+        # the --stats average covers the warm-up steps too: within 3 % of the steady-state window's; 6 % for the kernels with
+        # fewer than 12 launches per step (which NT launches take the paired form depends on the step's kept-sample counts, so
+        # the populations of gemm_p8_kernel<EPI,256> and gemm_p8_pair_kernel<EPI> differ a little between the two windows)
+        tol = 0.03 if step[k][0] >= 12 else 0.06
+        assert abs(stats[k][1] / step[k][1] - 1.0) <= tol, (k, stats[k][1], step[k][1])
     # the files bench.py reads are the evidence set's
     for a, b in (("gemm_traffic.json", "r05_final_traffic.json"), ("mfma_util.json", "r05_final_mfma_util.json"),
                  ("raster_traffic.json", "r05_final_raster_traffic.json")):
