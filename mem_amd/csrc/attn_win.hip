@@ -58,6 +58,23 @@ __device__ __forceinline__ void stage_chunk_win(char* dst, const __bf16* src, lo
   }
 }
 
+// Workgroup -> (group of 8 resident blocks, head, first sample) with all GROUPS of one (head, sample slot) on ONE XCD
+// (the hardware deals consecutive workgroup ids round-robin to the 8 XCDs): the groups of a pair stream the same K / V (or
+// Q' / dO) chunks, and with the natural (group, head, sample) grid they sat on different XCDs -- every chunk came from HBM once
+// per group (profiles/r05_final_vitl_traffic.json before the remap: forward 1 852 MB per launch for 630 MB of operands).
+// Grid = 8 * ceil(pairs / 8) * groups; ids behind the last pair return.
+struct WinWg { int group, h, bz; bool live; };
+__device__ __forceinline__ WinWg win_wg(int groups, int heads, int nbz) {
+  const int i = (int)blockIdx.x, xcd = i & 7, j = i >> 3;
+  const int pair = (j / groups) * 8 + xcd;
+  WinWg w;
+  w.group = j % groups;
+  w.h = pair % heads;
+  w.bz = pair / heads;
+  w.live = pair < heads * nbz;
+  return w;
+}
+
 struct __attribute__((packed, aligned(4))) F2u { float a, b; };
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
 typedef __attribute__((ext_vector_type(2))) float f32x2_t;
@@ -369,7 +386,7 @@ __device__ unsigned long long g_win_stamps[1024 * 8];
 template <int WW>
 __global__ __launch_bounds__(512) void attn_fwd_win_kernel(
     const __bf16* __restrict__ qkv, long long ldq, int B, int T, int TP, int D, int H, const float* __restrict__ table, int nrd,
-    int Wh, __bf16* __restrict__ out, long long ldo, float* __restrict__ lse) {
+    int Wh, __bf16* __restrict__ out, long long ldo, float* __restrict__ lse, int groups, int nbz) {
   using G = WinGeo<WW>;
   constexpr int CT = G::CT, IMG = CT * 128, CKB = CT / 32;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -377,12 +394,14 @@ __global__ __launch_bounds__(512) void attn_fwd_win_kernel(
   float* R = reinterpret_cast<float*>(smem);
   float* Cq = R + ((NB + 3) & ~3);
   char* imgs = reinterpret_cast<char*>(Cq + G::CQ);
-  const int h = blockIdx.y;
+  const WinWg wg_ = win_wg(groups, H, nbz);
+  if (!wg_.live) return;
+  const int h = wg_.h;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 31, hh = lane >> 5;
   const LaneOffs lo = lane_offs(lane);
   win_setup<WW>(R, Cq, table, nrd, H, h, Wh, 1.0f, true, nrd - 3);
-  const int qb = blockIdx.x * 8 + wave;
+  const int qb = wg_.group * 8 + wave;
   const bool active = qb * 32 < T;
   const int q = qb * 32 + r;
   const int qc = q < T ? q : T - 1;
@@ -405,7 +424,7 @@ __global__ __launch_bounds__(512) void attn_fwd_win_kernel(
 #ifdef WIN_STAMP
   unsigned long long st_acc[4] = {0, 0, 0, 0};
 #endif
-  for (int b = blockIdx.z; b < B; b += gridDim.z) {
+  for (int b = wg_.bz; b < B; b += nbz) {
     const __bf16* s0 = qkv + (long long)b * T * ldq + h * HD;
     bf16x8 Qf[4];
 #pragma unroll
@@ -475,7 +494,7 @@ __global__ __launch_bounds__(512) void attn_fwd_win_kernel(
   }
 #ifdef WIN_STAMP
   if ((wave == 0 || wave == 4) && lane == 0) {
-    const int wg = (int)((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) & 1023;
+    const int wg = (int)blockIdx.x & 1023;
 #pragma unroll
     for (int i = 0; i < 4; ++i) g_win_stamps[wg * 8 + (wave >> 2) * 4 + i] = st_acc[i];
   }
@@ -492,7 +511,7 @@ __global__ __launch_bounds__(512) void attn_bwd_kv_win_kernel(
     const __bf16* __restrict__ qkv, long long ldq, const __bf16* __restrict__ dout, long long ldo,
     const float* __restrict__ lse, const float* __restrict__ delta, float* __restrict__ stats,
     const float* __restrict__ table, int nrd, int Wh, __bf16* __restrict__ dqkv, long long lddq,
-    float* __restrict__ dvbias, int B, int T, int TP, int D, int H) {
+    float* __restrict__ dvbias, int B, int T, int TP, int D, int H, int groups, int nbz) {
   using G = WinGeo<WW>;
   constexpr int CT = G::CT, IMG = CT * 128, CKB = CT / 32;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -503,14 +522,16 @@ __global__ __launch_bounds__(512) void attn_bwd_kv_win_kernel(
   float* ndS = nlS + 2 * CT;                                 // [2][CT]  -delta by slot
   float* vsum = ndS + 2 * CT;                                // [64]
   char* imgs = reinterpret_cast<char*>(vsum + HD);
-  const int h = blockIdx.y;
+  const WinWg wg_ = win_wg(groups, H, nbz);
+  if (!wg_.live) return;
+  const int h = wg_.h;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 31, hh = lane >> 5;
   const LaneOffs lo = lane_offs(lane);
   win_setup<WW>(R, Cq, table, nrd, H, h, Wh, 1.0f, false, nrd - 2);
   if (threadIdx.x < HD) vsum[threadIdx.x] = 0.f;
   const unsigned sel_lo = sel_lo_reg();
-  const int kbg = blockIdx.x * 8 + wave;
+  const int kbg = wg_.group * 8 + wave;
   const bool active = kbg * 32 < T;
   const int key = kbg * 32 + r;
   const int kc_tok = key < T ? key : T - 1;
@@ -537,7 +558,7 @@ __global__ __launch_bounds__(512) void attn_bwd_kv_win_kernel(
 #pragma unroll
     for (int i = 0; i < (VB ? 32 : 1); ++i) bsum[i] = 0.f;
   }
-  for (int b = blockIdx.z; b < B; b += gridDim.z) {
+  for (int b = wg_.bz; b < B; b += nbz) {
     const __bf16* s0 = qkv + (long long)b * T * ldq + h * HD;
     const __bf16* d0 = dout + (long long)b * T * ldo + h * HD;
     bf16x8 Kf[4], Vf[4];
@@ -713,7 +734,7 @@ __global__ __launch_bounds__(512) void attn_bwd_q_win_kernel(
     const __bf16* __restrict__ qkv, long long ldq, const __bf16* __restrict__ dout, long long ldo,
     const float* __restrict__ lse, const float* __restrict__ delta, const float* __restrict__ stats,
     const float* __restrict__ table, int nrd, int Wh, __bf16* __restrict__ dqkv, long long lddq,
-    float* __restrict__ dtable, float* __restrict__ dqbias, int B, int T, int TP, int D, int H, float scale) {
+    float* __restrict__ dtable, float* __restrict__ dqbias, int B, int T, int TP, int D, int H, float scale, int groups, int nbz) {
   using G = WinGeo<WW>;
   constexpr int CT = G::CT, IMG = CT * 128, CKB = CT / 32;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -723,7 +744,9 @@ __global__ __launch_bounds__(512) void attn_bwd_q_win_kernel(
   int* binsR = reinterpret_cast<int*>(Cq + G::CQ);           // fixed-point buckets: image of [R | Cq]
   float* qsum = reinterpret_cast<float*>(binsR + NBP + G::CQ);
   char* imgs = reinterpret_cast<char*>(qsum + HD);
-  const int h = blockIdx.y;
+  const WinWg wg_ = win_wg(groups, H, nbz);
+  if (!wg_.live) return;
+  const int h = wg_.h;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 31, hh = lane >> 5;
   const LaneOffs lo = lane_offs(lane);
@@ -731,7 +754,7 @@ __global__ __launch_bounds__(512) void attn_bwd_q_win_kernel(
   for (int i = threadIdx.x; i < NBP + G::CQ + HD; i += blockDim.x) binsR[i] = 0;     // buckets, qsum
   const unsigned sel_lo = sel_lo_reg();
   const unsigned bins_delta = (unsigned)(NBP + G::CQ) * 4u;
-  const int qb = blockIdx.x * 8 + wave;
+  const int qb = wg_.group * 8 + wave;
   const bool active = qb * 32 < T;
   const int q = qb * 32 + r;
   const int qc = q < T ? q : T - 1;
@@ -761,7 +784,7 @@ __global__ __launch_bounds__(512) void attn_bwd_q_win_kernel(
   if (wave >= 4) __builtin_amdgcn_s_setprio(1);
 #endif
   const int nch = (Wh + G::RPC - 1) / G::RPC;
-  for (int b = blockIdx.z; b < B; b += gridDim.z) {
+  for (int b = wg_.bz; b < B; b += nbz) {
     const long long row = (long long)b * T + qc;
     const __bf16* s0 = qkv + (long long)b * T * ldq + h * HD;
     bf16x8 Qf[4], dOf[4];
@@ -952,8 +975,9 @@ int launch_fwd(const void* qkv, int64_t ldqkv, int B, int T, int D, int heads, c
   const long long per = (long long)groups * heads;
   const int cus = usable_cus(s);
   while (nbz > 1 && per * nbz > 6LL * cus) nbz = (nbz + 1) / 2;
-  hipLaunchKernelGGL((attn_fwd_win_kernel<WW>), dim3(groups, heads, nbz), dim3(512), sm, s, (const __bf16*)qkv, (long long)ldqkv,
-                     B, T, TP, D, heads, table, nrd, Wh, (__bf16*)out, (long long)ldo, lse);
+  const int grid = 8 * ((heads * nbz + 7) / 8) * groups;
+  hipLaunchKernelGGL((attn_fwd_win_kernel<WW>), dim3(grid), dim3(512), sm, s, (const __bf16*)qkv, (long long)ldqkv,
+                     B, T, TP, D, heads, table, nrd, Wh, (__bf16*)out, (long long)ldo, lse, groups, nbz);
   return check_launch("attn_fwd(win)");
 }
 
@@ -978,27 +1002,27 @@ int launch_bwd(const void* qkv, int64_t ldqkv, const void* dout, int64_t ldo, co
   const long long per = (long long)groups * heads;
   const int cus = usable_cus(s);
   while (nbz > 1 && per * nbz > 6LL * cus) nbz = (nbz + 1) / 2;
-  const dim3 grid(groups, heads, nbz);
+  const dim3 grid(8 * ((heads * nbz + 7) / 8) * groups);
   if (dv_bias)
     hipLaunchKernelGGL((attn_bwd_kv_win_kernel<WW, true>), grid, dim3(512), sm_kv, s, (const __bf16*)qkv, (long long)ldqkv,
                        (const __bf16*)dout, (long long)ldo, lse, delta, dtable ? stats : (float*)nullptr, table, nrd, Wh,
-                       (__bf16*)dqkv, (long long)lddqkv, dv_bias, B, T, TP, D, heads);
+                       (__bf16*)dqkv, (long long)lddqkv, dv_bias, B, T, TP, D, heads, groups, nbz);
   else
     hipLaunchKernelGGL((attn_bwd_kv_win_kernel<WW, false>), grid, dim3(512), sm_kv, s, (const __bf16*)qkv, (long long)ldqkv,
                        (const __bf16*)dout, (long long)ldo, lse, delta, dtable ? stats : (float*)nullptr, table, nrd, Wh,
-                       (__bf16*)dqkv, (long long)lddqkv, dv_bias, B, T, TP, D, heads);
+                       (__bf16*)dqkv, (long long)lddqkv, dv_bias, B, T, TP, D, heads, groups, nbz);
   // the dQ kernel is persistent over at most 16 samples per workgroup (the fixed-point bound of the buckets)
   int nbq = nbz;
   while ((B + nbq - 1) / nbq > 16) ++nbq;
-  const dim3 gq(groups, heads, nbq);
+  const dim3 gq(8 * ((heads * nbq + 7) / 8) * groups);
   if (dtable)
     hipLaunchKernelGGL((attn_bwd_q_win_kernel<WW, true>), gq, dim3(512), sm_q, s, (const __bf16*)qkv, (long long)ldqkv,
                        (const __bf16*)dout, (long long)ldo, lse, delta, stats, table, nrd, Wh, (__bf16*)dqkv, (long long)lddqkv,
-                       dtable, dq_bias, B, T, TP, D, heads, scale);
+                       dtable, dq_bias, B, T, TP, D, heads, scale, groups, nbq);
   else
     hipLaunchKernelGGL((attn_bwd_q_win_kernel<WW, false>), gq, dim3(512), sm_q, s, (const __bf16*)qkv, (long long)ldqkv,
                        (const __bf16*)dout, (long long)ldo, lse, delta, stats, table, nrd, Wh, (__bf16*)dqkv, (long long)lddqkv,
-                       dtable, dq_bias, B, T, TP, D, heads, scale);
+                       dtable, dq_bias, B, T, TP, D, heads, scale, groups, nbq);
   return check_launch("attn_bwd(win)");
 }
 
