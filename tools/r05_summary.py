@@ -55,7 +55,7 @@ a1 = stat("r05_final_vitl_kernel_stats.csv", "attn_fwd_win_kernel"); a2 = stat("
 L.append(f"* **config #5 counters (none existed before this round)**: `r05_final_vitl_kernel_stats.csv` (two-stream step under rocprofv3: forward {a1[1]:.0f} us, dK/dV {a2[1]:.0f}, "
          f"dQ + table gradient {a3[1]:.0f} per layer); `r05_final_vitl_mfma_util.json`: `attn_fwd_win` {mu(vu, 'attn_fwd_win_kernel')}, `attn_bwd_kv_win` {mu(vu, 'attn_bwd_kv_win_kernel')}, "
          f"`attn_bwd_q_win` {mu(vu, 'attn_bwd_q_win_kernel')}, `gemm_tn_p8` {mu(vu, 'gemm_tn_p8_kernel')}, whole step {vu['_whole_step']['mfma_util']}; `r05_final_vitl_traffic.json`: forward "
-         f"{mb(vt, 'attn_fwd_win_kernel'):.0f} MB per launch (operands + output: 787 MB at B = 64), dK/dV {mb(vt, 'attn_bwd_kv_win_kernel'):.0f}, dQ {mb(vt, 'attn_bwd_q_win_kernel'):.0f}, `gemm_tn_p8` {mb(vt, 'gemm_tn_p8_kernel'):.0f}.")
+         f"{mb(vt, 'attn_fwd_win_kernel'):.0f} MB per launch (Q, K, V read once + output written: 630 MB at B = 64; 1 852 MB before all groups of a (head, sample) pair were put on one XCD), dK/dV {mb(vt, 'attn_bwd_kv_win_kernel'):.0f}, dQ {mb(vt, 'attn_bwd_q_win_kernel'):.0f} (algorithmic 944 / 787), `gemm_tn_p8` {mb(vt, 'gemm_tn_p8_kernel'):.0f}.")
 L.append(f"* **config #4 rasterizer** (`tools/raster_bench.py`, 64 x 1 M events, 480x640): `r05_final_raster_kernel_stats.csv`: `raster_bin_keys` {rk[1]:.1f} us + `raster_bin_accum` {rc[1]:.1f} us "
          f"= {rk[1] + rc[1]:.1f} us for {ralg / 1e6:.0f} MB algorithmic = {ralg / ((rk[1] + rc[1]) * 1e-6) / 1e12:.2f} TB/s = **{ralg / ((rk[1] + rc[1]) * 1e-6) / 8e12:.3f}** of 8 TB/s; "
          f"`r05_final_raster_traffic.json` (= `raster_traffic.json`): {(rt['raster_bin_keys']['hbm_bytes_per_launch'] + rt['raster_bin_accum']['hbm_bytes_per_launch']) / 1e6:.0f} MB per launch = "
