@@ -362,7 +362,10 @@ __device__ __forceinline__ void fwd_phase_b(const char* Vs, const LaneOffs& lo, 
 //   * waves 4-7 half a chunk behind waves 0-3 (the gemm_p8 stagger; two barriers per chunk): 921 us;
 //   * one barrier in the MIDDLE of the chunk + the next chunk's first K fragments / bias words read ahead of phase B: 885-908 us
 //     (10 spilled registers);
-//   * the LDS reads of block kb + 2 forced to the front of region kb: no change.
+//   * the LDS reads of block kb + 2 forced to the front of region kb: no change;
+//   * THREE 4-wave workgroups per CU (<= 168 registers per lane: one block of K fragments / bias words at a time, K and V
+//     chunks single-buffered, 51.5 KB of LDS each): 1495 us -- 57 spilled registers and a phase A with nothing in flight
+//     cost far more than the third wave per SIMD hides.
 // Removal experiments (-DWIN_EXP, profiles/r05_attn_win_fwd_removals.txt): without the LDS reads of phase A (16 K-fragment and
 // 30 bias reads per chunk and wave) -28 %, without the score MFMAs -14 %, without the exponentials -12 %, without barrier and
 // staging -15 %, with the barrier kept but no LDS-DMA in the chunk loop -17 % (a per-lane staging plan that cuts the ~30
