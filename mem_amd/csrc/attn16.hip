@@ -32,6 +32,9 @@
 //     the bucket of (query, key), so the four keys of a register group are summed along the diagonal over neighbouring
 //     lanes of the whole wave (wave_shr:1) and a group costs 2 wave-wide atomics (round 4; an LDS atomic costs its wave
 //     ~52 cycles whatever its lane count).
+//     (Round 5: an EIGHTH wave that owns the table gradient -- reads the published dS tiles, does chains and adds -- was
+//     measured and dropped: 374 us per layer against 268; the LDS atomics of one wave do not overlap each other, spread over
+//     seven waves they do; fp32 buckets (ds_add_f32, single writer) 670 us.  tools/exp/attn16_bucket_wave.patch.)
 //   * FORWARD (round 4): eight waves -- the eighth only issues the LDS-DMA of the next sample (issue time, not memory
 //     time, was 23 % of the seven-wave kernel), and waves 4-6 run half a sample behind waves 0-3 so that the two waves of a
 //     SIMD alternate between their MFMA and VALU phases; K and V are double-buffered separately.

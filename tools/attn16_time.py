@@ -23,4 +23,5 @@ for rep in range(2):
     print(os.environ.get("MEMHIP_LIB", "default"),
           f"fwd {t(lambda: ops.attn_fwd(qkv, B, T, D, H, table, (14, 14), out, lse)):.1f} us  "
           f"bwd {t(lambda: ops.attn_bwd(qkv, dout, lse, delta, table, (14, 14), B, T, D, H, 0.125, dqkv, dtable, dqb, None)):.1f} us  "
-          f"bwd(no dtable) {t(lambda: ops.attn_bwd(qkv, dout, lse, delta, table, (14, 14), B, T, D, H, 0.125, dqkv, None, dqb, None)):.1f} us")
+          f"bwd(no dtable) {t(lambda: ops.attn_bwd(qkv, dout, lse, delta, table, (14, 14), B, T, D, H, 0.125, dqkv, None, dqb, None)):.1f} us  "
+          f"bwd(fused delta, as in the step) {t(lambda: ops.attn_bwd(qkv, dout, lse, delta, table, (14, 14), B, T, D, H, 0.125, dqkv, dtable, dqb, None, out=out)):.1f} us")
