@@ -33,8 +33,9 @@
 //     lanes of the whole wave (wave_shr:1) and a group costs 2 wave-wide atomics (round 4; an LDS atomic costs its wave
 //     ~52 cycles whatever its lane count).
 //     (Round 5: an EIGHTH wave that owns the table gradient -- reads the published dS tiles, does chains and adds -- was
-//     measured and dropped: 374 us per layer against 268; the LDS atomics of one wave do not overlap each other, spread over
-//     seven waves they do; fp32 buckets (ds_add_f32, single writer) 670 us.  tools/exp/attn16_bucket_wave.patch.)
+//     measured and dropped: 374 us per layer against 268 -- one wave does not get through the 28 dependent DPP chains of a step
+//     in the time the seven take for the step; with fp32 buckets (ds_add_f32, single writer) 670 us: a float LDS atomic takes
+//     195 cycles, an integer one 11 (tools/micro/lds_atomic_lat.hip).  tools/exp/attn16_bucket_wave.patch, tools/exp/README.md.)
 //   * FORWARD (round 4): eight waves -- the eighth only issues the LDS-DMA of the next sample (issue time, not memory
 //     time, was 23 % of the seven-wave kernel), and waves 4-6 run half a sample behind waves 0-3 so that the two waves of a
 //     SIMD alternate between their MFMA and VALU phases; K and V are double-buffered separately.
