@@ -56,7 +56,7 @@ const char* memhip_arch(void);
  * of samples start late at most, "gemm_stagger" (0): the same for the persistent GEMM workgroups, cycles per K-tile;
  * round 5: "attn_win" (1: windows 40 / 20 tokens wide and longer than 256 tokens run on the slot-layout kernels of
  * attn_win.hip, 0: attn_stream.hip), "gemm_p8_pair" (1: the full rounds and the ragged round of an NT product are ONE
- * launch, 0: two launches).
+ * launch, 0: two launches), "tn_group" (1: memhip_gemm_bf16_tn_group runs its products as one grid, 0: one by one).
  * Unknown name: MEMHIP_EINVAL.  Results do not depend on any option (same contract, different kernel or timing). */
 int memhip_set_option(const char* name, int value);
 int memhip_get_option(const char* name, int* value);
@@ -331,6 +331,24 @@ size_t memhip_gemm_bf16_tn_workspace(int R, int N, int K);
 int memhip_gemm_bf16_tn_ws(const void* A, int64_t lda, const void* B, int64_t ldb, int R, int N, int K,
                            float* out, int64_t ldo, int accumulate, void* workspace, size_t workspace_bytes,
                            memhip_stream_t stream);
+/* The weight gradients of up to 4 Linear layers whose operands are ready at the same time (fc2 + fc1, proj + qkv of a
+ * Block: mem/modeling_finetune.py:160-189 backward) as ONE launch: the products share one grid and one split count, so a
+ * small product (768 x 768: 9 tiles) runs with the 7 row slices of its neighbour instead of the 28 it needs alone to fill
+ * the chip, and the group has one reduction pass.  Each product has the contract of memhip_gemm_bf16_tn_ws (fixed sum order:
+ * run-to-run deterministic; the order differs from the single call's, so the two agree to fp32 rounding, not bitwise).
+ * workspace: memhip_gemm_bf16_tn_group_workspace(problems, count) bytes (also >= what each product needs alone).  When the
+ * group cannot run as one grid (count == 1, a shape outside the 256 x 256 tile kernel, workspace too small, option
+ * "tn_group" = 0) the products are computed one after the other by memhip_gemm_bf16_tn_ws -- same results contract. */
+typedef struct memhip_tn_problem {
+  const void* A; int64_t lda;       /* dY  bf16 [R, N] */
+  const void* B; int64_t ldb;       /* X   bf16 [R, K] */
+  float* out; int64_t ldo;          /* dW  f32  [N, K] */
+  int32_t R, N, K;
+  int32_t reserved0;
+} memhip_tn_problem_t;
+size_t memhip_gemm_bf16_tn_group_workspace(const memhip_tn_problem_t* problems, int count);
+int memhip_gemm_bf16_tn_group(const memhip_tn_problem_t* problems, int count, int accumulate, void* workspace,
+                              size_t workspace_bytes, memhip_stream_t stream);
 /* out f32 [C] += column sums of in bf16 [R, C]  (Linear bias gradients = grad_output.sum(0)) */
 int memhip_colsum_bf16(const void* in, int64_t ld, int R, int C, float* out, memhip_stream_t stream);
 /* out[n] += sum_k ws[k * N + n] for the `copies` accumulator copies a GEMM with colsum_copies > 1 filled; the copies

@@ -200,6 +200,9 @@ int gemm_tn256_dispatch(const void* A, long long lda, const void* B, long long l
 int gemm_tn_p8_dispatch(const void* A, long long lda, const void* B, long long ldb, int R, int N, int K, float* out,
                         long long ldo, int accumulate, float* ws, size_t ws_bytes, hipStream_t s);
 size_t gemm_tn_p8_workspace(int R, int N, int K);
+size_t gemm_tn_p8_group_workspace(const memhip_tn_problem_t* pr, int count);
+int gemm_tn_p8_group_dispatch(const memhip_tn_problem_t* pr, int count, int accumulate, float* ws, size_t ws_bytes,
+                              hipStream_t s);
 }
 
 extern "C" size_t memhip_gemm_bf16_tn_workspace(int R, int N, int K) { return memhip::gemm_tn_p8_workspace(R, N, K); }
@@ -253,6 +256,42 @@ extern "C" int memhip_gemm_bf16_tn_ws(const void* A, int64_t lda, const void* B,
                      (long long)lda, (const __bf16*)B, (long long)ldb, R, N, K, out, (long long)ldo, splits,
                      rows_per_split, use_atomics);
   return check_launch("gemm_bf16_tn");
+}
+
+extern "C" size_t memhip_gemm_bf16_tn_group_workspace(const memhip_tn_problem_t* problems, int count) {
+  if (!problems || count <= 0) return 0;
+  size_t need = memhip::gemm_tn_p8_group_workspace(problems, count);
+  for (int i = 0; i < count; ++i) {                        // ... and enough for the one-by-one path
+    const size_t one = memhip::gemm_tn_p8_workspace(problems[i].R, problems[i].N, problems[i].K);
+    need = one > need ? one : need;
+  }
+  return need;
+}
+
+extern "C" int memhip_gemm_bf16_tn_group(const memhip_tn_problem_t* problems, int count, int accumulate, void* workspace,
+                                         size_t workspace_bytes, memhip_stream_t stream) {
+  MEMHIP_REQUIRE(problems && count >= 1 && count <= 4, "gemm_tn_group: 1..4 problems, got %d", count);
+  bool all = true;
+  for (int i = 0; i < count; ++i) {
+    const memhip_tn_problem_t& q = problems[i];
+    MEMHIP_REQUIRE(q.R >= 0 && q.N > 0 && q.K > 0, "gemm_tn_group[%d]: bad shape R=%d N=%d K=%d", i, q.R, q.N, q.K);
+    MEMHIP_REQUIRE(q.R == 0 || (q.A && q.B && q.out), "gemm_tn_group[%d]: null pointer", i);
+    MEMHIP_REQUIRE(q.N % 8 == 0 && q.K % 8 == 0 && q.lda % 8 == 0 && q.ldb % 8 == 0 && ((uintptr_t)q.A & 15) == 0 &&
+                       ((uintptr_t)q.B & 15) == 0, "gemm_tn_group[%d]: operands must be 16-byte aligned, N/K/ld %% 8 == 0", i);
+    all = all && q.R > 0;
+  }
+  hipStream_t s = as_stream(stream);
+  if (all && count > 1 && opt(OPT_TN_P8) != 0 && opt(OPT_TN_GROUP) != 0) {
+    const int rc = gemm_tn_p8_group_dispatch(problems, count, accumulate, (float*)workspace, workspace_bytes, s);
+    if (rc != MEMHIP_EUNSUPPORTED) return rc;
+  }
+  for (int i = 0; i < count; ++i) {
+    const memhip_tn_problem_t& q = problems[i];
+    const int rc = memhip_gemm_bf16_tn_ws(q.A, q.lda, q.B, q.ldb, q.R, q.N, q.K, q.out, q.ldo, accumulate, workspace,
+                                          workspace_bytes, stream);
+    if (rc != MEMHIP_OK) return rc;
+  }
+  return MEMHIP_OK;
 }
 
 namespace {

@@ -90,22 +90,25 @@ __device__ __forceinline__ bf16x8 tr_pair(unsigned lds_addr) {
 // WS = false: the partial tile is added to `out` with fp32 atomics.  WS = true: it is written with
 // plain 16-byte stores to slab `sp` of a workspace [splits][N][K] (ldo = K), summed afterwards by
 // tn_reduce_kernel: 64 MB of atomics per GEMM run at ~1.3 TB/s, plain stores at 5-6 TB/s.
+// Workgroups b, b+8, ... share an XCD (and its L2).  All tiles of one token slice read the same
+// rows of A and B, so consecutive ids of the (slice, tile) space go to ONE XCD: bijective remap of
+// blockIdx (measured before: 1.13 GB fetched per launch for 0.39 GB of operands, HBM-bound).
+__device__ __forceinline__ int tn_xcd_wid() {
+  const int gq = (int)gridDim.x / 8, gr = (int)gridDim.x % 8, xcd = (int)blockIdx.x % 8;
+  return (xcd < gr ? xcd * (gq + 1) : gr * (gq + 1) + (xcd - gr) * gq) + (int)blockIdx.x / 8;
+}
+
+// one workgroup: id `wid` of the (slice, tile) space of ONE product
 template <bool WS>
-__global__ __launch_bounds__(kThreads) void gemm_tn_p8_kernel(const __bf16* __restrict__ A, long long lda,
-                                                              const __bf16* __restrict__ B, long long ldb,
-                                                              int R, int N, int K, float* __restrict__ out,
-                                                              long long ldo, int rows_per_split) {
+__device__ __forceinline__ void tn_p8_body(const __bf16* __restrict__ A, long long lda, const __bf16* __restrict__ B,
+                                           long long ldb, int R, int N, int K, float* __restrict__ out, long long ldo,
+                                           int rows_per_split, int wid) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wr = wave >> 2, wc = wave & 3;
   const int ntk = K / BN;
   const int tiles = (N / BM) * ntk;
-  // Workgroups b, b+8, ... share an XCD (and its L2).  All tiles of one token slice read the same
-  // rows of A and B, so consecutive ids of the (slice, tile) space go to ONE XCD: bijective remap of
-  // blockIdx (measured before: 1.13 GB fetched per launch for 0.39 GB of operands, HBM-bound).
-  const int gq = (int)gridDim.x / 8, gr = (int)gridDim.x % 8, xcd = (int)blockIdx.x % 8;
-  const int wid = (xcd < gr ? xcd * (gq + 1) : gr * (gq + 1) + (xcd - gr) * gq) + (int)blockIdx.x / 8;
   const int tile = wid % tiles, sp = wid / tiles;
   const int n0 = (tile / ntk) * BM, k0 = (tile % ntk) * BN;
   const int rbeg = sp * rows_per_split;
@@ -340,6 +343,69 @@ __global__ __launch_bounds__(kThreads) void gemm_tn_p8_kernel(const __bf16* __re
     }
 }
 
+template <bool WS>
+__global__ __launch_bounds__(kThreads) void gemm_tn_p8_kernel(const __bf16* __restrict__ A, long long lda,
+                                                              const __bf16* __restrict__ B, long long ldb,
+                                                              int R, int N, int K, float* __restrict__ out,
+                                                              long long ldo, int rows_per_split) {
+  tn_p8_body<WS>(A, lda, B, ldb, R, N, K, out, ldo, rows_per_split, tn_xcd_wid());
+}
+
+// ---- GROUPED launch (round 5): the weight gradients of up to four Linear layers whose operands are ready at the same time
+// (fc2 + fc1, proj + qkv of a block) as ONE grid with ONE common split count.  Alone, a 768 x 768 gradient has 9 tiles and
+// needs 28 row slices to fill 256 CUs (28 slabs of 2.4 MB for a 2.4 MB result, 1 800 rows of main loop per workgroup against
+// the same 256 KB write-out); beside the 27 tiles of the qkv gradient both run with 7 slices -- the shape of the fc1 launch.
+// Workgroup ids are laid out product after product, (slice, tile) inside a product, so an XCD still works on consecutive
+// (slice, tile) ids of one product.
+constexpr int kTnGroupMax = 4;
+struct TnGroupProblem {
+  const __bf16* A;
+  const __bf16* B;
+  float* ws;                 // this product's slabs [splits][N][K]
+  float* out;                // the gradient (reduction pass)
+  long long lda, ldb, ldo;
+  int R, N, K;
+  int rows_per_split, splits;
+  int wg_begin;              // first workgroup id of the product
+  int quad_begin;            // first float4 of the product in the reduction pass
+};
+struct TnGroup {
+  TnGroupProblem p[kTnGroupMax];
+  int count;
+};
+__global__ __launch_bounds__(kThreads) void gemm_tn_p8_group_kernel(const TnGroup g) {
+  const int wid = tn_xcd_wid();
+  int i = 0;
+#pragma unroll
+  for (int j = 1; j < kTnGroupMax; ++j)
+    if (j < g.count && wid >= g.p[j].wg_begin) i = j;
+  const TnGroupProblem& q = g.p[i];
+  tn_p8_body<true>(q.A, q.lda, q.B, q.ldb, q.R, q.N, q.K, q.ws, (long long)q.K, q.rows_per_split, wid - q.wg_begin);
+}
+__global__ __launch_bounds__(256) void tn_reduce_group_kernel(const TnGroup g, int accumulate) {
+  const int quad = blockIdx.x * 256 + threadIdx.x;
+  int i = 0;
+#pragma unroll
+  for (int j = 1; j < kTnGroupMax; ++j)
+    if (j < g.count && quad >= g.p[j].quad_begin) i = j;
+  const TnGroupProblem& q = g.p[i];
+  const long long i4 = (long long)(quad - q.quad_begin) * 4;
+  const long long slab = (long long)q.N * q.K;
+  if (i4 >= slab) return;
+  float4 a = *reinterpret_cast<const float4*>(q.ws + i4);
+  for (int s = 1; s < q.splits; ++s) {
+    const float4 b = *reinterpret_cast<const float4*>(q.ws + s * slab + i4);
+    a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+  }
+  const long long n = i4 / q.K, k = i4 - n * q.K;
+  float4* o = reinterpret_cast<float4*>(q.out + n * q.ldo + k);
+  if (accumulate) {
+    const float4 c = *o;
+    a.x += c.x; a.y += c.y; a.z += c.z; a.w += c.w;
+  }
+  *o = a;
+}
+
 // out[n][k] (+)= sum over the S slabs of the workspace
 __global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict__ ws, int S, long long slab, int N, int K,
                                                         float* __restrict__ out, long long ldo, int accumulate) {
@@ -430,6 +496,87 @@ int gemm_tn_p8_dispatch(const void* A, long long lda, const void* B, long long l
   hipLaunchKernelGGL(gemm_tn_p8_kernel<false>, dim3(tiles * splits), dim3(kThreads), kRing, s, (const __bf16*)A, lda,
                      (const __bf16*)B, ldb, R, N, K, out, ldo, rows_per_split);
   return check_launch("gemm_bf16_tn(p8)");
+}
+
+// ---- grouped launch: plan.  One split count for the whole group: the smallest number of rounds (grids of num_cu workgroups)
+// that keeps >= 95 % of the CUs busy, else the best of four.
+static bool tn_group_plan(const memhip_tn_problem_t* pr, int count, int num_cu, TnGroup& g, int& total_wgs, int& total_quads,
+                          size_t& ws_floats) {
+  if (count < 2 || count > kTnGroupMax || !num_cu) return false;
+  int tiles_total = 0;
+  for (int i = 0; i < count; ++i) {
+    if (pr[i].N % BM != 0 || pr[i].K % BN != 0 || pr[i].R < 2048 || pr[i].ldo % 4 != 0) return false;
+    tiles_total += (pr[i].N / BM) * (pr[i].K / BN);
+  }
+  int best_s = 0;
+  double best_eff = 0.0;
+  for (int r = 1; r <= 4; ++r) {
+    const int sp = (r * num_cu) / tiles_total;
+    if (sp < 2) continue;
+    const double eff = (double)tiles_total * sp / ((double)r * num_cu);
+    if (eff > best_eff + 1e-9) { best_eff = eff; best_s = sp; }
+    if (eff >= 0.95) break;
+  }
+  if (best_s < 2) return false;
+  total_wgs = 0; total_quads = 0; ws_floats = 0;
+  g.count = count;
+  for (int i = 0; i < count; ++i) {
+    TnGroupProblem& q = g.p[i];
+    const int tiles = (pr[i].N / BM) * (pr[i].K / BN);
+    const int pairs = cdiv(pr[i].R, 2 * BR);
+    int sp = best_s;
+    if (sp > pairs / 2) sp = pairs / 2 > 0 ? pairs / 2 : 1;
+    q.rows_per_split = cdiv(pairs, sp) * 2 * BR;
+    q.splits = cdiv(pr[i].R, q.rows_per_split);
+    q.A = (const __bf16*)pr[i].A; q.B = (const __bf16*)pr[i].B;
+    q.lda = pr[i].lda; q.ldb = pr[i].ldb; q.ldo = pr[i].ldo;
+    q.R = pr[i].R; q.N = pr[i].N; q.K = pr[i].K;
+    q.out = pr[i].out;
+    q.ws = nullptr;
+    q.wg_begin = total_wgs;
+    q.quad_begin = total_quads;
+    total_wgs += tiles * q.splits;
+    total_quads += (int)(((long long)pr[i].N * pr[i].K / 4 + 255) / 256 * 256);      // whole blocks per product
+    ws_floats += (size_t)q.splits * pr[i].N * pr[i].K;
+  }
+  return true;
+}
+
+size_t gemm_tn_p8_group_workspace(const memhip_tn_problem_t* pr, int count) {
+  const int num_cu = max_cus();
+  size_t need = 0;
+  for (int cu = num_cu; cu >= 8; cu -= 8) {
+    TnGroup g;
+    int wgs, quads;
+    size_t fl;
+    if (tn_group_plan(pr, count, cu, g, wgs, quads, fl) && fl * sizeof(float) > need) need = fl * sizeof(float);
+  }
+  return need;
+}
+
+// MEMHIP_EUNSUPPORTED: the caller runs the products one by one.
+int gemm_tn_p8_group_dispatch(const memhip_tn_problem_t* pr, int count, int accumulate, float* ws, size_t ws_bytes, hipStream_t s) {
+  TnGroup g;
+  int wgs, quads;
+  size_t fl;
+  if (!ws || ((uintptr_t)ws & 15) != 0 || !tn_group_plan(pr, count, tn_p8_num_cu(s), g, wgs, quads, fl) ||
+      fl * sizeof(float) > ws_bytes)
+    return MEMHIP_EUNSUPPORTED;
+  static bool attr_done = false;
+  if (!attr_done) {
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_p8_group_kernel),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, kRing);
+    if (e != hipSuccess) return fail(MEMHIP_ELAUNCH, "gemm_tn_p8(group): set smem attr: %s", hipGetErrorString(e));
+    attr_done = true;
+  }
+  float* w = ws;
+  for (int i = 0; i < count; ++i) {
+    g.p[i].ws = w;
+    w += (size_t)g.p[i].splits * g.p[i].N * g.p[i].K;
+  }
+  hipLaunchKernelGGL(gemm_tn_p8_group_kernel, dim3(wgs), dim3(kThreads), kRing, s, g);
+  hipLaunchKernelGGL(tn_reduce_group_kernel, dim3((unsigned)(quads / 256)), dim3(256), 0, s, g, accumulate);
+  return check_launch("gemm_bf16_tn_group(p8)");
 }
 
 }  // namespace memhip

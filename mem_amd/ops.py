@@ -355,6 +355,8 @@ declare({
     "memhip_gemm_bf16_tn": (i32, [vp, i64, vp, i64, i32, i32, i32, vp, i64, i32, vp]),
     "memhip_gemm_bf16_tn_ws": (i32, [vp, i64, vp, i64, i32, i32, i32, vp, i64, i32, vp, sz, vp]),
     "memhip_gemm_bf16_tn_workspace": (sz, [i32, i32, i32]),
+    "memhip_gemm_bf16_tn_group_workspace": (sz, [vp, i32]),
+    "memhip_gemm_bf16_tn_group": (i32, [vp, i32, i32, vp, sz, vp]),
     "memhip_colsum_bf16": (i32, [vp, i64, i32, i32, vp, vp]),
     "memhip_colsum_fold": (i32, [vp, i32, i32, vp, vp]),
     "memhip_residual_rows": (i32, [vp, i64, vp, vp, i64, vp, vp, f32, i32, i32, vp, i64, vp]),
@@ -380,6 +382,43 @@ def gemm_tn(A, B, R, N, K, out, accumulate=True, workspace=None):
                                          int(accumulate), ws, wsb, stream_ptr()), "gemm_bf16_tn")
         e1.record()
         GEMM_TIMER.append((e0, e1, 2.0 * R * N * K, 100))
+
+
+class TnProblem(C.Structure):
+    """memhip_tn_problem_t (include/memhip.h)"""
+    _fields_ = [("A", C.c_void_p), ("lda", C.c_int64), ("B", C.c_void_p), ("ldb", C.c_int64), ("out", C.c_void_p),
+                ("ldo", C.c_int64), ("R", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("reserved0", C.c_int32)]
+
+
+def _tn_problems(problems):
+    arr = (TnProblem * len(problems))()
+    for q, (A, B, R, N, K, out) in zip(arr, problems):
+        q.A, q.lda, q.B, q.ldb, q.out, q.ldo = A.data_ptr(), A.stride(0), B.data_ptr(), B.stride(0), out.data_ptr(), out.stride(0)
+        q.R, q.N, q.K, q.reserved0 = R, N, K, 0
+    return arr
+
+
+def gemm_tn_group_workspace(shapes):
+    """bytes of scratch for gemm_tn_group over products of the shapes [(R, N, K), ...]"""
+    arr = (TnProblem * len(shapes))()
+    for q, (R, N, K) in zip(arr, shapes):
+        q.R, q.N, q.K, q.lda, q.ldb, q.ldo = R, N, K, N, K, K
+    return int(lib.memhip_gemm_bf16_tn_group_workspace(arr, len(shapes)))
+
+
+def gemm_tn_group(problems, accumulate=True, workspace=None):
+    """The weight gradients [(A = dY, B = X, R, N, K, out f32 [N, K]), ...] of up to four layers as ONE launch
+    (memhip_gemm_bf16_tn_group); each product has the contract of gemm_tn."""
+    ws, wsb = (ptr(workspace), workspace.numel() * workspace.element_size()) if workspace is not None else (None, 0)
+    arr = _tn_problems(problems)
+    if GEMM_TIMER is None:
+        check(lib.memhip_gemm_bf16_tn_group(arr, len(problems), int(accumulate), ws, wsb, stream_ptr()), "gemm_bf16_tn_group")
+    else:
+        e0, e1 = _timer_event(), _timer_event()
+        e0.record()
+        check(lib.memhip_gemm_bf16_tn_group(arr, len(problems), int(accumulate), ws, wsb, stream_ptr()), "gemm_bf16_tn_group")
+        e1.record()
+        GEMM_TIMER.append((e0, e1, sum(2.0 * R * N * K for _, _, R, N, K, _ in problems), 100))
 
 
 def colsum_fold(ws, copies, N, out):

@@ -93,6 +93,7 @@ class ViTEngine:
         self._opt_ev = None               # bucket name -> event (parameters of that bucket are updated, cast)
         self._opt_done = None             # everything incl. the transposed copies
         self.wgrad_side_stream = True
+        self.wgrad_group = 1             # 1: proj + qkv weight gradients of a block as one launch (_wgrad_group); 2: fc2 + fc1 too; 0: off
         self.fwd_two_streams = False      # forward: uneven two-stream split (see forward_trunk / _split_point).  It paid
                                           # -0.24 ms at B = 256 while the GEMM epilogues stalled on their own stores (the
                                           # second part filled those stalls); with the branch-free epilogues of the 256-row
@@ -656,6 +657,35 @@ class ViTEngine:
         for gv, c0, c1 in bias_grads:
             ops.colsum_bf16(dY[:, c0:c1], R, c1 - c0, gv)
 
+    def _wg_mlp(self, pre, a, has_g, R, dY):
+        """fc2 and fc1 weight gradients of a block (+ the layer-scale gradient, a linear function of the fc2 one)."""
+        D, Hd = self.D, self.hidden
+        both = int(self.wgrad_group) >= 2
+        if both:
+            self._wgrad_group([(dY, a["a"], R, D, Hd, pre + "mlp.fc2.weight"), (self.dbig, a["h2"], R, Hd, D, pre + "mlp.fc1.weight")])
+        else:
+            self._wgrad(dY, a["a"], R, D, Hd, pre + "mlp.fc2.weight")
+        self._side_read_done("dY")
+        if has_g:
+            # layer-scale gradient from the weight gradient (no branch output y kept): memhip_layerscale_grad
+            ops.layerscale_grad(self.W16(pre + "mlp.fc2.weight", D, Hd), self.G(pre + "mlp.fc2.weight").view(D, Hd),
+                                self.P(pre + "mlp.fc2.bias"), self.G(pre + "mlp.fc2.bias"),
+                                self.P(pre + "gamma_2"), D, Hd, self.G(pre + "gamma_2"))
+        if not both:
+            self._wgrad(self.dbig, a["h2"], R, Hd, D, pre + "mlp.fc1.weight")
+        self._side_read_done("dbig")
+
+    def _wgrad_group(self, items):
+        """items = [(dY, X, R, n_out, n_in, gname), ...]: the weight gradients of layers whose operands are ready at the
+        same time as ONE launch (ops.gemm_tn_group): the 768 x 768 proj gradient rides with the 7 row slices of the qkv
+        gradient instead of the 28 it needs alone to fill the chip (proj + qkv: 241 -> 212 us per block; fc2 + fc1, two
+        rounds of workgroups, measured no faster than two launches and stay separate)."""
+        need = ops.gemm_tn_group_workspace([(R, n_out, n_in) for _, _, R, n_out, n_in, _ in items])
+        if need > self._tn_ws.numel():
+            self._tn_ws = torch.empty(need, dtype=torch.uint8, device=self.dev)
+        ops.gemm_tn_group([(dY, X, R, n_out, n_in, self.G(gname).view(n_out, n_in)) for dY, X, R, n_out, n_in, gname in items],
+                          accumulate=self.accumulate_grads, workspace=self._tn_ws)
+
     # ---- second stream for the weight-gradient products
     def _event(self):
         if self._ev_i == len(self._ev_pool):
@@ -677,7 +707,8 @@ class ViTEngine:
             # the wgrad workspace is sized once so that it is never reallocated while the side stream uses it
             D, Hd = self.D, self.hidden
             M = self.B * self.T
-            need = max(ops.gemm_tn_workspace(M, 3 * D, D), ops.gemm_tn_workspace(M, Hd, D), ops.gemm_tn_workspace(M, D, Hd),
+            need = max(ops.gemm_tn_group_workspace([(M, D, D), (M, 3 * D, D)]), ops.gemm_tn_group_workspace([(M, D, Hd), (M, Hd, D)]),
+                       ops.gemm_tn_workspace(M, 3 * D, D), ops.gemm_tn_workspace(M, Hd, D), ops.gemm_tn_workspace(M, D, Hd),
                        ops.gemm_tn_workspace(M, D, D), ops.gemm_tn_workspace(getattr(self, "Mm_cap", 0) or M, max(self.V, 1), D),
                        ops.gemm_tn_workspace(self.B * self.L, D, self.Kpe))
             if need > self._tn_ws.numel():
@@ -796,14 +827,7 @@ class ViTEngine:
         ops.colsum_fold(self.cs_ws, self.CS_COPIES, Hd, self.G(pre + "mlp.fc1.bias"))
 
         def wg_mlp():
-            self._wgrad(dY, a["a"], Mm, D, Hd, pre + "mlp.fc2.weight")
-            self._side_read_done("dY")
-            if has_g:
-                ops.layerscale_grad(self.W16(pre + "mlp.fc2.weight", D, Hd), self.G(pre + "mlp.fc2.weight").view(D, Hd),
-                                    self.P(pre + "mlp.fc2.bias"), self.G(pre + "mlp.fc2.bias"),
-                                    self.P(pre + "gamma_2"), D, Hd, self.G(pre + "gamma_2"))
-            self._wgrad(self.dbig, a["h2"], Mm, Hd, D, pre + "mlp.fc1.weight")
-            self._side_read_done("dbig")
+            self._wg_mlp(pre, a, has_g, Mm, dY)
         self._on_side(wg_mlp)
         ops.gemm_nt(self.dbig, self.wT[i]["fc1"], Mp, D, Hd, ops.EPI_BIAS_BF16, out0=self.dh_small)
         ops.layernorm_bwd(self.dh_small, self.x[2 * i + 1], self.P(pre + "norm2.weight"), a["mean2"], a["rstd2"], dx,
@@ -866,14 +890,7 @@ class ViTEngine:
                 ops.colsum_fold(self.cs_ws, self.CS_COPIES, Hd, self.G(pre + "mlp.fc1.bias"))
 
                 def wg_mlp(i=i, pre=pre, a=a, has_g=has_g, M2=M2):
-                    self._wgrad(dY, a["a"], M2, D, Hd, pre + "mlp.fc2.weight")
-                    self._side_read_done("dY")
-                    if has_g:
-                        ops.layerscale_grad(self.W16(pre + "mlp.fc2.weight", D, Hd), self.G(pre + "mlp.fc2.weight").view(D, Hd),
-                                            self.P(pre + "mlp.fc2.bias"), self.G(pre + "mlp.fc2.bias"),
-                                            self.P(pre + "gamma_2"), D, Hd, self.G(pre + "gamma_2"))
-                    self._wgrad(self.dbig, a["h2"], M2, Hd, D, pre + "mlp.fc1.weight")
-                    self._side_read_done("dbig")
+                    self._wg_mlp(pre, a, has_g, M2, dY)
                 self._on_side(wg_mlp)
                 ops.gemm_nt(self.dbig, self.wT[i]["fc1"], M2p, D, Hd, ops.EPI_BIAS_BF16, out0=self.dh_small)
             if tail is not None:
@@ -903,21 +920,28 @@ class ViTEngine:
             ops.gemv_acc(self.wT[i]["proj"], D, D, scr, self.G(pre + "attn.v_bias"),
                          x_acc=self.G(pre + "attn.proj.bias"), zero=self.bias_scr[(i & 1) ^ 1])
             if na > 0:
-                def wg_proj(pre=pre, a=a, has_g=has_g, M1=M1):
-                    self._wgrad(dY2, a["ao"], M1, D, D, pre + "attn.proj.weight")
+                def wg_proj(pre=pre, a=a, has_g=has_g, M1=M1, grouped=False):
+                    if not grouped:
+                        self._wgrad(dY2, a["ao"], M1, D, D, pre + "attn.proj.weight")
                     self._side_read_done("dY2")
                     if has_g:
                         ops.layerscale_grad(self.W16(pre + "attn.proj.weight", D, D), self.G(pre + "attn.proj.weight").view(D, D),
                                             self.P(pre + "attn.proj.bias"), self.G(pre + "attn.proj.bias"),
                                             self.P(pre + "gamma_1"), D, D, self.G(pre + "gamma_1"))
-                self._on_side(wg_proj)
+                if not self.wgrad_group:
+                    self._on_side(wg_proj)
                 self._before_overwrite("dqkv")
                 # (rowsum(dO * O) is computed inside the fused 14 x 14 backward; other windows: a delta pass in the library)
                 ops.attn_bwd(a["qkv"], self.dao, a["lse"], self.delta_ws, table, self.window, na, T, D, self.heads,
                              self.scale, self.dqkv, dtable, dq_bias=self.G(pre + "attn.q_bias"), out=a["ao"])
 
-                def wg_qkv(pre=pre, a=a, M1=M1):
-                    self._wgrad(self.dqkv, a["h1"], M1, 3 * D, D, pre + "attn.qkv.weight")
+                def wg_qkv(pre=pre, a=a, M1=M1, wg_proj=wg_proj):
+                    if self.wgrad_group:
+                        self._wgrad_group([(dY2, a["ao"], M1, D, D, pre + "attn.proj.weight"),
+                                           (self.dqkv, a["h1"], M1, 3 * D, D, pre + "attn.qkv.weight")])
+                        wg_proj(grouped=True)
+                    else:
+                        self._wgrad(self.dqkv, a["h1"], M1, 3 * D, D, pre + "attn.qkv.weight")
                     self._side_read_done("dqkv")
                 self._on_side(wg_qkv)
                 ops.gemm_nt(self.dqkv, self.wT[i]["qkv"], M1p, D, 3 * D, ops.EPI_BIAS_BF16, out0=self.dh_small)
@@ -987,15 +1011,7 @@ class ViTEngine:
                 ops.colsum_fold(self.cs_ws, self.CS_COPIES, Hd, self.G(pre + "mlp.fc1.bias"))
 
                 def wg_mlp(i=i, pre=pre, a=a, has_g=has_g):
-                    self._wgrad(dY, a["a"], M, D, Hd, pre + "mlp.fc2.weight")
-                    self._side_read_done("dY")
-                    if has_g:
-                        # layer-scale gradient from the weight gradient (no branch output y kept): memhip_layerscale_grad
-                        ops.layerscale_grad(self.W16(pre + "mlp.fc2.weight", D, Hd), self.G(pre + "mlp.fc2.weight").view(D, Hd),
-                                            self.P(pre + "mlp.fc2.bias"), self.G(pre + "mlp.fc2.bias"),
-                                            self.P(pre + "gamma_2"), D, Hd, self.G(pre + "gamma_2"))
-                    self._wgrad(self.dbig, a["h2"], M, Hd, D, pre + "mlp.fc1.weight")
-                    self._side_read_done("dbig")
+                    self._wg_mlp(pre, a, has_g, M, dY)
                 self._on_side(wg_mlp)
                 ops.gemm_nt(self.dbig, self.wT[i]["fc1"], M, D, Hd, ops.EPI_BIAS_BF16, out0=self.dh_small)
                 scr = self.bias_scr[i & 1]
@@ -1022,21 +1038,28 @@ class ViTEngine:
             ops.gemv_acc(self.wT[i]["proj"], D, D, scr, self.G(pre + "attn.v_bias"),
                          x_acc=self.G(pre + "attn.proj.bias"), zero=self.bias_scr[(i & 1) ^ 1])
 
-            def wg_proj(pre=pre, a=a, has_g=has_g):
-                self._wgrad(dY2, a["ao"], M, D, D, pre + "attn.proj.weight")
+            def wg_proj(pre=pre, a=a, has_g=has_g, grouped=False):
+                if not grouped:
+                    self._wgrad(dY2, a["ao"], M, D, D, pre + "attn.proj.weight")
                 self._side_read_done("dY2")
                 if has_g:
                     ops.layerscale_grad(self.W16(pre + "attn.proj.weight", D, D), self.G(pre + "attn.proj.weight").view(D, D),
                                         self.P(pre + "attn.proj.bias"), self.G(pre + "attn.proj.bias"),
                                         self.P(pre + "gamma_1"), D, D, self.G(pre + "gamma_1"))
-            self._on_side(wg_proj)
+            if not self.wgrad_group:
+                self._on_side(wg_proj)
             self._before_overwrite("dqkv")
             # (rowsum(dO * O) is computed inside the fused 14 x 14 backward; other windows: a delta pass in the library)
             ops.attn_bwd(a["qkv"], self.dao, a["lse"], self.delta_ws, table, self.window, B, T, D, self.heads,
                          self.scale, self.dqkv, dtable, dq_bias=self.G(pre + "attn.q_bias"), out=a["ao"])
 
-            def wg_qkv(pre=pre, a=a):
-                self._wgrad(self.dqkv, a["h1"], M, 3 * D, D, pre + "attn.qkv.weight")
+            def wg_qkv(pre=pre, a=a, wg_proj=wg_proj):
+                if self.wgrad_group:
+                    self._wgrad_group([(dY2, a["ao"], M, D, D, pre + "attn.proj.weight"),
+                                       (self.dqkv, a["h1"], M, 3 * D, D, pre + "attn.qkv.weight")])
+                    wg_proj(grouped=True)
+                else:
+                    self._wgrad(self.dqkv, a["h1"], M, 3 * D, D, pre + "attn.qkv.weight")
                 self._side_read_done("dqkv")
             self._on_side(wg_qkv)
             ops.gemm_nt(self.dqkv, self.wT[i]["qkv"], M, D, 3 * D, ops.EPI_BIAS_BF16, out0=self.dh_small)

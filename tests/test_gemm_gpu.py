@@ -167,6 +167,49 @@ def test_gemm_tn_weight_gradient(R, N, K):
     torch.testing.assert_close(cs, A.float().sum(0), rtol=1e-4, atol=1e-2)
 
 
+@pytest.mark.parametrize("shapes", [
+    [(50432, 768, 768), (50432, 2304, 768)],                       # proj + qkv of a ViT-B block: one grid, 7 row slices each
+    [(9001, 256, 512), (5000, 512, 256), (3000, 256, 256)],        # different row counts, ragged
+    [(4099, 768, 768), (4099, 768, 3072), (4099, 3072, 768), (4099, 2304, 768)],
+    [(3000, 768, 768), (300, 768, 768)],                           # second product outside the tile kernel: one by one
+    [(2500, 512, 256)],                                            # a group of one
+])
+def test_gemm_tn_group_equals_single_calls(shapes):
+    """memhip_gemm_bf16_tn_group: every product of the group has the single call's contract (exact on integer data, equal to
+    the single call to fp32 rounding -- the row slices differ --, accumulate adds, same bits every run), whether the group
+    runs as one grid or falls back to the single calls."""
+    from mem_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(len(shapes))
+    ints = [(torch.randint(-2, 3, (R, N), generator=g, device="cuda").float(),
+             torch.randint(-2, 3, (R, K), generator=g, device="cuda").float() + (torch.arange(K, device="cuda") % 3)) for R, N, K in shapes]
+    need = max(ops.gemm_tn_group_workspace(shapes), 16)
+    assert need >= max(ops.gemm_tn_workspace(*sh) for sh in shapes)
+    ws = torch.empty(need, dtype=torch.uint8, device="cuda")
+    outs = [torch.full((N, K), 3.0, device="cuda") for _, N, K in shapes]
+    ops.gemm_tn_group([(A.bfloat16(), B.bfloat16(), R, N, K, o) for (A, B), (R, N, K), o in zip(ints, shapes, outs)],
+                      accumulate=False, workspace=ws)
+    for (A, B), o in zip(ints, outs):
+        torch.testing.assert_close(o, A.t() @ B, rtol=0, atol=0)
+    ops_in = [(_rand((R, N), 60 + i).bfloat16(), _rand((R, K), 70 + i).bfloat16()) for i, (R, N, K) in enumerate(shapes)]
+    single = [torch.zeros((N, K), device="cuda") for _, N, K in shapes]
+    for (A, B), (R, N, K), o in zip(ops_in, shapes, single):
+        ops.gemm_tn(A, B, R, N, K, o, accumulate=False, workspace=ws)
+    probs = [(A, B, R, N, K, o) for (A, B), (R, N, K), o in zip(ops_in, shapes, outs)]
+    ops.gemm_tn_group(probs, accumulate=False, workspace=ws)
+    first = [o.clone() for o in outs]
+    for o, s1 in zip(outs, single):
+        torch.testing.assert_close(o, s1, rtol=1e-5, atol=1e-5 * float(s1.abs().max()))
+    ops.gemm_tn_group(probs, accumulate=False, workspace=ws)
+    assert all(torch.equal(o, f) for o, f in zip(outs, first))
+    ops.gemm_tn_group(probs, accumulate=True, workspace=ws)
+    for o, f in zip(outs, first):
+        torch.testing.assert_close(o, 2 * f, rtol=1e-6, atol=0)
+    # without a workspace the products run one by one (atomics): same values to rounding
+    ops.gemm_tn_group(probs, accumulate=False, workspace=None)
+    for o, s1 in zip(outs, single):
+        torch.testing.assert_close(o, s1, rtol=1e-4, atol=1e-5 * float(s1.abs().max()))
+
+
 @pytest.mark.parametrize("M,N,K", [(2048, 128, 64), (4000, 768, 768), (2304 + 17, 2304, 768), (5000, 384, 3072),
                                    (4096, 256, 64), (4096 + 100, 768, 768), (9000, 2304, 128), (4500, 512, 3072),
                                    (25600 + 13, 768, 1536)])       # last: 303 tiles -> row-split launch (p8 + 128x128)

@@ -1,0 +1,15 @@
+#!/bin/bash
+# round 5, call 15: engine.wgrad_group 0 / 1 / 2 interleaved (2 = fc2 + fc1 grouped too)
+cd /root/repo; mkdir -p gpurun_out
+python -m pytest tests/test_train_gpu.py -q -x 2>&1 | tail -2
+F="--steps 40 --warmup 10 --no-cpu-baseline --no-tokenizer-figure --no-raster-figure --no-entrypoint-figure --no-config5-figure --no-config4-figure"
+for rep in 1 2 3; do
+  for V in 2 1 0; do
+    python bench.py $F --wgrad-group $V > gpurun_out/r05_wg${V}_$rep.json 2> gpurun_out/r05_wg${V}_$rep.err
+    python - <<PY
+import json
+d=json.loads(open("gpurun_out/r05_wg${V}_$rep.json").read().strip().splitlines()[-1])
+print("wgrad_group $V rep $rep ms_per_step", d["ms_per_step"], "p50", d.get("ms_per_step_p50"))
+PY
+  done
+done 2>&1 | tee gpurun_out/r05_wgrad_group_ab.txt
