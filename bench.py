@@ -191,7 +191,7 @@ def config5_figure(B=64, steps=5, warmup=2):
     fam = {"nt_gemm": [0.0, 0.0], "weight_gradient_gemm": [0.0, 0.0], "attention_forward": [0.0, 0.0], "attention_backward": [0.0, 0.0]}
     for a0, a1, fl, code in log:
         k = ("attention_forward" if code == 200 else "attention_backward" if code == 201 else
-             "weight_gradient_gemm" if code == 100 else "nt_gemm")
+             "weight_gradient_gemm" if 100 <= code <= 104 else "nt_gemm")
         fam[k][0] += a0.elapsed_time(a1); fam[k][1] += fl
     out = {"workload": "BASELINE configs[4], one GPU: MEM pretrain ViT-Large/16, 480x640 2-bin voxels (1201 tokens, 600 masked), bf16, "
                        f"batch {B}; step = masks + fwd/CE/bwd + clip + AdamW",
@@ -960,11 +960,17 @@ def main():
             tj = _load_profile("gemm_traffic.json") or {}
             fam = {str(k): {"launches": v[0], "avg_us": round(v[1] / v[0] * 1e3, 2),
                             "tflops": round(v[2] / (v[1] * 1e-3) / 1e12, 1)} for k, v in sorted(per.items())}
-            # the dominant kernel of the step is the weight-gradient GEMM (gemm_tn_p8_kernel, logged as 100)
-            dom = per.get(100)
+            # the dominant kernel of the step is the weight-gradient GEMM (tn_p8_body of gemm_tn_p8.hip, launched product by
+            # product as gemm_tn_p8_kernel -- logged as 100 -- or as a group of n products in one grid, gemm_tn_p8_group_kernel,
+            # logged as 100 + n); launches / avg_launch_us count PRODUCTS (a pair = 2)
+            dom = None
+            for code, n_prod in ((100, 1), (102, 2), (103, 3), (104, 4)):
+                if code in per:
+                    v = per[code]
+                    dom = [v[0] * n_prod, v[1], v[2]] if dom is None else [dom[0] + v[0] * n_prod, dom[1] + v[1], dom[2] + v[2]]
             if dom:
                 d_ach = dom[2] / (dom[1] * 1e-3) / 1e12
-                roof = {"bound": "mfma", "kernel": "gemm_tn_p8_kernel (bf16 weight-gradient GEMM, split over token rows)",
+                roof = {"bound": "mfma", "kernel": "gemm_tn_p8_kernel / gemm_tn_p8_group_kernel (bf16 weight-gradient GEMM, split over token rows)",
                         "achieved": round(d_ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                         "frac": round(d_ach / PEAK_BF16_TFLOPS, 4),
                         "traffic": gemm_traffic_per_launch("gemm_tn_p8_kernel", tj),
@@ -972,7 +978,9 @@ def main():
                         "algorithmic_flop_per_launch": round(dom[2] / dom[0]),
                         "share_of_step": round(dom[1] / (dt * 1e3 * n_inst / a.steps), 3),
                         "instrumented_steps": n_inst,
-                        "note": "HIP events around one weight-gradient product = gemm_tn_p8_kernel + its tn_reduce_kernel; the "
+                        "products_in_group_launches": sum(per[c][0] * (c - 100) for c in (102, 103, 104) if c in per),
+                        "note": "HIP events around one weight-gradient call = gemm_tn_p8_kernel + its tn_reduce_kernel, or the group "
+                                "kernel (proj + qkv of a block in one grid) + its reduction pass; launches / avg_launch_us are per PRODUCT; the "
                                 "instrumented steps run on ONE stream (the events serialise the side stream), so compare with the "
                                 "sequential rocprofv3 summary (profiles/r05_final_seq_kernel_stats.csv; the steady-state steps alone: r05_final_seq_step_kernels.txt), not with the "
                                 "two-stream one, where concurrent launches stretch every kernel"}

@@ -418,7 +418,7 @@ def gemm_tn_group(problems, accumulate=True, workspace=None):
         e0.record()
         check(lib.memhip_gemm_bf16_tn_group(arr, len(problems), int(accumulate), ws, wsb, stream_ptr()), "gemm_bf16_tn_group")
         e1.record()
-        GEMM_TIMER.append((e0, e1, sum(2.0 * R * N * K for _, _, R, N, K, _ in problems), 100))
+        GEMM_TIMER.append((e0, e1, sum(2.0 * R * N * K for _, _, R, N, K, _ in problems), 100 + len(problems)))   # 102..104: a group
 
 
 def colsum_fold(ws, copies, N, out):
