@@ -372,6 +372,9 @@ __device__ __forceinline__ void fwd_phase_b(const char* Vs, const LaneOffs& lo, 
 // vector instructions per piece to a multiply-add + a scalar-base load changed nothing: it is the transfer, not its issue);
 // counters (profiles/r05_attn_win_fwd_pmc.txt): a wave issues 34 % of its cycles, is parked at a wait or the
 // barrier 33 % and is issue-stalled 33 %; the SIMD's vector unit is busy ~53 %, the matrix pipe 21 %.
+#ifndef WIN_Q_CKF_EARLY
+#define WIN_Q_CKF_EARLY 0   // dQ kernel with the table gradient: 1 = the K column fragments of the dQ product are read in front of the block's bucket atomics as well
+#endif
 #ifndef WIN_DMA_LATE
 #define WIN_DMA_LATE 0   // 1: forward: the LDS-DMA of chunk c + 1 is issued between phase A and phase B of chunk c
 #endif
@@ -504,6 +507,30 @@ __global__ __launch_bounds__(512) void attn_fwd_win_kernel(
 #endif
 }
 
+// Column sums of an accumulator tile (q_bias / v_bias gradients) WITHOUT 32 registers that live through the chunk loop: per sample
+// the 32 lanes of each half-wave are summed by DPP (row_shr 1 / 2 / 4 / 8: lane 15 of a row holds its total; row_bcast:15 into
+// rows 1 and 3: lanes 31 / 63 hold the half's total) and lanes 31 / 63 add four columns at a time to this wave's private row
+// of 64 floats in LDS (no atomics: one writer per word).  ~170 vector instructions per sample and wave.
+__device__ __forceinline__ float half_sum_dpp(float v) {
+#define WIN_DPP_ADD(ctrl, rmask) v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, rmask, 0xf, true))
+  WIN_DPP_ADD(0x111, 0xf);
+  WIN_DPP_ADD(0x112, 0xf);
+  WIN_DPP_ADD(0x114, 0xf);
+  WIN_DPP_ADD(0x118, 0xf);
+  WIN_DPP_ADD(0x142, 0xa);
+#undef WIN_DPP_ADD
+  return v;
+}
+__device__ __forceinline__ void colsum_add4(float* row64, int r, int hh, int db, int g, float a0, float a1, float a2, float a3) {
+  a0 = half_sum_dpp(a0); a1 = half_sum_dpp(a1); a2 = half_sum_dpp(a2); a3 = half_sum_dpp(a3);
+  if (r == 31) {
+    float4* p = reinterpret_cast<float4*>(row64 + db * 32 + 8 * g + 4 * hh);
+    float4 t = *p;
+    t.x += a0; t.y += a1; t.z += a2; t.w += a3;
+    *p = t;
+  }
+}
+
 // ------------------------------------------------------------------------------- backward (dK, dV)
 // A wave owns 32 resident keys (token order; K, V fragments in registers), the workgroup streams Q' / dO chunks in the SLOT
 // layout over queries: lane = key, registers = query slots, bucket(q, k) at Kp(k) + qy P + qx with the table in forward order.
@@ -523,8 +550,8 @@ __global__ __launch_bounds__(512) void attn_bwd_kv_win_kernel(
   float* Cq = R + ((NB + 3) & ~3);
   float* nlS = Cq + G::CQ;                                   // [2][CT]  -lse * log2(e) by slot
   float* ndS = nlS + 2 * CT;                                 // [2][CT]  -delta by slot
-  float* vsum = ndS + 2 * CT;                                // [64]
-  char* imgs = reinterpret_cast<char*>(vsum + HD);
+  float* vsum = ndS + 2 * CT;                                // [8 waves][64]: v_bias gradient, a private row per wave
+  char* imgs = reinterpret_cast<char*>(vsum + 8 * HD);
   const WinWg wg_ = win_wg(groups, H, nbz);
   if (!wg_.live) return;
   const int h = wg_.h;
@@ -532,7 +559,7 @@ __global__ __launch_bounds__(512) void attn_bwd_kv_win_kernel(
   const int r = lane & 31, hh = lane >> 5;
   const LaneOffs lo = lane_offs(lane);
   win_setup<WW>(R, Cq, table, nrd, H, h, Wh, 1.0f, false, nrd - 2);
-  if (threadIdx.x < HD) vsum[threadIdx.x] = 0.f;
+  vsum[threadIdx.x] = 0.f;                                   // (512 threads = 8 x 64)
   const unsigned sel_lo = sel_lo_reg();
   const int kbg = wg_.group * 8 + wave;
   const bool active = kbg * 32 < T;
@@ -556,11 +583,6 @@ __global__ __launch_bounds__(512) void attn_bwd_kv_win_kernel(
 #endif
   const int nch = (Wh + G::RPC - 1) / G::RPC;
   float vmax = 0.f, dmax = 0.f, nmax = 0.f;
-  float bsum[VB ? 32 : 1];
-  if (VB) {
-#pragma unroll
-    for (int i = 0; i < (VB ? 32 : 1); ++i) bsum[i] = 0.f;
-  }
   for (int b = wg_.bz; b < B; b += nbz) {
     const __bf16* s0 = qkv + (long long)b * T * ldq + h * HD;
     const __bf16* d0 = dout + (long long)b * T * ldo + h * HD;
@@ -692,10 +714,9 @@ __global__ __launch_bounds__(512) void attn_bwd_kv_win_kernel(
             *reinterpret_cast<bf16x4*>(drow + 2 * D + db * 32 + 8 * g + 4 * hh) = wv;
             *reinterpret_cast<bf16x4*>(drow + D + db * 32 + 8 * g + 4 * hh) = wk;
           }
-          if constexpr (VB) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) bsum[db * 16 + 4 * g + e] += (float)wv[e] * kmask;
-          }
+          if constexpr (VB)
+            colsum_add4(vsum + wave * HD, r, hh, db, g, (float)wv[0] * kmask, (float)wv[1] * kmask, (float)wv[2] * kmask,
+                        (float)wv[3] * kmask);
         }
     }
   }
@@ -713,16 +734,12 @@ __global__ __launch_bounds__(512) void attn_bwd_kv_win_kernel(
   }
   if (VB) {
     __syncthreads();
-    if (active) {
+    if (threadIdx.x < HD) {
+      float v = 0.f;
 #pragma unroll
-      for (int i = 0; i < 32; ++i) {
-        float v = bsum[i];
-        for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o);
-        if (r == 0) atomicAdd(vsum + (i >> 4) * 32 + 8 * ((i >> 2) & 3) + 4 * hh + (i & 3), v);
-      }
+      for (int w = 0; w < 8; ++w) v += vsum[w * HD + threadIdx.x];
+      atomicAdd(dvbias + h * HD + threadIdx.x, v);
     }
-    __syncthreads();
-    if (threadIdx.x < HD) atomicAdd(dvbias + h * HD + threadIdx.x, vsum[threadIdx.x]);
   }
 }
 
@@ -745,8 +762,8 @@ __global__ __launch_bounds__(512) void attn_bwd_q_win_kernel(
   float* R = reinterpret_cast<float*>(smem);
   float* Cq = R + NBP;
   int* binsR = reinterpret_cast<int*>(Cq + G::CQ);           // fixed-point buckets: image of [R | Cq]
-  float* qsum = reinterpret_cast<float*>(binsR + NBP + G::CQ);
-  char* imgs = reinterpret_cast<char*>(qsum + HD);
+  float* qsum = reinterpret_cast<float*>(binsR + NBP + G::CQ);   // [8 waves][64]: q_bias gradient, a private row per wave
+  char* imgs = reinterpret_cast<char*>(qsum + 8 * HD);
   const WinWg wg_ = win_wg(groups, H, nbz);
   if (!wg_.live) return;
   const int h = wg_.h;
@@ -754,7 +771,7 @@ __global__ __launch_bounds__(512) void attn_bwd_q_win_kernel(
   const int r = lane & 31, hh = lane >> 5;
   const LaneOffs lo = lane_offs(lane);
   win_setup<WW>(R, Cq, table, nrd, H, h, Wh, 1.0f, true, nrd - 3);
-  for (int i = threadIdx.x; i < NBP + G::CQ + HD; i += blockDim.x) binsR[i] = 0;     // buckets, qsum
+  for (int i = threadIdx.x; i < NBP + G::CQ + 8 * HD; i += blockDim.x) binsR[i] = 0;     // buckets, qsum
   const unsigned sel_lo = sel_lo_reg();
   const unsigned bins_delta = (unsigned)(NBP + G::CQ) * 4u;
   const int qb = wg_.group * 8 + wave;
@@ -778,9 +795,6 @@ __global__ __launch_bounds__(512) void attn_bwd_q_win_kernel(
     fx = bound > 0.f ? 262144.0f / bound : 0.f;
   }
   float gcls = 0.f;                                          // gradient of the cls-key bucket of this lane's query
-  float bsum[32];
-#pragma unroll
-  for (int i = 0; i < 32; ++i) bsum[i] = 0.f;
   const float qmask = q < T ? 1.f : 0.f;
   const bool qpadw = __builtin_amdgcn_readfirstlane(qb) * 32 + 32 > T;            // this wave holds queries >= T
 #if WIN_PRIO
@@ -825,10 +839,35 @@ __global__ __launch_bounds__(512) void attn_bwd_q_win_kernel(
         f32x16 St, dPt;
 #pragma unroll
         for (int i = 0; i < 16; ++i) { St[i] = 0.f; dPt[i] = 0.f; }
+        // every LDS read of the block is issued BEFORE its first bucket atomic: LDS operations return in order, so a bias read
+        // (or a K column fragment of the dQ product) behind the four atomics of the group before it waits for all of them
+        float bzs[4][4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int s0i = kb * 32 + 8 * g;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) bzs[g][e] = 0.f;
+          if (G::valid(s0i) || G::valid(s0i + 4)) {
+            const auto* p = reinterpret_cast<const __attribute__((address_space(3))) F2u*>(base + 4u * (unsigned)G::imm(s0i));
+            bzs[g][0] = p[0].a; bzs[g][1] = p[0].b; bzs[g][2] = p[1].a; bzs[g][3] = p[1].b;
+          }
+        }
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
           St = MFMA32(row_frag_o(Ks, lo, kb, t), Qf[t], St);
           dPt = MFMA32(row_frag_o(Vs, lo, kb, t), dOf[t], dPt);
+        }
+        bf16x8 ckf[2][2];
+        if (WIN_Q_CKF_EARLY && DT) {
+#pragma unroll
+          for (int ss = 0; ss < 2; ++ss)
+#pragma unroll
+            for (int db = 0; db < 2; ++db) ckf[ss][db] = col_frag_i<kb * 4096>(ka, ss, db);
+          LDS_TR_WAIT();
+#pragma unroll
+          for (int ss = 0; ss < 2; ++ss)
+#pragma unroll
+            for (int db = 0; db < 2; ++db) asm volatile("" : "+v"(ckf[ss][db]));
         }
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -840,12 +879,8 @@ __global__ __launch_bounds__(512) void attn_bwd_q_win_kernel(
             for (int e = 0; e < 4; ++e) dPt[4 * g + e] = 0.f;
             continue;
           }
-          float bz[4] = {0.f, 0.f, 0.f, 0.f};
+          float bz[4] = {bzs[g][0], bzs[g][1], bzs[g][2], bzs[g][3]};
           const unsigned a = base + 4u * (unsigned)G::imm(s0i);
-          if (v0 || v1) {
-            const auto* p = reinterpret_cast<const __attribute__((address_space(3))) F2u*>(a);
-            bz[0] = p[0].a; bz[1] = p[0].b; bz[2] = p[1].a; bz[3] = p[1].b;
-          }
           if (clsg) bz[0] = bcls;
           const unsigned s01 = pk_bf16(St[4 * g], St[4 * g + 1]), s23 = pk_bf16(St[4 * g + 2], St[4 * g + 3]);
           const unsigned d01 = pk_bf16(dPt[4 * g], dPt[4 * g + 1]), d23 = pk_bf16(dPt[4 * g + 2], dPt[4 * g + 3]);
@@ -872,15 +907,16 @@ __global__ __launch_bounds__(512) void attn_bwd_q_win_kernel(
             }
           }
         }
-        bf16x8 ckf[2][2];
+        if (!(WIN_Q_CKF_EARLY && DT)) {
 #pragma unroll
-        for (int ss = 0; ss < 2; ++ss)
+          for (int ss = 0; ss < 2; ++ss)
 #pragma unroll
-          for (int db = 0; db < 2; ++db) ckf[ss][db] = col_frag_i<kb * 4096>(ka, ss, db);
+            for (int db = 0; db < 2; ++db) ckf[ss][db] = col_frag_i<kb * 4096>(ka, ss, db);
+        }
         bf16x8 dsf[2];
 #pragma unroll
         for (int ss = 0; ss < 2; ++ss) dsf[ss] = acc_frag(dPt, ss, 1.0f);
-        LDS_TR_WAIT();
+        if (!(WIN_Q_CKF_EARLY && DT)) LDS_TR_WAIT();
 #pragma unroll
         for (int ss = 0; ss < 2; ++ss)
 #pragma unroll
@@ -905,8 +941,8 @@ __global__ __launch_bounds__(512) void attn_bwd_q_win_kernel(
           for (int e = 0; e < 4; ++e) w[e] = (__bf16)(bfr(dQt[db][4 * g + e]) * scale);
           if (q < T)
             *reinterpret_cast<bf16x4*>(dqkv + ((long long)b * T + q) * lddq + h * HD + db * 32 + 8 * g + 4 * hh) = w;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) bsum[db * 16 + 4 * g + e] += (float)w[e] * qmask;   // q_bias gradient
+          if (dqbias)                                                                   // q_bias gradient
+            colsum_add4(qsum + wave * HD, r, hh, db, g, (float)w[0] * qmask, (float)w[1] * qmask, (float)w[2] * qmask, (float)w[3] * qmask);
         }
     }
   }
@@ -933,17 +969,11 @@ __global__ __launch_bounds__(512) void attn_bwd_q_win_kernel(
       if (q == 0 && hh == 0 && both != 0.f) atomicAdd(dtable + (long long)(nrd - 1) * H + h, both);
     }
   }
-  if (dqbias) {
-    if (active) {
+  if (dqbias && threadIdx.x < HD) {                          // (behind the barrier above)
+    float v = 0.f;
 #pragma unroll
-      for (int i = 0; i < 32; ++i) {
-        float v = bsum[i];
-        for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o);
-        if (r == 0) atomicAdd(qsum + (i >> 4) * 32 + 8 * ((i >> 2) & 3) + 4 * hh + (i & 3), v);
-      }
-    }
-    __syncthreads();
-    if (threadIdx.x < HD) atomicAdd(dqbias + h * HD + threadIdx.x, qsum[threadIdx.x]);
+    for (int w = 0; w < 8; ++w) v += qsum[w * HD + threadIdx.x];
+    atomicAdd(dqbias + h * HD + threadIdx.x, v);
   }
 }
 
@@ -992,8 +1022,8 @@ int launch_bwd(const void* qkv, int64_t ldqkv, const void* dout, int64_t ldo, co
   const int TP = ((T + 31) / 32) * 32;
   const int nrd = (2 * Wh - 1) * (2 * WW - 1) + 3;
   const int NBP = ((2 * Wh - 1) * G::P + 3) & ~3;
-  const size_t sm_kv = (size_t)(NBP + G::CQ + 4 * G::CT + HD) * 4 + (size_t)4 * G::CT * 128;
-  const size_t sm_q = (size_t)(2 * (NBP + G::CQ) + HD) * 4 + (size_t)4 * G::CT * 128;
+  const size_t sm_kv = (size_t)(NBP + G::CQ + 4 * G::CT + 8 * HD) * 4 + (size_t)4 * G::CT * 128;
+  const size_t sm_q = (size_t)(2 * (NBP + G::CQ) + 8 * HD) * 4 + (size_t)4 * G::CT * 128;
   if (sm_kv > (size_t)kMaxLds || sm_q > (size_t)kMaxLds) return MEMHIP_EUNSUPPORTED;
   static bool d0 = false, d1 = false, d2 = false, d3 = false;
   if (int rc = set_lds_attr(attn_bwd_kv_win_kernel<WW, true>, &d0)) return rc;
