@@ -355,6 +355,43 @@ def test_drop_path_work_skipping_equals_masked_execution(fuse):
 
 
 @pytest.mark.parametrize("skip", [False, True])
+def test_grouped_weight_gradient_launches_equal_single_launches(skip):
+    """ViTEngine.wgrad_group: 0 = every weight gradient its own launch, 1 (default) = proj + qkv of a block as one grouped
+    launch (memhip_gemm_bf16_tn_group), 2 = fc2 + fc1 too.  Same step, same gradients: the weight gradients differ by the
+    row-slice boundaries of their split only (fp32 round-off), the layer-scale gradients are linear functions of them.  With and without the work-skipping plan of stochastic depth (different row counts for
+    the two branches of a block)."""
+    from mem_amd.modeling_pretrain import pt_vit
+    from oracle.gen_golden import BASE, vit_inputs
+    from oracle.vit_ref import fill_by_name
+    cfg = dict(BASE, in_chans=2, depth=3, drop_path_rate=0.3 if skip else 0.0)
+    B = 40
+    x, mask, labels = vit_inputs(cfg, B, 23, 98)
+    g = torch.Generator().manual_seed(7)
+    masks = (torch.rand(6, B, generator=g) > 0.3).float() if skip else None
+    res = {}
+    for level in (0, 1, 2):
+        m = pt_vit(**cfg)
+        m.load_state_dict(fill_by_name(m.state_dict(), seed=2))
+        m = m.cuda().train()
+        m.engine.wgrad_group = level
+        la = m.forward_loss(x.cuda(), mask.cuda(), labels.cuda(), drop_path_masks=masks.cuda() if skip else None)
+        m.backward()
+        torch.cuda.synchronize()
+        assert (m.engine.cur["plan"] is not None) == skip
+        res[level] = (la[0].item(), m.engine.flat_g.clone(), dict(m.engine.segs))
+        del m
+    l0, g0, segs = res[0]
+    for level in (1, 2):
+        l1, g1, _ = res[level]
+        assert l1 == l0
+        for name, (o, k) in segs.items():
+            a, b = g0[o:o + k], g1[o:o + k]
+            # (regrouped weight gradients: another split of the same fp32 sum; the rest: the same kernels, of which the
+            # column-sum / LayerNorm / table gradients add with fp32 atomics in an order that varies from run to run)
+            assert float((a - b).norm()) <= 1e-5 * float(a.norm()) + 1e-12, (level, name)
+
+
+@pytest.mark.parametrize("skip", [False, True])
 def test_last_block_tail_rows_equal_full_execution(skip):
     """Dead-row elimination in the last block (ViTEngine.tail_rows: its MLP branch runs only on the rows that reach the head,
     mem/modeling_pretrain.py:119-126) against the full execution of the same step, with stochastic depth on the last block's
