@@ -637,15 +637,15 @@ __device__ __forceinline__ void p8_body(const GemmArgs& p, int ntm, int ntn, int
         // flight, and spilled.  Here the 16 rows of a lane go one by one with the loads of the next kResidAhead rows in
         // flight (48 registers), in one basic block (counted waits, no store is ever waited for).
 #ifndef P8_RESID_ROWS_AHEAD
-#define P8_RESID_ROWS_AHEAD 2
-#endif
+#define P8_RESID_ROWS_AHEAD 2     // rows of residual loads in flight ahead of the row being computed.  3 / 4 measured (round 5): 14 / 21
+#endif                            // spilled registers, K = 768 projection 120 -> 127 / 131-134 us, fc2 248 -> 269-272 / 270 us
         // The row loads are inline asm with HAND-COUNTED waits: left to hipcc this block's schedule is a matter of luck
         // (with the loads visible to it, one build ran the load-independent arithmetic of all rows first and consumed
         // each row's loads right after issuing them; another spilled and waited with vmcnt(0) per row).  hipcc never
         // waits for its own stores here (nothing depends on them) and does not see the asm loads, so it inserts no wait
         // at all; the only waits are the vmcnt(N) below, N = the vector-memory operations issued behind the row's loads:
         // per row section [3 loads of row r+2][arithmetic of row r][kStores stores of row r].
-        constexpr int kResidAhead = 2;
+        constexpr int kResidAhead = P8_RESID_ROWS_AHEAD, kSlots = kResidAhead + 1;
         constexpr int kStores = 2 + (COPY ? 1 : 0);
         // FULL-LINE form (gemm_epilogue.hpp, pq_pack): a lane's 8 fp32 columns are 32 bytes of a 128-byte row segment; its
         // two 16-byte halves are exchanged with lane r ^ 8, so that the two loads (and the two stores) of a row-op cover
@@ -667,9 +667,9 @@ __device__ __forceinline__ void p8_body(const GemmArgs& p, int ntm, int ntn, int
         const int s0 = (tm * BMT + p.m_base) / p.rows_per_sample;
         const unsigned kid_lds = (unsigned)(unsigned long long)((__attribute__((address_space(3))) char*)smem) +
                                  (unsigned)(G::kColsOff + tile_par * G::kColsSlot + 2048);
-        f32x4 xa[3], xb[3];
-        float rmv[3];
-        int rrP[3], rrQ[3];                                     // residual rows of the slot's P / Q rows (32 bits: rows < 2^21)
+        f32x4 xa[kSlots], xb[kSlots];
+        float rmv[kSlots];
+        int rrP[kSlots], rrQ[kSlots];                           // residual rows of the slot's P / Q rows (32 bits: rows < 2^21)
         auto sample_of = [&](int mm) { return (int)(((float)mm + 0.5f) * inv_rps); };      // rows < 2^21 (p8_fits)
         auto resid_row = [&](int m) {                           // row m of this launch -> row of the residual stream
           const int mm = m + p.m_base;
@@ -689,14 +689,14 @@ __device__ __forceinline__ void p8_body(const GemmArgs& p, int ntm, int ntn, int
           asm volatile("global_load_dwordx4 %0, %3, off\n\tglobal_load_dwordx4 %1, %4, off\n\tglobal_load_dword %2, %5, off"
                        : "=&v"(xa[slot]), "=&v"(xb[slot]), "=&v"(rmv[slot]) : "v"(srcP), "v"(srcQ), "v"(rsrc) : "memory");
         };
-        issue_row(0, 0);
-        issue_row(1, 1);
+#pragma unroll
+        for (int r = 0; r < kResidAhead; ++r) issue_row(r, r);
         float cs[8];
         EpiCols cols;
         auto do_row = [&](int r, int slot, auto waitc) {
           __builtin_amdgcn_sched_barrier(0);
           if ((r & 7) == 0) cols_from_lds(wc * 64 + (elane >> 4) * 8 + (r >> 3) * 32, cols);
-          if (r + kResidAhead < 16) issue_row(r + kResidAhead, (slot + kResidAhead) % 3);
+          if (r + kResidAhead < 16) issue_row(r + kResidAhead, (slot + kResidAhead) % kSlots);
           const int q = ((r >> 2) & 1) * 2 + (r >> 3), mf = r & 3;
           float v[8];
 #pragma unroll
@@ -724,15 +724,21 @@ __device__ __forceinline__ void p8_body(const GemmArgs& p, int ntm, int ntn, int
           *reinterpret_cast<float4*>(dP) = float4{__uint_as_float(P[0]), __uint_as_float(P[1]), __uint_as_float(P[2]), __uint_as_float(P[3])};
           *reinterpret_cast<float4*>(dQ) = float4{__uint_as_float(Q[0]), __uint_as_float(Q[1]), __uint_as_float(Q[2]), __uint_as_float(Q[3])};
         };
-        using W2 = std::integral_constant<int, 2 * kStores + 6>;     // S(r-2) L(r+1) S(r-1) L(r+2) behind L(r)
-        using W1 = std::integral_constant<int, 2 * kStores + 3>;     // row 14: no L(16)
-        using W0 = std::integral_constant<int, 2 * kStores>;         // row 15
-        do_row(0, 0, std::integral_constant<int, 6>{});              // behind L(0): L(1) L(2)
-        do_row(1, 1, std::integral_constant<int, kStores + 6>{});    // behind L(1): L(2) S(0) L(3)
-#pragma unroll
-        for (int r = 2; r < 14; ++r) do_row(r, r % 3, W2{});
-        do_row(14, 14 % 3, W1{});
-        do_row(15, 15 % 3, W0{});
+        // vector-memory operations issued behind L(r) when row r is consumed: the loads of the rows r + 1 .. r + kResidAhead
+        // that exist (3 each) and the stores of the rows max(0, r - kResidAhead) .. r - 1 (kStores each)
+        auto row_step = [&](auto R) {
+          constexpr int r = decltype(R)::value;
+          constexpr int loads = (r + kResidAhead < 16 ? kResidAhead : 15 - r), stores = r < kResidAhead ? r : kResidAhead;
+          do_row(r, r % kSlots, std::integral_constant<int, 3 * loads + kStores * stores>{});
+        };
+        row_step(std::integral_constant<int, 0>{}); row_step(std::integral_constant<int, 1>{});
+        row_step(std::integral_constant<int, 2>{}); row_step(std::integral_constant<int, 3>{});
+        row_step(std::integral_constant<int, 4>{}); row_step(std::integral_constant<int, 5>{});
+        row_step(std::integral_constant<int, 6>{}); row_step(std::integral_constant<int, 7>{});
+        row_step(std::integral_constant<int, 8>{}); row_step(std::integral_constant<int, 9>{});
+        row_step(std::integral_constant<int, 10>{}); row_step(std::integral_constant<int, 11>{});
+        row_step(std::integral_constant<int, 12>{}); row_step(std::integral_constant<int, 13>{});
+        row_step(std::integral_constant<int, 14>{}); row_step(std::integral_constant<int, 15>{});
       } else if constexpr (EPI == MEMHIP_EPI_BIAS_BF16 || EPI == MEMHIP_EPI_BIAS_GELU || EPI == MEMHIP_EPI_BIAS_GELU_DG ||
                            EPI == MEMHIP_EPI_DGELU || EPI == MEMHIP_EPI_MUL_AUX) {
         // bf16 outputs (and the bf16 second operand of GELU' / MUL_AUX) in FULL 128-byte lines: the two column halves of a

@@ -20,3 +20,13 @@ for name, n, k in (("proj", 768, 768), ("fc2", 768, 3072)):
         db = t(lambda: ops.gemm_nt(A, B, M, n, k, ops.EPI_BIAS_BF16, out0=o, bias=bias))
         for kk in opts: assert _lib.lib.memhip_set_option(kk.encode(), 1) == 0
         print(f"{name} {str(opts):40s} residual {dr*1e6:7.1f} us = {2*M*n*k/dr/1e12:6.1f} TF, {byts/dr/1e12:5.2f} TB/s of operand + residual bytes | bias only {db*1e6:7.1f} us", flush=True)
+# phase stagger of the persistent workgroups (option gemm_stagger, cycles per K-tile; < 0: every workgroup): do desynchronised
+# epilogues hide under the other CUs' main loops?
+for name, n, k in (("proj", 768, 768), ("fc2", 768, 3072)):
+    A = torch.randn(M, k, device="cuda").bfloat16(); B = (torch.randn(n, k, device="cuda") * 0.05).bfloat16()
+    x = torch.randn(M, n, device="cuda"); x2 = torch.empty_like(x); g = torch.randn(n, device="cuda"); bias = torch.randn(n, device="cuda")
+    for st in (0, 500, 1000, 2000, 4000, -500, -1000, -2000, 0):
+        assert _lib.lib.memhip_set_option(b"gemm_stagger", st) == 0
+        dr = t(lambda: ops.gemm_nt(A, B, M, n, k, ops.EPI_RESIDUAL, out0=None, bias=bias, vec1=g, resid=x2, aux=x, ldaux=n, rows_per_sample=197))
+        print(f"{name} gemm_stagger {st:6d}: residual {dr*1e6:7.1f} us", flush=True)
+    assert _lib.lib.memhip_set_option(b"gemm_stagger", 0) == 0
