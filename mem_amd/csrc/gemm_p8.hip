@@ -43,6 +43,11 @@
 #define P8_REALIGN 1   // 1: all eight waves run a tile's epilogue together (waves 0-3 wait, waves 4-7 re-stagger after it);
                        // 0 (each group enters the epilogue when it is done) measured 8-12 % slower on the K = 768 shapes
 #endif
+#ifndef P8_RESID_NT
+#define P8_RESID_NT 1    // bit 0 = residual-input loads nontemporal (the row is read once here and again only in backward: it need not push
+#endif                   // the operand rows out of L2), bit 1 = residual-output stores nontemporal.  K = 768 projection alone 120-124 us ->
+                         // 110-112 (loads) / 105-107 (stores) / 116 (both); in the step 33.58-33.64 -> 33.48-33.58 ms (loads), 33.66-33.75
+                         // (stores: the LayerNorm behind it reads the row from HBM) -- profiles/r05_resid_nt_ab.txt
 #ifndef P8_EPI_RESID_LATE
 #define P8_EPI_RESID_LATE 2
 #endif
@@ -686,8 +691,13 @@ __device__ __forceinline__ void p8_body(const GemmArgs& p, int ntm, int ntn, int
           const float* srcP = xbase + (long long)rrP[slot] * xld + row_nP(r);
           const float* srcQ = xbase + (long long)rrQ[slot] * xld + row_nP(r);
           const float* rsrc = rmb + (p.rowmask ? sample_of(row_m(r) + p.m_base) : 0);
+#if P8_RESID_NT & 1
+          asm volatile("global_load_dwordx4 %0, %3, off nt\n\tglobal_load_dwordx4 %1, %4, off nt\n\tglobal_load_dword %2, %5, off"
+                       : "=&v"(xa[slot]), "=&v"(xb[slot]), "=&v"(rmv[slot]) : "v"(srcP), "v"(srcQ), "v"(rsrc) : "memory");
+#else
           asm volatile("global_load_dwordx4 %0, %3, off\n\tglobal_load_dwordx4 %1, %4, off\n\tglobal_load_dword %2, %5, off"
                        : "=&v"(xa[slot]), "=&v"(xb[slot]), "=&v"(rmv[slot]) : "v"(srcP), "v"(srcQ), "v"(rsrc) : "memory");
+#endif
         };
 #pragma unroll
         for (int r = 0; r < kResidAhead; ++r) issue_row(r, r);
@@ -721,8 +731,14 @@ __device__ __forceinline__ void p8_body(const GemmArgs& p, int ntm, int ntn, int
           pq_pack(o, o + 4, hi, P, Q);
           float* dP = p.resid + (long long)rrP[slot] * p.ldr + row_nP(r);
           float* dQ = p.resid + (long long)rrQ[slot] * p.ldr + row_nP(r);
+#if P8_RESID_NT & 2
+          typedef __attribute__((ext_vector_type(4))) float nt_f4;
+          __builtin_nontemporal_store(nt_f4{__uint_as_float(P[0]), __uint_as_float(P[1]), __uint_as_float(P[2]), __uint_as_float(P[3])}, reinterpret_cast<nt_f4*>(dP));
+          __builtin_nontemporal_store(nt_f4{__uint_as_float(Q[0]), __uint_as_float(Q[1]), __uint_as_float(Q[2]), __uint_as_float(Q[3])}, reinterpret_cast<nt_f4*>(dQ));
+#else
           *reinterpret_cast<float4*>(dP) = float4{__uint_as_float(P[0]), __uint_as_float(P[1]), __uint_as_float(P[2]), __uint_as_float(P[3])};
           *reinterpret_cast<float4*>(dQ) = float4{__uint_as_float(Q[0]), __uint_as_float(Q[1]), __uint_as_float(Q[2]), __uint_as_float(Q[3])};
+#endif
         };
         // vector-memory operations issued behind L(r) when row r is consumed: the loads of the rows r + 1 .. r + kResidAhead
         // that exist (3 each) and the stores of the rows max(0, r - kResidAhead) .. r - 1 (kStores each)
