@@ -443,8 +443,6 @@ def main():
                     help="skip the secondary figure that adds the frozen dVAE tokenizer forward (stock PyTorch-ROCm)")
     ap.add_argument("--no-raster-figure", action="store_true",
                     help="skip the secondary figure for BASELINE configs[3] (rasterizer at 1 M events per sample)")
-    ap.add_argument("--wgrad-mlp-late", action="store_true", help="A/B: engine.wgrad_mlp_late = True")
-    ap.add_argument("--wgrad-fc2-early", action="store_true", help="A/B: engine.wgrad_fc2_early = True")
     ap.add_argument("--wgrad-group", type=int, default=None,
                     help="A/B: engine.wgrad_group (0: every weight gradient its own launch, 1: proj + qkv of a block as one, 2: fc2 + fc1 too)")
     ap.add_argument("--no-side-stream", action="store_true",
@@ -544,8 +542,6 @@ def main():
                    use_abs_pos_emb=False, init_values=0.1).cuda().train()
     eng = model.engine
     eng.wgrad_side_stream = not a.no_side_stream
-    eng.wgrad_mlp_late = bool(a.wgrad_mlp_late)
-    eng.wgrad_fc2_early = bool(a.wgrad_fc2_early)
     if a.wgrad_group is not None:
         eng.wgrad_group = a.wgrad_group
     eng.dp_skip = not a.no_dp_skip

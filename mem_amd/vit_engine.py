@@ -93,8 +93,6 @@ class ViTEngine:
         self._opt_ev = None               # bucket name -> event (parameters of that bucket are updated, cast)
         self._opt_done = None             # everything incl. the transposed copies
         self.wgrad_side_stream = True
-        self.wgrad_fc2_early = False     # A/B: the fc2 weight gradient of a block is issued in front of its GELU' product (dY exists then)
-        self.wgrad_mlp_late = False      # A/B: the fc2 / fc1 weight gradients of a block are issued in front of its attention backward
         self.wgrad_group = 1             # 1: proj + qkv weight gradients of a block as one launch (_wgrad_group); 2: fc2 + fc1 too; 0: off
         self.fwd_two_streams = False      # forward: uneven two-stream split (see forward_trunk / _split_point).  It paid
                                           # -0.24 ms at B = 256 while the GEMM epilogues stalled on their own stores (the
@@ -659,21 +657,6 @@ class ViTEngine:
         for gv, c0, c1 in bias_grads:
             ops.colsum_bf16(dY[:, c0:c1], R, c1 - c0, gv)
 
-    def _wg_fc2(self, pre, a, has_g, R, dY):
-        """fc2 weight gradient of a block alone (+ the layer-scale gradient): needs only dY and the stored activation."""
-        D, Hd = self.D, self.hidden
-        self._wgrad(dY, a["a"], R, D, Hd, pre + "mlp.fc2.weight")
-        self._side_read_done("dY")
-        if has_g:
-            ops.layerscale_grad(self.W16(pre + "mlp.fc2.weight", D, Hd), self.G(pre + "mlp.fc2.weight").view(D, Hd),
-                                self.P(pre + "mlp.fc2.bias"), self.G(pre + "mlp.fc2.bias"),
-                                self.P(pre + "gamma_2"), D, Hd, self.G(pre + "gamma_2"))
-
-    def _wg_fc1(self, pre, a, R):
-        D, Hd = self.D, self.hidden
-        self._wgrad(self.dbig, a["h2"], R, Hd, D, pre + "mlp.fc1.weight")
-        self._side_read_done("dbig")
-
     def _wg_mlp(self, pre, a, has_g, R, dY):
         """fc2 and fc1 weight gradients of a block (+ the layer-scale gradient, a linear function of the fc2 one)."""
         D, Hd = self.D, self.hidden
@@ -899,8 +882,6 @@ class ViTEngine:
                 self._zero_grad_of(pre + "mlp.fc1.weight")      # every sample dropped this branch: zero, not last step's
                 self._zero_grad_of(pre + "mlp.fc2.weight")
             if tail is None and nm > 0:
-                if self.wgrad_fc2_early:
-                    self._on_side(lambda pre=pre, a=a, has_g=has_g, M2=M2: self._wg_fc2(pre, a, has_g, M2, dY))
                 self._before_overwrite("dbig")
                 if M2p > M2:
                     ops.zero_(dY[M2:M2p])   # rows of the padding: zero in, zero out (the epilogue's column sums see them)
@@ -909,15 +890,8 @@ class ViTEngine:
                 ops.colsum_fold(self.cs_ws, self.CS_COPIES, Hd, self.G(pre + "mlp.fc1.bias"))
 
                 def wg_mlp(i=i, pre=pre, a=a, has_g=has_g, M2=M2):
-                    if self.wgrad_fc2_early:
-                        self._wg_fc1(pre, a, M2)
-                    else:
-                        self._wg_mlp(pre, a, has_g, M2, dY)
-                pending_mlp = None
-                if self.wgrad_mlp_late and na > 0:
-                    pending_mlp = wg_mlp                          # issued in front of the attention backward (below)
-                else:
-                    self._on_side(wg_mlp)
+                    self._wg_mlp(pre, a, has_g, M2, dY)
+                self._on_side(wg_mlp)
                 ops.gemm_nt(self.dbig, self.wT[i]["fc1"], M2p, D, Hd, ops.EPI_BIAS_BF16, out0=self.dh_small)
             if tail is not None:
                 pass
@@ -956,8 +930,6 @@ class ViTEngine:
                                             self.P(pre + "gamma_1"), D, D, self.G(pre + "gamma_1"))
                 if not self.wgrad_group:
                     self._on_side(wg_proj)
-                if tail is None and nm > 0 and pending_mlp is not None:
-                    self._on_side(pending_mlp)
                 self._before_overwrite("dqkv")
                 # (rowsum(dO * O) is computed inside the fused 14 x 14 backward; other windows: a delta pass in the library)
                 ops.attn_bwd(a["qkv"], self.dao, a["lse"], self.delta_ws, table, self.window, na, T, D, self.heads,
