@@ -93,7 +93,7 @@ class ViTEngine:
         self._opt_ev = None               # bucket name -> event (parameters of that bucket are updated, cast)
         self._opt_done = None             # everything incl. the transposed copies
         self.wgrad_side_stream = True
-        self.wgrad_group = 1             # 1: proj + qkv weight gradients of a block as one launch (_wgrad_group); 2: fc2 + fc1 too; 0: off
+        self.wgrad_group = 2             # 1: proj + qkv weight gradients of a block as one launch (_wgrad_group); 2: fc2 + fc1 too; 0: off
         self.fwd_two_streams = False      # forward: uneven two-stream split (see forward_trunk / _split_point).  It paid
                                           # -0.24 ms at B = 256 while the GEMM epilogues stalled on their own stores (the
                                           # second part filled those stalls); with the branch-free epilogues of the 256-row
@@ -678,8 +678,9 @@ class ViTEngine:
     def _wgrad_group(self, items):
         """items = [(dY, X, R, n_out, n_in, gname), ...]: the weight gradients of layers whose operands are ready at the
         same time as ONE launch (ops.gemm_tn_group): the 768 x 768 proj gradient rides with the 7 row slices of the qkv
-        gradient instead of the 28 it needs alone to fill the chip (proj + qkv: 241 -> 212 us per block; fc2 + fc1, two
-        rounds of workgroups, measured no faster than two launches and stay separate)."""
+        gradient instead of the 28 it needs alone to fill the chip (proj + qkv: 241 -> 212 us per block); fc2 + fc1 run as
+        ONE round of 216 workgroups with 3 row slices each instead of two launches with 7 (as two rounds of 504 they were
+        no faster than two launches).  ViT-B step: 34.8 (single launches) -> 34.3 (proj + qkv) -> 33.9 ms (both pairs)."""
         need = ops.gemm_tn_group_workspace([(R, n_out, n_in) for _, _, R, n_out, n_in, _ in items])
         if need > self._tn_ws.numel():
             self._tn_ws = torch.empty(need, dtype=torch.uint8, device=self.dev)
