@@ -89,6 +89,19 @@ def gemm_traffic_per_launch(kernel, tj=None):
     return (tj or {}).get(kernel, {}).get("hbm_bytes_per_launch")
 
 
+def wgrad_traffic_per_product(tj=None):
+    """HBM bytes per weight-gradient PRODUCT from the PMC passes: the single launches (gemm_tn_p8_kernel, one product) and the
+    grouped launches of the engine (gemm_tn_p8_group_kernel, two products each: proj + qkv, fc2 + fc1), weighted by their
+    launch counts in that profile; None until collected."""
+    tj = _load_profile("gemm_traffic.json") if tj is None else tj
+    one, grp = (tj or {}).get("gemm_tn_p8_kernel"), (tj or {}).get("gemm_tn_p8_group_kernel")
+    if not one and not grp:
+        return None
+    byts = sum(e["hbm_bytes_per_launch"] * e["launches"] for e in (one, grp) if e)
+    prods = (one["launches"] if one else 0) + 2 * (grp["launches"] if grp else 0)
+    return round(byts / prods)
+
+
 def mfma_util_by_kernel(uj=None):
     uj = _load_profile("mfma_util.json") if uj is None else uj
     if not uj:
@@ -973,7 +986,7 @@ def main():
                 roof = {"bound": "mfma", "kernel": "gemm_tn_p8_kernel / gemm_tn_p8_group_kernel (bf16 weight-gradient GEMM, split over token rows)",
                         "achieved": round(d_ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                         "frac": round(d_ach / PEAK_BF16_TFLOPS, 4),
-                        "traffic": gemm_traffic_per_launch("gemm_tn_p8_kernel", tj),
+                        "traffic": wgrad_traffic_per_product(tj),
                         "launches": dom[0], "avg_launch_us": round(dom[1] / dom[0] * 1e3, 2),
                         "algorithmic_flop_per_launch": round(dom[2] / dom[0]),
                         "share_of_step": round(dom[1] / (dt * 1e3 * n_inst / a.steps), 3),

@@ -13,6 +13,9 @@ def test_profile_readers_find_their_keys():
     assert per_sample is not None and algorithmic <= per_sample <= 2.5 * algorithmic       # traffic >= algorithmic bytes
     t = bench.gemm_traffic_per_launch("gemm_tn_p8_kernel")
     assert isinstance(t, int) and t > 100e6
+    tp = bench.wgrad_traffic_per_product()                  # single + grouped weight-gradient launches, per product
+    assert isinstance(tp, int) and 150e6 < tp < 800e6
+    assert bench.wgrad_traffic_per_product({}) is None
     util = bench.mfma_util_by_kernel()
     assert util and "whole_step" in util and all(0.0 <= v <= 1.0 for v in util.values())
     assert any(k.startswith("gemm_tn_p8_kernel") for k in util)
