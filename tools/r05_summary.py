@@ -31,7 +31,7 @@ L.append(f"* `python bench.py` -> `r05_final_bench.json`: **{b['ms_per_step']} m
          f"`roofline` (dominant kernel: the weight-gradient GEMM, `gemm_tn_p8_kernel` / `gemm_tn_p8_group_kernel` + reduction pass, HIP events): {r['avg_launch_us']} us per product = {r['achieved']} TFLOP/s = "
          f"**{r['frac']}** of 2.5 PFLOP/s, traffic {r['traffic'] / 1e6:.1f} MB per product; `gemm_family` {g['achieved']} TFLOP/s = **{g['frac']}** "
          f"(bias {g['per_epilogue']['0']['tflops']}, residual {g['per_epilogue']['2']['tflops']}, GELU + stored derivative {g['per_epilogue']['6']['tflops']}, "
-         f"derivative product {g['per_epilogue']['7']['tflops']}, weight gradient {g['per_epilogue']['100']['tflops']}, grouped proj + qkv weight gradient {g['per_epilogue'].get('102', {}).get('tflops')}); `whole_step` {r['whole_step']['frac']} on executed "
+         f"derivative product {g['per_epilogue']['7']['tflops']}, single weight-gradient launches (head, patch embedding) {g['per_epilogue']['100']['tflops']}, grouped pairs (proj + qkv, fc2 + fc1) {g['per_epilogue'].get('102', {}).get('tflops')}); `whole_step` {r['whole_step']['frac']} on executed "
          f"FLOPs, {r['whole_step']['frac_on_reference_flop_count']} on the reference's count; attention 14x14 in the step: forward {att.get('forward', {}).get('avg_us')} us, "
          f"backward {att.get('backward', {}).get('avg_us')} us per layer.")
 L.append(f"* `with_tokenizer` (certified fp16x2 tokenizer, {f['label_mismatches']} label mismatches against the fp32 mode on {f['tokens_compared']} tokens; "
