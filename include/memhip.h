@@ -332,7 +332,7 @@ int memhip_gemm_bf16_tn_ws(const void* A, int64_t lda, const void* B, int64_t ld
                            float* out, int64_t ldo, int accumulate, void* workspace, size_t workspace_bytes,
                            memhip_stream_t stream);
 /* The weight gradients of up to 4 Linear layers whose operands are ready at the same time (fc2 + fc1, proj + qkv of a
- * Block: mem/modeling_finetune.py:160-189 backward) as ONE launch: the products share one grid and one split count, so a
+ * Block: mem/modeling_finetune.py:160-189 backward) as ONE launch: the products share one grid and one split count (the fewest rounds of workgroups that keep >= 80 % of the CUs busy), so a
  * small product (768 x 768: 9 tiles) runs with the 7 row slices of its neighbour instead of the 28 it needs alone to fill
  * the chip, and the group has one reduction pass.  Each product has the contract of memhip_gemm_bf16_tn_ws (fixed sum order:
  * run-to-run deterministic; the order differs from the single call's, so the two agree to fp32 rounding, not bitwise).
