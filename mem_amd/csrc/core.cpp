@@ -12,7 +12,7 @@ thread_local char g_err[512] = "";
 static std::atomic<int> g_opt[OPT_COUNT_] = {
     /*gemm_p8*/ {1}, /*gemm256*/ {1}, /*gemm_split*/ {1}, /*gemm_p8_half*/ {1}, /*gemm_p8_min_n*/ {512},
     /*gemm256_min_n*/ {1024}, /*tn_p8*/ {1}, /*tn256*/ {1}, /*raster_lds*/ {1}, /*attn16*/ {1}, /*attn16_stagger (cycles)*/ {40000}, /*attn16_stagger_fwd*/ {0}, /*gemm_stagger (cycles per K-tile)*/ {0}, /*gemm_prefetch (epilogue-operand L2 prefetch; measured slower: the touches share the in-order vmcnt queue with the operand stream)*/ {0},
-    /*reserve_cus*/ {0}, /*ln_bwd_grid (workgroups of the LayerNorm-backward kernels)*/ {768},
+    /*reserve_cus*/ {0}, /*ln_bwd_grid (workgroups of the LayerNorm-backward kernels; re-swept in round 5 inside the two-stream step: 768 -> 2048 = -0.25 ms)*/ {2048},
     /*attn_win (slot-layout streaming attention for windows 40 / 20 wide, attn_win.hip; 0 = attn_stream.hip)*/ {1},
     /*gemm_p8_pair (full rounds + ragged round of an NT product in ONE launch; 0 = two launches)*/ {1},
     /*tn_group (memhip_gemm_bf16_tn_group runs its products as ONE grid with one split count; 0 = one by one)*/ {1}};

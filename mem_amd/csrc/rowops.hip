@@ -653,7 +653,7 @@ extern "C" int memhip_layernorm_bwd(const void* dy, int64_t lddy, const float* x
   MEMHIP_REQUIRE(dy && x && gamma && mean && rstd && dres && dgamma && dbeta, "layernorm_bwd: null pointer");
   MEMHIP_REQUIRE(ldx % 4 == 0 && lddy % 4 == 0 && lddres % 4 == 0, "layernorm_bwd: ld must be a multiple of 4");
   int grid = cdiv(R, 4);
-  const int cap = opt(OPT_LN_BWD_GRID) * 4 / 3;      // default 1024: 4 workgroups per CU, ~50 rows per wave at ViT-B scale
+  const int cap = opt(OPT_LN_BWD_GRID) * 4 / 3;      // (4/3 of the fused kernel's grid: this one needs half the LDS per workgroup)
   if (grid > cap) grid = cap;
 #define LNB_LAUNCH(N)                                                                                    \
   hipLaunchKernelGGL(ln_bwd_kernel<N>, dim3(grid), dim3(256), (size_t)8 * D * sizeof(float), as_stream(stream), \
@@ -755,7 +755,11 @@ extern "C" int memhip_layernorm_bwd_branch_map(const void* dy, int64_t lddy, con
   MEMHIP_REQUIRE(ldx % 4 == 0 && lddy % 4 == 0 && lddres % 4 == 0 && ldyb % 4 == 0 && lddyb % 4 == 0,
                  "layernorm_bwd_branch: ld must be a multiple of 4");
   int grid = cdiv(R, 4);
-  int cap = opt(OPT_LN_BWD_GRID);                      // 768 = 3 resident workgroups per CU at this kernel's VGPR count: one full round
+  int cap = opt(OPT_LN_BWD_GRID);                      // 2048 (round 5).  768 = 3 resident workgroups per CU = one full round was the optimum of the
+                                                       // kernel ALONE; inside the step it runs beside the weight-gradient workgroups of the other stream (128 KB of
+                                                       // LDS each: a CU that holds one has no room for this kernel's 48 KB) and more, shorter workgroups find the
+                                                       // free CUs sooner: 512 / 768 / 1024 / 1536 / 2048 / 3072 / 4096 = 35.0 / 34.64 / 34.6 / 34.45 / 34.35-34.43 /
+                                                       // 34.5 / 34.65 ms per step (tools/exp/r05_run27.sh); ViT-L step 219 -> 216 ms
   if (D > 768 && cap > 512) cap = 512;                 // D = 1024: 64 KiB of LDS and 212 VGPRs per workgroup, two per CU (tools/ln_bwd_probe.py:
                                                        // 76 864 rows 301 -> 262 us, 19 216 rows 69 -> 64 us)
   if (grid > cap) grid = cap;
