@@ -291,10 +291,43 @@ def save_model(args, epoch, model, model_without_ddp, optimizer, loss_scaler, mo
     # additions to the reference's keys (its loaders index the five above and ignore the rest): the numerics switches the run
     # was trained with (tokenizer mode, stored GELU derivative, precision), and the state of the model's drop-path generator
     to_save["numerics"] = getattr(args, "numerics", None)
+    # (every rank has its OWN stream, seeded seed + rank: the checkpoint holds one state per rank -- all ranks call save_model,
+    # as in the reference, so the gather below is a collective every rank takes part in)
     dps = getattr(model_without_ddp, "_dp_stream", None)
     if dps is not None:
-        to_save["drop_path_rng"] = dps.state()
+        to_save["drop_path_rng"] = gather_rank_states(dps.state())
     save_on_master(to_save, output_dir / ("checkpoint-%s.pth" % str(epoch)))
+
+
+def gather_rank_states(state):
+    """{'world': W, 'states': [uint8 tensor of rank 0, ..., of rank W - 1]} from each rank's generator state."""
+    state = torch.as_tensor(state, dtype=torch.uint8).cpu()
+    world = get_world_size()
+    if world == 1:
+        return {"world": 1, "states": [state]}
+    states = [None] * world
+    dist.all_gather_object(states, state)
+    return {"world": world, "states": [torch.as_tensor(s, dtype=torch.uint8).cpu() for s in states]}
+
+
+def restore_rank_state(stream, saved):
+    """Rank r continues ITS OWN stream: states[r] when the checkpoint was written by a job of the same world size.  A
+    checkpoint of another world size (or one of the round-5 format: a single state, rank 0's) has no state for this rank's
+    stream -- the stream keeps the `seed + rank` the entrypoint has just given it (what the reference does on every resume:
+    it re-seeds per rank), and rank 0 says so.  Returns True when a saved state was loaded."""
+    if isinstance(saved, dict) and "states" in saved:
+        if int(saved.get("world", len(saved["states"]))) == get_world_size() and get_rank() < len(saved["states"]):
+            stream.load_state(saved["states"][get_rank()])
+            return True
+        print("drop-path streams: checkpoint of world size %s, this job %d -- every rank restarts its stream from seed + rank"
+              % (saved.get("world"), get_world_size()))
+        return False
+    if get_world_size() == 1:                              # round-5 checkpoints: one state, rank 0's
+        stream.load_state(saved)
+        return True
+    print("drop-path streams: single-state checkpoint in a %d-rank job -- every rank restarts its stream from seed + rank"
+          % get_world_size())
+    return False
 
 
 def auto_load_model(args, model, model_without_ddp, optimizer, loss_scaler, model_ema=None):
@@ -321,7 +354,7 @@ def auto_load_model(args, model, model_without_ddp, optimizer, loss_scaler, mode
             if "scaler" in checkpoint:
                 loss_scaler.load_state_dict(checkpoint["scaler"])
             if "drop_path_rng" in checkpoint and hasattr(model_without_ddp, "_dp_stream"):
-                model_without_ddp._dp_stream.load_state(checkpoint["drop_path_rng"])
+                restore_rank_state(model_without_ddp._dp_stream, checkpoint["drop_path_rng"])
             was = checkpoint.get("numerics")
             now = getattr(args, "numerics", None)
             if was is not None and now is not None and was != now:
@@ -507,8 +540,9 @@ def cap_host_threads(limit=4):
 class DropPathStream:
     """The model's own stochastic-depth generator (modeling_pretrain / modeling_finetune `_dp_uniform`): a CPU torch.Generator
     that no other consumer of the global stream shifts.  Seeded EXPLICITLY by the entrypoint (`seed(args.seed + rank)`), lazily
-    from torch's seed of the moment otherwise; `state()` / `load_state()` travel with the checkpoint (utils.save_model /
-    auto_load_model: key "drop_path_rng"), so a resumed run continues the mask stream instead of replaying it from step 0.
+    from torch's seed of the moment otherwise; `state()` / `load_state()` travel with the checkpoint, ONE STATE PER RANK
+    (utils.save_model / auto_load_model: key "drop_path_rng" = {world, states[rank]}), so every rank of a resumed run continues its
+    own mask stream (and the replicas' masks stay decorrelated) instead of replaying it from step 0.
     `uniform(rows, B, device)` uploads through a pinned ring (HostStager): no host-blocking copy on the launch stream."""
 
     def __init__(self):

@@ -241,3 +241,69 @@ def test_train_one_epoch_world2_mean_of_means():
         p.join(60)
     assert sorted(r[:2] for r in res) == [(0, True), (1, True)], res
     assert res[0][2] == res[1][2]                                # replicas hold identical parameters after the step
+
+
+def _worker_dp_resume(rank, world, port, q, tmp):
+    """the checkpoint holds ONE drop-path generator state PER RANK; after a resume every rank continues its own
+    stream (replicas keep drawing different masks), and a checkpoint of another world size falls back to seed + rank."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import argparse
+    from pathlib import Path
+    from mem_amd import utils
+
+    class Model(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.w = torch.nn.Parameter(torch.zeros(3))
+
+    class Scaler:
+        def state_dict(self): return {}
+        def load_state_dict(self, s): pass
+
+    def fresh(seed=7):
+        m = Model()
+        m._dp_stream = utils.DropPathStream()
+        m._dp_stream.seed(seed + utils.get_rank())           # what run_mem_pretraining does before auto_load_model
+        return m
+
+    args = argparse.Namespace(output_dir=tmp, auto_resume=True, resume="", epochs=10, start_epoch=0)
+    m = fresh()
+    opt = torch.optim.SGD(m.parameters(), lr=0.1)
+    m._dp_stream.uniform(12, 8)                              # the run has drawn some masks before the checkpoint
+    utils.save_model(args=args, epoch=0, model=m, model_without_ddp=m, optimizer=opt, loss_scaler=Scaler())
+    cont = m._dp_stream.uniform(12, 8)                       # what THIS rank would have drawn next
+    dist.barrier()
+    ck = torch.load(Path(tmp) / "checkpoint-0.pth", map_location="cpu", weights_only=False)
+    ok = ck["drop_path_rng"]["world"] == world and len(ck["drop_path_rng"]["states"]) == world
+    ok = ok and not torch.equal(ck["drop_path_rng"]["states"][0], ck["drop_path_rng"]["states"][1])
+    m2 = fresh(seed=1234)                                    # a resumed job (even one started with another seed)
+    utils.auto_load_model(args=args, model=m2, model_without_ddp=m2, optimizer=torch.optim.SGD(m2.parameters(), lr=0.1),
+                          loss_scaler=Scaler())
+    mine = m2._dp_stream.uniform(12, 8)
+    ok = ok and torch.equal(mine, cont)                      # every rank continues ITS stream
+    both = [None, None]
+    dist.all_gather_object(both, mine)
+    ok = ok and not torch.equal(both[0], both[1])            # and the replicas' masks differ
+    # a checkpoint written by a job of another world size: no state for this rank -> the stream keeps seed + rank
+    m3 = fresh(seed=99)
+    want = fresh(seed=99)._dp_stream.uniform(4, 4)
+    loaded = utils.restore_rank_state(m3._dp_stream, {"world": 4, "states": ck["drop_path_rng"]["states"] * 2})
+    ok = ok and not loaded and torch.equal(m3._dp_stream.uniform(4, 4), want)
+    loaded = utils.restore_rank_state(m3._dp_stream, ck["drop_path_rng"]["states"][0])     # round-5 format in a 2-rank job
+    ok = ok and not loaded
+    q.put((rank, bool(ok)))
+    dist.destroy_process_group()
+
+
+def test_drop_path_stream_resumes_per_rank(tmp_path):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_dp_resume, args=(r, 2, port, q, str(tmp_path))) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(60)
+    assert sorted(res) == [(0, True), (1, True)]
