@@ -80,7 +80,9 @@ class GradReducer:
         view = self.flat_g[b0:b1]
         if self.wire is not None:
             w = self.wire[b0:b1]
-            w.copy_(view / self.world)             # pre-divide in fp32, ONE rounding to bf16, then a bf16 SUM over the ranks
+            # pre-divide in fp32, ONE rounding to bf16 (the division writes straight into the preallocated wire buffer: no
+            # fp32 temporary of the bucket's size per call), then a bf16 SUM over the ranks
+            torch.div(view, self.world, out=w)
             h = dist.all_reduce(w, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
             self.handles.append((h, (view, w)))
             return

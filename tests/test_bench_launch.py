@@ -45,3 +45,19 @@ def test_world_size_mismatch_is_loud():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--rendezvous-only"], env=e,
                        capture_output=True, text=True, timeout=120)
     assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr
+
+
+def test_scale_ab_script_argument_forms():
+    """tools/scale_ab.sh (the A/B set for the first N > 1 run: --reserve-cus 0|16 x --bucket-dtype fp32|bf16): every
+    bench.py command line it builds parses, starts its ranks and returns a JSON line (SCALE_AB_DRY=1: --rendezvous-only)."""
+    e = _env(); e["SCALE_AB_DRY"] = "1"
+    r = subprocess.run(["bash", os.path.join(ROOT, "tools", "scale_ab.sh"), "2", "3", "1"], env=e, capture_output=True,
+                       text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
+    rows = [l for l in r.stdout.splitlines() if l.startswith("rep ")]
+    assert len(rows) == 8 and all("n_gpus 2" in l for l in rows), r.stdout
+    for cus in ("0", "16"):
+        for dt in ("fp32", "bf16"):
+            assert sum(f"reserve_cus={cus} bucket={dt}:" in l for l in rows) == 2
+    lines = open(os.path.join(ROOT, "gpurun_out", "scale_ab_N2.jsonl")).read().splitlines()
+    assert len(lines) == 8 and all(json.loads(l)["n_gpus"] == 2 for l in lines)
