@@ -26,6 +26,7 @@ sys.path.insert(0, ROOT)
 
 FLOP_PER_SAMPLE = {2: 108.85e9, 3: 109.08e9}      # BASELINE.md section 2 (GEMMs only, fwd+bwd)
 TIMER_EVERY = 32                                   # one timed step in 32 carries the per-GEMM HIP events (see timer_steps)
+POST_REGION_TIMER_STEPS = 4                        # instrumented steps run right behind the timed region (pooled with the ones inside)
 
 
 def timer_steps(k):
@@ -102,6 +103,17 @@ def wgrad_traffic_per_product(tj=None):
     return round(byts / prods)
 
 
+def wgrad_kernel_split(sj=None):
+    """Per weight-gradient PRODUCT, from the committed rocprofv3 --stats summary of the sequential step (profiles/wgrad_split.json,
+    written by tools/r06_collect.py from r06_final_seq_kernel_stats.csv): microseconds in the GEMM kernel (single + grouped
+    launches) and in its reduction pass, and the fraction of the 2.5 PFLOP/s peak of the kernel alone / with the reduction."""
+    sj = _load_profile("wgrad_split.json") if sj is None else sj
+    if not sj or "kernel_us_per_product" not in sj:
+        return None
+    return {k: sj[k] for k in ("kernel_us_per_product", "reduction_us_per_product", "frac_kernel_alone", "frac_with_reduction",
+                               "products", "source") if k in sj}
+
+
 def mfma_util_by_kernel(uj=None):
     uj = _load_profile("mfma_util.json") if uj is None else uj
     if not uj:
@@ -113,11 +125,11 @@ def kernel_clock(cj=None):
     """In-kernel shader clock of the GEMM main loops from profiles/r05_clock.json (tools/clock_probe.py: stamp build,
     d(s_memtime) / d(s_memrealtime) x 100 MHz after 2 s of back-to-back launches): {"gemm_p8_ghz", "gemm_tn_p8_ghz",
     "at_clock_peak_tflops", ...} or None.  The dense bf16 peak the chip can issue at that clock is 2.5 PFLOP/s x clock / 2.4."""
-    src = "r05_clock.json"
+    src = "r06_clock.json"
     if cj is None:
         cj = _load_profile(src)
         if cj is None:
-            src = "r04_clock.json"
+            src = "r05_clock.json"
             cj = _load_profile(src)
     if not cj or "kernels" not in cj:
         return None
@@ -129,6 +141,91 @@ def kernel_clock(cj=None):
     return {"gemm_p8_ghz": round(nt_g, 3), "gemm_tn_p8_ghz": round(tn_g, 3), "spec_clock_ghz": cj.get("spec_clock_ghz", 2.4),
             "at_clock_peak_tflops": round(PEAK_BF16_TFLOPS * min(nt_g, tn_g) / cj.get("spec_clock_ghz", 2.4), 1),
             "spec_peak_tflops": PEAK_BF16_TFLOPS, "source": "profiles/" + src + " (tools/clock_probe.py; " + cj.get("method", "") + ")"}
+
+
+HBM_ACHIEVABLE_TBS = 6.3                           # MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 measured (float4 copy)
+
+
+def speed_of_light(eng, hw, events_per_sample, at_clock_peak_tflops, ms_per_step):
+    """The floor of the step the engine just ran, launch by launch: max(algorithmic FLOPs / the MFMA peak AT THE CLOCK the chip holds
+    under the GEMM main loops, algorithmic HBM bytes / 6.3 TB/s achievable), every tensor a launch must read or write counted
+    once, summed per kernel family with NO overlap between launches (a sequential floor; the two-stream step can go below a
+    family's share, never below max(sum of MFMA floors, sum of HBM floors)).  Rows follow DESIGN.md section 4; block-level
+    launches count the samples stochastic depth kept and the last block's MLP the rows that reach the head, as executed."""
+    T, D, Hd, Lp, V = eng.T, eng.D, eng.hidden, eng.L, eng.V
+    B, M, Mm = eng.cur["B"], eng.cur["M"], eng.cur["Mm"]
+    plan = eng.cur.get("plan")
+    pk, bw = at_clock_peak_tflops * 1e12, HBM_ACHIEVABLE_TBS * 1e12
+    fam = {}
+
+    def add(name, flops, byts, n=1.0):
+        f = fam.setdefault(name, {"launches": 0.0, "flop": 0.0, "bytes": 0.0, "mfma_ms": 0.0, "hbm_ms": 0.0, "floor_ms": 0.0})
+        tf, tb = flops / pk * 1e3, byts / bw * 1e3
+        f["launches"] += n; f["flop"] += n * flops; f["bytes"] += n * byts
+        f["mfma_ms"] += n * tf; f["hbm_ms"] += n * tb; f["floor_ms"] += n * max(tf, tb)
+
+    def nt(name, m, n, k, extra_bytes):          # NT GEMM [m,k] x [n,k]^T: bf16 operands once + what the epilogue moves
+        add(name, 2.0 * m * n * k, 2.0 * m * k + 2.0 * n * k + extra_bytes)
+
+    def tn(name, r, n, k):                       # weight gradient [n,k] += sum_r dY[r,n] X[r,k]: operands once, fp32 result once
+        add(name, 2.0 * r * n * k, 2.0 * r * (n + k) + 4.0 * n * k)
+
+    # event path + patch embedding
+    Hh, Ww = hw
+    add("rasterize + event_norm (HBM)", 0.0, B * (32.0 * events_per_sample + 3.0 * Hh * Ww) + B * 10.0 * Hh * Ww)
+    nt("patch embedding GEMMs (fwd + wgrad)", B * Lp, D, eng.Kpe, 2.0 * B * Lp * eng.Kpe + 4.0 * M * D)
+    tn("patch embedding GEMMs (fwd + wgrad)", B * Lp, D, eng.Kpe)
+    for i in range(eng.depth):
+        ka = km = 1.0
+        if plan is not None:
+            if plan["n"][2 * i] is not None:
+                ka = plan["n"][2 * i] / B
+            if plan["n"][2 * i + 1] is not None:
+                km = plan["n"][2 * i + 1] / B
+        ma, mm_ = M * ka, M * km
+        if i == eng.depth - 1 and eng.cur.get("tail") is not None:
+            mm_ = float(Mm)
+        # ---- forward
+        add("LayerNorm forward (HBM)", 0.0, 6.0 * ma * D)                                  # fp32 in, bf16 out
+        nt("NT GEMMs, bf16 / GELU epilogues", ma, 3 * D, D, 2.0 * ma * 3 * D)              # qkv
+        add("attention forward", 4.0 * T * T * D * B * ka, 2.0 * ma * 3 * D + 2.0 * ma * D)
+        nt("NT GEMMs, fp32 residual epilogue", ma, D, D, 8.0 * ma * D)                     # proj: x read + x written (fp32)
+        add("LayerNorm forward (HBM)", 0.0, 6.0 * mm_ * D)
+        nt("NT GEMMs, bf16 / GELU epilogues", mm_, Hd, D, 4.0 * mm_ * Hd)                  # fc1: GELU out bf16 + stored derivative fp16
+        nt("NT GEMMs, fp32 residual epilogue", mm_, D, Hd, 8.0 * mm_ * D)                  # fc2
+        # ---- backward
+        nt("NT GEMMs, bf16 / GELU epilogues", mm_, Hd, D, 4.0 * mm_ * Hd)                  # fc2 dgrad x stored derivative
+        tn("weight-gradient GEMMs", mm_, D, Hd)
+        nt("NT GEMMs, bf16 / GELU epilogues", mm_, D, Hd, 2.0 * mm_ * D)                   # fc1 dgrad
+        tn("weight-gradient GEMMs", mm_, Hd, D)
+        add("LayerNorm backward + branch backward (HBM)", 0.0, 16.0 * mm_ * D)             # 3 fp32 streams + 2 bf16
+        nt("NT GEMMs, bf16 / GELU epilogues", ma, D, D, 2.0 * ma * D)                      # proj dgrad
+        tn("weight-gradient GEMMs", ma, D, D)
+        add("attention backward", 10.0 * T * T * D * B * ka, 2.0 * ma * 3 * D * 2 + 2.0 * ma * D * 2)
+        nt("NT GEMMs, bf16 / GELU epilogues", ma, D, 3 * D, 2.0 * ma * D)                  # qkv dgrad
+        tn("weight-gradient GEMMs", ma, 3 * D, D)
+        add("LayerNorm backward + branch backward (HBM)", 0.0, 16.0 * ma * D)
+    # head: final norm on the masked rows, lm_head, CE (logits bf16 read, dlogits written in place), dgrad + wgrad
+    add("LayerNorm forward (HBM)", 0.0, 6.0 * Mm * D)
+    nt("NT GEMMs, bf16 / GELU epilogues", Mm, V, D, 2.0 * Mm * V)
+    add("cross entropy (HBM)", 0.0, 4.0 * Mm * V)
+    nt("NT GEMMs, bf16 / GELU epilogues", Mm, D, V, 2.0 * Mm * D)
+    tn("weight-gradient GEMMs", Mm, V, D)
+    add("LayerNorm backward + branch backward (HBM)", 0.0, 14.0 * Mm * D)
+    # optimizer: gradient norm (4 B / parameter), AdamW (p, g, m, v read; p, m, v written), bf16 shadow + transposed matrices
+    add("grad norm + AdamW + bf16 weight copies (HBM)", 0.0, (4.0 + 28.0 + 2.0 + 2.0) * eng.nflat)
+    rows = {k: {"launches": round(v["launches"], 1), "gflop": round(v["flop"] / 1e9, 1), "mbytes": round(v["bytes"] / 1e6, 1),
+                "mfma_ms": round(v["mfma_ms"], 3), "hbm_ms": round(v["hbm_ms"], 3), "floor_ms": round(v["floor_ms"], 3)}
+            for k, v in fam.items()}
+    tot = sum(v["floor_ms"] for v in fam.values())
+    tot_m, tot_h = sum(v["mfma_ms"] for v in fam.values()), sum(v["hbm_ms"] for v in fam.values())
+    return {"families": rows, "sum_floor_ms": round(tot, 3), "sum_mfma_ms": round(tot_m, 3), "sum_hbm_ms": round(tot_h, 3),
+            "perfect_overlap_floor_ms": round(max(tot_m, tot_h), 3),
+            "ms_per_step": round(ms_per_step, 3), "ms_per_step_over_sum_floor": round(ms_per_step / tot, 3),
+            "mfma_peak_at_clock_tflops": at_clock_peak_tflops, "hbm_tbs": HBM_ACHIEVABLE_TBS,
+            "note": "per launch max(algorithmic FLOP / at-clock MFMA peak, algorithmic bytes / 6.3 TB/s), summed without overlap; "
+                    "perfect_overlap_floor_ms = max(all MFMA time, all HBM time): what two streams that never stall each other "
+                    "could reach; the at-clock peak is 2.5 PFLOP/s x (clock held inside the GEMM main loops / 2.4 GHz), profiles/r06_clock.json"}
 
 
 class _CachedEvents:
@@ -632,9 +729,10 @@ def main():
     # records around each of the 149 GEMM products of a step cost ~1.2 ms of dispatch bubbles per step
     # (measured) and serialise the side stream, so few timed steps are instrumented (timer_steps).
     timer_log = [] if not a.no_gemm_timer else None
+    timer_marks = []                                  # (first, last + 1) entries of timer_log per instrumented step
     if timer_log is not None:
         # pre-create and pre-record the timer's events (2 per GEMM product, ~150 products per instrumented step)
-        need = 2 * 160 * len(timer_steps(a.steps))
+        need = 2 * 160 * (len(timer_steps(a.steps)) + POST_REGION_TIMER_STEPS)
         ops.GEMM_EVENT_POOL = [torch.cuda.Event(enable_timing=True) for _ in range(need)]
         for e in ops.GEMM_EVENT_POOL:
             e.record()
@@ -648,14 +746,26 @@ def main():
     exec_flop = 0.0
     for it in range(a.steps):
         ops.GEMM_TIMER = timer_log if (timer_log is not None and it in inst) else None
+        i0 = len(timer_log) if timer_log is not None else 0
         la = step(a.warmup + it)
         step_ev[it + 1].record()
         host_t.append(time.perf_counter())
         exec_flop += executed_flop_per_sample(eng, C)
+        if ops.GEMM_TIMER is not None:
+            timer_marks.append((i0, len(timer_log)))
     exec_flop /= max(1, a.steps)                                    # mean executed GEMM FLOPs per sample of the timed steps
     ops.GEMM_TIMER = timer_log
     fence()
     dt = time.perf_counter() - t0
+    # ---- more instrumented steps right BEHIND the timed region (round 6: one instrumented step inside K = 20 timed steps gave a
+    # dominant-kernel figure that moved by 7 % between runs; every instrumented step costs ~5 ms, so the others do not sit
+    # inside the region `value` is computed from).  The roofline pools all of them and lists the per-step figures.
+    if timer_log is not None:
+        for j in range(POST_REGION_TIMER_STEPS):
+            i0 = len(timer_log)
+            step(a.warmup + a.steps + j)
+            timer_marks.append((i0, len(timer_log)))
+        fence()
     if os.environ.get("MEMHIP_BENCH_STEP_TIMES") == "1":
         print("[bench] host per-step ms:", [round((host_t[i + 1] - host_t[i]) * 1e3, 1) for i in range(a.steps)], file=sys.stderr)
         print("[bench] per-step ms:", [round(step_ev[i].elapsed_time(step_ev[i + 1]), 2) for i in range(a.steps)], file=sys.stderr)
@@ -952,9 +1062,9 @@ def main():
     if rank == 0:
         ms = dt / a.steps * 1e3
         value = world * B * a.steps / dt
-        roof = None
+        roof = sol = None
         if timer:
-            n_inst = len(inst)
+            n_inst = len(timer_marks)
             tot_ms, tot_fl, per = 0.0, 0.0, {}
             attn_per = {}
             for e0, e1, fl, epi in timer:
@@ -981,6 +1091,15 @@ def main():
                 if code in per:
                     v = per[code]
                     dom = [v[0] * n_prod, v[1], v[2]] if dom is None else [dom[0] + v[0] * n_prod, dom[1] + v[1], dom[2] + v[2]]
+            # the same figure per instrumented step (how far one step's sample is from the pooled mean)
+            per_step_frac = []
+            for i0, i1 in timer_marks:
+                fl_s = ms_s = 0.0
+                for e0, e1, fl, epi in timer[i0:i1]:
+                    if int(epi) in (100, 102, 103, 104):
+                        fl_s += fl; ms_s += e0.elapsed_time(e1)
+                if ms_s > 0:
+                    per_step_frac.append(round(fl_s / (ms_s * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4))
             if dom:
                 d_ach = dom[2] / (dom[1] * 1e-3) / 1e12
                 roof = {"bound": "mfma", "kernel": "gemm_tn_p8_kernel / gemm_tn_p8_group_kernel (bf16 weight-gradient GEMM, split over token rows)",
@@ -990,13 +1109,19 @@ def main():
                         "launches": dom[0], "avg_launch_us": round(dom[1] / dom[0] * 1e3, 2),
                         "algorithmic_flop_per_launch": round(dom[2] / dom[0]),
                         "share_of_step": round(dom[1] / (dt * 1e3 * n_inst / a.steps), 3),
-                        "instrumented_steps": n_inst,
+                        "instrumented_steps": n_inst, "instrumented_steps_inside_timed_region": len(inst),
+                        "frac_per_instrumented_step": per_step_frac,
+                        "kernel_vs_reduction": wgrad_kernel_split(),
                         "products_in_group_launches": sum(per[c][0] * (c - 100) for c in (102, 103, 104) if c in per),
                         "note": "HIP events around one weight-gradient call = gemm_tn_p8_kernel + its tn_reduce_kernel, or the group "
                                 "kernel (proj + qkv of a block in one grid) + its reduction pass; launches / avg_launch_us are per PRODUCT; the "
                                 "instrumented steps run on ONE stream (the events serialise the side stream), so compare with the "
-                                "sequential rocprofv3 summary (profiles/r05_final_seq_kernel_stats.csv; the steady-state steps alone: r05_final_seq_step_kernels.txt), not with the "
-                                "two-stream one, where concurrent launches stretch every kernel"}
+                                "sequential rocprofv3 summary (profiles/r06_final_seq_kernel_stats.csv; the steady-state steps alone: r06_final_seq_step_kernels.txt), not with the "
+                                "two-stream one, where concurrent launches stretch every kernel.  achieved / frac / avg_launch_us pool "
+                                "every instrumented step: the one(s) inside the timed region and POST_REGION_TIMER_STEPS more run right "
+                                "behind it (an instrumented step costs ~5 ms, so they are kept out of `value`); frac_per_instrumented_step "
+                                "lists them one by one; kernel_vs_reduction splits a product into the GEMM kernel and its reduction pass "
+                                "from the committed rocprofv3 summary (the events bracket both)"}
             else:
                 roof = {"bound": "mfma", "kernel": "bf16 MFMA GEMM family", "achieved": round(ach, 1),
                         "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
@@ -1012,6 +1137,10 @@ def main():
             if clk is not None:
                 clk["frac_of_at_clock_peak"] = round(roof["achieved"] / clk["at_clock_peak_tflops"], 4)
                 roof["clock"] = clk
+            try:
+                sol = speed_of_light(eng, (H, W), NE, clk["at_clock_peak_tflops"] if clk else PEAK_BF16_TFLOPS, ms)
+            except Exception as e:                                    # a reporting object must never cost the headline
+                print(f"[bench] speed_of_light skipped: {e!r}", file=sys.stderr)
             # the honest headline next to the dominant kernel: the model-level rate of the WHOLE step (all kernels, all
             # gaps) against the dense bf16 peak, and the GEMM family as a whole (below)
             ws = value / world * exec_flop / 1e12
@@ -1047,6 +1176,7 @@ def main():
                                    "launches": len(timer), "avg_launch_us": round(tot_ms / len(timer) * 1e3, 2),
                                    "share_of_step": round(tot_ms / (dt * 1e3 * n_inst / a.steps), 3), "per_epilogue": fam,
                                    "traffic": {k: v.get("hbm_bytes_per_launch") for k, v in tj.items() if k.startswith("gemm")}}
+        from mem_amd import _lib as _L
         out = {"metric": "pretrain samples/sec (ViT-B, 224^2 event voxels)", "value": round(value, 1),
                "unit": "samples/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
                "ms_per_step": round(ms, 3), "ms_per_step_p50": round(step_ms[len(step_ms) // 2], 3),
@@ -1065,6 +1195,14 @@ def main():
                                         "per bucket" if eng.overlap_optimizer else "AdamW as one launch in front of the next forward"),
                           "last_block_mlp_rows": "rows that reach the head" if eng.tail_rows else "all"},
                "roofline": roof}
+        if roof is not None and sol is not None:
+            out["speed_of_light"] = sol
+        out["library"] = {"path": os.path.relpath(_L.LIB_PATH, ROOT), "build_flags": _L.BUILD_FLAGS, "shipped_build": _L.IS_SHIPPED_LIB,
+                          "abi": _L.ABI_VERSION, "options_set": sorted(a.opt)}
+        if not _L.IS_SHIPPED_LIB:
+            # a measurement build (MEMHIP_LIB / extra compiler flags) is never the headline: the A/B tools read ab_value
+            out["metric"] = "NOT THE HEADLINE: measurement build of libmemhip.so (MEMHIP_LIB / build flags set) -- " + out["metric"]
+            out["ab_value"], out["value"] = out["value"], None
         if tok_ms is not None:
             fp32_fig = {"value": round(world * B / (tok_step_ms * 1e-3), 1), "unit": "samples/sec",
                         "ms_per_step": round(tok_step_ms, 3), "sequential_sum_ms": round(ms + tok_ms, 3),

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define MEMHIP_ABI_VERSION 4   /* 4 (round 5): epilogues 6 / 7 carry the stored GELU derivative as FP16 (since round 4), certified-tokenizer entry points */
+#define MEMHIP_ABI_VERSION 5   /* 5 (round 6): memhip_build_flags; 4 (round 5): epilogues 6 / 7 carry the stored GELU derivative as FP16 (since round 4), certified-tokenizer entry points */
 
 #define MEMHIP_OK 0
 #define MEMHIP_EINVAL (-1)   /* bad argument (shape / alignment / null) */
@@ -49,6 +49,9 @@ int memhip_abi_version(void);
 const char* memhip_last_error(void);
 /* Name of the device code object this library was built for ("gfx950"). */
 const char* memhip_arch(void);
+/* Extra compiler flags this library was built with ("" for the shipped build; a measurement build made by
+ * tools/build_variant.sh names its -D switches here, and bench.py prints them next to the path of the library it measured). */
+const char* memhip_build_flags(void);
 /* Kernel-selection switches for A/B measurements (tools/): the library reads NO environment variable; the only
  * process-wide state is this explicit table.  Names: "gemm_p8", "gemm256", "gemm_split", "gemm_p8_half", "tn_p8",
  * "tn256", "raster_lds", "attn16" (0/1, default 1 = shipped dispatch), "gemm_p8_min_n" (768), "gemm256_min_n" (1024),

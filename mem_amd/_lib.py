@@ -21,7 +21,7 @@ if not os.path.exists(LIB_PATH):
 
 lib = C.CDLL(LIB_PATH)
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 vp, i32, i64, f32, f64, sz = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_double, C.c_size_t
 
@@ -42,12 +42,17 @@ declare({
     "memhip_abi_version": (i32, []),
     "memhip_last_error": (C.c_char_p, []),
     "memhip_arch": (C.c_char_p, []),
+    "memhip_build_flags": (C.c_char_p, []),
     "memhip_set_option": (i32, [C.c_char_p, i32]),
     "memhip_get_option": (i32, [C.c_char_p, C.POINTER(i32)]),
 })
 
 if lib.memhip_abi_version() != ABI_VERSION:
     raise ImportError(f"libmemhip.so ABI {lib.memhip_abi_version()} != expected {ABI_VERSION}; rebuild")
+
+
+BUILD_FLAGS = lib.memhip_build_flags().decode()      # "" = the shipped build
+IS_SHIPPED_LIB = os.environ.get("MEMHIP_LIB") in (None, "") and BUILD_FLAGS == ""
 
 
 def check(rc, what=""):

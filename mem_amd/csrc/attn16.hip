@@ -42,19 +42,10 @@
 #include "attn_common.hpp"
 #include <type_traits>
 
-#ifndef ATTN16_FD_POS
 #define ATTN16_FD_POS 0   // where the fused-delta loads of the next sample are issued: 0 = in front of the Q / dO DMA (B = 256:
                           // 300.5 us per layer), 1 = behind dQ's LDS staging (306.5 us); attn_delta + unfused backward: 314.4 us
-#endif
-#ifndef ATTN16_SKEW
 #define ATTN16_SKEW 1     // forward: waves 4..6 half a sample behind waves 0..3 (0: lockstep, one barrier per sample)
-#endif
-#ifndef ATTN16_W3STAGE
 #define ATTN16_W3STAGE 0  // backward: 1 = wave 3 (alone on its SIMD) stages the Q / dO images of the next sample for everybody: measured 278 vs 266 us
-#endif
-#ifndef ATTN16_EXP
-#define ATTN16_EXP 0      // timing experiments (tools/build_variant.sh); 0 = the shipped kernel
-#endif
 
 namespace {
 
@@ -336,16 +327,9 @@ __device__ __forceinline__ void stage_tokens_lean(unsigned lds_dst, const __bf16
 }
 
 // -DATTN16_TIMING: per-section s_memtime totals of wave 0 / wave 4 of every workgroup (tools/attn16_sections.py)
-#ifdef ATTN16_TIMING
-__device__ unsigned long long g_attn16_prof[2][16];
-#define T16_DECL() unsigned long long t_last_ = __builtin_readcyclecounter(), t_acc_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
-#define T16_TICK(i) do { const unsigned long long t_ = __builtin_readcyclecounter(); t_acc_[i] += t_ - t_last_; t_last_ = t_; } while (0)
-#define T16_FLUSH() do { if (lane == 0 && (wave == 0 || wave == 4)) for (int i_ = 0; i_ < 12; ++i_) atomicAdd(&g_attn16_prof[wave >> 2][i_], t_acc_[i_]); } while (0)
-#else
 #define T16_DECL()
 #define T16_TICK(i)
 #define T16_FLUSH()
-#endif
 // ------------------------------------------------------------------------------------------------ forward
 // 8 waves: 7 compute a block of 32 queries each, the 8th only issues the LDS-DMA of the next sample.  Measured (B = 256,
 // tools/exp/r04_run13.sh): with the K / V staging of the next sample left out the 7-wave kernel took 83 us instead of 109 --
@@ -391,7 +375,6 @@ __global__ __launch_bounds__(kThreadsFwd16) void attn16_fwd_kernel(const __bf16*
   }
   if (wave == NB16) {                          // the staging wave
     const SlotOffs16 so = slot_offs16(ldq);
-#if ATTN16_SKEW
     // barrier j = 2 b: the early waves start the scores of sample b (K image), the late ones the softmax / PV of b - 1 (V);
     // j = 2 b + 1: the other way round.  K(b - 1) is dead at barrier 2 b, V(b - 1) at 2 b + 1: K(b + 1) / V(b + 1) are
     // issued there and have a whole period (two barriers) to land; the piece issued after barrier j - 1 may still be in
@@ -411,31 +394,17 @@ __global__ __launch_bounds__(kThreadsFwd16) void attn16_fwd_kernel(const __bf16*
         else stage_slots_fast(dst, s1 + D, so);
       }
     }
-#else
-    for (int b = b0; b < b1; ++b) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();                         // sample b landed; b-1 consumed: its buffers are free
-      if (b + 1 < b1) {
-        const __bf16* s1 = qkv + (long long)(b + 1) * T16 * ldq + h * HD;
-        const unsigned dst = lds_addr_of(imgs + (((b - b0) & 1) ^ 1) * 2 * IMG16);
-        stage_slots_fast(dst, s1 + D, so);
-        stage_slots_fast(dst + IMG16, s1 + 2 * D, so);
-      }
-    }
-#endif
     return;
   }
   bf16x8 Qn[4];
 #pragma unroll
   for (int t = 0; t < 4; ++t) Qn[t] = ld16(qkv + ((long long)b0 * T16 + qc) * ldq + h * HD + 16 * t + 8 * hh);
   T16_DECL();
-#if ATTN16_SKEW
   // waves 4..6 (the second wave of SIMD 0..2) run HALF A SAMPLE behind waves 0..3: while one wave of a SIMD is in its MFMA
   // phases the other is in its VALU phases (in lockstep the two add up: 28 + 28 MFMAs with the vector ALU idle, then
   // bias / max / exp with the matrix core idle).  Same code, one barrier more in front (late) or behind (early).
   const bool late = __builtin_amdgcn_readfirstlane(wave) >= 4;
   if (late) { ATTN16_WAIT_VM(4); __syncthreads(); }
-#endif
   for (int b = b0; b < b1; ++b) {
     T16_TICK(5);
     const int cur = (b - b0) & 1;
@@ -482,30 +451,17 @@ __global__ __launch_bounds__(kThreadsFwd16) void attn16_fwd_kernel(const __bf16*
           bias[2] = hh1 ? (kb == 0 && g == 1 ? clsb : -INFINITY) : bias[2];
           bias[3] = hh1 ? -INFINITY : bias[3];
         }
-#if ATTN16_EXP == 14
-#pragma unroll
-        for (int e = 0; e < 4; ++e) s[kb][4 * g + e] += bias[e];
-#elif ATTN16_EXP == 17
-        const unsigned p0 = pk_bf16(s[kb][4 * g], s[kb][4 * g + 1]), p1 = pk_bf16(s[kb][4 * g + 2], s[kb][4 * g + 3]);
-        s[kb][4 * g] = __uint_as_float(p0 << 16) + bias[0];
-        s[kb][4 * g + 1] = __uint_as_float(p0 & 0xffff0000u) + bias[1];
-        s[kb][4 * g + 2] = __uint_as_float(p1 << 16) + bias[2];
-        s[kb][4 * g + 3] = __uint_as_float(p1 & 0xffff0000u) + bias[3];
-#else
         const unsigned p0 = pk_bf16(s[kb][4 * g], s[kb][4 * g + 1]), p1 = pk_bf16(s[kb][4 * g + 2], s[kb][4 * g + 3]);
         s[kb][4 * g] = add_lo(p0, bias[0], sel_lo);
         s[kb][4 * g + 1] = add_hi(p0, bias[1]);
         s[kb][4 * g + 2] = add_lo(p1, bias[2], sel_lo);
         s[kb][4 * g + 3] = add_hi(p1, bias[3]);
-#endif
 #pragma unroll
         for (int e = 0; e < 4; ++e) mx = fmaxf(mx, s[kb][4 * g + e]);
       }
     }
     T16_TICK(2);
-#if ATTN16_SKEW
     __syncthreads();                         // the V image of sample b has landed
-#endif
     mx = fmaxf(mx, __shfl_xor(mx, 32));
     const float mneg = -mx * kLog2e;
     float sum = 0.f;
@@ -513,11 +469,7 @@ __global__ __launch_bounds__(kThreadsFwd16) void attn16_fwd_kernel(const __bf16*
     for (int kb = 0; kb < NB16; ++kb)
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
-#if ATTN16_EXP == 15
-        const float p = fmaf(s[kb][i], kLog2e, mneg);
-#else
         const float p = fexp2(fmaf(s[kb][i], kLog2e, mneg));
-#endif
         s[kb][i] = p;
         sum += p;
       }
@@ -563,24 +515,14 @@ __global__ __launch_bounds__(kThreadsFwd16) void attn16_fwd_kernel(const __bf16*
       for (int i = 0; i < 4; ++i) {
         const int row = (lane >> 3) + 8 * i, qq = wave * 32 + row;
         const bf16x8 v = tile_get(st, row, lane & 7);
-#if ATTN16_EXP == 16
-        __bf16* dst = reinterpret_cast<__bf16*>(g_attn16_trash) + lane * 8;
-#else
         __bf16* dst = qq < T16 ? out + ((long long)b * T16 + qq) * ldo + h * HD + (lane & 7) * 8
                                : reinterpret_cast<__bf16*>(g_attn16_trash) + lane * 8;
-#endif
         *reinterpret_cast<bf16x8*>(dst) = v;
       }
     }
   }
-#if ATTN16_SKEW
   if (!late) __syncthreads();
-#endif
   T16_TICK(5);
-#ifdef ATTN16_TIMING
-  if (lane == 0 && (wave == 0 || wave == 4))
-    for (int i_ = 0; i_ < 6; ++i_) atomicAdd(&g_attn16_prof[wave >> 2][6 + i_] , t_acc_[i_]);   // forward: slots 6..11
-#endif
 }
 
 // ------------------------------------------------------------------------------------------------ fused backward
@@ -912,40 +854,6 @@ __global__ __launch_bounds__(kThreads16) void attn16_bwd_kernel(const __bf16* __
           const float c1 = fmaf(dpp_shr1(xb[0]), link, xb[1]);
           const float c2 = fmaf(dpp_shr1(c1), link, xb[2]);
           const float c3 = fmaf(dpp_shr1(c2), link, xb[3]);
-#if ATTN16_EXP == 1      // timing experiment: arithmetic kept, no atomics
-          dcls += __int_as_float(fx_round(c3, fx) ^ fx_round(xb[0], fx) ^ fx_round(c1, fx) ^ fx_round(c2, fx));
-#elif ATTN16_EXP == 2    // timing experiment: only the full-wave atomic
-          lds_add_i32_abs(na + KOFF16(g, 3), fx_round(c3, fx));
-          dcls += __int_as_float(fx_round(xb[0], fx) ^ fx_round(c1, fx) ^ fx_round(c2, fx));
-#elif ATTN16_EXP == 3    // debugging: whole-wave chains, every run end adds its three unfinished chains itself
-          lds_add_i32_abs(na + KOFF16(g, 3), fx_round(c3, fx));
-          if (chain_end) {
-            lds_add_i32_abs(na + KOFF16(g, 0), fx_round(xb[0], fx));
-            lds_add_i32_abs(na + KOFF16(g, 1), fx_round(c1, fx));
-            lds_add_i32_abs(na + KOFF16(g, 2), fx_round(c2, fx));
-          }
-#elif ATTN16_EXP == 4    // debugging: only chain 1 is delegated
-          lds_add_i32_abs(na + KOFF16(g, 3), fx_round(c3, fx));
-          lds_add_i32_abs(na + KOFF16(g, 0), fx_round(fmaf(fD1, dpp_shl1(c1), fEnd * xb[0]), fx));
-          if (chain_end) {
-            if (s1) lds_add_i32_abs(na + KOFF16(g, 1), fx_round(c1, fx));
-            lds_add_i32_abs(na + KOFF16(g, 2), fx_round(c2, fx));
-          }
-#elif ATTN16_EXP == 7    // debugging: chain 1 delegated, the neighbour's value through ds_bpermute instead of DPP
-          lds_add_i32_abs(na + KOFF16(g, 3), fx_round(c3, fx));
-          lds_add_i32_abs(na + KOFF16(g, 0), fx_round(fmaf(fD1, __shfl_down(c1, 1), fEnd * xb[0]), fx));
-          if (chain_end) {
-            if (s1) lds_add_i32_abs(na + KOFF16(g, 1), fx_round(c1, fx));
-            lds_add_i32_abs(na + KOFF16(g, 2), fx_round(c2, fx));
-          }
-#elif ATTN16_EXP == 5    // debugging: only chain 2 is delegated
-          lds_add_i32_abs(na + KOFF16(g, 3), fx_round(c3, fx));
-          lds_add_i32_abs(na + KOFF16(g, 0), fx_round(fmaf(fD2, dpp_shl1(dpp_shl1(c2)), fEnd * xb[0]), fx));
-          if (chain_end) {
-            lds_add_i32_abs(na + KOFF16(g, 1), fx_round(c1, fx));
-            if (s2) lds_add_i32_abs(na + KOFF16(g, 2), fx_round(c2, fx));
-          }
-#else
           lds_add_i32_abs(na + KOFF16(g, 3), fx_round(c3, fx));
           {
             const float wsum = fmaf(fD2, dpp_shl1(dpp_shl1(c2)), fmaf(fD1, dpp_shl1(c1), fEnd * xb[0]));
@@ -955,7 +863,6 @@ __global__ __launch_bounds__(kThreads16) void attn16_bwd_kernel(const __bf16* __
           // (ROCm 7.2) into a test of an unrelated data register: tools/dt_dbg.py)
           if (any_s1) lds_add_i32_abs(na + KOFF16(g, 1), fx_round(fS1 * c1, fx));
           if (any_s2) lds_add_i32_abs(na + KOFF16(g, 2), fx_round(fS2 * c2, fx));
-#endif
         }
       }
       const bf16x8 pf0 = acc_frag(S, 0, 1.0f), pf1 = acc_frag(S, 1, 1.0f);
@@ -1004,25 +911,11 @@ __global__ __launch_bounds__(kThreads16) void attn16_bwd_kernel(const __bf16* __
     }
     __syncthreads();                                         // all reads of the images and all bucket atomics are done
     T16_TICK(8);
-#if ATTN16_FD_POS == 0
     if constexpr (FD) load_o(b + 1 < b1 ? b + 1 : b);      // in front of the Q / dO DMA of the next sample
-#endif
     if (b + 1 < b1) {
       stage_rows(b + 1);
-#if ATTN16_W3STAGE
-      // wave 3 -- alone on its SIMD, so half of its issue slots are free -- stages the Q / dO images of the next sample for everybody
-      // (the other six waves share SIMDs pairwise: an LDS-DMA issue there costs the partner wave's issue slots as well)
-      if (wave == 3) {
-#pragma unroll
-        for (int w = 0; w < NB16; ++w) {
-          stage_tokens_lean(lds_addr_of(Qs), qkv + (long long)(b + 1) * T16 * ldq + h * HD, (int)ldq, w);
-          stage_tokens_lean(lds_addr_of(dOs), dout + (long long)(b + 1) * T16 * ldo + h * HD, (int)ldo, w);
-        }
-      }
-#else
       stage_tokens_lean(lds_addr_of(Qs), qkv + (long long)(b + 1) * T16 * ldq + h * HD, (int)ldq, wave);
       stage_tokens_lean(lds_addr_of(dOs), dout + (long long)(b + 1) * T16 * ldo + h * HD, (int)ldo, wave);
-#endif
     }
     // ---------------- epilogue of sample b (under the LDS-DMA of sample b + 1)
     if (DT) {
@@ -1048,10 +941,6 @@ __global__ __launch_bounds__(kThreads16) void attn16_bwd_kernel(const __bf16* __
       // (the forward-output rows of the next sample are requested HERE: the dQ accumulators are dead -- 16 registers are
       // free -- and none of the sample's twelve stores has been issued yet, so the loads wait for nothing but the DMA in
       // front of them and all twelve stores stay behind them for the counted wait at the top of the next sample)
-#if ATTN16_FD_POS == 1
-      // (issued for the last sample as well -- its own rows once more, never used: no branch, the loads stay in this block)
-      if constexpr (FD) load_o(b + 1 < b1 ? b + 1 : b);
-#endif
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int row = (lane >> 3) + 8 * i, qq = wave * 32 + row;
@@ -1176,13 +1065,3 @@ int attn16_bwd(const void* qkv, int64_t ldqkv, const void* dout, int64_t ldo, co
 
 }  // namespace memhip
 
-#ifdef ATTN16_TIMING
-extern "C" int memhip_attn16_prof(unsigned long long* out32, int reset) {
-  if (out32) MEMHIP_HIP(hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_attn16_prof), sizeof(unsigned long long) * 32));
-  if (reset) {
-    unsigned long long z[32] = {0};
-    MEMHIP_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_attn16_prof), z, sizeof(z)));
-  }
-  return MEMHIP_OK;
-}
-#endif

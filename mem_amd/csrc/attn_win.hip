@@ -162,35 +162,21 @@ __device__ __forceinline__ void fwd_phase_a(const char* Ks, const LaneOffs& lo, 
       const int s0i = kb * 32 + 8 * g;
       if (!G::valid(s0i) && !G::valid(s0i + 4)) continue;
       const auto* p = reinterpret_cast<const __attribute__((address_space(3))) F2u*>(base + 4u * (unsigned)G::imm(s0i));
-#if defined(WIN_EXP) && (WIN_EXP == 2 || WIN_EXP == 6)     // timing experiment (wrong results): no bias reads
-      (void)p;
-      bz[kb & 1][4 * g] = bz[kb & 1][4 * g + 1] = bz[kb & 1][4 * g + 2] = bz[kb & 1][4 * g + 3] = bcls;
-#else
       bz[kb & 1][4 * g] = p[0].a; bz[kb & 1][4 * g + 1] = p[0].b; bz[kb & 1][4 * g + 2] = p[1].a; bz[kb & 1][4 * g + 3] = p[1].b;
-#endif
     }
   };
   bf16x8 kf[2][4];
   auto kread = [&](int kb) {
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-#if defined(WIN_EXP) && (WIN_EXP == 5 || WIN_EXP == 6)     // timing experiment (wrong results): no K fragment reads
-      kf[kb & 1][t] = Qf[t];
-#else
       kf[kb & 1][t] = row_frag_o(Ks, lo, kb, t);
-#endif
     }
   };
   auto chain = [&](int kb) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) s[kb][i] = 0.f;
-#if defined(WIN_EXP) && WIN_EXP == 7       // timing experiment (wrong results): no score MFMAs
-#pragma unroll
-    for (int i = 0; i < 16; ++i) s[kb][i] = (float)kf[kb & 1][i & 3][i >> 2];
-#else
 #pragma unroll
     for (int t = 0; t < 4; ++t) s[kb] = MFMA32(kf[kb & 1][t], Qf[t], s[kb]);
-#endif
   };
   float cmax = -INFINITY;
   float cls_raw = 0.f;
@@ -280,13 +266,9 @@ __device__ __forceinline__ void fwd_phase_b(const char* Vs, const LaneOffs& lo, 
   auto exps = [&](int kb) {
 #pragma unroll
     for (int i = 0; i < 16; i += 2) {
-#if defined(WIN_EXP) && WIN_EXP == 1     // timing experiment (wrong results): no exp / fma / add per element
-      const f32x2_t p = {s[kb][i], s[kb][i + 1]};
-#else
       const f32x2_t a = f32x2_t{s[kb][i], s[kb][i + 1]} * l2e2 + mneg2;
       const f32x2_t p = {fexp2(a[0]), fexp2(a[1])};
       sum2 += p;
-#endif
       s[kb][i] = p[0];
       s[kb][i + 1] = p[1];
     }
@@ -312,14 +294,10 @@ __device__ __forceinline__ void fwd_phase_b(const char* Vs, const LaneOffs& lo, 
       asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(vf[kb & 1][0][0]), "+v"(vf[kb & 1][0][1]), "+v"(vf[kb & 1][1][0]), "+v"(vf[kb & 1][1][1])::"memory");
     else
       asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(vf[kb & 1][0][0]), "+v"(vf[kb & 1][0][1]), "+v"(vf[kb & 1][1][0]), "+v"(vf[kb & 1][1][1])::"memory");
-#if defined(WIN_EXP) && WIN_EXP == 3     // timing experiment (wrong results): no PV MFMAs
-    o[0][0] += (float)vf[kb & 1][0][0][0] + (float)vf[kb & 1][1][1][0] + (float)vf[kb & 1][0][1][0] + (float)vf[kb & 1][1][0][0] + (float)pf[0][0] + (float)pf[1][0];
-#else
 #pragma unroll
     for (int ss = 0; ss < 2; ++ss)
 #pragma unroll
       for (int db = 0; db < 2; ++db) o[db] = MFMA32(vf[kb & 1][ss][db], pf[ss], o[db]);
-#endif
   };
   static_assert(CKB == 4, "four 32-slot blocks per chunk");
   using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
@@ -372,15 +350,9 @@ __device__ __forceinline__ void fwd_phase_b(const char* Vs, const LaneOffs& lo, 
 // vector instructions per piece to a multiply-add + a scalar-base load changed nothing: it is the transfer, not its issue);
 // counters (profiles/r05_attn_win_fwd_pmc.txt): a wave issues 34 % of its cycles, is parked at a wait or the
 // barrier 33 % and is issue-stalled 33 %; the SIMD's vector unit is busy ~53 %, the matrix pipe 21 %.
-#ifndef WIN_Q_CKF_EARLY
 #define WIN_Q_CKF_EARLY 0   // dQ kernel with the table gradient: 1 = the K column fragments of the dQ product are read in front of the block's bucket atomics as well
-#endif
-#ifndef WIN_DMA_LATE
 #define WIN_DMA_LATE 0   // 1: forward: the LDS-DMA of chunk c + 1 is issued between phase A and phase B of chunk c
-#endif
-#ifndef WIN_PRIO
 #define WIN_PRIO 0     // 1: waves 4-7 (the second-dispatched, arbitration-losing half of the workgroup) run at priority 1 (measured: forward 834 vs 812 us, backward unchanged)
-#endif
 #ifdef WIN_STAMP
 // diagnostic build (tools/build_variant_fast.sh ... -DWIN_STAMP): waves 0 and 4 of every workgroup accumulate shader cycles
 // (s_memtime) per section of the chunk loop: [0] DMA wait + barrier + staging issue, [1] phase A, [2] phase B, [3] chunks
@@ -423,9 +395,6 @@ __global__ __launch_bounds__(512) void attn_fwd_win_kernel(
   }
   base0 += 16u * hh;
   const float bcls = table[(long long)(q == 0 ? nrd - 1 : nrd - 2) * H + h];      // bias towards the cls key
-#if WIN_PRIO
-  if (wave >= 4) __builtin_amdgcn_s_setprio(1);
-#endif
   const int nch = (Wh + G::RPC - 1) / G::RPC;
 #ifdef WIN_STAMP
   unsigned long long st_acc[4] = {0, 0, 0, 0};
@@ -455,18 +424,12 @@ __global__ __launch_bounds__(512) void attn_fwd_win_kernel(
       unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0;
       (void)t0; (void)t1; (void)t2; (void)t3;
       WIN_T(t0);
-#if !(defined(WIN_EXP) && WIN_EXP == 4)   // (4: timing experiment, wrong results: no staging, no barrier in the chunk loop)
       ATTN_DMA_WAIT();
       __syncthreads();                         // chunk c landed; chunk c-1 fully consumed
-#if defined(WIN_EXP) && WIN_EXP == 8        // (8: timing experiment, wrong results: barrier kept, but no LDS-DMA in the chunk loop)
-      if (c + 1 < nch && T < 0) {
-#else
       if (c + 1 < nch && !WIN_DMA_LATE) {
-#endif
         stage_chunk_win<WW>(imgs + (cur ^ 1) * 2 * IMG, s0 + D, ldq, c + 1, Wh);
         stage_chunk_win<WW>(imgs + (cur ^ 1) * 2 * IMG + IMG, s0 + 2 * D, ldq, c + 1, Wh);
       }
-#endif
       WIN_T(t1);
       if (active) fwd_phase_a<WW>(Ks, lo, Qf, base, rows_left, c, hh, bcls, s, cmax);
       WIN_T(t2);
@@ -578,9 +541,6 @@ __global__ __launch_bounds__(512) void attn_bwd_kv_win_kernel(
   const float bcls = table[(long long)(key == 0 ? nrd - 1 : nrd - 3) * H + h];       // bias from the cls query
   const float kmask = key < T ? 1.f : 0.f;
   const bool kpad = __builtin_amdgcn_readfirstlane(kbg) * 32 + 32 > T;               // this wave holds keys >= T
-#if WIN_PRIO
-  if (wave >= 4) __builtin_amdgcn_s_setprio(1);
-#endif
   const int nch = (Wh + G::RPC - 1) / G::RPC;
   float vmax = 0.f, dmax = 0.f, nmax = 0.f;
   for (int b = wg_.bz; b < B; b += nbz) {
@@ -797,9 +757,6 @@ __global__ __launch_bounds__(512) void attn_bwd_q_win_kernel(
   float gcls = 0.f;                                          // gradient of the cls-key bucket of this lane's query
   const float qmask = q < T ? 1.f : 0.f;
   const bool qpadw = __builtin_amdgcn_readfirstlane(qb) * 32 + 32 > T;            // this wave holds queries >= T
-#if WIN_PRIO
-  if (wave >= 4) __builtin_amdgcn_s_setprio(1);
-#endif
   const int nch = (Wh + G::RPC - 1) / G::RPC;
   for (int b = wg_.bz; b < B; b += nbz) {
     const long long row = (long long)b * T + qc;

@@ -61,6 +61,10 @@ extern "C" {
 int memhip_abi_version(void) { return MEMHIP_ABI_VERSION; }
 const char* memhip_last_error(void) { return memhip::g_err; }
 const char* memhip_arch(void) { return "gfx950"; }
+#ifndef MEMHIP_BUILD_FLAGS
+#define MEMHIP_BUILD_FLAGS ""
+#endif
+const char* memhip_build_flags(void) { return MEMHIP_BUILD_FLAGS; }
 
 int memhip_stream_reserve_cus(memhip_stream_t stream, int cus) {
   MEMHIP_REQUIRE(cus >= 0, "stream_reserve_cus: negative count");

@@ -158,14 +158,7 @@ __device__ __forceinline__ ef32x2 splat2(float v) { return ef32x2{v, v}; }
 // bias+GELU product, which writes 620 MB per launch: the lines do not linger in L2 as dirty data)
 typedef __attribute__((ext_vector_type(4))) unsigned eu32x4;
 __device__ __forceinline__ void st_stream16(void* base, long long elem_off, unsigned a, unsigned b, unsigned c, unsigned d) {
-#ifdef MEMHIP_EXP_NOSTORE
-  if ((a ^ b ^ c ^ d) != 0x12345677u) return;
-#endif
-#ifdef MEMHIP_EXP_PLAINSTORE
-  *reinterpret_cast<eu32x4*>(reinterpret_cast<__bf16*>(base) + elem_off) = eu32x4{a, b, c, d};
-#else
   __builtin_nontemporal_store(eu32x4{a, b, c, d}, reinterpret_cast<eu32x4*>(reinterpret_cast<__bf16*>(base) + elem_off));
-#endif
 }
 
 // erf(x / sqrt 2) and exp(-x^2 / 2) for two values (A&S 7.1.26, see erf_fast)
@@ -184,9 +177,6 @@ __device__ __forceinline__ void erf_exp2(ef32x2 x, ef32x2& erf, ef32x2& e) {
   erf = ef32x2{copysignf(y.x, z.x), copysignf(y.y, z.y)};
 }
 __device__ __forceinline__ ef32x2 gelu2(ef32x2 x) {
-#ifdef MEMHIP_EXP_NOGELU
-  return x * splat2(0.5f);
-#endif
   ef32x2 erf, e;
   erf_exp2(x, erf, e);
   const ef32x2 hx = x * splat2(0.5f);
@@ -201,9 +191,6 @@ __device__ __forceinline__ void gelu_and_grad2(ef32x2 x, ef32x2& g, ef32x2& dg) 
   dg = fma2(x * splat2(0.39894228040143267794f), e, cdf);
 }
 __device__ __forceinline__ ef32x2 gelu_grad2(ef32x2 x) {
-#ifdef MEMHIP_EXP_NOGELU
-  return x * splat2(0.5f);
-#endif
   ef32x2 erf, e;
   erf_exp2(x, erf, e);
   const ef32x2 cdf = fma2(splat2(0.5f), erf, splat2(0.5f));
@@ -275,10 +262,6 @@ __device__ __attribute__((aligned(256))) unsigned char g_epi_trash[1024];
 template <int EPI, bool BIGROWS = true>
 __device__ __forceinline__ void epi_row_load(const GemmArgs& p, int m, int n, EpiRow<EPI>& r) {
   if constexpr (EPI == MEMHIP_EPI_DGELU || EPI == MEMHIP_EPI_MUL_AUX) {
-#ifdef MEMHIP_EXP_NOLOAD
-    r.h = uint4{0x3f803f80u + (unsigned)m, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u + (unsigned)n};
-    return;
-#endif
     r.h = *reinterpret_cast<const uint4*>(reinterpret_cast<const __bf16*>(p.aux) + (long long)m * p.ldaux + n);
   } else if constexpr (EPI == MEMHIP_EPI_RESIDUAL) {
     // (base pointer and leading dimension are selected as scalars: one address computation per lane)

@@ -36,37 +36,19 @@
 #include "gemm_epilogue.hpp"
 #include <type_traits>
 
-#ifndef P8_EPI_AHEAD
 #define P8_EPI_AHEAD 2
-#endif
-#ifndef P8_REALIGN
 #define P8_REALIGN 1   // 1: all eight waves run a tile's epilogue together (waves 0-3 wait, waves 4-7 re-stagger after it);
                        // 0 (each group enters the epilogue when it is done) measured 8-12 % slower on the K = 768 shapes
-#endif
-#ifndef P8_RESID_NT
 #define P8_RESID_NT 1    // bit 0 = residual-input loads nontemporal (the row is read once here and again only in backward: it need not push
-#endif                   // the operand rows out of L2), bit 1 = residual-output stores nontemporal.  K = 768 projection alone 120-124 us ->
                          // 110-112 (loads) / 105-107 (stores) / 116 (both); in the step 33.58-33.64 -> 33.48-33.58 ms (loads), 33.66-33.75
                          // (stores: the LayerNorm behind it reads the row from HBM) -- profiles/r05_resid_nt_ab.txt
-#ifndef P8_EPI_RESID_LATE
 #define P8_EPI_RESID_LATE 2
-#endif
-#ifndef P8_STAGE_MID
 #define P8_STAGE_MID 0   // 1: a phase's LDS-DMA issue sits between the two halves of its MFMA block instead of in its load
                          // segment (the counted waits then allow that many fewer pieces in flight)
-#endif
 
-#ifndef P8_PRIO_MODE
-#ifndef P8_BAR_MID
 #define P8_BAR_MID 0   // n > 0: 2 n MFMAs of a phase in front of its first barrier (see P8_PHASE; measured: n = 1 neutral, 2 and 4 slower)
-#endif
 #define P8_PRIO_MODE 0   // 0: s_setprio 1 around every MFMA block; 1: none; 2: none + waves 4-7 at priority 1 for the whole kernel
-#endif
-#if P8_PRIO_MODE == 0
 #define P8_PRIO(x) __builtin_amdgcn_s_setprio(x)
-#else
-#define P8_PRIO(x) do { } while (0)
-#endif
 
 #ifdef P8_STAMP
 // diagnostic build (tools/build_variant.sh stamp -DP8_STAMP): wave 0 of every workgroup records s_memtime at the main-loop
@@ -145,11 +127,9 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst) {
                                    (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
 }
 
-#ifndef P8_SADDR
 #define P8_SADDR 1     // 1: operand pieces as global_load_lds with a scalar base + 32-bit lane offset (inline asm) instead of a
                        // 64-bit address per lane (two VALU adds per piece and twice the address traffic): NT GEMMs +0.5-1 %,
                        // weight gradients +2-3 %, step -0.2 ms (tools/exp/r04_run19.sh)
-#endif
 __device__ __forceinline__ void glds16s(const void* sbase, unsigned voff, const void* lds_dst) {
   const unsigned lds = (unsigned)(unsigned long long)((const __attribute__((address_space(3))) char*)lds_dst);
   asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds) : "memory", "m0");
@@ -237,19 +217,7 @@ __device__ __forceinline__ void p8_body(const GemmArgs& p, int ntm, int ntn, int
     tn = rem / rows;
     tm = grp * kGroupM + (rem - tn * rows);
   };
-#ifdef P8_EXP_NODMA
-  int exp_calls = 0;
-#endif
   auto stage = [&](int H, int buf, int tm, int tn, int kt) {
-#ifdef P8_EXP_NODMA      // timing experiment (wrong results): no operand stream at all -- what do reads + MFMAs + barriers take?
-    if (P8_EXP_NODMA + 0 <= 1) return;          // (2: no B half-tiles, 3: no A half-tiles)
-    if (P8_EXP_NODMA + 0 == 2 && (H == HB0 || H == HB1)) return;
-    if (P8_EXP_NODMA + 0 == 3 && (H == HA0 || H == HA1)) return;
-    if (P8_EXP_NODMA + 0 == 4 && exp_calls++ >= 8) return;   // (4: the first two K-tiles are staged -- both buffers hold real data -- then the stream stops)
-#endif
-#ifdef P8_EXP_L2HOT      // timing experiment (wrong results): every piece comes from the first tile's first two K-tiles (L2-hot):
-    { int z_; asm volatile("s_mov_b32 %0, 0" : "=s"(z_)); tm = z_; tn = z_; kt &= 1; }   // the issue cost of the stream without its memory latency
-#endif
     if (H == HA0 || H == HA1) {
       char* slot = smem + buf * kBuf + (H == HA1 ? kAHalf : 0) + wave * AP * 1024;
       const int r0 = tm * BMT + (H == HA1 ? BMT / 2 : 0);
@@ -297,9 +265,6 @@ __device__ __forceinline__ void p8_body(const GemmArgs& p, int ntm, int ntn, int
   P8_WAIT_VM(G::kWaitA);
   P8_BARRIER();
   if (wr == 1) P8_BARRIER();                            // waves 4-7 run half a phase behind
-#if P8_PRIO_MODE == 2
-  if (wr == 1) __builtin_amdgcn_s_setprio(1);
-#endif
 
   // ---- fragment read addresses: row = 16*x + (lane & 15), chunk = 4*kh + (lane >> 4)
   const int sw = (lane >> 1) & 7;
@@ -309,18 +274,6 @@ __device__ __forceinline__ void p8_body(const GemmArgs& p, int ntm, int ntn, int
   const int roffb = (((bi >> 2) * 8 + (bi & 3)) * 128) + (((lane >> 4) ^ key_b((bi >> 2) * 8 + (bi & 3))) << 4);
   const char* rdB[2] = {smem + G::kBOff + wc * 4096 + roffb, smem + G::kBOff + wc * 4096 + (roffb ^ 64)};
 
-#ifdef P8_EXP_MFMA32
-  // timing experiment (WRONG results: the fragments are read for the 16x16x32 layout): the main loop on
-  // v_mfma_f32_32x32x16_bf16 -- half the MFMA issues and half the operand-register reads per FLOP, same LDS reads
-  f32x16 acc32[4][MF / 2];
-#pragma unroll
-  for (int q = 0; q < 4; ++q)
-#pragma unroll
-    for (int i = 0; i < MF / 2; ++i)
-#pragma unroll
-      for (int j = 0; j < 16; ++j) acc32[q][i][j] = 0.f;
-#define ACC_EL(q, mf, nf, r) acc32[q][(mf) >> 1][((((mf) & 1) * 2 + (nf)) << 2) + (r)]
-#else
   f32x4 acc[4][MF][2];
 #pragma unroll
   for (int q = 0; q < 4; ++q)
@@ -329,20 +282,9 @@ __device__ __forceinline__ void p8_body(const GemmArgs& p, int ntm, int ntn, int
 #pragma unroll
       for (int j = 0; j < 2; ++j) acc[q][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 #define ACC_EL(q, mf, nf, r) acc[q][mf][nf][r]
-#endif
 
   int c_tile = first, c_k = 0;
   bf16x8 a[MF][2], bx[2][2], by[2][2];
-#ifdef P8_EXP_NOREAD
-#pragma unroll
-  for (int mf = 0; mf < MF; ++mf)
-#pragma unroll
-    for (int kh = 0; kh < 2; ++kh) asm volatile("" : "=v"(a[mf][kh]));
-#pragma unroll
-  for (int nf = 0; nf < 2; ++nf)
-#pragma unroll
-    for (int kh = 0; kh < 2; ++kh) { asm volatile("" : "=v"(bx[nf][kh])); asm volatile("" : "=v"(by[nf][kh])); }
-#endif
 
 #define P8_READ_A(half)                                                                                   \
   _Pragma("unroll") for (int mf = 0; mf < MF; ++mf) _Pragma("unroll") for (int kh = 0; kh < 2; ++kh)      \
@@ -351,25 +293,11 @@ __device__ __forceinline__ void p8_body(const GemmArgs& p, int ntm, int ntn, int
   _Pragma("unroll") for (int nf = 0; nf < 2; ++nf) _Pragma("unroll") for (int kh = 0; kh < 2; ++kh)       \
       dst[nf][kh] = *reinterpret_cast<const bf16x8*>(rdB[kh] + (boff) + (half) * kHalf + nf * 512)
 // P8_EXP_NOREAD = 1: no fragment reads at all, 2: A fragments are not read, 3: B fragments are not read
-#if defined(P8_EXP_NOREAD) && P8_EXP_NOREAD + 0 == 2
-#define P8_NR_A(h) (void)0
-#define P8_NR_B(d, o, h) P8_READ_B(d, o, h)
-#elif defined(P8_EXP_NOREAD) && P8_EXP_NOREAD + 0 == 3
-#define P8_NR_A(h) P8_READ_A(h)
-#define P8_NR_B(d, o, h) (void)0
-#else
 #define P8_NR_A(h) (void)0
 #define P8_NR_B(d, o, h) (void)0
-#endif
-#ifdef P8_EXP_MFMA32
-#define P8_MFMA_HALF(q, bsrc, kh)                                                                         \
-  _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int mb = 0; mb < MF / 2; ++mb)  \
-      acc32[q][mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bsrc[ks][kh], a[2 * mb + ks][kh], acc32[q][mb], 0, 0, 0)
-#else
 #define P8_MFMA_HALF(q, bsrc, kh)                                                                         \
   _Pragma("unroll") for (int mf = 0; mf < MF; ++mf) _Pragma("unroll") for (int nf = 0; nf < 2; ++nf)      \
       acc[q][mf][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bsrc[nf][kh], a[mf][kh], acc[q][mf][nf], 0, 0, 0)
-#endif
 #define P8_MFMA_PART(q, bsrc, kh, m0, m1)                                                                 \
   _Pragma("unroll") for (int mf = (m0); mf < (m1) && mf < MF; ++mf) _Pragma("unroll") for (int nf = 0; nf < 2; ++nf) \
       acc[q][mf][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bsrc[nf][kh], a[mf][kh], acc[q][mf][nf], 0, 0, 0)
@@ -394,30 +322,6 @@ __device__ __forceinline__ void p8_body(const GemmArgs& p, int ntm, int ntn, int
 // One K-tile = four phases.  B0 of this K-tile is already in `bq0` (read during phase 4 of the
 // previous K-tile); phase 4 reads B0 of the next K-tile into `bq1`, so the two register sets swap
 // roles from one K-tile to the next and the phases read 8 / 4 / 8 / 4 fragments.
-#if P8_STAGE_MID
-#define P8_PHASE(READS, STAGE_CALL, WAITN, PIECES, q, bsrc)                                               \
-    READS;                                                                                                \
-    __builtin_amdgcn_sched_barrier(0);                                                                    \
-    P8_WAIT_VM((WAITN) - (PIECES));                                                                       \
-    P8_BARRIER();                                                                                         \
-    P8_MFMA_STAGE(q, bsrc, STAGE_CALL);                                                                   \
-    P8_BARRIER();
-#elif P8_BAR_MID
-// the phase's first barrier sits in the MIDDLE of its MFMA block: the wave that arrives at a barrier from its load segment
-// still has MFMAs in the pipe, and the wave that leaves it for the second half of its block has its operands in registers
-#define P8_PHASE(READS, STAGE_CALL, WAITN, PIECES, q, bsrc)                                               \
-    READS;                                                                                                \
-    __builtin_amdgcn_sched_barrier(0);                                                                    \
-    STAGE_CALL;                                                                                           \
-    P8_WAIT_VM(WAITN);                                                                                    \
-    P8_PRIO(1);                                                                                           \
-    P8_MFMA_PART(q, bsrc, 0, 0, P8_BAR_MID);                                                              \
-    P8_BARRIER();                                                                                         \
-    P8_MFMA_PART(q, bsrc, 0, P8_BAR_MID, MF);                                                             \
-    P8_MFMA_HALF(q, bsrc, 1);                                                                             \
-    P8_PRIO(0);                                                                                           \
-    P8_BARRIER();
-#else
 #define P8_PHASE(READS, STAGE_CALL, WAITN, PIECES, q, bsrc)                                               \
     READS;                                                                                                \
     __builtin_amdgcn_sched_barrier(0);                                                                    \
@@ -426,43 +330,8 @@ __device__ __forceinline__ void p8_body(const GemmArgs& p, int ntm, int ntn, int
     P8_BARRIER();                                                                                         \
     P8_MFMA(q, bsrc);                                                                                     \
     P8_BARRIER();
-#endif
 // X1..X4: vector-memory instructions besides the half-tile stream that the phase's wait must leave in flight as well
 // (the epilogue-operand prefetch, one LDS-DMA per wave and loop iteration: see `prefetch_aux`)
-#ifdef P8_EXP_HALFN
-// timing experiment (wrong results): the main loop of a 256 x 128 tile inside this kernel's skeleton -- the two quadrants of
-// B1 are not computed and B1 is not read from LDS (its DMA, the barriers and the waits of those phases stay): per K-tile
-// 8 + 8 + 4 fragment reads for 32 MFMAs, i.e. the LDS-read / MFMA mix a parked-accumulator 256 x 128 kernel would have,
-// with twice its barriers and 4/3 of its operand traffic.  How far above half the full K-tile time does it run?
-#define P8_PHASE_NOMMA(READS, STAGE_CALL, WAITN)                                                          \
-    READS;                                                                                                \
-    __builtin_amdgcn_sched_barrier(0);                                                                    \
-    STAGE_CALL;                                                                                           \
-    P8_WAIT_VM(WAITN);                                                                                    \
-    P8_BARRIER();                                                                                         \
-    P8_BARRIER();
-#define P8_KTILE(bq0, bq1, X1, X2, X3, X4)                                                                \
-  do {                                                                                                    \
-    const int bo = bc * kBuf;                                                                             \
-    (void)bo;                                                                                             \
-    P8_PHASE(P8_READ_A(0), stage(HA1, bc ^ 1, tm1, tn1, k1), G::kWaitB + (X1), AP, 0, bq0)                \
-    P8_PHASE_NOMMA((void)0, stage(HB0, bc, tm2, tn2, k2), G::kWaitA + (X2))                               \
-    P8_PHASE_NOMMA(P8_READ_A(1), stage(HA0, bc, tm2, tn2, k2), G::kWaitB + (X3))                          \
-    P8_PHASE(P8_READ_B(bq1, (bc ^ 1) * kBuf, 0), stage(HB1, bc, tm2, tn2, k2), G::kWaitA + (X4), 2, 2, bq0) \
-  } while (0)
-#elif defined(P8_EXP_NOREAD)
-// timing experiment (wrong results): the operand stream and the MFMAs as shipped, no fragment reads in the main loop (the
-// registers keep what the prologue read): how much of the loop is the LDS array shared between ds_read and LDS-DMA writes?
-#define P8_KTILE(bq0, bq1, X1, X2, X3, X4)                                                                \
-  do {                                                                                                    \
-    const int bo = bc * kBuf;                                                                             \
-    (void)bo;                                                                                             \
-    P8_PHASE(P8_NR_A(0), stage(HA1, bc ^ 1, tm1, tn1, k1), G::kWaitB + (X1), AP, 0, bq0)                  \
-    P8_PHASE(P8_NR_B(bq1, bo, 1), stage(HB0, bc, tm2, tn2, k2), G::kWaitA + (X2), 2, 1, bq1)              \
-    P8_PHASE(P8_NR_A(1), stage(HA0, bc, tm2, tn2, k2), G::kWaitB + (X3), AP, 3, bq1)                      \
-    P8_PHASE(P8_NR_B(bq1, (bc ^ 1) * kBuf, 0), stage(HB1, bc, tm2, tn2, k2), G::kWaitA + (X4), 2, 2, bq0) \
-  } while (0)
-#else
 #define P8_KTILE(bq0, bq1, X1, X2, X3, X4)                                                                \
   do {                                                                                                    \
     const int bo = bc * kBuf;                                                                             \
@@ -475,7 +344,6 @@ __device__ __forceinline__ void p8_body(const GemmArgs& p, int ntm, int ntn, int
     /* phase 4: quadrant (A1, B0); B0 of the next K-tile comes from the other buffer */                   \
     P8_PHASE(P8_READ_B(bq1, (bc ^ 1) * kBuf, 0), stage(HB1, bc, tm2, tn2, k2), G::kWaitA + (X4), 2, 2, bq0) \
   } while (0)
-#endif
 #define P8_READ_B0_FIRST() P8_READ_B(bx, 0, 0)
 
   // ---- one extra LDS-DMA per wave and loop iteration (two K-tiles), always issued, so that the counted waits stay
@@ -617,18 +485,10 @@ __device__ __forceinline__ void p8_body(const GemmArgs& p, int ntm, int ntn, int
       // a CU has 32 KB outstanding, i.e. ~20 GB/s per CU at ~1.5 us latency -- the epilogue was latency
       // bound, not HBM bound.  Row indices are clamped instead of branched, so that nothing orders the loads.
       // (the residual epilogue carries 8 registers per row: no room for a second batch beside 128 accumulators)
-#ifdef P8_RESID_AHEAD
-      constexpr int kAhead = (EPI == MEMHIP_EPI_RESIDUAL || EPI == MEMHIP_EPI_PATCH_EMBED) ? P8_RESID_AHEAD : kEpiAhead;
-#else
       constexpr int kAhead = (EPI == MEMHIP_EPI_RESIDUAL || EPI == MEMHIP_EPI_PATCH_EMBED) ? 0 : kEpiAhead;
-#endif
       // residual epilogue: batch 0 alone; batches 1 and 2 go out together once batch 0 has released its
       // accumulators and row registers (the accumulators are re-zeroed after the loop, not inside it)
-#ifdef P8_RESID_AHEAD
-      constexpr bool kLate = false;
-#else
       constexpr bool kLate = (EPI == MEMHIP_EPI_RESIDUAL || EPI == MEMHIP_EPI_PATCH_EMBED) && P8_EPI_RESID_LATE;
-#endif
       // The row guard (m < M) is a per-lane branch: a basic block per row, and at every block entry hipcc's waitcnt pass
       // falls back to s_waitcnt vmcnt(0) in front of the first use of a loaded row -- which also waits for the STORE of
       // the previous row (one store round trip per row, 16 per tile: the GELU' epilogue spent 22 us per tile that way).
@@ -641,9 +501,7 @@ __device__ __forceinline__ void p8_body(const GemmArgs& p, int ntm, int ntn, int
         // lane state of the prefetch stream: the generic form (batches of 4 rows) could keep a single batch of row loads in
         // flight, and spilled.  Here the 16 rows of a lane go one by one with the loads of the next kResidAhead rows in
         // flight (48 registers), in one basic block (counted waits, no store is ever waited for).
-#ifndef P8_RESID_ROWS_AHEAD
 #define P8_RESID_ROWS_AHEAD 2     // rows of residual loads in flight ahead of the row being computed.  3 / 4 measured (round 5): 14 / 21
-#endif                            // spilled registers, K = 768 projection 120 -> 127 / 131-134 us, fc2 248 -> 269-272 / 270 us
         // The row loads are inline asm with HAND-COUNTED waits: left to hipcc this block's schedule is a matter of luck
         // (with the loads visible to it, one build ran the load-independent arithmetic of all rows first and consumed
         // each row's loads right after issuing them; another spilled and waited with vmcnt(0) per row).  hipcc never
@@ -691,13 +549,8 @@ __device__ __forceinline__ void p8_body(const GemmArgs& p, int ntm, int ntn, int
           const float* srcP = xbase + (long long)rrP[slot] * xld + row_nP(r);
           const float* srcQ = xbase + (long long)rrQ[slot] * xld + row_nP(r);
           const float* rsrc = rmb + (p.rowmask ? sample_of(row_m(r) + p.m_base) : 0);
-#if P8_RESID_NT & 1
           asm volatile("global_load_dwordx4 %0, %3, off nt\n\tglobal_load_dwordx4 %1, %4, off nt\n\tglobal_load_dword %2, %5, off"
                        : "=&v"(xa[slot]), "=&v"(xb[slot]), "=&v"(rmv[slot]) : "v"(srcP), "v"(srcQ), "v"(rsrc) : "memory");
-#else
-          asm volatile("global_load_dwordx4 %0, %3, off\n\tglobal_load_dwordx4 %1, %4, off\n\tglobal_load_dword %2, %5, off"
-                       : "=&v"(xa[slot]), "=&v"(xb[slot]), "=&v"(rmv[slot]) : "v"(srcP), "v"(srcQ), "v"(rsrc) : "memory");
-#endif
         };
 #pragma unroll
         for (int r = 0; r < kResidAhead; ++r) issue_row(r, r);
@@ -731,14 +584,8 @@ __device__ __forceinline__ void p8_body(const GemmArgs& p, int ntm, int ntn, int
           pq_pack(o, o + 4, hi, P, Q);
           float* dP = p.resid + (long long)rrP[slot] * p.ldr + row_nP(r);
           float* dQ = p.resid + (long long)rrQ[slot] * p.ldr + row_nP(r);
-#if P8_RESID_NT & 2
-          typedef __attribute__((ext_vector_type(4))) float nt_f4;
-          __builtin_nontemporal_store(nt_f4{__uint_as_float(P[0]), __uint_as_float(P[1]), __uint_as_float(P[2]), __uint_as_float(P[3])}, reinterpret_cast<nt_f4*>(dP));
-          __builtin_nontemporal_store(nt_f4{__uint_as_float(Q[0]), __uint_as_float(Q[1]), __uint_as_float(Q[2]), __uint_as_float(Q[3])}, reinterpret_cast<nt_f4*>(dQ));
-#else
           *reinterpret_cast<float4*>(dP) = float4{__uint_as_float(P[0]), __uint_as_float(P[1]), __uint_as_float(P[2]), __uint_as_float(P[3])};
           *reinterpret_cast<float4*>(dQ) = float4{__uint_as_float(Q[0]), __uint_as_float(Q[1]), __uint_as_float(Q[2]), __uint_as_float(Q[3])};
-#endif
         };
         // vector-memory operations issued behind L(r) when row r is consumed: the loads of the rows r + 1 .. r + kResidAhead
         // that exist (3 each) and the stores of the rows max(0, r - kResidAhead) .. r - 1 (kStores each)
@@ -1013,9 +860,6 @@ int gemm_p8_split_rows(const GemmArgs& p, hipStream_t s) {
 int gemm_p8_half_dispatch(const GemmArgs& p, hipStream_t s);
 int gemm_p8_dispatch(const GemmArgs& p, hipStream_t s) {
   if (!p8_fits(p) || p.M % BM != 0) return MEMHIP_EUNSUPPORTED;   // whole 256-row tiles only (no row guard in the epilogue)
-#ifdef P8_FORCE_HALF      // measurement build: every row on the 128-row form of the kernel
-  { const int rc = gemm_p8_half_dispatch(p, s); if (rc != MEMHIP_EUNSUPPORTED) return rc; }
-#endif
   const int num_cu = p8_num_cu(s);
   if (!num_cu) return MEMHIP_EUNSUPPORTED;
   switch (p.epilogue) {

@@ -16,15 +16,9 @@
 // both are staged through the idle ring.
 #include "common.h"
 
-#ifndef P8_PRIO_MODE
 #define P8_PRIO_MODE 0   // 0: s_setprio 1 around every MFMA block; 1: none; 2: none + waves 4-7 at priority 1 for the whole kernel
-#endif                   // (this kernel alone: 1 and 2 measured +2.5 % (964 -> 990, 1099 -> 1117 TFLOP/s); inside the step, beside the
                          // dgrad kernels of the other stream, no difference: 38.28 vs 38.35 ms.  gemm_p8.hip: no difference either way)
-#if P8_PRIO_MODE == 0
 #define P8_PRIO(x) __builtin_amdgcn_s_setprio(x)
-#else
-#define P8_PRIO(x) do { } while (0)
-#endif
 
 namespace {
 
@@ -51,11 +45,9 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
                                    (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
 }
-#ifndef P8_SADDR
 #define P8_SADDR 1     // 1: operand pieces as global_load_lds with a scalar base + 32-bit lane offset (inline asm) instead of a
                        // 64-bit address per lane (two VALU adds per piece and twice the address traffic): NT GEMMs +0.5-1 %,
                        // weight gradients +2-3 %, step -0.2 ms (tools/exp/r04_run19.sh)
-#endif
 __device__ __forceinline__ void glds16s(const void* sbase, unsigned voff, const void* lds_dst) {
   const unsigned lds = (unsigned)(unsigned long long)((const __attribute__((address_space(3))) char*)lds_dst);
   asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds) : "memory", "m0");
@@ -156,9 +148,6 @@ __device__ __forceinline__ void tn_p8_body(const __bf16* __restrict__ A, long lo
   TP_WAIT_VM();
   TP_BARRIER();
   if (wr == 1) TP_BARRIER();                                // waves 4-7 run half a phase behind
-#if P8_PRIO_MODE == 2
-  if (wr == 1) __builtin_amdgcn_s_setprio(1);
-#endif
 
   // ---- transposing fragment reads: this lane addresses 4 columns (p) of token row 4g+q (+16)
   const int g4 = lane >> 4, q4 = (lane >> 2) & 3, pp = lane & 3;
@@ -170,17 +159,6 @@ __device__ __forceinline__ void tn_p8_body(const __bf16* __restrict__ A, long lo
 #pragma unroll
   for (int f = 0; f < 2; ++f) boff[f] = lds0 + 2 * kHalf + row0 * 256 + (((wc * 2 + f) ^ r7) << 5) + pp * 8;
 
-#ifdef P8_EXP_MFMA32
-  // timing experiment (WRONG results): the main loop on v_mfma_f32_32x32x16_bf16 (see gemm_p8.hip)
-  f32x16 acc32[4][2];
-#pragma unroll
-  for (int q = 0; q < 4; ++q)
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < 16; ++j) acc32[q][i][j] = 0.f;
-#define TP_ACC_EL(q, nf, kf, r) acc32[q][(nf) >> 1][((((nf) & 1) * 2 + (kf)) << 2) + (r)]
-#else
   f32x4 acc[4][4][2];
 #pragma unroll
   for (int q = 0; q < 4; ++q)
@@ -189,7 +167,6 @@ __device__ __forceinline__ void tn_p8_body(const __bf16* __restrict__ A, long lo
 #pragma unroll
       for (int j = 0; j < 2; ++j) acc[q][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 #define TP_ACC_EL(q, nf, kf, r) acc[q][nf][kf][r]
-#endif
   bf16x8 a[4][2], bx[2][2], by[2][2];
 
 #define TP_READ_A(half)                                                                                   \
@@ -202,17 +179,10 @@ __device__ __forceinline__ void tn_p8_body(const __bf16* __restrict__ A, long lo
     dst[kf][0] = tr_pair<(half) * kHalf>(boff[kf] + (boff_));                                             \
     dst[kf][1] = tr_pair<(half) * kHalf + 8192>(boff[kf] + (boff_));                                      \
   }
-#ifdef P8_EXP_MFMA32
-#define TP_MFMA_BODY(q, bsrc)                                                                             \
-    _Pragma("unroll") for (int rh = 0; rh < 2; ++rh) _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)     \
-        _Pragma("unroll") for (int nb = 0; nb < 2; ++nb) acc32[q][nb] =                                   \
-            __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2 * nb + ks][rh], bsrc[ks][rh], acc32[q][nb], 0, 0, 0)
-#else
 #define TP_MFMA_BODY(q, bsrc)                                                                             \
     _Pragma("unroll") for (int rh = 0; rh < 2; ++rh) _Pragma("unroll") for (int nf = 0; nf < 4; ++nf)     \
         _Pragma("unroll") for (int kf = 0; kf < 2; ++kf) acc[q][nf][kf] =                                 \
             __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[nf][rh], bsrc[kf][rh], acc[q][nf][kf], 0, 0, 0)
-#endif
 #define TP_MFMA(q, bsrc)                                                                                  \
   do {                                                                                                    \
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   /* the asm reads are not tracked by the compiler */ \
@@ -289,21 +259,6 @@ __device__ __forceinline__ void tn_p8_body(const __bf16* __restrict__ A, long lo
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the idle tail of the prefetch stream has landed
   TP_BARRIER();                                            // every wave is done with the ring
 
-#ifdef TN_EXP_NOSTORE     // timing experiment (wrong results): the partial tile is neither staged nor stored -- what the slab write-out costs
-  {
-    float t = 0.f;                                    // (every accumulator stays live: 128 adds instead of the write-out)
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-#pragma unroll
-      for (int nf = 0; nf < 4; ++nf)
-#pragma unroll
-        for (int kf = 0; kf < 2; ++kf)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) t += TP_ACC_EL(q, nf, kf, r);
-    if (t == 12345.678f) out[0] = t;
-  }
-  return;
-#endif
   // ---- epilogue: fp32 atomics.  C layout of a 16x16 tile: col (k) = lane & 15, row (n) =
   // 4 * (lane >> 4) + reg.  A pass moves 16 n-rows x 64 k (the wave's 32 columns in each B half)
   // through this wave's 4 KiB, then adds row by row: one wave-instruction = two 128-byte runs.

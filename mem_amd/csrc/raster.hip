@@ -8,9 +8,6 @@
 
 static_assert(sizeof(memhip_event_aug_t) == 56, "memhip_event_aug_t ABI layout");
 
-#ifndef RASTER_EXP
-#define RASTER_EXP 0      // timing experiments (tools/build_variant.sh); 0 = the shipped kernels
-#endif
 
 namespace {
 
@@ -38,18 +35,9 @@ struct Ev { double x, y, t, p; long long pos; bool keep; };
 // the first event is looked at -- inside the per-event branches (out of range, filtered, bad index) hipcc waits for
 // every load right where it is issued, i.e. one event's 32 bytes in flight per thread)
 struct RawEv { double2 xy, tp; };
-#ifndef RASTER_NT
 #define RASTER_NT 0
-#endif
 __device__ __forceinline__ RawEv load_raw(const double* __restrict__ ev, long long row) {
-#if RASTER_NT   // read-once stream: nontemporal loads (A/B: tools/build_variant.sh raster_nt -DRASTER_NT=1)
-  typedef double __attribute__((ext_vector_type(2))) d2;
-  const d2 a = __builtin_nontemporal_load(reinterpret_cast<const d2*>(ev) + 2 * row);
-  const d2 b = __builtin_nontemporal_load(reinterpret_cast<const d2*>(ev) + 2 * row + 1);
-  return RawEv{double2{a[0], a[1]}, double2{b[0], b[1]}};
-#else
   return RawEv{reinterpret_cast<const double2*>(ev)[2 * row], reinterpret_cast<const double2*>(ev)[2 * row + 1]};
-#endif
 }
 // The sample's augmentation as wave-uniform float64 constants (neutral when there is none: x * 1.0 and x + 0.0 are exact,
 // the sign of a zero does not survive the truncation to a pixel index): the per-event arithmetic is branch-free and
@@ -346,12 +334,6 @@ __global__ __launch_bounds__(kBinThreads) void raster_bin_keys(
       const long long i = c * kBinChunk + (long long)k * kBinThreads + tid;
       raw[k] = load_raw(ev, beg + (i < n ? i : n - 1));          // (n > 0: nchunks > 0)
     }
-#if RASTER_EXP == 2       // timing experiment: the loads alone
-#pragma unroll
-    for (int k = 0; k < kBinEvPerThread; ++k) bad += (raw[k].xy.x == 12345.5) + (raw[k].tp.y == 12345.5);
-    if (tid <= nb) hdr[(hbase + c) * (kBinMaxBands + 1) + tid] = 0u;      // empty segments for pass 2
-    continue;
-#endif
 #pragma unroll
     for (int k = 0; k < kBinEvPerThread; ++k) {
       const long long i = c * kBinChunk + (long long)k * kBinThreads + tid;
@@ -371,20 +353,8 @@ __global__ __launch_bounds__(kBinThreads) void raster_bin_keys(
       const unsigned int f32 = (unsigned int)flat;          // 0 <= flat < H * W <= 64 * 32764
       const unsigned int band = udiv_apply(f32, band_div);
       key[k] = (f32 - band * (unsigned int)band_px) | (isneg ? 0x8000u : 0u);
-#if RASTER_EXP == 1      // timing experiment: no band atomics (wrong segment positions)
-      where[k] = (band << 16) | (unsigned)((k * kBinThreads + tid) & 0x1FF);
-      if (key[k] == 0x12345u) atomicAdd(&cnt[band], 1u);
-#else
       where[k] = (band << 16) | atomicAdd(&cnt[band], 1u);   // slot inside the band's segment
-#endif
     }
-#if RASTER_EXP == 3       // timing experiment: loads + keys + band atomics, no sort / write-out
-#pragma unroll
-    for (int k = 0; k < kBinEvPerThread; ++k) bad += (key[k] == 0x7654321u) + (where[k] == 0x7654321u);
-    if (tid <= nb) hdr[(hbase + c) * (kBinMaxBands + 1) + tid] = 0u;      // empty segments for pass 2
-    __syncthreads();
-    continue;
-#endif
     __syncthreads();
     if (tid < 64) {                          // exclusive scan of <= 64 band counts (rounded up to 8) in one wave
       const unsigned int v = tid < nb ? ((cnt[tid] + 7u) & ~7u) : 0u;

@@ -1,5 +1,5 @@
 """Per-section cycle totals of the fused attention backward (a -DATTN16_TIMING build: tools/build_variant.sh timing
--DATTN16_TIMING; run with MEMHIP_LIB=mem_amd/exp/timing.so)."""
+-DATTN16_TIMING; run with MEMHIP_LIB=variants/timing.so)."""
 import ctypes, os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mem_amd import ops, _lib

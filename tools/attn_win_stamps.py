@@ -1,4 +1,4 @@
-"""Section cycles of the forward window-attention kernel (stamp build: MEMHIP_LIB=mem_amd/exp/winstamp.so)."""
+"""Section cycles of the forward window-attention kernel (stamp build: MEMHIP_LIB=variants/winstamp.so)."""
 import ctypes as C, os, sys, numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mem_amd import ops, _lib

@@ -1,15 +1,12 @@
 #!/bin/bash
-# tools/build_variant.sh <name> <extra hipcc flags...>: an A/B build of libmemhip.so into mem_amd/exp/<name>.so
-# (select it with MEMHIP_LIB=mem_amd/exp/<name>.so); objects under mem_amd/csrc/_build_<name>/
+# tools/build_variant.sh <name> <extra hipcc flags...>: a measurement build of libmemhip.so -> variants/<name>.so (select it with
+# MEMHIP_LIB=variants/<name>.so; bench.py prints the path and the flags of the library it measured and refuses the headline for
+# anything but the shipped build).  Objects under variants/_obj_<name>/ (not shipped to the GPU box: .gpurunignore).  variants/ is
+# git-ignored: delete it when the measurement is done.  Experiments whose switches are no longer in the sources are patches under
+# tools/exp/ (r05_lab_switches.patch restores every round-5 switch): apply, build, revert.
 set -e
 name=$1; shift
-cd "$(dirname "$0")/../mem_amd/csrc"
-mkdir -p _build_$name ../exp
-for f in core.cpp mask.cpp *.hip; do
-  extra=""; case $f in augment.hip|raster.hip|event_norm.hip|records.hip) extra="-ffp-contract=off";; esac
-  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function -fno-fast-math $extra "$@" -c $f -o _build_$name/$f.o &
-  while [ $(jobs -r | wc -l) -ge 8 ]; do sleep 0.2; done
-done
-wait
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../exp/$name.so _build_$name/*.o
-echo built ../exp/$name.so
+root="$(cd "$(dirname "$0")/.." && pwd)"
+mkdir -p "$root/variants"
+make -C "$root/mem_amd/csrc" -j8 BUILD="$root/variants/_obj_$name" OUT="$root/variants/$name.so" EXTRA="$*" 2>&1 | grep -E "error|Error|built|rror:" || true
+ls -la "$root/variants/$name.so"

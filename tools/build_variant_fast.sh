@@ -1,22 +1,15 @@
 #!/bin/bash
 # tools/build_variant_fast.sh <name> "<file1.hip file2.hip ...>" <extra hipcc flags...>: like build_variant.sh, but only the named
-# sources are recompiled with the extra flags; every other object is taken from the shipped build (mem_amd/csrc/_build, made
-# current by `make` first).  Output: mem_amd/exp/<name>.so (select with MEMHIP_LIB=mem_amd/exp/<name>.so).
+# sources (and core.cpp, which records the flags) are compiled with the extra flags; every other object is a copy of the shipped
+# build's (mem_amd/csrc/_build, made current by `make` first).  Output: variants/<name>.so.
 set -e
 name=$1; files=$2; shift 2
-cd "$(dirname "$0")/../mem_amd/csrc"
-mkdir -p _build_$name ../exp
-objs=""
-for o in _build/*.o; do
-  b=$(basename $o .o); skip=0
-  for f in $files; do [ "$b" = "$f" ] && skip=1; done
-  [ $skip = 0 ] && objs="$objs $o"
-done
-for f in $files; do
-  extra=""; case $f in augment.hip|raster.hip|event_norm.hip|records.hip) extra="-ffp-contract=off";; esac
-  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function -fno-fast-math -w $extra "$@" -c $f -o _build_$name/$f.o &
-done
-wait
-for f in $files; do objs="$objs _build_$name/$f.o"; done
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../exp/$name.so $objs
-echo built ../exp/$name.so
+root="$(cd "$(dirname "$0")/.." && pwd)"
+make -C "$root/mem_amd/csrc" -j8 > /dev/null 2>&1
+obj="$root/variants/_obj_$name"
+mkdir -p "$obj"
+cp -p "$root"/mem_amd/csrc/_build/*.o "$obj/"
+for f in $files core.cpp; do rm -f "$obj/$f.o"; done
+# objects copied with their time stamps are newer than every source: make rebuilds exactly the deleted ones
+make -C "$root/mem_amd/csrc" -j8 BUILD="$obj" OUT="$root/variants/$name.so" EXTRA="$*" 2>&1 | grep -E "error|rror:" || true
+ls -la "$root/variants/$name.so"

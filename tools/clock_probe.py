@@ -1,5 +1,5 @@
 """In-kernel shader clock of gemm_p8 / gemm_tn_p8 (MI355X_MICROARCH.md, DVFS give-back item 6): a -DP8_STAMP build
-(tools/build_variant.sh stamp -DP8_STAMP; MEMHIP_LIB=mem_amd/exp/stamp.so) stamps s_memtime (shader cycles) and s_memrealtime
+(tools/build_variant.sh stamp -DP8_STAMP; MEMHIP_LIB=variants/stamp.so) stamps s_memtime (shader cycles) and s_memrealtime
 (constant 100 MHz) around the main loops; after >= 2 s of back-to-back launches on random data the quotient
 d(s_memtime) / d(s_memrealtime) x 100 MHz is the clock the chip holds under that load.  Writes gpurun_out/r04_clock.json."""
 import ctypes as C, json, os, sys, time, numpy as np, torch

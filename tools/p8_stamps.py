@@ -1,4 +1,4 @@
-"""Per-tile timeline of gemm_p8 (diagnostic build: tools/build_variant.sh stamp -DP8_STAMP; MEMHIP_LIB=mem_amd/exp/stamp.so):
+"""Per-tile timeline of gemm_p8 (diagnostic build: tools/build_variant.sh stamp -DP8_STAMP; MEMHIP_LIB=variants/stamp.so):
 main-loop and epilogue cycles of each workgroup's first tiles, per epilogue kind."""
 import ctypes as C, os, sys, numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

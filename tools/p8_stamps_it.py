@@ -1,4 +1,4 @@
-"""Per-ITERATION timeline of gemm_p8 (diagnostic build: tools/build_variant.sh stampit -DP8_STAMP=2; MEMHIP_LIB=mem_amd/exp/stampit.so):
+"""Per-ITERATION timeline of gemm_p8 (diagnostic build: tools/build_variant.sh stampit -DP8_STAMP=2; MEMHIP_LIB=variants/stampit.so):
 cycles between consecutive loop iterations (two K-tiles each) of a workgroup; the first iteration of a tile contains the previous
 tile's epilogue."""
 import ctypes as C, os, sys, numpy as np, torch

@@ -52,5 +52,5 @@ tools/prof_pmc_raster.sh r05fin_raster > /dev/null 2>&1
 # ---- attention kernels alone, GEMM clock
 python tools/attn16_time.py 2>&1 | tail -2 > gpurun_out/r05fin_attn16.txt
 WIN_MODES=0,1 python tools/attn_win_check.py all time 2>&1 | grep "^mode" > gpurun_out/r05fin_attn_win.txt
-MEMHIP_CLOCK_OUT=gpurun_out/r05fin_clock.json MEMHIP_LIB=mem_amd/exp/stamp.so python tools/clock_probe.py > gpurun_out/r05fin_clock.log 2>&1
+MEMHIP_CLOCK_OUT=gpurun_out/r05fin_clock.json MEMHIP_LIB=variants/stamp.so python tools/clock_probe.py > gpurun_out/r05fin_clock.log 2>&1
 ls -la gpurun_out | grep r05fin
