@@ -49,7 +49,7 @@ def run(B, H, win, seed=0, time_it=False, ref64=False):
             print(msg, flush=True)
     names = ("out", "lse", "dqkv", "dtable", "dq_bias")
     for mode in MODES[1:]:
-        for n, a, b in list(zip(names, res[0], res[mode]))[: (5 if what == "all" else 2)]:
+        for n, a, b in list(zip(names, res[MODES[0]], res[mode]))[: (5 if what == "all" else 2)]:
             d = (a - b).abs().max().item(); rel = ((a - b).norm() / (a.norm() + 1e-30)).item()
             print(f"B={B} H={H} win={win} mode {mode} {n}: max|old-new| {d:.3e}  rel-L2 {rel:.3e}  max|old| {a.abs().max().item():.3e}  finite {bool(torch.isfinite(b).all())}", flush=True)
     if ref64:

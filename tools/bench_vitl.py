@@ -18,6 +18,8 @@ torch.manual_seed(0)
 model = pt_vit(img_size=(H, W), patch_size=(16, 16), in_chans=2, vocab_size=8192, embed_dim=1024, depth=24, num_heads=16,
                mlp_ratio=4, drop_path_rate=0.1, use_shared_rel_pos_bias=True, use_abs_pos_emb=False, init_values=1e-5).cuda().train()
 eng = model.engine
+if os.environ.get("MEMHIP_NO_SIDE") == "1":                                  # per-kernel accounting: weight gradients on the launch stream
+    eng.wgrad_side_stream = False
 if os.environ.get("MEMHIP_WGRAD_GROUP"):                                     # A/B: engine.wgrad_group = 0 / 1 / 2
     eng.wgrad_group = int(os.environ["MEMHIP_WGRAD_GROUP"])
 with contextlib.redirect_stdout(io.StringIO()):
