@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define MEMHIP_ABI_VERSION 5   /* 5 (round 6): memhip_build_flags; 4 (round 5): epilogues 6 / 7 carry the stored GELU derivative as FP16 (since round 4), certified-tokenizer entry points */
+#define MEMHIP_ABI_VERSION 5   /* 5 (round 6): memhip_build_flags, memhip_attn_bwd_ws / _out_ws / _workspace; 4 (round 5): epilogues 6 / 7 carry the stored GELU derivative as FP16 (since round 4), certified-tokenizer entry points */
 
 #define MEMHIP_OK 0
 #define MEMHIP_EINVAL (-1)   /* bad argument (shape / alignment / null) */
@@ -485,6 +485,23 @@ int memhip_attn_bwd_out(const void* qkv, int64_t ldqkv, const void* dout, int64_
                         const float* lse, float* delta, const float* table, int window_h, int window_w, int B, int T,
                         int D, int heads, float scale, void* dqkv, int64_t lddqkv, float* dtable, float* dq_bias,
                         float* dv_bias, memhip_stream_t stream);
+/* The same two calls with a caller-owned WORKSPACE (round 6).  For the long windows the slot-layout kernels take (40 or 20 tokens
+ * wide, more than 256 tokens: BASELINE configs[4]) the backward then runs in its dS-storing form: the dK / dV kernel writes
+ * dS (bf16) to the workspace and owns the table gradient, the dQ kernel is a streaming product over it -- the score tile is
+ * computed once instead of twice.  memhip_attn_bwd_workspace returns the bytes that form wants (0: this shape has no such
+ * form); ws == NULL, too few bytes or any other shape = exactly memhip_attn_bwd / memhip_attn_bwd_out.  The workspace is
+ * scratch: nothing is kept in it between calls.  Same outputs and rounding points either way (the table gradient is summed
+ * in another order: fixed-point buckets per workgroup, then float atomics).  (Attention.forward backward,
+ * mem/modeling_finetune.py:137-154, RelativePositionBias :213-247.) */
+int64_t memhip_attn_bwd_workspace(int B, int T, int heads, int window_h, int window_w);
+int memhip_attn_bwd_ws(const void* qkv, int64_t ldqkv, const void* dout, int64_t ldo, const float* lse,
+                       float* delta, const float* table, int window_h, int window_w, int B, int T, int D,
+                       int heads, float scale, void* dqkv, int64_t lddqkv, float* dtable, float* dq_bias,
+                       float* dv_bias, void* ws, int64_t ws_bytes, memhip_stream_t stream);
+int memhip_attn_bwd_out_ws(const void* qkv, int64_t ldqkv, const void* dout, int64_t ldo, const void* out, int64_t ldout,
+                           const float* lse, float* delta, const float* table, int window_h, int window_w, int B, int T,
+                           int D, int heads, float scale, void* dqkv, int64_t lddqkv, float* dtable, float* dq_bias,
+                           float* dv_bias, void* ws, int64_t ws_bytes, memhip_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * fp32 PARITY MODE (`--precision fp32`): the ViT path with fp32 operands / accumulation and no bf16 rounding points --

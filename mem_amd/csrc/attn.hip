@@ -602,7 +602,8 @@ int attn_fwd_win(const void* qkv, int64_t ldqkv, int B, int T, int D, int heads,
                  void* out, int64_t ldo, float* lse, hipStream_t s);
 int attn_bwd_win(const void* qkv, int64_t ldqkv, const void* dout, int64_t ldo, const float* lse, float* delta, float* stats,
                  const float* table, int window_h, int window_w, int B, int T, int D, int heads, float scale, void* dqkv,
-                 int64_t lddqkv, float* dtable, float* dq_bias, float* dv_bias, hipStream_t s);
+                 int64_t lddqkv, float* dtable, float* dq_bias, float* dv_bias, void* ws, int64_t ws_bytes, hipStream_t s);
+int64_t attn_bwd_win_workspace(int B, int T, int heads, int window_h, int window_w);
 // attn16.hip: the 14 x 14 window (197 tokens) -- key-slot layout, fused backward
 bool attn16_fits(int T, int window_h, int window_w);
 int attn16_fwd(const void* qkv, int64_t ldqkv, int B, int D, int heads, const float* table, void* out, int64_t ldo,
@@ -679,6 +680,14 @@ extern "C" int memhip_attn_bwd_out(const void* qkv, int64_t ldqkv, const void* d
                                    const float* lse, float* delta, const float* table, int window_h, int window_w, int B,
                                    int T, int D, int heads, float scale, void* dqkv, int64_t lddqkv, float* dtable,
                                    float* dq_bias, float* dv_bias, memhip_stream_t stream) {
+  return memhip_attn_bwd_out_ws(qkv, ldqkv, dout, ldo, out, ldout, lse, delta, table, window_h, window_w, B, T, D, heads, scale, dqkv,
+                                lddqkv, dtable, dq_bias, dv_bias, nullptr, 0, stream);
+}
+
+extern "C" int memhip_attn_bwd_out_ws(const void* qkv, int64_t ldqkv, const void* dout, int64_t ldo, const void* out, int64_t ldout,
+                                      const float* lse, float* delta, const float* table, int window_h, int window_w, int B,
+                                      int T, int D, int heads, float scale, void* dqkv, int64_t lddqkv, float* dtable,
+                                      float* dq_bias, float* dv_bias, void* ws, int64_t ws_bytes, memhip_stream_t stream) {
   MEMHIP_REQUIRE(B >= 0 && T > 0 && heads > 0 && D == heads * HD, "attn_bwd: head_dim must be 64");
   MEMHIP_REQUIRE(window_h > 0 && window_w > 0 && window_h * window_w + 1 == T, "attn_bwd: T must be window_h*window_w + 1");
   if (B == 0) return MEMHIP_OK;
@@ -690,14 +699,27 @@ extern "C" int memhip_attn_bwd_out(const void* qkv, int64_t ldqkv, const void* d
   MEMHIP_REQUIRE(ldo == ldout, "attn_bwd: dout and out must share a leading dimension on this path");
   const int rc = memhip_attn_delta(dout, out, ldo, (int64_t)B * T, heads, delta, stream);
   if (rc != MEMHIP_OK) return rc;
-  return memhip_attn_bwd(qkv, ldqkv, dout, ldo, lse, delta, table, window_h, window_w, B, T, D, heads, scale, dqkv, lddqkv, dtable,
-                         dq_bias, dv_bias, stream);
+  return memhip_attn_bwd_ws(qkv, ldqkv, dout, ldo, lse, delta, table, window_h, window_w, B, T, D, heads, scale, dqkv, lddqkv, dtable,
+                            dq_bias, dv_bias, ws, ws_bytes, stream);
 }
 
 extern "C" int memhip_attn_bwd(const void* qkv, int64_t ldqkv, const void* dout, int64_t ldo, const float* lse,
                                float* delta, const float* table, int window_h, int window_w, int B,
                                int T, int D, int heads, float scale, void* dqkv, int64_t lddqkv, float* dtable,
                                float* dq_bias, float* dv_bias, memhip_stream_t stream) {
+  return memhip_attn_bwd_ws(qkv, ldqkv, dout, ldo, lse, delta, table, window_h, window_w, B, T, D, heads, scale, dqkv, lddqkv, dtable,
+                            dq_bias, dv_bias, nullptr, 0, stream);
+}
+
+extern "C" int64_t memhip_attn_bwd_workspace(int B, int T, int heads, int window_h, int window_w) {
+  if (B <= 0 || T <= 0 || heads <= 0) return 0;
+  return memhip::attn_bwd_win_workspace(B, T, heads, window_h, window_w);
+}
+
+extern "C" int memhip_attn_bwd_ws(const void* qkv, int64_t ldqkv, const void* dout, int64_t ldo, const float* lse,
+                                  float* delta, const float* table, int window_h, int window_w, int B,
+                                  int T, int D, int heads, float scale, void* dqkv, int64_t lddqkv, float* dtable,
+                                  float* dq_bias, float* dv_bias, void* ws, int64_t ws_bytes, memhip_stream_t stream) {
   MEMHIP_REQUIRE(B >= 0 && T > 0 && heads > 0 && D == heads * HD, "attn_bwd: head_dim must be 64");
   MEMHIP_REQUIRE(window_h > 0 && window_w > 0 && window_h * window_w + 1 == T, "attn_bwd: T must be window_h*window_w + 1");
   if (B == 0) return MEMHIP_OK;
@@ -718,7 +740,7 @@ extern "C" int memhip_attn_bwd(const void* qkv, int64_t ldqkv, const void* dout,
   if (nkb > 8) {
     if (opt(OPT_ATTN_WIN) && memhip::attn_win_fits(T, window_h, window_w)) {
       const int rc = memhip::attn_bwd_win(qkv, ldqkv, dout, ldo, lse, delta, stats, table, window_h, window_w, B, T, D, heads,
-                                          scale, dqkv, lddqkv, dtable, dq_bias, dv_bias, s);
+                                          scale, dqkv, lddqkv, dtable, dq_bias, dv_bias, ws, ws_bytes, s);
       if (rc != MEMHIP_EUNSUPPORTED) return rc;
     }
     return memhip::attn_bwd_stream(qkv, ldqkv, dout, ldo, lse, delta, stats, table, window_h, window_w, B, T, D, heads,

@@ -95,6 +95,10 @@ declare({
     "memhip_attn_delta": (i32, [vp, vp, i64, i64, i32, vp, vp]),
     "memhip_attn_bwd": (i32, [vp, i64, vp, i64, vp, vp, vp, i32, i32, i32, i32, i32, i32, f32, vp, i64, vp, vp, vp, vp]),
     "memhip_attn_bwd_out": (i32, [vp, i64, vp, i64, vp, i64, vp, vp, vp, i32, i32, i32, i32, i32, i32, f32, vp, i64, vp, vp, vp, vp]),
+    "memhip_attn_bwd_workspace": (i64, [i32, i32, i32, i32, i32]),
+    "memhip_attn_bwd_ws": (i32, [vp, i64, vp, i64, vp, vp, vp, i32, i32, i32, i32, i32, i32, f32, vp, i64, vp, vp, vp, vp, i64, vp]),
+    "memhip_attn_bwd_out_ws": (i32, [vp, i64, vp, i64, vp, i64, vp, vp, vp, i32, i32, i32, i32, i32, i32, f32, vp, i64, vp, vp, vp,
+                                      vp, i64, vp]),
     "memhip_cast_f32_bf16": (i32, [vp, vp, i64, vp]),
     "memhip_copy_samples_f32": (i32, [vp, vp, vp, i32, i64, vp]),
     "memhip_zero": (i32, [vp, i64, vp]),
@@ -262,19 +266,26 @@ def attn_delta(dout, out, rows, heads, delta):
           "attn_delta")
 
 
-def attn_bwd(qkv, dout, lse, delta, table, window, B, T, D, heads, scale, dqkv, dtable, dq_bias=None, dv_bias=None, out=None):
+def attn_bwd_workspace(B, T, heads, window):
+    """Bytes of scratch the dS-storing backward of the long-window kernels wants for this shape (0: no such form)."""
+    return int(lib.memhip_attn_bwd_workspace(B, T, heads, window[0], window[1]))
+
+
+def attn_bwd(qkv, dout, lse, delta, table, window, B, T, D, heads, scale, dqkv, dtable, dq_bias=None, dv_bias=None, out=None, ws=None):
     """out = the forward output: rowsum(dout * out) is computed by the library (inside the fused 14 x 14 kernel when it
-    applies); without it `delta` must have been filled by attn_delta."""
+    applies); without it `delta` must have been filled by attn_delta.  ws = a uint8 scratch tensor of at least
+    attn_bwd_workspace(...) bytes: the long-window backward then stores dS instead of computing it twice."""
+    wsp, wsn = (ptr(ws), ws.numel() * ws.element_size()) if ws is not None else (None, 0)
     if out is not None:
         _timed(201, 10.0 * B * T * T * D, lambda: check(
-            lib.memhip_attn_bwd_out(ptr(qkv), qkv.stride(0), ptr(dout), dout.stride(0), ptr(out), out.stride(0), ptr(lse),
-                                    ptr(delta), ptr(table), window[0], window[1], B, T, D, heads, scale, ptr(dqkv),
-                                    dqkv.stride(0), ptr(dtable), ptr(dq_bias), ptr(dv_bias), stream_ptr()), "attn_bwd_out"))
+            lib.memhip_attn_bwd_out_ws(ptr(qkv), qkv.stride(0), ptr(dout), dout.stride(0), ptr(out), out.stride(0), ptr(lse),
+                                       ptr(delta), ptr(table), window[0], window[1], B, T, D, heads, scale, ptr(dqkv),
+                                       dqkv.stride(0), ptr(dtable), ptr(dq_bias), ptr(dv_bias), wsp, wsn, stream_ptr()), "attn_bwd_out"))
         return
     _timed(201, 10.0 * B * T * T * D, lambda: check(
-        lib.memhip_attn_bwd(ptr(qkv), qkv.stride(0), ptr(dout), dout.stride(0), ptr(lse), ptr(delta), ptr(table),
-                            window[0], window[1], B, T, D, heads, scale, ptr(dqkv), dqkv.stride(0), ptr(dtable),
-                            ptr(dq_bias), ptr(dv_bias), stream_ptr()), "attn_bwd"))
+        lib.memhip_attn_bwd_ws(ptr(qkv), qkv.stride(0), ptr(dout), dout.stride(0), ptr(lse), ptr(delta), ptr(table),
+                               window[0], window[1], B, T, D, heads, scale, ptr(dqkv), dqkv.stride(0), ptr(dtable),
+                               ptr(dq_bias), ptr(dv_bias), wsp, wsn, stream_ptr()), "attn_bwd"))
 
 
 def residual_rows(x, rows_i32, y, gamma, rowkeep, keep_prob, R, D, out):

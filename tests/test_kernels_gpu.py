@@ -154,9 +154,33 @@ def _attn_ref(qkv, bias, B, T, D, H, scale):
                                        (64, 290, 16, (17, 17)),
                                        # windows 40 / 20 wide: the slot-layout kernels (attn_win.hip, round 5); ragged last chunks
                                        # (7 = 2 x 3 + 1 grid rows, 13 = 2 x 5 + 3), workgroups persistent over several samples
-                                       (2, 321, 2, (16, 20)), (3, 261, 3, (13, 20)), (4, 281, 3, (7, 40)), (40, 1201, 16, (30, 40))])
+                                       (2, 321, 2, (16, 20)), (3, 261, 3, (13, 20)), (4, 281, 3, (7, 40)), (40, 1201, 16, (30, 40)),
+                                       # (round 6) the ragged windows whose padded-row buckets reach the pad behind the table (the NaN
+                                       # bug of round 5 lived there) against the ORACLE, not only against the stream kernels
+                                       (9, 1041, 4, (26, 40)), (9, 921, 4, (23, 40)), (5, 281, 3, (7, 40))])
 def test_attention_fwd_bwd(B, T, H, win):
     _attention_case(B, T, H, win)
+
+
+@pytest.mark.parametrize("B,T,H,win", [(2, 321, 2, (16, 20)), (3, 261, 3, (13, 20)), (4, 281, 3, (7, 40)), (9, 1041, 4, (26, 40)),
+                                       (9, 921, 4, (23, 40)), (3, 1201, 2, (30, 40)), (40, 1201, 16, (30, 40))])
+def test_attention_bwd_ds_storing_form(B, T, H, win):
+    """The dS-storing backward of the long-window kernels (memhip_attn_bwd_ws: the dK / dV kernel stores dS and owns the table
+    gradient, the dQ kernel is a streaming product over it) against the same oracle as the recomputing form; B = 40 x 16 heads:
+    workgroups persistent over several samples, more than 16 samples per workgroup split."""
+    from mem_amd import ops
+    nbytes = ops.attn_bwd_workspace(B, T, H, win)
+    assert nbytes == B * H * ops.attn_tokens_padded(T) * 128 * -(-win[0] // (128 // ((win[1] + 7) // 8 * 8))) * 2
+    ws = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    ws.fill_(0xFF)                                  # NaN patterns: every word the dQ kernel reads must have been written
+    _attention_case(B, T, H, win, ws=ws)
+
+
+def test_attention_bwd_workspace_is_optional():
+    """No workspace form for the short windows (0 bytes); a workspace that is too small falls back to the recomputing kernels."""
+    from mem_amd import ops
+    assert ops.attn_bwd_workspace(4, 197, 12, (14, 14)) == 0 and ops.attn_bwd_workspace(4, 325, 4, (18, 18)) == 0
+    _attention_case(2, 321, 2, (16, 20), ws=torch.empty(1024, dtype=torch.uint8, device="cuda"))
 
 
 def test_attn_win_equals_stream_kernels():
@@ -280,7 +304,7 @@ def test_attention_backward_from_the_forward_output(B, T, H, win, with_table):
     assert (res[0][0] == res[1][0]).float().mean().item() > 0.999           # bf16 outputs: equal except rounding-boundary cases
 
 
-def _attention_case(B, T, H, win):
+def _attention_case(B, T, H, win, ws=None):
     from mem_amd import ops
     from oracle.vit_ref import rel_pos_index
     D = 64 * H
@@ -324,7 +348,7 @@ def _attention_case(B, T, H, win):
     # general two-kernel backward of attn.hip runs (both forms are covered at 14 x 14)
     fused = win == (14, 14) and B > 3
     ops.attn_bwd(qkv, dout, lse, delta, table, win, B, T, D, H, scale, dqkv, dtable, dq_bias=dqb,
-                 dv_bias=None if fused else dvb)
+                 dv_bias=None if fused else dvb, ws=ws)
     torch.testing.assert_close(dqb, dqkv[:, :D].float().sum(0), rtol=1e-3, atol=1e-2)
     if not fused:
         torch.testing.assert_close(dvb, dqkv[:, 2 * D:].float().sum(0), rtol=1e-3, atol=1e-2)

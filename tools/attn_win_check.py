@@ -11,7 +11,7 @@ do_time = len(sys.argv) > 2
 MODES = tuple(int(x) for x in os.environ.get('WIN_MODES', '0,1,2').split(','))
 
 def setopt(v):
-    assert _lib.lib.memhip_set_option(b"attn_win", v) == 0
+    assert _lib.lib.memhip_set_option(b"attn_win", 1 if v == 9 else v) == 0       # mode 9 = the kernels of mode 1 + a dS workspace
 
 def tm(f, n=10):
     for _ in range(3): f()
@@ -35,17 +35,18 @@ def run(B, H, win, seed=0, time_it=False, ref64=False):
         out = torch.zeros(B * T, D, dtype=torch.bfloat16, device="cuda"); lse = torch.zeros(B, H, TP, device="cuda")
         dqkv = torch.full((B * T, 3 * D), 3.0, dtype=torch.bfloat16, device="cuda"); dtable = torch.zeros(nrd, H, device="cuda")
         delta = torch.zeros(2 * B * T + 4, H, device="cuda"); dqb = torch.zeros(D, device="cuda")
+        ws = torch.empty(ops.attn_bwd_workspace(B, T, H, win), dtype=torch.uint8, device="cuda") if mode == 9 else None
         ops.attn_fwd(qkv, B, T, D, H, table, win, out, lse)
         if what == "all":
             ops.attn_delta(dout, out, B * T, H, delta)
-            ops.attn_bwd(qkv, dout, lse, delta, table, win, B, T, D, H, 0.125, dqkv, dtable, dqb, None)
+            ops.attn_bwd(qkv, dout, lse, delta, table, win, B, T, D, H, 0.125, dqkv, dtable, dqb, None, ws=ws)
         torch.cuda.synchronize()
         res[mode] = (out.float(), lse[:, :, :T].clone(), dqkv.float(), dtable.clone(), dqb.clone())
         for rep in range(2 if time_it else 0):
             msg = f"mode {mode}: fwd {tm(lambda: ops.attn_fwd(qkv, B, T, D, H, table, win, out, lse)):.1f} us"
             if what == "all":
-                msg += f"  bwd {tm(lambda: ops.attn_bwd(qkv, dout, lse, delta, table, win, B, T, D, H, 0.125, dqkv, dtable, dqb, None)):.1f} us"
-                msg += f"  bwd(no dtable) {tm(lambda: ops.attn_bwd(qkv, dout, lse, delta, table, win, B, T, D, H, 0.125, dqkv, None, dqb, None)):.1f} us"
+                msg += f"  bwd {tm(lambda: ops.attn_bwd(qkv, dout, lse, delta, table, win, B, T, D, H, 0.125, dqkv, dtable, dqb, None, ws=ws)):.1f} us"
+                msg += f"  bwd(no dtable) {tm(lambda: ops.attn_bwd(qkv, dout, lse, delta, table, win, B, T, D, H, 0.125, dqkv, None, dqb, None, ws=ws)):.1f} us"
             print(msg, flush=True)
     names = ("out", "lse", "dqkv", "dtable", "dq_bias")
     for mode in MODES[1:]:
@@ -66,10 +67,11 @@ def run(B, H, win, seed=0, time_it=False, ref64=False):
                   f"lse max {(res[mode][1].double() - lse_ref).abs().max().item():.3e}", flush=True)
     setopt(1)
 
-run(2, 4, (16, 20), ref64=True)
-run(3, 2, (30, 40), seed=1, ref64=True)
-run(1, 16, (30, 40), seed=2)
-run(5, 3, (7, 40), seed=3, ref64=True)       # ragged last chunk (7 rows = 2 chunks of 3 + 1)
-run(4, 3, (13, 20), seed=4, ref64=True)      # ragged (13 = 2 x 5 + 3), 261 tokens
+if os.environ.get("WIN_TIME_ONLY") != "1":
+    run(2, 4, (16, 20), ref64=True)
+    run(3, 2, (30, 40), seed=1, ref64=True)
+    run(1, 16, (30, 40), seed=2)
+    run(5, 3, (7, 40), seed=3, ref64=True)       # ragged last chunk (7 rows = 2 chunks of 3 + 1)
+    run(4, 3, (13, 20), seed=4, ref64=True)      # ragged (13 = 2 x 5 + 3), 261 tokens
 if do_time:
     run(64, 16, (30, 40), seed=5, time_it=True)
