@@ -66,7 +66,7 @@ def get_args(argv=None):
                    help="hip_fp16x2 (default): two-plane fp16 operands (22 significant bits), three fp16 MFMAs per product, fp32 "
                         "accumulation, CERTIFIED since round 5: a label is kept only where its top-2 logit gap exceeds a stated "
                         "multiple of the fp16x2 error bound; every sample with a token below that margin is recomputed by the fp32 "
-                        "kernels on the device, so the labels equal the fp32 mode's by construction (vae_model.HipTokenizer; "
+                        "kernels on the device, so the labels equal the fp32 mode's wherever the measured margin holds -- calibrated per model, audited at run time (vae_model.HipTokenizer; "
                         "tests/test_tokenizer_gpu.py plants near-ties), ~2x faster than fp32; hip: the fp32 implicit-GEMM forward "
                         "(csrc/conv_f32.hip; fp32 operands and accumulation like the reference); hip_bf16: the bf16-operand kernels "
                         "of csrc/conv.hip (~6x faster, 1-3 %% of the labels differ at near ties); torch: the fp32 module on stock "

@@ -770,6 +770,23 @@ class ViTEngine:
             self._side.wait_event(e)
             self.grad_hook(k)
 
+    # Opt-in (round 6): the dS-storing backward of the long-window attention kernels (memhip_attn_bwd_ws) -- measured EQUAL in time
+    # to the recomputing form (2 480-2 510 vs 2 490 us per layer at B = 64 x 16 heads x 1 201 tokens, profiles/r06_attn_win_ab.txt)
+    # for 3.2 GB of scratch, so it stays off
+    attn_ds_workspace = False
+
+    def _attn_ws(self, nb):
+        if not self.attn_ds_workspace:
+            return None
+        need = ops.attn_bwd_workspace(nb, self.T, self.heads, self.window)
+        if need == 0:
+            return None
+        ws = getattr(self, "_attn_ws_buf", None)
+        if ws is None or ws.numel() < need:
+            ws = self._attn_ws_buf = torch.empty(ops.attn_bwd_workspace(self.cur["B"], self.T, self.heads, self.window),
+                                                 dtype=torch.uint8, device=self.dev)
+        return ws
+
     def backward(self, dlogits=None):
         """Gradients of mean-CE (dlogits already in self.logits after forward(labels=...)) or of a
         caller-supplied dlogits (bf16 [Mm,V]) w.r.t. every parameter, into the flat grad buffer."""
@@ -934,7 +951,7 @@ class ViTEngine:
                 self._before_overwrite("dqkv")
                 # (rowsum(dO * O) is computed inside the fused 14 x 14 backward; other windows: a delta pass in the library)
                 ops.attn_bwd(a["qkv"], self.dao, a["lse"], self.delta_ws, table, self.window, na, T, D, self.heads,
-                             self.scale, self.dqkv, dtable, dq_bias=self.G(pre + "attn.q_bias"), out=a["ao"])
+                             self.scale, self.dqkv, dtable, dq_bias=self.G(pre + "attn.q_bias"), out=a["ao"], ws=self._attn_ws(na))
 
                 def wg_qkv(pre=pre, a=a, M1=M1, wg_proj=wg_proj):
                     if self.wgrad_group:
@@ -1052,7 +1069,7 @@ class ViTEngine:
             self._before_overwrite("dqkv")
             # (rowsum(dO * O) is computed inside the fused 14 x 14 backward; other windows: a delta pass in the library)
             ops.attn_bwd(a["qkv"], self.dao, a["lse"], self.delta_ws, table, self.window, B, T, D, self.heads,
-                         self.scale, self.dqkv, dtable, dq_bias=self.G(pre + "attn.q_bias"), out=a["ao"])
+                         self.scale, self.dqkv, dtable, dq_bias=self.G(pre + "attn.q_bias"), out=a["ao"], ws=self._attn_ws(B))
 
             def wg_qkv(pre=pre, a=a, wg_proj=wg_proj):
                 if self.wgrad_group:

@@ -60,13 +60,20 @@ def test_tiny_forward_backward_fp32_vs_reference():
         assert ((p.grad - ref).norm() / (ref.norm() + 1e-20)).item() <= 2e-5, k
 
 
-def _run(cfg, n_steps, batch_fn, lr, wd, clip, seed_w):
+def _run(cfg, n_steps, batch_fn, lr, wd, clip, seed_w, precision="fp32", keep=None):
+    from mem_amd.modeling_pretrain import pt_vit
     from mem_amd.optim_factory import create_optimizer
     from mem_amd.utils import NativeScalerWithGradNormCount
+    from oracle.vit_ref import fill_by_name
 
     class A:
         opt = "adamw"; weight_decay = 0.05; lr = 5e-4; opt_eps = 1e-8; opt_betas = [0.9, 0.999]; momentum = 0.9
-    m = _model(cfg, seed_w)
+    if precision == "fp32":
+        m = _model(cfg, seed_w)
+    else:
+        m = pt_vit(**cfg)
+        m.load_state_dict(fill_by_name(m.state_dict(), seed=seed_w))
+        m = m.cuda().train()
     with contextlib.redirect_stdout(io.StringIO()):
         opt = create_optimizer(A(), m)
     scaler = NativeScalerWithGradNormCount()
@@ -77,7 +84,8 @@ def _run(cfg, n_steps, batch_fn, lr, wd, clip, seed_w):
             if grp["weight_decay"] > 0:
                 grp["weight_decay"] = wd[it]
         x, mask, labels = batch_fn(it)
-        la = m.forward_loss(x.cuda(), mask.cuda(), labels.cuda())
+        dpm = None if keep is None else torch.from_numpy(keep[it].astype(np.float32)).cuda()
+        la = m.forward_loss(x.cuda(), mask.cuda(), labels.cuda(), drop_path_masks=dpm)
         m._fused_loss_pending = True
         gn = scaler(la, opt, clip_grad=clip, parameters=m.parameters(), model=m)
         rec.append((la[0].item(), gn.item()))
@@ -123,3 +131,53 @@ def test_vit_base_c2_gradients_fp32():
         q = pd[k].grad[::st]
         rel = ((q - r).norm() / (r.norm() + 1e-20)).item()
         assert rel <= 5e-5, (k, rel)
+
+
+# ---- ViT-B at 100 steps (round 6; oracle/gen_golden_train100.py -> tests/golden/vit_base_train100.npz: the REFERENCE model + the
+# reference optimizer, C = 2, B = 2, clip 30, four recurring batches).  North star: step-100 loss within 1e-4 of the reference.
+def _train100(precision, which, drop_path_rate=0.0):
+    from oracle.gen_golden import BASE, vit_inputs
+    g = np.load(os.path.join(GOLDEN, "vit_base_train100.npz"))
+    cfg = dict(BASE, in_chans=2, drop_path_rate=drop_path_rate)
+    keep = g["dp1__keep"] if which == "dp1" else None
+    rec = _run(cfg, 100, lambda it: vit_inputs(cfg, 2, 2000 + it % 4, 98), g["lr"], g["wd"], 30.0, 1, precision=precision, keep=keep)
+    return rec, g
+
+
+def test_vit_base_100_steps_fp32_within_1e4_of_reference():
+    rec, g = _train100("fp32", "dp0")
+    d = np.abs(rec[:, 0] - g["dp0__fp32__loss"])
+    print("ViT-B fp32 mode vs the reference's fp32 curve: max |dloss| %.2e, at step 100 %.2e; grad-norm rel %.2e" %
+          (d.max(), d[-1], np.abs(rec[:, 1] / g["dp0__fp32__gnorm"] - 1).max()), "worst step", int(d.argmax()) + 1)
+    # the north star's bar is the loss at step 100; along the way two fp32 trajectories (other summation orders) drift apart and
+    # re-converge while the loss falls from 9.5 to 4.8 -- measured worst 2.6e-4 (mid-curve), stated here at 1e-3
+    assert d[-1] <= 1e-4 and d[:10].max() <= 1e-5 and d.max() <= 1e-3
+    assert np.abs(rec[:, 1] / g["dp0__fp32__gnorm"] - 1).max() <= 5e-3
+
+
+def test_vit_base_100_steps_fp32_with_the_references_drop_path_masks():
+    """drop_path_rate 0.1: the keep masks the reference drew (recorded by the generator) are fed to the product."""
+    rec, g = _train100("fp32", "dp1", drop_path_rate=0.1)
+    assert int((g["dp1__keep"] == 0).sum()) > 50                    # the masks do drop samples
+    d = np.abs(rec[:, 0] - g["dp1__fp32__loss"])
+    print("ViT-B fp32 mode, reference drop-path masks: max |dloss| %.2e, at step 100 %.2e" % (d.max(), d[-1]))
+    assert d[-1] <= 1e-4 and d[:10].max() <= 1e-5 and d.max() <= 1e-3
+    assert np.abs(rec[:, 1] / g["dp1__fp32__gnorm"] - 1).max() <= 5e-3
+
+
+def test_vit_base_100_steps_bf16_engine_deviation():
+    """The bf16 product engine on the same 100 steps: its distance from the reference's bf16-autocast curve and from the fp32
+    curve, next to the reference's own autocast-vs-fp32 distance (bf16 operands: accumulation-order noise, not 1e-4)."""
+    rec, g = _train100("bf16", "dp0")
+    d16 = np.abs(rec[:, 0] - g["dp0__bf16__loss"])
+    d32 = np.abs(rec[:, 0] - g["dp0__fp32__loss"])
+    own = np.abs(g["dp0__bf16__loss"] - g["dp0__fp32__loss"])
+    print("ViT-B bf16 engine vs reference bf16 curve: max %.2e, step 100 %.2e | vs fp32 curve: max %.2e, step 100 %.2e | "
+          "reference autocast vs its fp32 run: max %.2e, step 100 %.2e" % (d16.max(), d16[-1], d32.max(), d32[-1], own.max(), own[-1]))
+    # measured (round 6): the product's bf16 engine ends 1.8e-3 from the reference's FP32 curve (worst step 4.3e-2), while the
+    # reference's own bf16-autocast CPU run ends 3.9e-2 from its fp32 run (worst 3.3e-1): the engine keeps fp32 accumulation, an
+    # fp32 residual stream and fp32 LayerNorm / softmax statistics.  So the bar is stated against the fp32 curve, and the engine
+    # must be at least as close to it as the reference's autocast run is.
+    assert d32[-1] <= 1e-2 and d32.max() <= 1e-1
+    assert d32[-1] <= own[-1] and d32.max() <= own.max()
+    assert d16[-1] <= own[-1] + 1e-2            # (and it ends no further from the autocast curve than that curve is from fp32)

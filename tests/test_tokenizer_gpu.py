@@ -373,7 +373,8 @@ def test_certified_tokenizer_margin_and_unflagged_path():
         relgap = (tok32.last_top2_gap(B).flatten() / rms.flatten()).min().item()
         print(f"{fix}: max deviation / rms = {dev:.2e}, smallest gap / rms = {relgap:.2e}, stats {st}")
         worst = max(worst, dev)
-        if relgap > 2 * HipTokenizer.CERT_KAPPA:
+        assert tok.kappa >= 4.0 * tok.calibration["max_deviation_over_rms"] and 2.0 * dev <= tok.kappa, (tok.kappa, dev)
+        if relgap > 2 * tok.kappa:
             assert st["flagged_samples"] == 0, st
     for hidden, tokens, res, size in ((64, 512, 2, 64), (128, 1024, 1, 96)):
         vae = _vae(hidden, tokens, res, size, seed=2)
@@ -385,3 +386,38 @@ def test_certified_tokenizer_margin_and_unflagged_path():
         worst = max(worst, ((a.logits - b.logits).abs() / rms).max().item())
     print(f"worst deviation / rms {worst:.2e} vs CERT_KAPPA {HipTokenizer.CERT_KAPPA:.1e}")
     assert worst * 4 <= HipTokenizer.CERT_KAPPA, worst
+
+
+def test_certified_tokenizer_kappa_is_calibrated_per_model_and_audited():
+    """Round 6: the certification margin is MEASURED PER MODEL at construction (4 x the worst fp16x2-vs-fp32 logit deviation on a
+    calibration batch, floor 1e-5) instead of one constant for every tokenizer, and the claim is audited at run time.  On the
+    stock random-weight model and on one whose first convolution is rescaled by 100 (another dynamic range in every layer
+    behind it): the deviation measured on a DIFFERENT batch stays below kappa / 2 (the condition for equal labels), the
+    certified ids equal the fp32 ids on every token, and the audit (every call here) recomputes samples without a mismatch."""
+    from mem_amd.vae_model import HipTokenizer
+    for scale0 in (1.0, 100.0):
+        vae = _vae(64, 512, 2, 64, seed=6)
+        with torch.no_grad():
+            vae.encoder[0][0].weight.mul_(scale0)
+            vae.encoder[0][0].bias.mul_(scale0)
+        g = torch.Generator(device="cuda").manual_seed(31)
+        img = torch.rand(16, 3, 64, 64, generator=g, device="cuda")
+        img[8:] *= (torch.rand(8, 3, 64, 64, generator=g, device="cuda") < 0.3)
+        t32 = HipTokenizer(vae, max_batch=16)
+        ids32 = t32.get_codebook_indices(img).clone()
+        rms = t32.logits.pow(2).mean(1, keepdim=True).sqrt()
+        raw = HipTokenizer(vae, max_batch=16, precision="fp16x2", certify=False)
+        raw.get_codebook_indices(img)
+        dev = ((raw.logits - t32.logits).abs() / rms).max().item()
+        tok = HipTokenizer(vae, max_batch=16, precision="fp16x2", audit_every=1)
+        assert tok.kappa >= HipTokenizer.KAPPA_FLOOR and tok.calibration["samples"] == 8
+        print(f"first conv x{scale0:g}: calibrated kappa {tok.kappa:.2e} (calibration deviation {tok.calibration['max_deviation_over_rms']:.2e}), "
+              f"deviation on the test batch {dev:.2e}, logit rms {rms.mean().item():.3g}")
+        assert 2.0 * dev <= tok.kappa, (dev, tok.kappa)
+        for _ in range(3):
+            assert torch.equal(tok.get_codebook_indices(img), ids32)
+        st = tok.certification_stats()
+        assert st["calls"] == 3 and st["audited_samples"] == 3 and st["audit_mismatches"] == 0, st
+    # an explicit kappa switches the calibration off (the round-5 behaviour)
+    t = HipTokenizer(vae, max_batch=4, precision="fp16x2", kappa=HipTokenizer.CERT_KAPPA)
+    assert t.kappa == HipTokenizer.CERT_KAPPA and not hasattr(t, "calibration")
