@@ -14,6 +14,7 @@
 // The fp32 partial tile is either added to the gradient with atomics shaped as two 128-byte runs
 // per wave-instruction, or (with a caller workspace) stored to a slab and summed by a reduction pass;
 // both are staged through the idle ring.
+#include <atomic>
 #include "common.h"
 
 #define P8_PRIO_MODE 0   // 0: s_setprio 1 around every MFMA block; 1: none; 2: none + waves 4-7 at priority 1 for the whole kernel
@@ -425,7 +426,7 @@ int gemm_tn_p8_dispatch(const void* A, long long lda, const void* B, long long l
   if (!num_cu) return MEMHIP_EUNSUPPORTED;
   int tiles, splits, rows_per_split;
   tn_p8_plan(R, N, K, num_cu, tiles, splits, rows_per_split);
-  static bool attr_done = false;
+  static std::atomic<bool> attr_done{false};
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_p8_kernel<false>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, kRing);
@@ -436,7 +437,9 @@ int gemm_tn_p8_dispatch(const void* A, long long lda, const void* B, long long l
     attr_done = true;
   }
   const size_t need = (size_t)splits * N * K * sizeof(float);
-  if (ws && splits > 1 && ws_bytes >= need && ((uintptr_t)ws & 15) == 0 && ldo % 4 == 0) {
+  // (the reduction pass reads and writes `out` as float4: the pointer itself must be 16-byte aligned, not only ldo -- a caller's
+  // 4-byte-aligned gradient view takes the atomic path below)
+  if (ws && splits > 1 && ws_bytes >= need && ((uintptr_t)ws & 15) == 0 && ldo % 4 == 0 && ((uintptr_t)out & 15) == 0) {
     hipLaunchKernelGGL(gemm_tn_p8_kernel<true>, dim3(tiles * splits), dim3(kThreads), kRing, s, (const __bf16*)A, lda,
                        (const __bf16*)B, ldb, R, N, K, ws, (long long)K, rows_per_split);
     const long long quads = (long long)N * K / 4;
@@ -462,7 +465,7 @@ static bool tn_group_plan(const memhip_tn_problem_t* pr, int count, int num_cu, 
   if (count < 2 || count > kTnGroupMax || !num_cu) return false;
   int tiles_total = 0;
   for (int i = 0; i < count; ++i) {
-    if (pr[i].N % BM != 0 || pr[i].K % BN != 0 || pr[i].R < 2048 || pr[i].ldo % 4 != 0) return false;
+    if (pr[i].N % BM != 0 || pr[i].K % BN != 0 || pr[i].R < 2048 || pr[i].ldo % 4 != 0 || ((uintptr_t)pr[i].out & 15) != 0) return false;
     tiles_total += (pr[i].N / BM) * (pr[i].K / BN);
   }
   int best_s = 0;
@@ -519,7 +522,7 @@ int gemm_tn_p8_group_dispatch(const memhip_tn_problem_t* pr, int count, int accu
   if (!ws || ((uintptr_t)ws & 15) != 0 || !tn_group_plan(pr, count, tn_p8_num_cu(s), g, wgs, quads, fl) ||
       fl * sizeof(float) > ws_bytes)
     return MEMHIP_EUNSUPPORTED;
-  static bool attr_done = false;
+  static std::atomic<bool> attr_done{false};
   if (!attr_done) {
     const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_p8_group_kernel),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, kRing);

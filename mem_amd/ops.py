@@ -375,8 +375,16 @@ declare({
 })
 
 
+_TN_WS_CACHE = {}       # (the library plans up to 32 split counts per query, and the engine asks in front of every weight-gradient launch;
+                        # the answer depends on the shape only: it is sized for every CU of the device whatever a stream has reserved)
+
+
 def gemm_tn_workspace(R, N, K):
-    return int(lib.memhip_gemm_bf16_tn_workspace(R, N, K))
+    key = (R, N, K)
+    v = _TN_WS_CACHE.get(key)
+    if v is None:
+        v = _TN_WS_CACHE[key] = int(lib.memhip_gemm_bf16_tn_workspace(R, N, K))
+    return v
 
 
 def gemm_tn(A, B, R, N, K, out, accumulate=True, workspace=None):
@@ -411,10 +419,14 @@ def _tn_problems(problems):
 
 def gemm_tn_group_workspace(shapes):
     """bytes of scratch for gemm_tn_group over products of the shapes [(R, N, K), ...]"""
+    key = tuple(shapes)
+    if key in _TN_WS_CACHE:
+        return _TN_WS_CACHE[key]
     arr = (TnProblem * len(shapes))()
     for q, (R, N, K) in zip(arr, shapes):
         q.R, q.N, q.K, q.lda, q.ldb, q.ldo = R, N, K, N, K, K
-    return int(lib.memhip_gemm_bf16_tn_group_workspace(arr, len(shapes)))
+    v = _TN_WS_CACHE[key] = int(lib.memhip_gemm_bf16_tn_group_workspace(arr, len(shapes)))
+    return v
 
 
 def gemm_tn_group(problems, accumulate=True, workspace=None):
