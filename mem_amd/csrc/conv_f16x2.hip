@@ -18,7 +18,6 @@ namespace {
 using namespace memhip;
 
 constexpr int BM = 128, BN = 128, BK = 64;
-constexpr int kThreads = 256;
 constexpr int kTileBytes = BM * BK * 2;              // one fp16 tile
 constexpr int kStageBytes = 4 * kTileBytes;          // A_hi A_lo B_hi B_lo
 constexpr float kLoScale = 2048.0f, kLoInv = 1.0f / 2048.0f;
@@ -47,7 +46,13 @@ __device__ __forceinline__ void split16(float v, _Float16& hi, _Float16& lo) {
   lo = (_Float16)((v - (float)hi) * kLoScale);
 }
 
-__global__ __launch_bounds__(kThreads) void conv_gemm_f16x2_kernel(ConvArgsH p) {
+// NW = waves per workgroup: 4 (2 x 2 waves, 64 x 64 outputs each: ONE wave per SIMD -- nothing covers a wave's fragment reads, waits
+// and barriers, the matrix pipe idles meanwhile) or 8 (4 x 2 waves, 32 x 64 each: two waves per SIMD; 12 instead of 16 fragment
+// reads per 48 MFMAs and wave).  Same tile, staging and arithmetic: every accumulator sees the same sum order.
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void conv_gemm_f16x2_kernel(ConvArgsH p) {
+  constexpr int MI = 8 / NW * 2;                // 16-row fragments per wave: 4 (NW = 4) / 2 (NW = 8)
+  constexpr int PW = 16 / NW;                   // LDS-DMA pieces per wave and tile: 4 / 2
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -61,11 +66,11 @@ __global__ __launch_bounds__(kThreads) void conv_gemm_f16x2_kernel(ConvArgsH p) 
   }
   const int ntn = (p.Cout + BN - 1) / BN;
   const int m0 = (pid / ntn) * BM, n0 = (pid % ntn) * BN;
-  long long abase[4], bbase[4];
-  int chunkg[4];
+  long long abase[PW], bbase[PW];
+  int chunkg[PW];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int inst = wave * 4 + j;
+  for (int j = 0; j < PW; ++j) {
+    const int inst = wave * PW + j;
     const int row = inst * 8 + (lane >> 3);
     chunkg[j] = (lane & 7) ^ ((row >> 1) & 7);
     int m = m0 + row;
@@ -87,8 +92,8 @@ __global__ __launch_bounds__(kThreads) void conv_gemm_f16x2_kernel(ConvArgsH p) 
       koff = ((long long)ky * p.Wp + kx) * p.Cin + c0;
     }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int inst = wave * 4 + j;
+    for (int j = 0; j < PW; ++j) {
+      const int inst = wave * PW + j;
       const long long ao = p.cin4 ? ((long long)(chunkg[j] >> 1) * p.Wp + 2 * (chunkg[j] & 1)) * 4 : koff + chunkg[j] * 8;
       const long long bo = bbase[j] + k0 + chunkg[j] * 8;
       glds16(p.in + abase[j] + ao, dst + inst * 1024);
@@ -97,9 +102,9 @@ __global__ __launch_bounds__(kThreads) void conv_gemm_f16x2_kernel(ConvArgsH p) 
       glds16(p.w + p.w_plane + bo, dst + 3 * kTileBytes + inst * 1024);
     }
   };
-  f32x4 acch[4][4], accx[4][4];
+  f32x4 acch[MI][4], accx[MI][4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < MI; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) { acch[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; accx[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 
@@ -115,11 +120,11 @@ __global__ __launch_bounds__(kThreads) void conv_gemm_f16x2_kernel(ConvArgsH p) 
     const char* Bl = Ah + 3 * kTileBytes;
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
-      half8 ah[4], al[4], bh[4], bl[4];
+      half8 ah[MI], al[MI], bh[4], bl[4];
       const int chunk = kk * 4 + (lane >> 4);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int s = swz_slot(wr * 64 + i * 16 + (lane & 15), chunk) * 16;
+      for (int i = 0; i < MI; ++i) {
+        const int s = swz_slot(wr * (MI * 16) + i * 16 + (lane & 15), chunk) * 16;
         ah[i] = *reinterpret_cast<const half8*>(Ah + s);
         al[i] = *reinterpret_cast<const half8*>(Al + s);
       }
@@ -130,7 +135,7 @@ __global__ __launch_bounds__(kThreads) void conv_gemm_f16x2_kernel(ConvArgsH p) 
         bl[j] = *reinterpret_cast<const half8*>(Bl + s);
       }
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           acch[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bh[j], acch[i][j], 0, 0, 0);
@@ -143,7 +148,7 @@ __global__ __launch_bounds__(kThreads) void conv_gemm_f16x2_kernel(ConvArgsH p) 
   }
 
   // ---- epilogue: the wave's 64x64 sub-tile through LDS, 32 rows at a time (conv.hip's scheme); v = hh + x / 2048
-  const int mw = m0 + wr * 64, nw = n0 + wc * 64;
+  const int mw = m0 + wr * (MI * 16), nw = n0 + wc * 64;
   constexpr int LS = 72;
   float* wreg = reinterpret_cast<float*>(smem + wave * 16384);
   const int c8 = (lane & 7) * 8;
@@ -152,7 +157,7 @@ __global__ __launch_bounds__(kThreads) void conv_gemm_f16x2_kernel(ConvArgsH p) 
 #pragma unroll
   for (int k = 0; k < 8; ++k) bias[k] = (p.bias && n + k < p.Cout) ? p.bias[n + k] : 0.f;
 #pragma unroll
-  for (int half = 0; half < 2; ++half) {
+  for (int half = 0; half < MI / 2; ++half) {
 #pragma unroll
     for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
@@ -253,11 +258,16 @@ extern "C" int memhip_conv2d_nhwc_f16x2(const void* in, int64_t in_plane, const 
   const int grid = cdiv(M, BM) * cdiv(Cout, BN);
   static bool attr_done = false;
   if (!attr_done) {
-    MEMHIP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_gemm_f16x2_kernel),
+    MEMHIP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_gemm_f16x2_kernel<4>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kStageBytes));
+    MEMHIP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_gemm_f16x2_kernel<8>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kStageBytes));
     attr_done = true;
   }
-  hipLaunchKernelGGL(conv_gemm_f16x2_kernel, dim3(grid), dim3(kThreads), 2 * kStageBytes, as_stream(stream), p);
+  if (opt(OPT_CONV_WAVES) == 4)
+    hipLaunchKernelGGL(conv_gemm_f16x2_kernel<4>, dim3(grid), dim3(256), 2 * kStageBytes, as_stream(stream), p);
+  else
+    hipLaunchKernelGGL(conv_gemm_f16x2_kernel<8>, dim3(grid), dim3(512), 2 * kStageBytes, as_stream(stream), p);
   return check_launch("conv2d_nhwc_f16x2");
 }
 
