@@ -54,7 +54,7 @@ const char* memhip_arch(void);
 const char* memhip_build_flags(void);
 /* Kernel-selection switches for A/B measurements (tools/): the library reads NO environment variable; the only
  * process-wide state is this explicit table.  Names: "gemm_p8", "gemm256", "gemm_split", "gemm_p8_half", "tn_p8",
- * "tn256", "raster_lds", "attn16" (0/1, default 1 = shipped dispatch), "gemm_p8_min_n" (768), "gemm256_min_n" (1024),
+ * "raster_lds", "attn16" (0/1, default 1 = shipped dispatch), "gemm_p8_min_n" (768), "gemm256_min_n" (1024),
  * "attn16_stagger" (40000) / "attn16_stagger_fwd" (0): cycles by which the 14x14 attention workgroups with the smaller share
  * of samples start late at most, "gemm_stagger" (0): the same for the persistent GEMM workgroups, cycles per K-tile;
  * round 5: "attn_win" (1: windows 40 / 20 tokens wide and longer than 256 tokens run on the slot-layout kernels of

@@ -195,8 +195,6 @@ __global__ __launch_bounds__(256) void colsum_kernel(const __bf16* __restrict__ 
 }  // namespace
 
 namespace memhip {
-int gemm_tn256_dispatch(const void* A, long long lda, const void* B, long long ldb, int R, int N, int K, float* out,
-                        long long ldo, int accumulate, hipStream_t s);
 int gemm_tn_p8_dispatch(const void* A, long long lda, const void* B, long long ldb, int R, int N, int K, float* out,
                         long long ldo, int accumulate, float* ws, size_t ws_bytes, hipStream_t s);
 size_t gemm_tn_p8_workspace(int R, int N, int K);
@@ -229,11 +227,6 @@ extern "C" int memhip_gemm_bf16_tn_ws(const void* A, int64_t lda, const void* B,
   if (p8_on) {
     const int rc = gemm_tn_p8_dispatch(A, lda, B, ldb, R, N, K, out, ldo, accumulate, (float*)workspace,
                                        workspace_bytes, s);
-    if (rc != MEMHIP_EUNSUPPORTED) return rc;
-  }
-  const bool k256_on = opt(OPT_TN256) != 0;
-  if (k256_on) {
-    const int rc = gemm_tn256_dispatch(A, lda, B, ldb, R, N, K, out, ldo, accumulate, s);
     if (rc != MEMHIP_EUNSUPPORTED) return rc;
   }
   const int tiles = cdiv(N, BM) * cdiv(K, BN);

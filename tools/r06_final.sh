@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-5 evidence set: ONE call on ONE box after the last kernel commit (run from the repo root on the GPU box; outputs under
+# Round-6 evidence set: ONE call on ONE box after the last kernel commit (run from the repo root on the GPU box; outputs under
 # gpurun_out/r06fin_*, copied to profiles/r06_final_* by tools/r06_collect.py):
 #   r06fin_tests.txt               python -m pytest tests -m gpu
 #   r06fin_bench.json              python bench.py (defaults: every secondary figure, cpu_baseline, config5 ViT-L line)
@@ -10,7 +10,8 @@
 #   r06fin_traffic.json            HBM FETCH_SIZE / WRITE_SIZE per kernel (separate passes)
 #   r06fin_vitl_kernel_stats.csv   ViT-L/16 480x640 (config #5), B = 64;  r06fin_vitl_mfma_util.json, r06fin_vitl_traffic.json
 #   r06fin_raster_kernel_stats.csv config #4 rasterizer (64 x 1 M events);  r06fin_raster_traffic.json
-#   r06fin_attn16.txt, r06fin_attn_win.txt   attention kernels alone
+#   r06fin_attn16.txt, r06fin_attn_win.txt   attention kernels alone (attn_win: 0 = stream kernels, 1 = slot layout, 9 = 1 + dS workspace)
+#   r06fin_conv_waves.txt          fp16x2 tokenizer convolutions, 4 vs 8 waves per workgroup
 #   r06fin_clock.json              in-kernel shader clock of the GEMM main loops (stamp build)
 cd /root/repo; mkdir -p gpurun_out
 python -m pytest tests -m gpu -q 2>&1 | tail -5 > gpurun_out/r06fin_tests.txt; cat gpurun_out/r06fin_tests.txt
@@ -51,6 +52,7 @@ cp $(ls gpurun_out/r06fin_raster/*/*kernel_stats.csv | head -1) gpurun_out/r06fi
 tools/prof_pmc_raster.sh r06fin_raster > /dev/null 2>&1
 # ---- attention kernels alone, GEMM clock
 python tools/attn16_time.py 2>&1 | tail -2 > gpurun_out/r06fin_attn16.txt
-WIN_MODES=0,1 python tools/attn_win_check.py all time 2>&1 | grep "^mode" > gpurun_out/r06fin_attn_win.txt
+WIN_TIME_ONLY=1 WIN_MODES=0,1,9 python tools/attn_win_check.py all time 2>&1 | grep "^mode" > gpurun_out/r06fin_attn_win.txt
+python tools/exp/r06_conv_waves.py 2>&1 | grep -v amdgpu > gpurun_out/r06fin_conv_waves.txt
 MEMHIP_CLOCK_OUT=gpurun_out/r06fin_clock.json MEMHIP_LIB=variants/stamp.so python tools/clock_probe.py > gpurun_out/r06fin_clock.log 2>&1
 ls -la gpurun_out | grep r06fin
