@@ -10,6 +10,7 @@ from oracle.vit_ref import rel_pos_index
 seed = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 cases = int(sys.argv[2]) if len(sys.argv) > 2 else 12
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 10
+USE_WS = os.environ.get("WIN_WS") == "1"          # round 6: the dS-storing backward (caller workspace) under the same stress
 gen = torch.Generator().manual_seed(seed)
 
 def run(B, H, win, s, mode):
@@ -26,7 +27,10 @@ def run(B, H, win, s, mode):
     delta = torch.zeros(2 * B * T + 4, H, device="cuda"); dqb = torch.zeros(D, device="cuda")
     ops.attn_fwd(qkv, B, T, D, H, table, win, out, lse)
     ops.attn_delta(dout, out, B * T, H, delta)
-    ops.attn_bwd(qkv, dout, lse, delta, table, win, B, T, D, H, 0.125, dqkv, dtable, dqb, None)
+    ws = None
+    if USE_WS and mode == 1:
+        ws = torch.empty(ops.attn_bwd_workspace(B, T, H, win), dtype=torch.uint8, device="cuda"); ws.fill_(0xFF)
+    ops.attn_bwd(qkv, dout, lse, delta, table, win, B, T, D, H, 0.125, dqkv, dtable, dqb, None, ws=ws)
     torch.cuda.synchronize()
     return out, lse[:, :, :T].clone(), dqkv, dtable, dqb
 
