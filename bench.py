@@ -819,6 +819,7 @@ def main():
         dist.all_reduce(med, op=dist.ReduceOp.MAX)
         with_x, without_x, no_hook = float(med[0].item()), float(med[1].item()), float(med[2].item())
         rccl_info = {"world_size": dist.get_world_size(), "backend": dist.get_backend(), "ranks": ranks,
+                     "distinct_pci_bus_ids": len({str(r.get("pci_bus_id")) for r in ranks if r}),     # = world_size on a real N-GPU run
                      "buckets_per_step": len(eng.buckets), "bytes_per_step": reducer.bytes_per_step,
                      "bucket_dtype": a.bucket_dtype, "reserve_cus": a.reserve_cus,
                      "ms_per_step_p50_with_exchange": round(with_x, 3), "ms_per_step_p50_without_exchange": round(without_x, 3),
