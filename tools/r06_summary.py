@@ -43,6 +43,14 @@ L.append(f"* `with_tokenizer` (certified fp16x2 tokenizer, {f['label_mismatches'
 L.append(f"* **`config5_vitl_1gpu`** (ViT-L/16 480x640, 1201 tokens, B = 64): **{c5['value']} samples/s** ({c5['ms_per_step']} ms), {c5['model_flops_frac_of_peak']} of peak on "
          f"executed FLOPs, {c5['model_flops_frac_of_peak_reference_count']} on the reference count; one-stream family split: "
          + ", ".join(f"{k} {v['ms']} ms ({v['tflops']} TFLOP/s)" for k, v in c5["family_split_one_stream_step"].items()) + ".")
+sol = b["speed_of_light"]; lib = b["library"]
+L.append(f"* `roofline.frac` per instrumented step: {r['frac_per_instrumented_step']} (pooled {r['frac']}); `kernel_vs_reduction` (rocprofv3, same call): "
+         f"{r['kernel_vs_reduction']['kernel_us_per_product']} + {r['kernel_vs_reduction']['reduction_us_per_product']} us per product = {r['kernel_vs_reduction']['frac_kernel_alone']} kernel alone, "
+         f"{r['kernel_vs_reduction']['frac_with_reduction']} with its reduction pass; `library`: {lib['path']}, build flags '{lib['build_flags']}', shipped build {lib['shipped_build']}, ABI {lib['abi']}."
+         if r.get("kernel_vs_reduction") else f"* `roofline.frac` per instrumented step: {r['frac_per_instrumented_step']} (pooled {r['frac']}); `library`: {lib}.")
+L.append("* `speed_of_light` (per launch max(FLOPs / at-clock MFMA peak " + str(sol["mfma_peak_at_clock_tflops"]) + " TFLOP/s, bytes / 6.3 TB/s), no overlap): "
+         + "; ".join(f"{k} {v['floor_ms']} ms" for k, v in sol["families"].items())
+         + f" -> **sum {sol['sum_floor_ms']} ms** (all-MFMA {sol['sum_mfma_ms']}, all-HBM {sol['sum_hbm_ms']}); step {sol['ms_per_step']} ms = **{sol['ms_per_step_over_sum_floor']} x** the floor.")
 L.append(f"* `cpu_baseline`: {b['cpu_baseline'].get('value')} samples/s on {b['cpu_baseline'].get('cores')} CPUs.")
 L.append(f"* sequential trace (`--no-side-stream`) -> `r06_final_seq_kernel_stats.csv`, per-step table from the same trace -> `r06_final_seq_step_kernels.txt`: {step[0]}; top rows:")
 for l in step[1:13]:
