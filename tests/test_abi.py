@@ -202,3 +202,19 @@ def test_asm_lds_dma_owns_its_m0(tmp_path):
                 j -= 1
             assert found is not None, (f, i, l, "no m0 write within 8 instructions in front of the LDS-DMA")
     assert total >= 100, total
+
+
+def test_shipped_kernels_carry_no_measurement_switches():
+    """Round 6: the laboratory stays out of the product.  tools/strip_lab.py (the small `unifdef` that resolved the
+    ~60 measurement switches of round 5 at their shipped values) finds nothing left to resolve in mem_amd/csrc, and the sources
+    hold at most 20 `#if` lines (the stamp builds of gemm_p8 / gemm_tn_p8 / attn_win)."""
+    import glob
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    files = sorted(glob.glob(os.path.join(root, "mem_amd", "csrc", "*.hip")) + glob.glob(os.path.join(root, "mem_amd", "csrc", "*.hpp")))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "strip_lab.py"), "--check"] + files, capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-2000:]
+    n_if = sum(sum("#if" in line for line in open(f)) for f in files)
+    assert n_if <= 20, n_if
+    assert not os.path.exists(os.path.join(root, "mem_amd", "exp")) and not glob.glob(os.path.join(root, "mem_amd", "csrc", "_build_*"))
