@@ -26,7 +26,7 @@ inline int check_launch(const char* what) {
 
 // kernel-selection options (core.cpp; memhip_set_option)
 enum { OPT_GEMM_P8, OPT_GEMM256, OPT_GEMM_SPLIT, OPT_GEMM_P8_HALF, OPT_GEMM_P8_MIN_N, OPT_GEMM256_MIN_N, OPT_TN_P8,
-       OPT_RASTER_LDS, OPT_ATTN16, OPT_ATTN16_STAGGER, OPT_ATTN16_STAGGER_FWD, OPT_GEMM_STAGGER, OPT_GEMM_PREFETCH, OPT_RESERVE_CUS, OPT_LN_BWD_GRID, OPT_ATTN_WIN, OPT_GEMM_P8_PAIR, OPT_TN_GROUP, OPT_CONV_WAVES, OPT_COUNT_ };
+       OPT_RASTER_LDS, OPT_ATTN16, OPT_ATTN16_STAGGER, OPT_ATTN16_STAGGER_FWD, OPT_GEMM_STAGGER, OPT_GEMM_PREFETCH, OPT_RESERVE_CUS, OPT_LN_BWD_GRID, OPT_ATTN_WIN, OPT_GEMM_P8_PAIR, OPT_TN_GROUP, OPT_CONV_WAVES, OPT_RASTER_BANDS, OPT_COUNT_ };
 int opt(int id);
 // CUs the persistent one-workgroup-per-CU launches (GEMMs, attention) size their grids for: the device's CU count minus
 // the `reserve_cus` option (a multiple of 8 is kept, so that every XCD gives up the same number).  The data-parallel

@@ -35,7 +35,6 @@ struct Ev { double x, y, t, p; long long pos; bool keep; };
 // the first event is looked at -- inside the per-event branches (out of range, filtered, bad index) hipcc waits for
 // every load right where it is issued, i.e. one event's 32 bytes in flight per thread)
 struct RawEv { double2 xy, tp; };
-#define RASTER_NT 0
 __device__ __forceinline__ RawEv load_raw(const double* __restrict__ ev, long long row) {
   return RawEv{reinterpret_cast<const double2*>(ev)[2 * row], reinterpret_cast<const double2*>(ev)[2 * row + 1]};
 }
@@ -300,6 +299,38 @@ constexpr int kBinSlots = kBinChunk + 8 * kBinMaxBands;    // key slots of a chu
 constexpr int kAccThreads = 1024;
 constexpr int kBinOverflow = 1 << 30;                      // status flag: n_events smaller than the offsets say
 
+// The wave's 64 rows of one step as TWO fully contiguous 1-KiB wave-instructions (lane l loads 16 bytes at 16 l: half a row):
+// an even lane 2e ends up with row e (its own (x, y) from the first KiB, (t, p) from its odd neighbour), an odd lane 2e + 1
+// with row 32 + e (its own (t, p) from the second KiB, (x, y) from its even neighbour) -- one DPP exchange inside the lane pair.
+// With every byte of a 128-byte line requested by ONE instruction the rows can be loaded nontemporal: a read-only sweep of
+// the 2 GB stream of 64 x 1 M events runs at 6.1 TB/s with default-policy loads of either shape and at 6.85 TB/s with nt loads
+// of this shape (tools/exp/r06_raster_read_probe.hip); a row-per-lane nt load fetches every line twice and is SLOWER than the
+// default policy (round 3, re-measured in round 6: +35 us on 470).  `row0` = the wave's first row of the step, rows clamped
+// to n - 1.
+typedef double d2v_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ RawEv load_raw_pair(const double* __restrict__ ev, long long beg, long long n, long long row0, int lane) {
+  const int half = lane & 1, e = lane >> 1;
+  long long ra = row0 + e, rb = row0 + 32 + e;
+  ra = ra < n ? ra : n - 1; rb = rb < n ? rb : n - 1;
+  const d2v_t* pa = reinterpret_cast<const d2v_t*>(ev) + 2 * (beg + ra) + half;
+  const d2v_t* pb = reinterpret_cast<const d2v_t*>(ev) + 2 * (beg + rb) + half;
+  const d2v_t a = __builtin_nontemporal_load(pa), b = __builtin_nontemporal_load(pb);
+  const d2v_t send = half ? a : b;                       // odd: (t, p) of row e; even: (x, y) of row 32 + e
+  // (plain doubles first: __builtin_bit_cast of a vector ELEMENT expression reads element 0 with this clang)
+  const double sx = send.x, sy = send.y;
+  d2v_t recv;
+  recv.x = __hiloint2double(__builtin_amdgcn_mov_dpp(__double2hiint(sx), 0xB1, 0xF, 0xF, true),
+                            __builtin_amdgcn_mov_dpp(__double2loint(sx), 0xB1, 0xF, 0xF, true));
+  recv.y = __hiloint2double(__builtin_amdgcn_mov_dpp(__double2hiint(sy), 0xB1, 0xF, 0xF, true),
+                            __builtin_amdgcn_mov_dpp(__double2loint(sy), 0xB1, 0xF, 0xF, true));
+  const d2v_t xy = half ? recv : a, tp = half ? b : recv;
+  return RawEv{make_double2(xy.x, xy.y), make_double2(tp.x, tp.y)};
+}
+
+// workgroup barrier that orders LDS traffic only: the event rows of the NEXT chunk stay in flight across it (__syncthreads()
+// carries a release fence that waits for every outstanding global load and store of the wave)
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 __global__ __launch_bounds__(kBinThreads) void raster_bin_keys(
     const double* __restrict__ ev, const int64_t* __restrict__ offsets,
     const memhip_event_aug_t* __restrict__ augs, int H, int W, int band_px, int nb, long long n_cap,
@@ -322,21 +353,28 @@ __global__ __launch_bounds__(kBinThreads) void raster_bin_keys(
   const long long nchunks = (n + kBinChunk - 1) / kBinChunk;
   const long long hbase = rel / kBinChunk + b;
   int bad = 0;
+  // The rows of a workgroup's next chunk are requested as soon as the current rows have been turned into keys (their registers
+  // are free then) and arrive under the counting sort and the key write-out of the current chunk; the barriers inside the
+  // loop order LDS traffic only.  (Two workgroups per CU at 125 registers: without the prefetch the pair-exchange form needs
+  // 138 registers, one workgroup per CU, and runs at 0.51 instead of 0.62 of 8 TB/s.)
+  RawEv raw[kBinEvPerThread];
+  const int slot = (tid & ~63) + ((tid & 1) << 5) + ((tid & 63) >> 1);        // this thread's row inside a step (load_raw_pair)
+  auto fetch_row = [&](long long cc, int k) -> RawEv {
+    return load_raw_pair(ev, beg, n, cc * kBinChunk + (long long)k * kBinThreads + (tid & ~63), tid & 63);
+  };
+  if (blockIdx.x < nchunks) {
+#pragma unroll
+    for (int k = 0; k < kBinEvPerThread; ++k) raw[k] = fetch_row(blockIdx.x, k);       // (n > 0: nchunks > 0)
+  }
   for (long long c = blockIdx.x; c < nchunks; c += gridDim.x) {
     if (tid < nb) cnt[tid] = 0u;
     for (int i = tid; i < kBinSlots / 8; i += kBinThreads)                     // pad key everywhere first
       reinterpret_cast<uint4*>(sorted)[i] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
-    __syncthreads();
+    lds_barrier();
     unsigned int key[kBinEvPerThread], where[kBinEvPerThread];
-    RawEv raw[kBinEvPerThread];
 #pragma unroll
     for (int k = 0; k < kBinEvPerThread; ++k) {
-      const long long i = c * kBinChunk + (long long)k * kBinThreads + tid;
-      raw[k] = load_raw(ev, beg + (i < n ? i : n - 1));          // (n > 0: nchunks > 0)
-    }
-#pragma unroll
-    for (int k = 0; k < kBinEvPerThread; ++k) {
-      const long long i = c * kBinChunk + (long long)k * kBinThreads + tid;
+      const long long i = c * kBinChunk + (long long)k * kBinThreads + slot;
       where[k] = 0xFFFFFFFFu;
       if (i >= n) continue;
       const Ev e = make_event_k(raw[k], n, i, K, t_last);
@@ -355,7 +393,11 @@ __global__ __launch_bounds__(kBinThreads) void raster_bin_keys(
       key[k] = (f32 - band * (unsigned int)band_px) | (isneg ? 0x8000u : 0u);
       where[k] = (band << 16) | atomicAdd(&cnt[band], 1u);   // slot inside the band's segment
     }
-    __syncthreads();
+    if (c + gridDim.x < nchunks) {
+#pragma unroll
+      for (int k = 0; k < kBinEvPerThread; ++k) raw[k] = fetch_row(c + gridDim.x, k);
+    }
+    lds_barrier();
     if (tid < 64) {                          // exclusive scan of <= 64 band counts (rounded up to 8) in one wave
       const unsigned int v = tid < nb ? ((cnt[tid] + 7u) & ~7u) : 0u;
       unsigned int inc = v;
@@ -366,16 +408,16 @@ __global__ __launch_bounds__(kBinThreads) void raster_bin_keys(
       if (tid < nb) base[tid] = inc - v;
       if (tid == nb - 1) base[nb] = inc;
     }
-    __syncthreads();
+    lds_barrier();
 #pragma unroll
     for (int k = 0; k < kBinEvPerThread; ++k)
       if (where[k] != 0xFFFFFFFFu) sorted[base[where[k] >> 16] + (where[k] & 0xFFFFu)] = (unsigned short)key[k];
-    __syncthreads();
+    lds_barrier();
     const unsigned int total8 = base[nb] >> 3;                                  // 16-byte groups to write
     uint4* kout = reinterpret_cast<uint4*>(keys + (hbase + c) * kBinSlots);
     for (unsigned int j = tid; j < total8; j += kBinThreads) kout[j] = reinterpret_cast<const uint4*>(sorted)[j];
     if (tid <= nb) hdr[(hbase + c) * (kBinMaxBands + 1) + tid] = base[tid] >> 3;   // boundaries in 16-byte groups
-    __syncthreads();
+    lds_barrier();
   }
   if (bad) atomicAdd(status + b, bad);
 }
@@ -457,9 +499,10 @@ __global__ __launch_bounds__(kAccThreads) void raster_bin_accum(
 }
 
 // bands of whole pixels (not rows): band_px pixels each, the last one shorter
-inline bool bin_geometry(int H, int W, int* band_px, int* nb) {
+inline bool bin_geometry(int H, int W, int* band_px, int* nb, int want_nb = 0) {
   const long long HW = (long long)H * W;
   long long n = (HW + kBinBandPixels - 1) / kBinBandPixels;
+  if (want_nb > n && want_nb <= kBinMaxBands) n = want_nb;
   if (n > kBinMaxBands) return false;
   long long px = (HW + n - 1) / n;
   px = (px + 3) & ~3ll;                     // 4-pixel aligned bands keep the u32 output stores
@@ -467,6 +510,33 @@ inline bool bin_geometry(int H, int W, int* band_px, int* nb) {
   *band_px = (int)px;
   *nb = (int)n;
   return true;
+}
+
+// Bands per sample for a batch of B samples.  Pass 2 runs one workgroup per (sample, band); a workgroup with 128 KB of counters
+// has a CU to itself and takes ~6 us (launch, clearing and writing its planes) + ~220 us per million events / bands (its keys), so what the pass
+// costs is set by how many ROUNDS of workgroups the chip needs: 32 x 10 bands = 320 workgroups are two rounds on 256 CUs
+// (50 us), 32 x 16 bands of 77 KB (two workgroups per CU) one round (measured 241 -> 232 us for 32 x 1 M events, 461 -> 440
+// for 64 x 1 M with 12 bands = three full rounds instead of two and a half).  The candidates run from the fewest bands the
+// 15-bit key allows to twice that; more bands cost pass 1 padding and shorter segments, so a larger count has to
+// promise 10 % and batches that fit one round keep the fewest bands.
+inline int choose_bands(int H, int W, int B, long long n_events) {
+  const int forced = memhip::opt(memhip::OPT_RASTER_BANDS);
+  if (forced > 0) return forced;
+  const long long HW = (long long)H * W;
+  const int nmin = (int)((HW + kBinBandPixels - 1) / kBinBandPixels);
+  int cus = memhip::max_cus();
+  if (cus <= 0) cus = 256;
+  if ((long long)B * nmin <= cus) return nmin;                                  // one round either way
+  int best = nmin;
+  double best_cost = 0.0;
+  for (int nbv = nmin; nbv <= 2 * nmin + 4 && nbv <= kBinMaxBands; ++nbv) {
+    const long long px = ((HW + nbv - 1) / nbv + 3) & ~3ll;
+    const int per_cu = (size_t)px * 4 * 2 + 1024 <= 160 * 1024 ? 2 : 1;       // 1024-thread workgroups: two per CU at most
+    const long long rounds = ((long long)B * nbv + (long long)cus * per_cu - 1) / ((long long)cus * per_cu);
+    const double cost = (double)rounds * (6.0 + 220.0e-6 * ((double)n_events / B) / nbv) * (per_cu == 2 ? 2.0 : 1.0);
+    if (nbv == nmin || cost < best_cost * 0.9) { best = nbv; best_cost = cost; }
+  }
+  return best;
 }
 
 }  // namespace
@@ -693,7 +763,7 @@ extern "C" int memhip_rasterize_binned_f64(const double* ev, const int64_t* offs
   MEMHIP_REQUIRE(ev && offsets && out && status && workspace, "rasterize_binned: null pointer");
   MEMHIP_REQUIRE(((uintptr_t)ev & 15) == 0 && ((uintptr_t)out & 3) == 0, "rasterize_binned: ev must be 16-byte, out 4-byte aligned");
   int band_px = 0, nb = 0;
-  if (!bin_geometry(H, W, &band_px, &nb))
+  if (!bin_geometry(H, W, &band_px, &nb, choose_bands(H, W, B, n_events)))
     return memhip::fail(MEMHIP_EUNSUPPORTED, "rasterize_binned: %dx%d canvas needs more than %d bands", H, W, kBinMaxBands);
   const size_t need = memhip_rasterize_binned_workspace(B, H, W, n_events);
   if (workspace_bytes < need)

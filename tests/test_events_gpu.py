@@ -247,6 +247,15 @@ def test_binned_rasterizer_vs_oracle_ragged_and_edges():
         for b, n in enumerate(ns):
             want = E.event_arr_to_img(evs[b], H, W, False).transpose(2, 0, 1) if n else np.zeros((3, H, W), np.uint8)
             assert np.array_equal(got[b], want), (H, W, b)
+        # the band count is chosen from the batch size (csrc/raster.hip::choose_bands): every count gives the same image
+        from mem_amd import _lib
+        try:
+            for bands in (1, 2, 10, 13, 16, 40, 64):
+                _lib.set_option("raster_bands", bands)               # (counts below the canvas' minimum are raised to it)
+                again = D.rasterize(_ev_dev(allv), _off(*ns), H, W, False, binned=True).cpu().numpy()
+                assert np.array_equal(again, ref), (H, W, bands)
+        finally:
+            _lib.set_option("raster_bands", 0)
     # out-of-canvas events raise like the reference, on both paths
     bad = np.array([[5.0, 3.0, 0.0, 1.0], [10.0, 480.0, 1.0, 1.0]])
     for binned in (True, False):
