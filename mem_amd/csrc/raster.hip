@@ -297,6 +297,7 @@ constexpr int kBinMaxBands = 64;
 constexpr int kBinBandPixels = 32764;                      // 15-bit pixel index inside a band (0xFFFF is the pad key)
 constexpr int kBinSlots = kBinChunk + 8 * kBinMaxBands;    // key slots of a chunk: events + padding of every segment to 8
 constexpr int kAccThreads = 1024;
+constexpr int kBinKeyGrid = 4096;                           // pass-1 workgroups in all (rounded up to whole samples)
 constexpr int kBinOverflow = 1 << 30;                      // status flag: n_events smaller than the offsets say
 
 // The wave's 64 rows of one step as TWO fully contiguous 1-KiB wave-instructions (lane l loads 16 bytes at 16 l: half a row):
@@ -334,7 +335,7 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 __global__ __launch_bounds__(kBinThreads) void raster_bin_keys(
     const double* __restrict__ ev, const int64_t* __restrict__ offsets,
     const memhip_event_aug_t* __restrict__ augs, int H, int W, int band_px, int nb, long long n_cap,
-    unsigned short* __restrict__ keys, unsigned int* __restrict__ hdr, int32_t* __restrict__ status, UDiv band_div) {
+    unsigned short* __restrict__ keys, unsigned int* __restrict__ hdr, int32_t* __restrict__ bad_slots, UDiv band_div) {
   // (measured: a counter set per wave is slower for its extra LDS reads in the scatter, four sub-counters per band selected by
   // lane & 3 change nothing -- the returning atomics on these ~10 counters are not what bounds the kernel)
   __shared__ unsigned int cnt[kBinMaxBands];
@@ -344,9 +345,13 @@ __global__ __launch_bounds__(kBinThreads) void raster_bin_keys(
   const long long beg = offsets[b], n = offsets[b + 1] - beg, rel = beg - offsets[0];
   const long long HW = (long long)H * W;
   if (rel + n > n_cap) {
-    if (blockIdx.x == 0 && tid == 0) atomicAdd(status + b, kBinOverflow);
+    if (tid == 0) bad_slots[(long long)b * gridDim.x + blockIdx.x] = blockIdx.x == 0 ? kBinOverflow : 0;
     return;
   }
+  // events the reference would raise IndexError for: counted per workgroup, one plain store per workgroup; pass 2 adds the
+  // slots of a sample up into status[b] (no memset node, no global atomics)
+  __shared__ int bad_wg;
+  if (tid == 0) bad_wg = 0;
   const memhip_event_aug_t* a = augs ? augs + b : nullptr;
   const double t_last = (a && a->time_flip && n > 0) ? ev[4 * (beg + n - 1) + 2] : 0.0;
   const AugK K = aug_k(a);
@@ -419,7 +424,10 @@ __global__ __launch_bounds__(kBinThreads) void raster_bin_keys(
     if (tid <= nb) hdr[(hbase + c) * (kBinMaxBands + 1) + tid] = base[tid] >> 3;   // boundaries in 16-byte groups
     lds_barrier();
   }
-  if (bad) atomicAdd(status + b, bad);
+  __syncthreads();
+  if (bad) atomicAdd(&bad_wg, bad);
+  __syncthreads();
+  if (tid == 0) bad_slots[(long long)b * gridDim.x + blockIdx.x] = bad_wg;
 }
 
 __device__ __forceinline__ void bin_count8(unsigned int* cnt, const uint4& q) {
@@ -442,9 +450,16 @@ __device__ __forceinline__ void bin_count8(unsigned int* cnt, const uint4& q) {
 
 __global__ __launch_bounds__(kAccThreads) void raster_bin_accum(
     const int64_t* __restrict__ offsets, int H, int W, int band_px, long long n_cap,
-    const unsigned short* __restrict__ keys, const unsigned int* __restrict__ hdr, uint8_t* __restrict__ out) {
+    const unsigned short* __restrict__ keys, const unsigned int* __restrict__ hdr, uint8_t* __restrict__ out,
+    const int32_t* __restrict__ bad_slots, int nslots, int32_t* __restrict__ status) {
   extern __shared__ unsigned int cnt[];       // [band_px]: neg << 16 | pos
   const int band = blockIdx.x, b = blockIdx.y;
+  if (band == 0 && threadIdx.x < 64) {        // status[b] = what the sample's pass-1 workgroups counted (raster_bin_keys)
+    int v = 0;
+    for (int i = threadIdx.x; i < nslots; i += 64) v += bad_slots[(long long)b * nslots + i];
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    if (threadIdx.x == 0) status[b] = v;
+  }
   const long long HW = (long long)H * W;
   const long long lo = (long long)band * band_px;
   const int npx = (int)((lo + band_px <= HW ? band_px : HW - lo));
@@ -751,7 +766,7 @@ extern "C" size_t memhip_rasterize_binned_workspace(int B, int H, int W, int64_t
   const size_t chunks = (size_t)n_events / kBinChunk + (size_t)B + 1;
   const size_t keys = (chunks * kBinSlots * sizeof(unsigned short) + 15) & ~(size_t)15;
   const size_t hdr = chunks * (kBinMaxBands + 1) * sizeof(unsigned int);
-  return keys + hdr;
+  return keys + hdr + ((size_t)kBinKeyGrid + (size_t)B) * sizeof(int32_t);     // + one slot per pass-1 workgroup
 }
 
 extern "C" int memhip_rasterize_binned_f64(const double* ev, const int64_t* offsets,
@@ -772,7 +787,8 @@ extern "C" int memhip_rasterize_binned_f64(const double* ev, const int64_t* offs
   unsigned short* keys = (unsigned short*)workspace;
   const size_t keys_bytes = ((((size_t)n_events / kBinChunk + (size_t)B + 1) * kBinSlots * sizeof(unsigned short)) + 15) & ~(size_t)15;
   unsigned int* hdr = (unsigned int*)((char*)workspace + keys_bytes);
-  MEMHIP_HIP(hipMemsetAsync(status, 0, (size_t)B * sizeof(int32_t), s));
+  const size_t chunk_slots = (size_t)n_events / kBinChunk + (size_t)B + 1;
+  int32_t* bad_slots = (int32_t*)((char*)hdr + chunk_slots * (kBinMaxBands + 1) * sizeof(unsigned int));
   static bool attr_done = false;
   if (!attr_done) {
     MEMHIP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(raster_bin_accum),
@@ -782,12 +798,14 @@ extern "C" int memhip_rasterize_binned_f64(const double* ev, const int64_t* offs
   // chunks per sample are only known on the device: enough workgroups per sample to fill the chip at
   // small B, grid-stride beyond
   const long long avg_chunks = n_events / ((long long)B * kBinChunk) + 1;
-  long long bx = (2048 + B - 1) / B;
+  // (4096 workgroups in all: 64 x 1 M events 462 -> 454 us against 2048, 470 with 1024; 32 x 1 M: 241 / 241 / 246 / 249 us
+  // with 4096 / 2048 / 1024 / 512)
+  long long bx = (kBinKeyGrid + B - 1) / B;                                    // (bx * B <= kBinKeyGrid + B slots)
   if (bx > 4 * avg_chunks) bx = 4 * avg_chunks;
   if (bx < 1) bx = 1;
   hipLaunchKernelGGL(raster_bin_keys, dim3((unsigned)bx, B), dim3(kBinThreads), 0, s, ev, offsets, aug, H, W, band_px, nb,
-                     (long long)n_events, keys, hdr, status, udiv_prepare((unsigned)band_px));
+                     (long long)n_events, keys, hdr, bad_slots, udiv_prepare((unsigned)band_px));
   hipLaunchKernelGGL(raster_bin_accum, dim3(nb, B), dim3(kAccThreads), (size_t)band_px * 4, s, offsets, H, W, band_px,
-                     (long long)n_events, keys, hdr, out);
+                     (long long)n_events, keys, hdr, out, bad_slots, (int)bx, status);
   return memhip::check_launch("rasterize_binned");
 }

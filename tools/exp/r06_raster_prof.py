@@ -8,6 +8,6 @@ t = torch.rand((B * n,), generator=g, device="cuda", dtype=torch.float64) * 3e5
 p = torch.randint(0, 2, (B * n,), generator=g, device="cuda") * 2 - 1
 ev = torch.stack([x.double(), y.double(), t, p.double()], 1).contiguous()
 off = torch.arange(0, B + 1, device="cuda", dtype=torch.int64) * n
-_lib.set_option("raster_pipe", int(os.environ.get("RP", "61")))
+_lib.set_option("raster_bands", int(os.environ.get("RP", "0")))
 for _ in range(12): D.rasterize(ev, off, H, W, False, strict=False, binned=True)
 torch.cuda.synchronize()
