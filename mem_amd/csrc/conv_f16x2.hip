@@ -208,6 +208,213 @@ __global__ __launch_bounds__(NW * 64) void conv_gemm_f16x2_kernel(ConvArgsH p) {
   }
 }
 
+// ---- 256 x 128 x 32 tile, eight waves of 64 x 64 outputs (4 x 2), phase-interleaved.  In the 128 x 128 kernel above a wave reads
+// 12 fragments for 24 MFMAs and all eight waves run in lockstep: they stage, read and compute together, so on every SIMD the
+// matrix pipe idles while both of its waves load (~0.39 of the fp16 peak).  A 64 x 64 wave tile reads 16 fragments for 48 MFMAs;
+// eight such waves need 256 output rows; with BK = 32 a stage is {A_hi, A_lo} x 16 KiB + {B_hi, B_lo} x 8 KiB = 48 KiB, three
+// stages 144 KiB.  Measured on the 56 x 56 and 28 x 28 layers (B = 256): the wide tile alone 14.4 -> 12.9 ms (a third stage and
+// conflict-free reads changed nothing: neither the loads nor the LDS were the limit), with the two waves of a SIMD half a phase
+// apart -> 11.6 ms; the whole fp16x2 forward 21.45 -> 18.64 ms = 1.006 PFLOP/s of fp16 MFMA work, logits bit-equal.
+// Rows are 64 bytes (4 chunks of 16 B): slot(row, chunk) = row * 4 + (chunk ^ wswz(row)).  A ds_read_b128 is served in four groups of
+// 16 NON-contiguous lanes ({0-3, 12-15, 20-27}, ...): a group holds rows 0-3 and 12-15 of the fragment at chunk c and rows 4-11 at
+// chunk c ^ 1, and the four row quads must land on four different 16-byte columns of the 256-byte bank row: wswz = 0, 3, 2, 1 for
+// quad 0, 1, 2, 3 gives c, c ^ 2, c ^ 3, c ^ 1.  Same arithmetic and the same k order per accumulator as the 128 x 128 kernel:
+// bit-equal output.
+constexpr int WBM = 256, WBN = 128, WBK = 32;
+__device__ __forceinline__ int wswz(int row) { return (0 - (row >> 2)) & 3; }
+constexpr int kWATile = WBM * WBK * 2, kWBTile = WBN * WBK * 2;     // bytes of one fp16 plane
+constexpr int kWStage = 2 * kWATile + 2 * kWBTile;
+
+__global__ __launch_bounds__(512) void conv_gemm_f16x2_wide_kernel(ConvArgsH p) {
+  constexpr int MI = 4;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wr = wave >> 1, wc = wave & 1;
+  const int M = p.B * p.Ho * p.Wo;
+  const int nwg = gridDim.x;
+  int pid = blockIdx.x;
+  {
+    const int q = nwg >> 3, r = nwg & 7, xcd = pid & 7, idx = pid >> 3;
+    pid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int ntn = (p.Cout + WBN - 1) / WBN;
+  const int m0 = (pid / ntn) * WBM, n0 = (pid % ntn) * WBN;
+  // LDS-DMA pieces of 1 KiB = 16 rows x 64 B: the wave stages A rows [32 wave, 32 wave + 32) and B rows [16 wave, 16 wave + 16)
+  long long abase[2], bbase;
+  int chunka[2], chunkb;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int row = (wave * 2 + j) * 16 + (lane >> 2);
+    chunka[j] = (lane & 3) ^ wswz(row);
+    int m = m0 + row;
+    m = m < M ? m : M - 1;
+    const int hw = p.Ho * p.Wo;
+    const int b = m / hw, r = m - b * hw;
+    const int oy = r / p.Wo, ox = r - oy * p.Wo;
+    abase[j] = (((long long)b * p.Hp + oy * p.stride + p.off) * p.Wp + ox * p.stride + p.off) * p.Cin;
+  }
+  {
+    const int row = wave * 16 + (lane >> 2);
+    chunkb = (lane & 3) ^ wswz(row);
+    int n = n0 + row;
+    n = n < p.Cout ? n : p.Cout - 1;
+    bbase = (long long)n * p.K;
+  }
+  // pieces of k-step t in two sets of three (one set per phase): set 0 = A rows of piece 0 (hi, lo) + B hi, set 1 = A piece 1 + B lo
+  auto stage_set = [&](int t, char* dst, int set) {
+    const int k0 = t * WBK;
+    const int tap = k0 / p.Cin, c0 = k0 - tap * p.Cin;
+    const int ky = tap / p.kw, kx = tap - ky * p.kw;
+    const long long koff = ((long long)ky * p.Wp + kx) * p.Cin + c0;
+    const long long ao = abase[set] + koff + chunka[set] * 8;
+    glds16(p.in + ao, dst + (wave * 2 + set) * 1024);
+    glds16(p.in + p.in_plane + ao, dst + kWATile + (wave * 2 + set) * 1024);
+    const long long bo = bbase + k0 + chunkb * 8;
+    if (set == 0) glds16(p.w + bo, dst + 2 * kWATile + wave * 1024);
+    else glds16(p.w + p.w_plane + bo, dst + 2 * kWATile + kWBTile + wave * 1024);
+  };
+  f32x4 acch[MI][4], accx[MI][4];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { acch[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; accx[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+  // Phase-interleaved schedule (gemm_p8.hip's): a k-step is two PHASES (output rows 0-31 and 32-63 of the wave), a phase is a LOAD
+  // segment (its fragment reads + three LDS-DMA pieces of k-step t + 2), s_barrier, a COMPUTE segment of 24 MFMAs, s_barrier.
+  // Waves 4-7 (the second wave of every SIMD) pass one extra barrier first, so that on every SIMD one wave computes while the other
+  // loads.  Three stage buffers.  RAW (LDS-DMA -> ds_read): the counted wait of a LOAD segment leaves only this and the previous
+  // phase's pieces in flight; k-step t + 2's pieces are issued in the phases of k-step t and first read two phases after the wait
+  // that retires them.  WAR (ds_read -> LDS-DMA): reads are retired (lgkmcnt(0)) before the barrier that ends their LOAD segment;
+  // the buffer is restaged at least one barrier later.
+#define CW_BARRIER() do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); } while (0)
+  const int nk = p.K / WBK;
+  const bool late = wave >= 4;
+  stage_set(0, smem, 0); stage_set(0, smem, 1);
+  if (nk > 1) { stage_set(1, smem + kWStage, 0); stage_set(1, smem + kWStage, 1); }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  CW_BARRIER();
+  if (late) CW_BARRIER();
+  int cur = 0;
+  const int chunk = lane >> 4;
+  half8 a_h[2], a_l[2], bh[4], bl[4];
+  for (int t = 0; t < nk; ++t) {
+    const char* Ah = smem + cur * kWStage;
+    const char* Al = Ah + kWATile;
+    const char* Bh = Ah + 2 * kWATile;
+    const char* Bl = Bh + kWBTile;
+    char* nxt = smem + (cur >= 1 ? cur - 1 : 2) * kWStage;
+    const bool more = t + 2 < nk;
+#pragma unroll
+    for (int ph = 0; ph < 2; ++ph) {
+      // ---- LOAD segment
+      if (ph == 0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int row = wc * 64 + j * 16 + (lane & 15);
+          const int sl = (row * 4 + (chunk ^ wswz(row))) * 16;
+          bh[j] = *reinterpret_cast<const half8*>(Bh + sl);
+          bl[j] = *reinterpret_cast<const half8*>(Bl + sl);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int row = wr * 64 + (ph * 2 + i) * 16 + (lane & 15);
+        const int sl = (row * 4 + (chunk ^ wswz(row))) * 16;
+        a_h[i] = *reinterpret_cast<const half8*>(Ah + sl);
+        a_l[i] = *reinterpret_cast<const half8*>(Al + sl);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (more) {
+        stage_set(t + 2, nxt, ph);
+        asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      }
+      CW_BARRIER();
+      // ---- COMPUTE segment: 24 MFMAs (the two products into accx[i][j] keep their order, eight MFMAs apart)
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          acch[ph * 2 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_h[i], bh[j], acch[ph * 2 + i][j], 0, 0, 0);
+          accx[ph * 2 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_h[i], bl[j], accx[ph * 2 + i][j], 0, 0, 0);
+        }
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+          accx[ph * 2 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_l[i], bh[j], accx[ph * 2 + i][j], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+      CW_BARRIER();
+    }
+    cur = cur == 2 ? 0 : cur + 1;
+  }
+  if (!late) CW_BARRIER();                      // waves 0-3 are one barrier ahead: realign before the epilogue reuses the LDS
+#undef CW_BARRIER
+
+  // ---- epilogue: as above, the wave's 64 x 64 sub-tile through 9 KiB of LDS, 32 rows at a time
+  const int mw = m0 + wr * 64, nw = n0 + wc * 64;
+  constexpr int LS = 72;
+  float* wreg = reinterpret_cast<float*>(smem + wave * (32 * LS * 4));
+  const int c8 = (lane & 7) * 8;
+  const int n = nw + c8;
+  float bias[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) bias[k] = (p.bias && n + k < p.Cout) ? p.bias[n + k] : 0.f;
+#pragma unroll
+  for (int half = 0; half < MI / 2; ++half) {
+#pragma unroll
+    for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          wreg[(ii * 16 + (lane >> 4) * 4 + r) * LS + j * 16 + (lane & 15)] =
+              acch[half * 2 + ii][j][r] + accx[half * 2 + ii][j][r] * kLoInv;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int row = it * 8 + (lane >> 3);
+      const int m = mw + half * 32 + row;
+      if (m >= M || n >= p.Cout) continue;
+      long long mo = m;
+      if (p.out_padded) {
+        const int hw = p.Ho * p.Wo;
+        const int b = m / hw, r = m - b * hw;
+        const int oy = r / p.Wo, ox = r - oy * p.Wo;
+        mo = ((long long)b * (p.Ho + 2) + oy + 1) * (p.Wo + 2) + ox + 1;
+      }
+      const float4 v0 = *reinterpret_cast<const float4*>(wreg + row * LS + c8);
+      const float4 v1 = *reinterpret_cast<const float4*>(wreg + row * LS + c8 + 4);
+      float v[8] = {v0.x + bias[0], v0.y + bias[1], v0.z + bias[2], v0.w + bias[3],
+                    v1.x + bias[4], v1.y + bias[5], v1.z + bias[6], v1.w + bias[7]};
+      if (p.relu) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = fmaxf(v[k], 0.f);
+      }
+      if (p.add) {
+        const half8 xh = *reinterpret_cast<const half8*>(p.add + mo * p.Cout + n);
+        const half8 xl = *reinterpret_cast<const half8*>(p.add + p.add_plane + mo * p.Cout + n);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] += (float)xh[k] + (float)xl[k] * kLoInv;
+      }
+      if (p.out_f32) {
+        float* o = reinterpret_cast<float*>(p.out) + mo * p.Cout + n;
+        reinterpret_cast<float4*>(o)[0] = make_float4(v[0], v[1], v[2], v[3]);
+        reinterpret_cast<float4*>(o)[1] = make_float4(v[4], v[5], v[6], v[7]);
+      } else {
+        half8 oh, ol;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { _Float16 h, l; split16(v[k], h, l); oh[k] = h; ol[k] = l; }
+        _Float16* o = reinterpret_cast<_Float16*>(p.out) + mo * p.Cout + n;
+        *reinterpret_cast<half8*>(o) = oh;
+        *reinterpret_cast<half8*>(o + p.out_plane) = ol;
+      }
+    }
+  }
+}
+
 // images f32 NCHW [B, C<=4, H, W] -> two fp16 planes of padded NHWC4, optional (x - mean) / std
 __global__ __launch_bounds__(256) void nchw_to_padded_nhwc4_f16x2_kernel(const float* __restrict__ x, int B, int C, int H,
                                                                          int W, const float* __restrict__ mean,
@@ -264,7 +471,18 @@ extern "C" int memhip_conv2d_nhwc_f16x2(const void* in, int64_t in_plane, const 
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kStageBytes));
     attr_done = true;
   }
-  if (opt(OPT_CONV_WAVES) == 4)
+  // the 256 x 128 tile where its grid is at least four full rounds of the chip (the encoder's 56 x 56 and 28 x 28 layers at
+  // batch 256; the 14 x 14 layers keep the finer 128 x 128 tiles: 588 wide workgroups would be 2.3 rounds)
+  const int wgrid = cdiv(M, WBM) * cdiv(Cout, WBN);
+  if (!cin4 && opt(OPT_CONV_WAVES) == 16 && wgrid >= 4 * max_cus()) {
+    static bool wattr_done = false;
+    if (!wattr_done) {
+      MEMHIP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_gemm_f16x2_wide_kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 3 * kWStage));
+      wattr_done = true;
+    }
+    hipLaunchKernelGGL(conv_gemm_f16x2_wide_kernel, dim3(wgrid), dim3(512), 3 * kWStage, as_stream(stream), p);
+  } else if (opt(OPT_CONV_WAVES) == 4)
     hipLaunchKernelGGL(conv_gemm_f16x2_kernel<4>, dim3(grid), dim3(256), 2 * kStageBytes, as_stream(stream), p);
   else
     hipLaunchKernelGGL(conv_gemm_f16x2_kernel<8>, dim3(grid), dim3(512), 2 * kStageBytes, as_stream(stream), p);
