@@ -60,7 +60,8 @@ const char* memhip_build_flags(void);
  * round 5: "attn_win" (1: windows 40 / 20 tokens wide and longer than 256 tokens run on the slot-layout kernels of
  * attn_win.hip, 0: attn_stream.hip), "gemm_p8_pair" (1: the full rounds and the ragged round of an NT product are ONE
  * launch, 0: two launches), "tn_group" (1: memhip_gemm_bf16_tn_group runs its products as one grid, 0: one by one);
- * round 6: "conv_waves" (8: the fp16x2 tokenizer convolutions run 8 waves per workgroup, two per SIMD; 4: one per SIMD),
+ * round 6: "conv_waves" (16: the fp16x2 tokenizer convolutions run 8 waves per workgroup and the phase-interleaved 256 x 128 tile
+ * on every layer whose grid fills the chip twice; 8: 8 waves, 128 x 128 tiles only; 4: 4 waves, one per SIMD),
  * "raster_bands" (0: memhip_rasterize_binned_f64 chooses the bands per sample from the batch size; n > 0: n bands, raised to
  * the fewest the canvas allows).
  * Unknown name: MEMHIP_EINVAL.  Results do not depend on any option (same contract, different kernel or timing). */

@@ -471,10 +471,10 @@ extern "C" int memhip_conv2d_nhwc_f16x2(const void* in, int64_t in_plane, const 
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kStageBytes));
     attr_done = true;
   }
-  // the 256 x 128 tile where its grid is at least four full rounds of the chip (the encoder's 56 x 56 and 28 x 28 layers at
-  // batch 256; the 14 x 14 layers keep the finer 128 x 128 tiles: 588 wide workgroups would be 2.3 rounds)
+  // the 256 x 128 tile where its grid is at least two full rounds of the chip: every layer of the encoder at batch 256 but the first
+  // (the 14 x 14 layers are 588 workgroups = 2.3 rounds and still gain: forward 18.55 -> 18.30 ms against the finer 128 x 128 tiles)
   const int wgrid = cdiv(M, WBM) * cdiv(Cout, WBN);
-  if (!cin4 && opt(OPT_CONV_WAVES) == 16 && wgrid >= 4 * max_cus()) {
+  if (!cin4 && opt(OPT_CONV_WAVES) == 16 && wgrid >= 2 * max_cus()) {
     static bool wattr_done = false;
     if (!wattr_done) {
       MEMHIP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_gemm_f16x2_wide_kernel),

@@ -16,7 +16,7 @@ static std::atomic<int> g_opt[OPT_COUNT_] = {
     /*attn_win (slot-layout streaming attention for windows 40 / 20 wide, attn_win.hip; 0 = attn_stream.hip)*/ {1},
     /*gemm_p8_pair (full rounds + ragged round of an NT product in ONE launch; 0 = two launches)*/ {1},
     /*tn_group (memhip_gemm_bf16_tn_group runs its products as ONE grid with one split count; 0 = one by one)*/ {1},
-    /*conv_waves (fp16x2 tokenizer convolutions: 16 = eight waves per workgroup and the 256 x 128 tile where its grid fills the chip four times, 8 = eight waves, 128 x 128 tiles only, 4 = four waves)*/ {16},
+    /*conv_waves (fp16x2 tokenizer convolutions: 16 = eight waves per workgroup and the phase-interleaved 256 x 128 tile where its grid fills the chip twice, 8 = eight waves, 128 x 128 tiles only, 4 = four waves)*/ {16},
     /*raster_bands (bands per sample of the two-pass rasterizer; 0 = chosen from the batch size, see memhip_rasterize_binned_f64)*/ {0}};
 static const char* const g_opt_name[OPT_COUNT_] = {"gemm_p8", "gemm256", "gemm_split", "gemm_p8_half", "gemm_p8_min_n",
                                                    "gemm256_min_n", "tn_p8", "raster_lds", "attn16", "attn16_stagger", "attn16_stagger_fwd", "gemm_stagger", "gemm_prefetch", "reserve_cus", "ln_bwd_grid", "attn_win", "gemm_p8_pair", "tn_group", "conv_waves", "raster_bands"};

@@ -11,7 +11,7 @@
 #   r06fin_vitl_kernel_stats.csv   ViT-L/16 480x640 (config #5), B = 64;  r06fin_vitl_mfma_util.json, r06fin_vitl_traffic.json
 #   r06fin_raster_kernel_stats.csv config #4 rasterizer (64 x 1 M events);  r06fin_raster_traffic.json
 #   r06fin_attn16.txt, r06fin_attn_win.txt   attention kernels alone (attn_win: 0 = stream kernels, 1 = slot layout, 9 = 1 + dS workspace)
-#   r06fin_conv_waves.txt          fp16x2 tokenizer convolutions, 4 vs 8 waves per workgroup
+#   r06fin_conv_waves.txt          fp16x2 tokenizer convolutions: 4 / 8 waves per workgroup (128 x 128 tiles) / 8 waves + the phase-interleaved 256 x 128 tile
 #   r06fin_clock.json              in-kernel shader clock of the GEMM main loops (stamp build)
 cd /root/repo; mkdir -p gpurun_out
 python -m pytest tests -m gpu -q 2>&1 | tail -5 > gpurun_out/r06fin_tests.txt; cat gpurun_out/r06fin_tests.txt
@@ -53,6 +53,6 @@ tools/prof_pmc_raster.sh r06fin_raster > /dev/null 2>&1
 # ---- attention kernels alone, GEMM clock
 python tools/attn16_time.py 2>&1 | tail -2 > gpurun_out/r06fin_attn16.txt
 WIN_TIME_ONLY=1 WIN_MODES=0,1,9 python tools/attn_win_check.py all time 2>&1 | grep "^mode" > gpurun_out/r06fin_attn_win.txt
-python tools/exp/r06_conv_waves.py 2>&1 | grep -v amdgpu > gpurun_out/r06fin_conv_waves.txt
+WAVES=4,8,16 python tools/exp/r06_conv_waves.py 2>&1 | grep -v amdgpu > gpurun_out/r06fin_conv_waves.txt
 MEMHIP_CLOCK_OUT=gpurun_out/r06fin_clock.json MEMHIP_LIB=variants/stamp.so python tools/clock_probe.py > gpurun_out/r06fin_clock.log 2>&1
 ls -la gpurun_out | grep r06fin
