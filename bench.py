@@ -980,6 +980,20 @@ def main():
                                        "achieved": round(byts / rdt / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
                                        "frac": round(byts / rdt / 8e12, 4), "algorithmic_bytes_per_sample": 32 * rn + 3 * rh * rw,
                                        "traffic": None}}
+            # the same kernels at 64 samples per launch (what profiles/r06_final_raster_* trace): launch gaps and the last, partly
+            # filled round of pass-2 workgroups weigh half as much
+            try:
+                ev = torch.cat([ev, ev]); off = torch.arange(0, 2 * rb + 1, device="cuda", dtype=torch.int64) * rn
+                for _ in range(2):
+                    D.rasterize(ev, off, rh, rw, False, strict=False)
+                e0.record()
+                for _ in range(10):
+                    D.rasterize(ev, off, rh, rw, False, strict=False)
+                e1.record()
+                torch.cuda.synchronize()
+                raster_fig["frac_at_64_samples_per_launch"] = round(2 * byts / (e0.elapsed_time(e1) * 1e-3 / 10) / 8e12, 4)
+            except Exception as e2:
+                print(f"[bench] rasterizer 64-sample figure skipped: {e2}", file=sys.stderr)
             # HBM bytes per launch from the PMC passes (tools/prof_pmc_raster.sh -> profiles/raster_traffic.json)
             per_sample = raster_traffic_per_sample()
             if per_sample is not None:
