@@ -44,6 +44,10 @@ L.append(f"* **`config5_vitl_1gpu`** (ViT-L/16 480x640, 1201 tokens, B = 64): **
          f"executed FLOPs, {c5['model_flops_frac_of_peak_reference_count']} on the reference count; one-stream family split: "
          + ", ".join(f"{k} {v['ms']} ms ({v['tflops']} TFLOP/s)" for k, v in c5["family_split_one_stream_step"].items()) + ".")
 sol = b["speed_of_light"]; lib = b["library"]
+# the split of THIS call's trace (tools/r06_collect.py -> wgrad_split.json); the copy inside the bench line was read from the file
+# that was committed when bench.py ran, i.e. from the previous call
+if os.path.exists(os.path.join(P, "wgrad_split.json")):
+    r = dict(r); r["kernel_vs_reduction"] = json.load(open(os.path.join(P, "wgrad_split.json")))
 L.append(f"* `roofline.frac` per instrumented step: {r['frac_per_instrumented_step']} (pooled {r['frac']}); `kernel_vs_reduction` (rocprofv3, same call): "
          f"{r['kernel_vs_reduction']['kernel_us_per_product']} + {r['kernel_vs_reduction']['reduction_us_per_product']} us per product = {r['kernel_vs_reduction']['frac_kernel_alone']} kernel alone, "
          f"{r['kernel_vs_reduction']['frac_with_reduction']} with its reduction pass; `library`: {lib['path']}, build flags '{lib['build_flags']}', shipped build {lib['shipped_build']}, ABI {lib['abi']}."
