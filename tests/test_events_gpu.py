@@ -315,3 +315,30 @@ def test_binned_rasterizer_config4_properties():
     assert torch.equal(img[:, 0].long(), pos % 256) and torch.equal(img[:, 2].long(), neg % 256)
     assert int(img[:, 1].sum()) == 0
     assert torch.equal(img, D.rasterize(ev, off, H, W, False, binned=False))
+
+def test_binned_rasterizer_key_workspace_too_small_is_flagged_per_sample():
+    """include/memhip.h: `n_events` sizes the key workspace; a sample whose rows would not fit gets status |= 1 << 30 and a
+    zero image, the samples in front of it are rasterized as usual (status = its count of out-of-canvas events, written by
+    pass 2 from the per-workgroup slots: the caller zeroes nothing)."""
+    from mem_amd import datasets as D
+    from mem_amd._lib import lib, ptr, stream_ptr
+    H, W = 480, 640
+    rng = np.random.default_rng(5)
+    ns = [5000, 7000, 300]
+    evs = [np.stack([rng.integers(0, W, n), rng.integers(0, H, n), np.sort(rng.integers(0, 300000, n)), rng.integers(0, 2, n) * 2 - 1],
+                    1).astype(np.float64) for n in ns]
+    evs[0][:3, 1] = H + 5                                            # three events below the canvas: IndexError in the reference
+    ev, off = _ev_dev(np.concatenate(evs)), _off(*ns)
+    n_cap = 9000                                                     # sample 0 fits (5000), sample 1 ends at 12000, sample 2 at 12300
+    wsb = lib.memhip_rasterize_binned_workspace(3, H, W, n_cap)
+    ws = torch.empty((wsb,), dtype=torch.uint8, device="cuda")
+    out = torch.full((3, 3, H, W), 7, dtype=torch.uint8, device="cuda")
+    status = torch.full((3,), -1, dtype=torch.int32, device="cuda")
+    rc = lib.memhip_rasterize_binned_f64(ptr(ev), ptr(off), None, 3, H, W, n_cap, ptr(out), ptr(status), ptr(ws), wsb, stream_ptr())
+    assert rc == 0
+    st = status.cpu().tolist()
+    assert st == [3, 1 << 30, 1 << 30], st
+    assert int(out[1:].sum()) == 0
+    ok = evs[0][3:]
+    want = D.rasterize(_ev_dev(ok), _off(len(ok)), H, W, False, binned=False)[0]
+    assert torch.equal(out[0], want)
