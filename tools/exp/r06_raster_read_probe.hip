@@ -2,6 +2,8 @@
 //   shape 0: the kernel's shape -- a lane owns one 32-byte row, two 16-byte loads at a 32-byte lane stride
 //   shape 1: contiguous -- a wave-instruction covers 1 KiB, lane l loads bytes [16 l, 16 l + 16) (a row is split over a lane pair)
 //   shape 2: shape 1 with nontemporal loads
+//   shape 3: the same KiB per wave-instruction, nontemporal, but lanes 0-31 take the (x, y) halves of 32 rows and lanes 32-63 their (t, p) halves
+//            (the lane order a v_permlane32_swap exchange wants)
 // Build: hipcc -O3 --offload-arch=gfx950 -o variants/rrp tools/exp/r06_raster_read_probe.hip ; run: variants/rrp
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -27,7 +29,11 @@ __global__ __launch_bounds__(THREADS) void read_probe(const d2v* __restrict__ ev
       } else {
         // the wave's 64 rows of step k = 2 KiB = 128 double2: lane l takes element l and 64 + l
         const long long base = 2 * (c * CHUNK + (long long)k * THREADS + wave * 64);
-        if (SHAPE == 2) {
+        if (SHAPE == 3) {
+          const int e = lane & 31, hf = lane >> 5;
+          r[2 * k] = __builtin_nontemporal_load(ev + base + 2 * e + hf);
+          r[2 * k + 1] = __builtin_nontemporal_load(ev + base + 64 + 2 * e + hf);
+        } else if (SHAPE == 2) {
           r[2 * k] = __builtin_nontemporal_load(ev + base + lane);
           r[2 * k + 1] = __builtin_nontemporal_load(ev + base + 64 + lane);
         } else {
@@ -64,10 +70,11 @@ int main() {
   d2v* ev; unsigned int* sink;
   CK(hipMalloc(&ev, nrows * 32)); CK(hipMalloc(&sink, 4));
   CK(hipMemset(ev, 0, nrows * 32));
-  for (int grid : {512, 1024, 2048, 4096}) {
+  for (int grid : {1024, 4096}) {
     run<0, 512, 8>("rows per lane, 512 thr x 8 rows", ev, nrows, sink, grid);
     run<1, 512, 8>("contiguous, 512 thr x 8 rows", ev, nrows, sink, grid);
     run<2, 512, 8>("contiguous nt, 512 thr x 8 rows", ev, nrows, sink, grid);
+    run<3, 512, 8>("contiguous nt, halves by lane half", ev, nrows, sink, grid);
     run<0, 512, 4>("rows per lane, 512 thr x 4 rows", ev, nrows, sink, grid);
     run<1, 512, 4>("contiguous, 512 thr x 4 rows", ev, nrows, sink, grid);
     run<0, 256, 8>("rows per lane, 256 thr x 8 rows", ev, nrows, sink, grid);
