@@ -61,7 +61,7 @@ const char* memhip_build_flags(void);
  * attn_win.hip, 0: attn_stream.hip), "gemm_p8_pair" (1: the full rounds and the ragged round of an NT product are ONE
  * launch, 0: two launches), "tn_group" (1: memhip_gemm_bf16_tn_group runs its products as one grid, 0: one by one);
  * round 6: "conv_waves" (16: the fp16x2 tokenizer convolutions run 8 waves per workgroup and the phase-interleaved 256 x 128 tile
- * on every layer whose grid fills the chip twice; 8: 8 waves, 128 x 128 tiles only; 4: 4 waves, one per SIMD),
+ * on every layer whose grid fills the chip twice; 32: that tile at every size; 8: 8 waves, 128 x 128 tiles only; 4: 4 waves, one per SIMD),
  * "raster_bands" (0: memhip_rasterize_binned_f64 chooses the bands per sample from the batch size; n > 0: n bands, raised to
  * the fewest the canvas allows).
  * Unknown name: MEMHIP_EINVAL.  Results do not depend on any option (same contract, different kernel or timing). */

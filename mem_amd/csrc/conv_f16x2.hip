@@ -474,7 +474,7 @@ extern "C" int memhip_conv2d_nhwc_f16x2(const void* in, int64_t in_plane, const 
   // the 256 x 128 tile where its grid is at least two full rounds of the chip: every layer of the encoder at batch 256 but the first
   // (the 14 x 14 layers are 588 workgroups = 2.3 rounds and still gain: forward 18.55 -> 18.30 ms against the finer 128 x 128 tiles)
   const int wgrid = cdiv(M, WBM) * cdiv(Cout, WBN);
-  if (!cin4 && opt(OPT_CONV_WAVES) == 16 && wgrid >= 2 * max_cus()) {
+  if (!cin4 && (opt(OPT_CONV_WAVES) == 32 || (opt(OPT_CONV_WAVES) == 16 && wgrid >= 2 * max_cus()))) {     // 32: the wide tile at any size (tests)
     static bool wattr_done = false;
     if (!wattr_done) {
       MEMHIP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_gemm_f16x2_wide_kernel),

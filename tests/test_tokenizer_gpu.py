@@ -273,6 +273,58 @@ def test_tokenizer_fp16x2_mode():
     assert out2[:, :, 0].abs().max() == 0 and out2[:, :, :, 0].abs().max() == 0
 
 
+def test_fp16x2_wide_tile_equals_the_128_tile_bit_for_bit():
+    """csrc/conv_f16x2.hip::conv_gemm_f16x2_wide_kernel (256 x 128 x 32 tile, phase-interleaved waves) is chosen by grid size, which
+    the small fixtures never reach: option conv_waves = 32 forces it.  Same k order per accumulator -> logits and ids bit-equal to
+    the 128 x 128 kernel on both fixtures (ragged row tiles: 6 x 64, 2 x 196 output pixels; ResBlock add, 1 x 1 head), and one ragged
+    layer (588 rows, 192 output channels = 1.5 column tiles) in all three epilogue forms."""
+    import numpy as np
+    from mem_amd import _lib, ops
+    from oracle.vae_ref import BASE_VAE, TINY_VAE, fill_vae_by_name, vae_inputs
+    from mem_amd.vae_model import DiscreteVAE, HipTokenizer
+    try:
+        for cfg, seed, B in ((TINY_VAE, 0, 6), (BASE_VAE, 1, 2)):
+            m = DiscreteVAE(**cfg).eval()
+            m.load_state_dict(fill_vae_by_name(m.state_dict(), seed=seed))
+            m = m.cuda()
+            img = (vae_inputs(cfg, 6, 11) if cfg is TINY_VAE else vae_inputs(cfg, 2, 12)).cuda()
+            tok = HipTokenizer(m, max_batch=B, precision="fp16x2", certify=False)
+            res = {}
+            for w in (8, 32):
+                _lib.set_option("conv_waves", w)
+                ids = tok.get_codebook_indices(img).clone()
+                res[w] = (ids, tok.logits.clone())
+            assert torch.equal(res[8][0], res[32][0]) and torch.equal(res[8][1], res[32][1])
+        g = torch.Generator(device="cuda").manual_seed(6)
+        Bn, cin, cout, h, k, s, p = 3, 128, 192, 14, 3, 1, 1
+        x = torch.randn(Bn, cin, h, h, generator=g, device="cuda")
+        wt = torch.randn(cout, cin, k, k, generator=g, device="cuda") * 0.05
+        b = torch.randn(cout, generator=g, device="cuda")
+
+        def planes(t):
+            hi = t.half()
+            return torch.stack([hi, ((t - hi.float()) * 2048.0).half()]).contiguous()
+        xp = torch.zeros(Bn, h + 2, h + 2, cin, device="cuda")
+        xp[:, 1:-1, 1:-1] = x.permute(0, 2, 3, 1)
+        x2, w2 = planes(xp), planes(wt.permute(0, 2, 3, 1).reshape(cout, -1).contiguous())
+        addp = planes(torch.randn(Bn, h + 2, h + 2, cout, generator=g, device="cuda"))
+        outs = {}
+        for w in (8, 32):
+            _lib.set_option("conv_waves", w)
+            dense = torch.full((Bn * h * h, cout), 7.0, device="cuda")
+            ops.conv2d_nhwc_f16x2(x2, w2, b, dense, Bn, h, h, cin, cout, k, s, p, relu=False, out_padded=False)
+            o_relu = torch.zeros(2, Bn, h + 2, h + 2, cout, dtype=torch.float16, device="cuda")
+            ops.conv2d_nhwc_f16x2(x2, w2, b, o_relu, Bn, h, h, cin, cout, k, s, p, relu=True)
+            o_add = torch.zeros(2, Bn, h + 2, h + 2, cout, dtype=torch.float16, device="cuda")
+            ops.conv2d_nhwc_f16x2(x2, w2, b, o_add, Bn, h, h, cin, cout, k, s, p, relu=False, add2=addp)
+            outs[w] = (dense, o_relu, o_add)
+        for a, c in zip(outs[8], outs[32]):
+            assert torch.equal(a, c)
+        assert outs[32][1][:, :, 0].abs().max() == 0 and outs[32][1][:, :, :, 0].abs().max() == 0     # the zero border stays zero
+    finally:
+        _lib.set_option("conv_waves", 16)
+
+
 def test_tokenizer_fp16x2_labels_equal_fp32_on_rasterised_streams():
     """The entrypoint's default tokenizer mode (--tokenizer_impl hip_fp16x2) against the fp32-operand mode on the ViT-B
     tokenizer shape (hidden 384, 3 ResBlocks, 8192 tokens, 224^2) over 2 x 256 rasterised synthetic event streams (positive /
