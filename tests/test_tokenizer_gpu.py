@@ -273,6 +273,33 @@ def test_tokenizer_fp16x2_mode():
     assert out2[:, :, 0].abs().max() == 0 and out2[:, :, :, 0].abs().max() == 0
 
 
+def test_tok_flag_samples_list_is_ordered_and_complete():
+    """csrc/conv_f32.hip::tok_flag_samples_kernel: the samples holding a token with gap <= kappa * rms (or a NaN), ascending, for
+    batches below and above the kernel's group of 1024 samples; the statistics words accumulate."""
+    from mem_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(9)
+    stats = torch.zeros((4,), dtype=torch.int64, device="cuda")
+    total = 0
+    for B, hw in ((1, 196), (40, 196), (256, 196), (1500, 49), (2500, 7)):
+        gap = torch.rand((B, hw), generator=g, device="cuda") + 0.01
+        rms = torch.rand((B, hw), generator=g, device="cuda") + 0.5
+        kappa = 0.05
+        bad = torch.rand((B,), generator=g, device="cuda") < 0.03
+        pos = torch.randint(0, hw, (B,), generator=g, device="cuda")
+        gap[torch.arange(B, device="cuda")[bad], pos[bad]] = 0.0                # a planted near-tie
+        if B > 8:
+            gap[7, hw - 1] = float("nan")
+        want = torch.nonzero(~(gap > kappa * rms).all(1)).view(-1).to(torch.int32)
+        lst = torch.full((B,), -1, dtype=torch.int32, device="cuda")
+        cnt = torch.full((1,), -1, dtype=torch.int32, device="cuda")
+        ops.tok_flag_samples(gap, rms, B, hw, kappa, lst, cnt, stats)
+        n = int(cnt.item())
+        assert n == want.numel(), (B, n, want.numel())
+        assert torch.equal(lst[:n], want)
+        total += n
+    assert stats.tolist()[:2] == [total, 5]
+
+
 def test_fp16x2_wide_tile_equals_the_128_tile_bit_for_bit():
     """csrc/conv_f16x2.hip::conv_gemm_f16x2_wide_kernel (256 x 128 x 32 tile, phase-interleaved waves) is chosen by grid size, which
     the small fixtures never reach: option conv_waves = 32 forces it.  Same k order per accumulator -> logits and ids bit-equal to
