@@ -415,6 +415,163 @@ __global__ __launch_bounds__(512) void conv_gemm_f16x2_wide_kernel(ConvArgsH p) 
   }
 }
 
+// ---- the FIRST layer (C_in = 4: K = 64 is one k-tile; at batch 256 it writes 4.9 GB of planes).  As 75 264 workgroups of the
+// 128 x 128 kernel it took 1.82 ms -- 1.43 ms of it with the stores removed: a workgroup's address arithmetic, LDS-DMA round trip,
+// 48 MFMAs and epilogue run strictly one after the other, alone on the CU (tools/exp: two workgroups per CU gave -5 %).  Here ONE
+// workgroup per CU is persistent: its column tile of the weights stays in LDS, the input rows of the NEXT row tile are requested before
+// the current tile's epilogue (their LDS-DMA pieces are older than the epilogue's stores in the in-order vmcnt queue, so the wait
+// for them leaves the eight stores per lane in flight: the stores of tile i drain under the MFMAs of tile i + 1).
+// LDS: B hi / lo 32 KiB + A hi / lo x 2 buffers 64 KiB + 8 x 4.5 KiB epilogue staging (16 rows at a time) = 133 KiB.
+// Same arithmetic, same k order: bit-equal to the 128 x 128 kernel.
+__global__ __launch_bounds__(512) void conv_gemm_f16x2_first_kernel(ConvArgsH p) {
+  constexpr int MI = 2, PW = 2;
+  constexpr int kBBytes = 2 * kTileBytes, kABytes = 2 * kTileBytes, kWreg = 16 * 72 * 4;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* Bs = smem;                               // [B_hi | B_lo]
+  char* As = smem + kBBytes;                     // two buffers of [A_hi | A_lo]
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  float* wreg = reinterpret_cast<float*>(smem + kBBytes + 2 * kABytes + wave * kWreg);
+  const unsigned wreg_lds = (unsigned)(unsigned long long)((__attribute__((address_space(3))) char*)smem) + (unsigned)(kBBytes + 2 * kABytes + wave * kWreg);
+  const int wr = wave >> 1, wc = wave & 1;
+  const int M = p.B * p.Ho * p.Wo;
+  const int ntn = (p.Cout + BN - 1) / BN;
+  const int ncol = gridDim.x / ntn;              // workgroups per column tile (gridDim.x is a multiple of ntn)
+  const int n0 = ((int)blockIdx.x % ntn) * BN;
+  const int mt0 = (int)blockIdx.x / ntn;
+  int chunkg[PW];
+  long long abase[PW];
+#pragma unroll
+  for (int j = 0; j < PW; ++j) {
+    const int row = (wave * PW + j) * 8 + (lane >> 3);
+    chunkg[j] = (lane & 7) ^ ((row >> 1) & 7);
+  }
+  auto a_setup = [&](int mt) {                   // gather bases of row tile mt (rows clamped to M - 1)
+#pragma unroll
+    for (int j = 0; j < PW; ++j) {
+      const int row = (wave * PW + j) * 8 + (lane >> 3);
+      int m = mt * BM + row;
+      m = m < M ? m : M - 1;
+      const int hw = p.Ho * p.Wo;
+      const int b = m / hw, r = m - b * hw;
+      const int oy = r / p.Wo, ox = r - oy * p.Wo;
+      abase[j] = (((long long)b * p.Hp + oy * p.stride + p.off) * p.Wp + ox * p.stride + p.off) * p.Cin;
+    }
+  };
+  auto a_stage = [&](char* dst) {                // C_in = 4: chunk c of a row = taps (ky, kx) = (c >> 1, 2 (c & 1) .. + 1), 4 channels each
+#pragma unroll
+    for (int j = 0; j < PW; ++j) {
+      const int inst = wave * PW + j;
+      const long long ao = abase[j] + ((long long)(chunkg[j] >> 1) * p.Wp + 2 * (chunkg[j] & 1)) * 4;
+      glds16(p.in + ao, dst + inst * 1024);
+      glds16(p.in + p.in_plane + ao, dst + kTileBytes + inst * 1024);
+    }
+  };
+  // the weights of this column tile: once
+#pragma unroll
+  for (int j = 0; j < PW; ++j) {
+    const int inst = wave * PW + j;
+    const int row = inst * 8 + (lane >> 3);
+    int n = n0 + row;
+    n = n < p.Cout ? n : p.Cout - 1;
+    const long long bo = (long long)n * p.K + chunkg[j] * 8;
+    glds16(p.w + bo, Bs + inst * 1024);
+    glds16(p.w + p.w_plane + bo, Bs + kTileBytes + inst * 1024);
+  }
+  const int c8 = (lane & 7) * 8;
+  const int n = n0 + wc * 64 + c8;
+  float bias[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) bias[k] = p.bias ? p.bias[n + k] : 0.f;
+  const int nmt = M / BM;                       // whole tiles only (the launcher checks): every lane issues every store
+  if (mt0 < nmt) { a_setup(mt0); a_stage(As); }
+  __builtin_amdgcn_s_waitcnt(0 | (7 << 4) | (15 << 8));          // weights, bias and the first rows are in
+  int cur = 0;
+  for (int mt = mt0; mt < nmt; mt += ncol) {
+    // A(mt) has landed; the only younger vector-memory operations are the previous tile's 8 stores, which stay in flight.  Behind the barrier every wave has finished the previous tile, whose buffer takes the next rows.
+    // (the waits go through the builtin so that the compiler's own bookkeeping sees them: behind the vmcnt(0) in front of the loop the
+    // bias registers are known to be loaded, and it adds no draining wait of its own in front of their first use in the epilogue)
+    __builtin_amdgcn_s_waitcnt(8 | (7 << 4) | (15 << 8));
+    asm volatile("s_barrier" ::: "memory");
+    if (mt + ncol < nmt) { a_setup(mt + ncol); a_stage(As + (cur ^ 1) * kABytes); }
+    const char* Ah = As + cur * kABytes;
+    const char* Al = Ah + kTileBytes;
+    const char* Bh = Bs;
+    const char* Bl = Bs + kTileBytes;
+    f32x4 acch[MI][4], accx[MI][4];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { acch[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; accx[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      half8 ah[MI], al[MI], bh[4], bl[4];
+      const int chunk = kk * 4 + (lane >> 4);
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        const int sl = swz_slot(wr * (MI * 16) + i * 16 + (lane & 15), chunk) * 16;
+        ah[i] = *reinterpret_cast<const half8*>(Ah + sl);
+        al[i] = *reinterpret_cast<const half8*>(Al + sl);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int sl = swz_slot(wc * 64 + j * 16 + (lane & 15), chunk) * 16;
+        bh[j] = *reinterpret_cast<const half8*>(Bh + sl);
+        bl[j] = *reinterpret_cast<const half8*>(Bl + sl);
+      }
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          acch[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bh[j], acch[i][j], 0, 0, 0);
+          accx[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bl[j], accx[i][j], 0, 0, 0);
+          accx[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i], bh[j], accx[i][j], 0, 0, 0);
+        }
+    }
+    // ---- epilogue, 16 rows at a time through the wave's own 4.5 KiB
+    constexpr int LS = 72;
+    const int mw = mt * BM + wr * 32;
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) wreg[((lane >> 4) * 4 + r) * LS + j * 16 + (lane & 15)] = acch[i][j][r] + accx[i][j][r] * kLoInv;
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {
+        const int row = it * 8 + (lane >> 3);
+        const int m = mw + i * 16 + row;
+        long long mo = m;
+        if (p.out_padded) {
+          const int hw = p.Ho * p.Wo;
+          const int b = m / hw, r = m - b * hw;
+          const int oy = r / p.Wo, ox = r - oy * p.Wo;
+          mo = ((long long)b * (p.Ho + 2) + oy + 1) * (p.Wo + 2) + ox + 1;
+        }
+        // (read with inline asm: in front of a C++ LDS read hipcc drains the LDS-DMA stream -- s_waitcnt vmcnt(0) -- since it cannot
+        // tell that the pieces in flight land in other LDS bytes)
+        f32x4 v0, v1;
+        asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:16\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&v"(v0), "=&v"(v1) : "v"(wreg_lds + (unsigned)((row * LS + c8) * 4)) : "memory");
+        float v[8] = {v0[0] + bias[0], v0[1] + bias[1], v0[2] + bias[2], v0[3] + bias[3],
+                      v1[0] + bias[4], v1[1] + bias[5], v1[2] + bias[6], v1[3] + bias[7]};
+        if (p.relu) {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) v[k] = fmaxf(v[k], 0.f);
+        }
+        half8 oh, ol;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { _Float16 h, l; split16(v[k], h, l); oh[k] = h; ol[k] = l; }
+        _Float16* o = reinterpret_cast<_Float16*>(p.out) + mo * p.Cout + n;
+        *reinterpret_cast<half8*>(o) = oh;
+        *reinterpret_cast<half8*>(o + p.out_plane) = ol;
+      }
+    }
+    cur ^= 1;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // no LDS-DMA may outlive the workgroup
+}
+
 // images f32 NCHW [B, C<=4, H, W] -> two fp16 planes of padded NHWC4, optional (x - mean) / std
 __global__ __launch_bounds__(256) void nchw_to_padded_nhwc4_f16x2_kernel(const float* __restrict__ x, int B, int C, int H,
                                                                          int W, const float* __restrict__ mean,
@@ -474,6 +631,23 @@ extern "C" int memhip_conv2d_nhwc_f16x2(const void* in, int64_t in_plane, const 
   // the 256 x 128 tile where its grid is at least two full rounds of the chip: every layer of the encoder at batch 256 but the first
   // (the 14 x 14 layers are 588 workgroups = 2.3 rounds and still gain: forward 18.55 -> 18.30 ms against the finer 128 x 128 tiles)
   const int wgrid = cdiv(M, WBM) * cdiv(Cout, WBN);
+  if (cin4 && opt(OPT_CONV_WAVES) >= 16 && p.K == BK && !add && !out_f32 && M % BM == 0 && Cout % BN == 0) {
+    // the first layer, persistent (whole tiles only: every lane then issues every store, which the kernel's counted waits rely on)
+    const int ntn = Cout / BN;
+    int cols = max_cus() / ntn;
+    cols = cols < 1 ? 1 : cols;
+    const int nmt = (int)(M / BM);
+    cols = cols > nmt ? nmt : cols;
+    constexpr int kFirstLds = 2 * kTileBytes + 2 * 2 * kTileBytes + 8 * 16 * 72 * 4;
+    static bool fattr_done = false;
+    if (!fattr_done) {
+      MEMHIP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_gemm_f16x2_first_kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, kFirstLds));
+      fattr_done = true;
+    }
+    hipLaunchKernelGGL(conv_gemm_f16x2_first_kernel, dim3(cols * ntn), dim3(512), kFirstLds, as_stream(stream), p);
+    return check_launch("conv2d_nhwc_f16x2(first)");
+  }
   if (!cin4 && (opt(OPT_CONV_WAVES) == 32 || (opt(OPT_CONV_WAVES) == 16 && wgrid >= 2 * max_cus()))) {     // 32: the wide tile at any size (tests)
     static bool wattr_done = false;
     if (!wattr_done) {
