@@ -530,8 +530,9 @@ inline bool bin_geometry(int H, int W, int* band_px, int* nb, int want_nb = 0) {
 // Bands per sample for a batch of B samples.  Pass 2 runs one workgroup per (sample, band); a workgroup with 128 KB of counters
 // has a CU to itself and takes ~6 us (launch, clearing and writing its planes) + ~220 us per million events / bands (its keys), so what the pass
 // costs is set by how many ROUNDS of workgroups the chip needs: 32 x 10 bands = 320 workgroups are two rounds on 256 CUs
-// (50 us), 32 x 16 bands of 77 KB (two workgroups per CU) one round (measured 241 -> 232 us for 32 x 1 M events, 461 -> 440
-// for 64 x 1 M with 12 bands = three full rounds instead of two and a half).  The candidates run from the fewest bands the
+// (50 us), 32 x 16 bands of 77 KB (two workgroups per CU) one round (one interleaved sweep: 241 -> 232 us for 32 x 1 M events, 461 -> 440
+// for 64 x 1 M with 12 bands = three full rounds instead of two and a half; under rocprofv3 on another box pass 2 took 44 us with 10 and
+// with 16 bands at 32 samples and 75 -> 68 us at 64: a few per cent of the call at best, never a loss).  The candidates run from the fewest bands the
 // 15-bit key allows to twice that; more bands cost pass 1 padding and shorter segments, so a larger count has to
 // promise 10 % and batches that fit one round keep the fewest bands.
 inline int choose_bands(int H, int W, int B, long long n_events) {
