@@ -279,12 +279,14 @@ __global__ __launch_bounds__(kLdsThreads) void raster_lds_kernel(
 
 // ---- long streams (N-ImageNet scale, ~1 M events per sample) on canvases whose counters do not fit one
 // workgroup's LDS: two streaming passes instead of one global atomic per event.
-//   pass 1 (raster_bin_keys): every event is read ONCE (32 B), reduced to a 2-byte key (pixel inside its band
-//     | polarity << 15) and the keys of each chunk of kBinChunk events are written back sorted by band (counting
-//     sort in LDS).  Every band's segment starts at a multiple of 8 keys (padded with 0xFFFF), so that pass 2
-//     reads 16 bytes per lane; the segment boundaries of the chunk go to a small header.
-//   pass 2 (raster_bin_accum): one workgroup per (sample, band) walks the headers, reads only its own segments
-//     (one 16-byte load per lane covers the average segment; the next chunk's load is in flight while the current
+//   pass 1 (raster_bin_keys): every event is read ONCE (32 B), reduced to a 2-byte key (its pixel inside its band) and the keys of
+//     each chunk of kBinChunk events are written back sorted by (band, polarity) (counting sort in LDS).  Every segment starts at a
+//     multiple of 8 keys (padded with 0xFFFF), so that pass 2 reads 16 bytes per lane; the segment boundaries of the chunk go to a
+//     small header.  (Until round 6 the polarity was bit 15 of the key: 15-bit pixel indices, bands of <= 32 764 pixels, TEN bands on
+//     480 x 640 -- 320 pass-2 workgroups for 32 samples, i.e. two rounds on 256 CUs; with the polarity in the segment a band is bounded
+//     by the 160 KB of LDS: 40 000 pixels, EIGHT bands, 256 workgroups.)
+//   pass 2 (raster_bin_accum): one workgroup per (sample, band) walks the headers, reads only its own two segments of every chunk
+//     (they are neighbours: one 16-byte load per lane covers both on average; the next chunk's load is in flight while the current
 //     keys are counted), counts in LDS and writes the wrapped uint8 planes.
 // HBM traffic per event: 32 B read + ~2.3 B written + ~2.3 B read, against 32 B algorithmic.
 // Counters: ONE u32 per pixel = [neg count : 16 | pos count : 16].  Only counts mod 256 are observable, so
@@ -294,8 +296,10 @@ constexpr int kBinThreads = 512;
 constexpr int kBinEvPerThread = 8;
 constexpr int kBinChunk = kBinThreads * kBinEvPerThread;   // 4096 events
 constexpr int kBinMaxBands = 64;
-constexpr int kBinBandPixels = 32764;                      // 15-bit pixel index inside a band (0xFFFF is the pad key)
-constexpr int kBinSlots = kBinChunk + 8 * kBinMaxBands;    // key slots of a chunk: events + padding of every segment to 8
+constexpr int kBinBandPixels = 40000;                      // pixels of a band: 16-bit key (0xFFFF is the pad key), 160 000 B of LDS counters in pass 2
+constexpr int kBinSegs = 2 * kBinMaxBands;                 // a chunk's keys are sorted by (band, polarity): two segments per band
+constexpr int kBinHdr = kBinSegs + 1;                      // segment boundaries of a chunk
+constexpr int kBinSlots = kBinChunk + 8 * kBinSegs;        // key slots of a chunk: events + padding of every segment to 8
 constexpr int kAccThreads = 1024;
 constexpr int kBinKeyGrid = 4096;                           // pass-1 workgroups in all (rounded up to whole samples)
 constexpr int kBinOverflow = 1 << 30;                      // status flag: n_events smaller than the offsets say
@@ -338,8 +342,8 @@ __global__ __launch_bounds__(kBinThreads) void raster_bin_keys(
     unsigned short* __restrict__ keys, unsigned int* __restrict__ hdr, int32_t* __restrict__ bad_slots, UDiv band_div) {
   // (measured: a counter set per wave is slower for its extra LDS reads in the scatter, four sub-counters per band selected by
   // lane & 3 change nothing -- the returning atomics on these ~10 counters are not what bounds the kernel)
-  __shared__ unsigned int cnt[kBinMaxBands];
-  __shared__ unsigned int base[kBinMaxBands + 1];
+  __shared__ unsigned int cnt[kBinSegs];
+  __shared__ unsigned int base[kBinSegs + 1];
   __shared__ __attribute__((aligned(16))) unsigned short sorted[kBinSlots];
   const int b = blockIdx.y, tid = threadIdx.x;
   const long long beg = offsets[b], n = offsets[b + 1] - beg, rel = beg - offsets[0];
@@ -372,7 +376,7 @@ __global__ __launch_bounds__(kBinThreads) void raster_bin_keys(
     for (int k = 0; k < kBinEvPerThread; ++k) raw[k] = fetch_row(blockIdx.x, k);       // (n > 0: nchunks > 0)
   }
   for (long long c = blockIdx.x; c < nchunks; c += gridDim.x) {
-    if (tid < nb) cnt[tid] = 0u;
+    if (tid < 2 * nb) cnt[tid] = 0u;
     for (int i = tid; i < kBinSlots / 8; i += kBinThreads)                     // pad key everywhere first
       reinterpret_cast<uint4*>(sorted)[i] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
     lds_barrier();
@@ -393,35 +397,36 @@ __global__ __launch_bounds__(kBinThreads) void raster_bin_keys(
       if (flat < 0) flat += HW;                             // NumPy negative index
       const bool isneg = e.p == -1.0;
       if (!(e.p == 1.0) && !isneg) continue;
-      const unsigned int f32 = (unsigned int)flat;          // 0 <= flat < H * W <= 64 * 32764
+      const unsigned int f32 = (unsigned int)flat;          // 0 <= flat < H * W <= 64 * 40000
       const unsigned int band = udiv_apply(f32, band_div);
-      key[k] = (f32 - band * (unsigned int)band_px) | (isneg ? 0x8000u : 0u);
-      where[k] = (band << 16) | atomicAdd(&cnt[band], 1u);   // slot inside the band's segment
+      key[k] = f32 - band * (unsigned int)band_px;           // < band_px <= 40 000: never the pad key
+      const unsigned int seg = 2u * band + (isneg ? 1u : 0u);
+      where[k] = (seg << 16) | atomicAdd(&cnt[seg], 1u);     // slot inside the (band, polarity) segment
     }
     if (c + gridDim.x < nchunks) {
 #pragma unroll
       for (int k = 0; k < kBinEvPerThread; ++k) raw[k] = fetch_row(c + gridDim.x, k);
     }
     lds_barrier();
-    if (tid < 64) {                          // exclusive scan of <= 64 band counts (rounded up to 8) in one wave
-      const unsigned int v = tid < nb ? ((cnt[tid] + 7u) & ~7u) : 0u;
-      unsigned int inc = v;
+    if (tid < 64) {                          // exclusive scan of <= 128 segment counts (rounded up to 8) in one wave: lane = band
+      const unsigned int v0 = tid < nb ? ((cnt[2 * tid] + 7u) & ~7u) : 0u, v1 = tid < nb ? ((cnt[2 * tid + 1] + 7u) & ~7u) : 0u;
+      unsigned int inc = v0 + v1;
       for (int o = 1; o < 64; o <<= 1) {
         const unsigned int u = __shfl_up(inc, o);
         if (tid >= o) inc += u;
       }
-      if (tid < nb) base[tid] = inc - v;
-      if (tid == nb - 1) base[nb] = inc;
+      if (tid < nb) { base[2 * tid] = inc - v0 - v1; base[2 * tid + 1] = inc - v1; }
+      if (tid == nb - 1) base[2 * nb] = inc;
     }
     lds_barrier();
 #pragma unroll
     for (int k = 0; k < kBinEvPerThread; ++k)
       if (where[k] != 0xFFFFFFFFu) sorted[base[where[k] >> 16] + (where[k] & 0xFFFFu)] = (unsigned short)key[k];
     lds_barrier();
-    const unsigned int total8 = base[nb] >> 3;                                  // 16-byte groups to write
+    const unsigned int total8 = base[2 * nb] >> 3;                              // 16-byte groups to write
     uint4* kout = reinterpret_cast<uint4*>(keys + (hbase + c) * kBinSlots);
     for (unsigned int j = tid; j < total8; j += kBinThreads) kout[j] = reinterpret_cast<const uint4*>(sorted)[j];
-    if (tid <= nb) hdr[(hbase + c) * (kBinMaxBands + 1) + tid] = base[tid] >> 3;   // boundaries in 16-byte groups
+    if (tid <= 2 * nb) hdr[(hbase + c) * kBinHdr + tid] = base[tid] >> 3;      // boundaries in 16-byte groups
     lds_barrier();
   }
   __syncthreads();
@@ -430,16 +435,15 @@ __global__ __launch_bounds__(kBinThreads) void raster_bin_keys(
   if (tid == 0) bad_slots[(long long)b * gridDim.x + blockIdx.x] = bad_wg;
 }
 
-__device__ __forceinline__ void bin_count8(unsigned int* cnt, const uint4& q) {
+__device__ __forceinline__ void bin_count8(unsigned int* cnt, const uint4& q, bool isneg) {
   const unsigned int w[4] = {q.x, q.y, q.z, q.w};
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int hhalf = 0; hhalf < 2; ++hhalf) {
-      const unsigned int key = hhalf ? (w[i] >> 16) : (w[i] & 0xFFFFu);
-      if (key == 0xFFFFu) continue;                                             // segment padding
-      const unsigned int l = key & 0x7FFFu;
-      if (key & 0x8000u) {
+      const unsigned int l = hhalf ? (w[i] >> 16) : (w[i] & 0xFFFFu);
+      if (l == 0xFFFFu) continue;                                               // segment padding
+      if (isneg) {
         atomicAdd(cnt + l, 0x10000u);
       } else {
         const unsigned int old = atomicAdd(cnt + l, 1u);
@@ -469,27 +473,27 @@ __global__ __launch_bounds__(kAccThreads) void raster_bin_accum(
   if (rel + n <= n_cap) {
     const long long nchunks = (n + kBinChunk - 1) / kBinChunk;
     const long long hbase = rel / kBinChunk + b;
-    const unsigned int* h = hdr + hbase * (kBinMaxBands + 1) + band;
+    const unsigned int* h = hdr + hbase * kBinHdr + 2 * band;     // [s, m) = the band's positive keys of a chunk, [m, e) its negative ones
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     constexpr int kWaves = kAccThreads / 64;
     const uint4 kPad = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
     // software pipeline over this wave's chunks: header two chunks ahead, first 16-byte group one chunk ahead
     long long c = wave;
-    unsigned int s = 0, e = 0, s1 = 0, e1 = 0;
-    if (c < nchunks) { s = h[c * (kBinMaxBands + 1)]; e = h[c * (kBinMaxBands + 1) + 1]; }
-    if (c + kWaves < nchunks) { s1 = h[(c + kWaves) * (kBinMaxBands + 1)]; e1 = h[(c + kWaves) * (kBinMaxBands + 1) + 1]; }
+    unsigned int s = 0, m = 0, e = 0, s1 = 0, m1 = 0, e1 = 0;
+    if (c < nchunks) { s = h[c * kBinHdr]; m = h[c * kBinHdr + 1]; e = h[c * kBinHdr + 2]; }
+    if (c + kWaves < nchunks) { s1 = h[(c + kWaves) * kBinHdr]; m1 = h[(c + kWaves) * kBinHdr + 1]; e1 = h[(c + kWaves) * kBinHdr + 2]; }
     uint4 q = kPad;
     if (c < nchunks && s + lane < e) q = reinterpret_cast<const uint4*>(keys + (hbase + c) * kBinSlots)[s + lane];
     while (c < nchunks) {
       const long long c1 = c + kWaves, c2 = c + 2 * kWaves;
-      unsigned int s2 = 0, e2 = 0;
-      if (c2 < nchunks) { s2 = h[c2 * (kBinMaxBands + 1)]; e2 = h[c2 * (kBinMaxBands + 1) + 1]; }
+      unsigned int s2 = 0, m2 = 0, e2 = 0;
+      if (c2 < nchunks) { s2 = h[c2 * kBinHdr]; m2 = h[c2 * kBinHdr + 1]; e2 = h[c2 * kBinHdr + 2]; }
       uint4 qn = kPad;
       if (c1 < nchunks && s1 + lane < e1) qn = reinterpret_cast<const uint4*>(keys + (hbase + c1) * kBinSlots)[s1 + lane];
-      bin_count8(cnt, q);
+      bin_count8(cnt, q, s + lane >= m);
       const uint4* kin = reinterpret_cast<const uint4*>(keys + (hbase + c) * kBinSlots);
-      for (unsigned int j = s + 64 + lane; j < e; j += 64) bin_count8(cnt, kin[j]);   // segments beyond 512 keys
-      c = c1; s = s1; e = e1; s1 = s2; e1 = e2; q = qn;
+      for (unsigned int j = s + 64 + lane; j < e; j += 64) bin_count8(cnt, kin[j], j >= m);   // segments beyond 512 keys
+      c = c1; s = s1; m = m1; e = e1; s1 = s2; m1 = m2; e1 = e2; q = qn;
     }
   }
   __syncthreads();
@@ -527,14 +531,13 @@ inline bool bin_geometry(int H, int W, int* band_px, int* nb, int want_nb = 0) {
   return true;
 }
 
-// Bands per sample for a batch of B samples.  Pass 2 runs one workgroup per (sample, band); a workgroup with 128 KB of counters
-// has a CU to itself and takes ~6 us (launch, clearing and writing its planes) + ~220 us per million events / bands (its keys), so what the pass
-// costs is set by how many ROUNDS of workgroups the chip needs: 32 x 10 bands = 320 workgroups are two rounds on 256 CUs
-// (50 us), 32 x 16 bands of 77 KB (two workgroups per CU) one round (one interleaved sweep: 241 -> 232 us for 32 x 1 M events, 461 -> 440
-// for 64 x 1 M with 12 bands = three full rounds instead of two and a half; under rocprofv3 on another box pass 2 took 44 us with 10 and
-// with 16 bands at 32 samples and 75 -> 68 us at 64: a few per cent of the call at best, never a loss).  The candidates run from the fewest bands the
-// 15-bit key allows to twice that; more bands cost pass 1 padding and shorter segments, so a larger count has to
-// promise 10 % and batches that fit one round keep the fewest bands.
+// Bands per sample for a batch of B samples.  Pass 2 runs one workgroup per (sample, band); a workgroup with > 80 KB of counters has a
+// CU to itself and takes ~0.22 us per 1000 pixels of its band (launch, clearing and writing its planes) + ~220 us per million events /
+// bands (its keys), so what the pass costs is set by how many ROUNDS of workgroups the chip needs.  480 x 640 needs eight bands of
+// 38 400 pixels: 32 samples are 256 workgroups = one round (36.9 us under rocprofv3; the ten 15-bit-key bands of the first half of
+// round 6 were 320 workgroups = two rounds, 44.3 us), 64 samples two rounds (72 us; twelve bands = three rounds of smaller workgroups:
+// 68 us -- the model calls them equal).  The candidates run from the fewest bands the LDS allows to twice that; more bands cost pass 1
+// padding and shorter segments, so a larger count has to promise 10 % and batches that fit one round keep the fewest bands.
 inline int choose_bands(int H, int W, int B, long long n_events) {
   const int forced = memhip::opt(memhip::OPT_RASTER_BANDS);
   if (forced > 0) return forced;
@@ -549,7 +552,7 @@ inline int choose_bands(int H, int W, int B, long long n_events) {
     const long long px = ((HW + nbv - 1) / nbv + 3) & ~3ll;
     const int per_cu = (size_t)px * 4 * 2 + 1024 <= 160 * 1024 ? 2 : 1;       // 1024-thread workgroups: two per CU at most
     const long long rounds = ((long long)B * nbv + (long long)cus * per_cu - 1) / ((long long)cus * per_cu);
-    const double cost = (double)rounds * (6.0 + 220.0e-6 * ((double)n_events / B) / nbv) * (per_cu == 2 ? 2.0 : 1.0);
+    const double cost = (double)rounds * (0.22e-3 * (double)px + 220.0e-6 * ((double)n_events / B) / nbv) * (per_cu == 2 ? 2.0 : 1.0);
     if (nbv == nmin || cost < best_cost * 0.9) { best = nbv; best_cost = cost; }
   }
   return best;
@@ -766,7 +769,7 @@ extern "C" size_t memhip_rasterize_binned_workspace(int B, int H, int W, int64_t
   if (B <= 0 || n_events < 0) return 0;
   const size_t chunks = (size_t)n_events / kBinChunk + (size_t)B + 1;
   const size_t keys = (chunks * kBinSlots * sizeof(unsigned short) + 15) & ~(size_t)15;
-  const size_t hdr = chunks * (kBinMaxBands + 1) * sizeof(unsigned int);
+  const size_t hdr = chunks * kBinHdr * sizeof(unsigned int);
   return keys + hdr + ((size_t)kBinKeyGrid + (size_t)B) * sizeof(int32_t);     // + one slot per pass-1 workgroup
 }
 
@@ -789,7 +792,7 @@ extern "C" int memhip_rasterize_binned_f64(const double* ev, const int64_t* offs
   const size_t keys_bytes = ((((size_t)n_events / kBinChunk + (size_t)B + 1) * kBinSlots * sizeof(unsigned short)) + 15) & ~(size_t)15;
   unsigned int* hdr = (unsigned int*)((char*)workspace + keys_bytes);
   const size_t chunk_slots = (size_t)n_events / kBinChunk + (size_t)B + 1;
-  int32_t* bad_slots = (int32_t*)((char*)hdr + chunk_slots * (kBinMaxBands + 1) * sizeof(unsigned int));
+  int32_t* bad_slots = (int32_t*)((char*)hdr + chunk_slots * kBinHdr * sizeof(unsigned int));
   static bool attr_done = false;
   if (!attr_done) {
     MEMHIP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(raster_bin_accum),

@@ -33,7 +33,7 @@ declare({
 
 # rasterize() uses the two-pass binned kernels (csrc/raster.hip) whenever there is no time surface and the canvas is
 # within their band limit; the time surface keeps the global-atomic form; binned=False forces the single-pass kernels
-_BINNED_MAX_PIXELS = 64 * 32764
+_BINNED_MAX_PIXELS = 64 * 40000
 
 
 
