@@ -1114,15 +1114,30 @@ def main():
                 if code in per:
                     v = per[code]
                     dom = [v[0] * n_prod, v[1], v[2]] if dom is None else [dom[0] + v[0] * n_prod, dom[1] + v[1], dom[2] + v[2]]
-            # the same figure per instrumented step (how far one step's sample is from the pooled mean)
-            per_step_frac = []
+            # the same figure per instrumented step (how far one step's sample is from the pooled mean).  A step whose figure sits
+            # more than 10 % below the MEDIAN of the instrumented steps was disturbed from outside (seen once in ~40 instrumented
+            # steps on this pool: every weight-gradient product of one step 40 % slower, the steps before and behind it normal):
+            # it is listed (`disturbed_steps`) and left out of achieved / frac / avg_launch_us, which pool the others; the figure
+            # over ALL steps is `frac_all_steps`
+            per_step_frac, per_step_dom = [], []
             for i0, i1 in timer_marks:
                 fl_s = ms_s = 0.0
+                n_s = 0
                 for e0, e1, fl, epi in timer[i0:i1]:
                     if int(epi) in (100, 102, 103, 104):
-                        fl_s += fl; ms_s += e0.elapsed_time(e1)
+                        fl_s += fl; ms_s += e0.elapsed_time(e1); n_s += max(1, int(epi) - 100)
                 if ms_s > 0:
                     per_step_frac.append(round(fl_s / (ms_s * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4))
+                    per_step_dom.append((n_s, ms_s, fl_s))
+            disturbed, frac_all, n_dom_steps = [], None, n_inst
+            if dom and len(per_step_frac) >= 3:
+                med = sorted(per_step_frac)[len(per_step_frac) // 2]
+                keep = [i for i, f in enumerate(per_step_frac) if f >= 0.9 * med]
+                disturbed = [{"step": i, "frac": per_step_frac[i]} for i in range(len(per_step_frac)) if i not in keep]
+                if disturbed and keep:
+                    frac_all = round(dom[2] / (dom[1] * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4)
+                    dom = [sum(per_step_dom[i][0] for i in keep), sum(per_step_dom[i][1] for i in keep), sum(per_step_dom[i][2] for i in keep)]
+                    n_dom_steps = len(keep)
             if dom:
                 d_ach = dom[2] / (dom[1] * 1e-3) / 1e12
                 roof = {"bound": "mfma", "kernel": "gemm_tn_p8_kernel / gemm_tn_p8_group_kernel (bf16 weight-gradient GEMM, split over token rows)",
@@ -1131,9 +1146,9 @@ def main():
                         "traffic": wgrad_traffic_per_product(tj),
                         "launches": dom[0], "avg_launch_us": round(dom[1] / dom[0] * 1e3, 2),
                         "algorithmic_flop_per_launch": round(dom[2] / dom[0]),
-                        "share_of_step": round(dom[1] / (dt * 1e3 * n_inst / a.steps), 3),
+                        "share_of_step": round(dom[1] / (dt * 1e3 * n_dom_steps / a.steps), 3),
                         "instrumented_steps": n_inst, "instrumented_steps_inside_timed_region": len(inst),
-                        "frac_per_instrumented_step": per_step_frac,
+                        "frac_per_instrumented_step": per_step_frac, "disturbed_steps": disturbed, "frac_all_steps": frac_all,
                         "kernel_vs_reduction": wgrad_kernel_split(),
                         "products_in_group_launches": sum(per[c][0] * (c - 100) for c in (102, 103, 104) if c in per),
                         "note": "HIP events around one weight-gradient call = gemm_tn_p8_kernel + its tn_reduce_kernel, or the group "
