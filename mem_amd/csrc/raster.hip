@@ -295,6 +295,7 @@ __global__ __launch_bounds__(kLdsThreads) void raster_lds_kernel(
 constexpr int kBinThreads = 512;
 constexpr int kBinEvPerThread = 8;
 constexpr int kBinChunk = kBinThreads * kBinEvPerThread;   // 4096 events
+constexpr int kBinParts = 2;                               // the next chunk is requested in this many parts (4: the same, 8: 5 % slower)
 constexpr int kBinMaxBands = 64;
 constexpr int kBinBandPixels = 40000;                      // pixels of a band: 16-bit key (0xFFFF is the pad key), 160 000 B of LDS counters in pass 2
 constexpr int kBinSegs = 2 * kBinMaxBands;                 // a chunk's keys are sorted by (band, polarity): two segments per band
@@ -381,8 +382,13 @@ __global__ __launch_bounds__(kBinThreads) void raster_bin_keys(
       reinterpret_cast<uint4*>(sorted)[i] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
     lds_barrier();
     unsigned int key[kBinEvPerThread], where[kBinEvPerThread];
+    // two halves: the next chunk's first four rows are requested as soon as the current first four are keys, its last four behind the
+    // current last four -- the workgroup always has rows in flight while it computes (requested all at once behind the whole chunk,
+    // they had only the short sort + write-out to land in, and nothing of this workgroup was in flight during its ~3 us of key arithmetic)
 #pragma unroll
-    for (int k = 0; k < kBinEvPerThread; ++k) {
+    for (int hk = 0; hk < kBinParts; ++hk) {
+#pragma unroll
+    for (int k = hk * (kBinEvPerThread / kBinParts); k < (hk + 1) * (kBinEvPerThread / kBinParts); ++k) {
       const long long i = c * kBinChunk + (long long)k * kBinThreads + slot;
       where[k] = 0xFFFFFFFFu;
       if (i >= n) continue;
@@ -405,7 +411,8 @@ __global__ __launch_bounds__(kBinThreads) void raster_bin_keys(
     }
     if (c + gridDim.x < nchunks) {
 #pragma unroll
-      for (int k = 0; k < kBinEvPerThread; ++k) raw[k] = fetch_row(c + gridDim.x, k);
+      for (int k = hk * (kBinEvPerThread / kBinParts); k < (hk + 1) * (kBinEvPerThread / kBinParts); ++k) raw[k] = fetch_row(c + gridDim.x, k);
+    }
     }
     lds_barrier();
     if (tid < 64) {                          // exclusive scan of <= 128 segment counts (rounded up to 8) in one wave: lane = band
