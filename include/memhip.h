@@ -132,6 +132,7 @@ int memhip_rasterize_aug_f64(const double* ev, const int64_t* offsets, const mem
  * as memhip_rasterize_aug_f64(time_surface = 0).
  * n_events  upper bound on offsets[B] - offsets[0] (sizes the key workspace; a
  *           sample that would exceed it gets status |= 1<<30 and a zero image)
+ * status    written for every sample by the second pass (the caller zeroes nothing)
  * Canvas limit: H*W <= 64 * 40000 pixels (MEMHIP_EUNSUPPORTED beyond). */
 size_t memhip_rasterize_binned_workspace(int B, int H, int W, int64_t n_events);
 int memhip_rasterize_binned_f64(const double* ev, const int64_t* offsets, const memhip_event_aug_t* aug,
