@@ -770,10 +770,13 @@ class ViTEngine:
             self._side.wait_event(e)
             self.grad_hook(k)
 
-    # Opt-in (round 6): the dS-storing backward of the long-window attention kernels (memhip_attn_bwd_ws) -- measured EQUAL in time
-    # to the recomputing form (2 480-2 510 vs 2 490 us per layer at B = 64 x 16 heads x 1 201 tokens, profiles/r06_attn_win_ab.txt)
-    # for 3.2 GB of scratch, so it stays off
-    attn_ds_workspace = False
+    # The dS-storing backward of the long-window attention kernels (memhip_attn_bwd_ws; round 6).  Kernels alone it measured equal to the
+    # recomputing form on the first boxes (2 480-2 510 vs 2 490 us per layer at B = 64 x 16 heads x 1 201 tokens, profiles/r06_attn_win_ab.txt)
+    # and 2-3 % faster on the later ones (2 484 vs 2 526-2 541, 2 397 vs 2 482); INSIDE the ViT-L step (tools/bench_vitl.py, MEMHIP_DS_WS=1,
+    # interleaved on two boxes) it is 3 % faster: 222.1-224.2 vs 229.7-235.3 ms and 216.1-221.9 vs 227.0-227.7 ms -- its dQ kernel streams dS from
+    # HBM while the weight-gradient GEMMs of the other stream hold the matrix pipes.  3 GB of scratch at B = 64 (46 MB per sample); windows the
+    # kernels do not serve (14 x 14) return a zero workspace size and are not affected.
+    attn_ds_workspace = True
 
     def _attn_ws(self, nb):
         if not self.attn_ds_workspace:

@@ -20,6 +20,8 @@ model = pt_vit(img_size=(H, W), patch_size=(16, 16), in_chans=2, vocab_size=8192
 eng = model.engine
 if os.environ.get("MEMHIP_NO_SIDE") == "1":                                  # per-kernel accounting: weight gradients on the launch stream
     eng.wgrad_side_stream = False
+if os.environ.get("MEMHIP_DS_WS") in ("0", "1"):                             # A/B: the dS-storing attention backward (the default; 3 GB workspace at B = 64) / the recomputing one
+    eng.attn_ds_workspace = os.environ["MEMHIP_DS_WS"] == "1"
 if os.environ.get("MEMHIP_WGRAD_GROUP"):                                     # A/B: engine.wgrad_group = 0 / 1 / 2
     eng.wgrad_group = int(os.environ["MEMHIP_WGRAD_GROUP"])
 with contextlib.redirect_stdout(io.StringIO()):
