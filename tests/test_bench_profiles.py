@@ -102,5 +102,5 @@ def test_round6_evidence_set_is_consistent():
     # config #5 has counters of its own since round 5
     vu = json.load(open(os.path.join(pdir, "r06_final_vitl_mfma_util.json")))
     vt = json.load(open(os.path.join(pdir, "r06_final_vitl_traffic.json")))
-    assert any(k.startswith("attn_fwd_win_kernel") for k in vu) and any(k.startswith("attn_bwd_q_win_kernel") for k in vt)
+    assert any(k.startswith("attn_fwd_win_kernel") for k in vu) and any(k.startswith(("attn_bwd_q_win_kernel", "attn_bwd_qs_win_kernel")) for k in vt)
     assert "raster_bin_keys" in json.load(open(os.path.join(pdir, "r06_final_raster_traffic.json")))

@@ -63,11 +63,14 @@ L.append(f"* counters of the ViT-B step -> `r06_final_mfma_util.json` (= `mfma_u
          f"`gemm_p8<0,256>` {mu(u, 'gemm_p8_kernel<0,256')}, attention forward {mu(u, 'attn16_fwd')}, backward {mu(u, 'attn16_bwd')}, whole step {u['_whole_step']['mfma_util']}; "
          f"`r06_final_traffic.json` (= `gemm_traffic.json`): `gemm_tn_p8` {mb(t, 'gemm_tn_p8_kernel'):.0f} MB per launch, `gemm_p8_pair` {mb(t, 'gemm_p8_pair_kernel'):.0f}, `gemm_p8` {mb(t, 'gemm_p8_kernel'):.0f}, "
          f"`attn16_bwd` {mb(t, 'attn16_bwd'):.0f}, `attn16_fwd` {mb(t, 'attn16_fwd'):.0f}, `ln_bwd_branch` {mb(t, 'ln_bwd_branch'):.0f}, AdamW {mb(t, 'adamw'):.0f}.")
-a1 = stat("r06_final_vitl_kernel_stats.csv", "attn_fwd_win_kernel"); a2 = stat("r06_final_vitl_kernel_stats.csv", "attn_bwd_kv_win_kernel"); a3 = stat("r06_final_vitl_kernel_stats.csv", "attn_bwd_q_win_kernel")
+# (the dS-storing backward -- the engine's default since the end of round 6 -- runs attn_bwd_kvs_win_kernel / attn_bwd_qs_win_kernel)
+KV = "attn_bwd_kvs_win_kernel" if stat("r06_final_vitl_kernel_stats.csv", "attn_bwd_kvs_win_kernel") else "attn_bwd_kv_win_kernel"
+DQ = "attn_bwd_qs_win_kernel" if stat("r06_final_vitl_kernel_stats.csv", "attn_bwd_qs_win_kernel") else "attn_bwd_q_win_kernel"
+a1 = stat("r06_final_vitl_kernel_stats.csv", "attn_fwd_win_kernel"); a2 = stat("r06_final_vitl_kernel_stats.csv", KV); a3 = stat("r06_final_vitl_kernel_stats.csv", DQ)
 L.append(f"* **config #5 counters (none existed before this round)**: `r06_final_vitl_kernel_stats.csv` (two-stream step under rocprofv3: forward {a1[1]:.0f} us, dK/dV {a2[1]:.0f}, "
-         f"dQ + table gradient {a3[1]:.0f} per layer); `r06_final_vitl_mfma_util.json`: `attn_fwd_win` {mu(vu, 'attn_fwd_win_kernel')}, `attn_bwd_kv_win` {mu(vu, 'attn_bwd_kv_win_kernel')}, "
-         f"`attn_bwd_q_win` {mu(vu, 'attn_bwd_q_win_kernel')}, `gemm_tn_p8` {mu(vu, 'gemm_tn_p8_kernel')}, whole step {vu['_whole_step']['mfma_util']}; `r06_final_vitl_traffic.json`: forward "
-         f"{mb(vt, 'attn_fwd_win_kernel'):.0f} MB per launch (Q, K, V read once + output written: 630 MB at B = 64; 1 852 MB before all groups of a (head, sample) pair were put on one XCD), dK/dV {mb(vt, 'attn_bwd_kv_win_kernel'):.0f}, dQ {mb(vt, 'attn_bwd_q_win_kernel'):.0f} (algorithmic 944 / 787), `gemm_tn_p8` {mb(vt, 'gemm_tn_p8_kernel'):.0f}.")
+         f"dQ {a3[1]:.0f} per layer); `r06_final_vitl_mfma_util.json`: `attn_fwd_win` {mu(vu, 'attn_fwd_win_kernel')}, `{KV[:-7]}` {mu(vu, KV)}, "
+         f"`{DQ[:-7]}` {mu(vu, DQ)}, `gemm_tn_p8` {mu(vu, 'gemm_tn_p8_kernel')}, whole step {vu['_whole_step']['mfma_util']}; `r06_final_vitl_traffic.json`: forward "
+         f"{mb(vt, 'attn_fwd_win_kernel'):.0f} MB per launch (Q, K, V read once + output written: 630 MB at B = 64; 1 852 MB before all groups of a (head, sample) pair were put on one XCD), dK/dV {mb(vt, KV):.0f}, dQ {mb(vt, DQ):.0f} (algorithmic, recomputing form: 944 / 787; the dS-storing form adds 2 x 3.0 GB of dS per layer at B = 64: written by dK/dV, read by dQ), `gemm_tn_p8` {mb(vt, 'gemm_tn_p8_kernel'):.0f}.")
 L.append(f"* **config #4 rasterizer** (`tools/raster_bench.py`, 64 x 1 M events, 480x640): `r06_final_raster_kernel_stats.csv`: `raster_bin_keys` {rk[1]:.1f} us + `raster_bin_accum` {rc[1]:.1f} us "
          f"= {rk[1] + rc[1]:.1f} us for {ralg / 1e6:.0f} MB algorithmic = {ralg / ((rk[1] + rc[1]) * 1e-6) / 1e12:.2f} TB/s = **{ralg / ((rk[1] + rc[1]) * 1e-6) / 8e12:.3f}** of 8 TB/s; "
          f"`r06_final_raster_traffic.json` (= `raster_traffic.json`): {(rt['raster_bin_keys']['hbm_bytes_per_launch'] + rt['raster_bin_accum']['hbm_bytes_per_launch']) / 1e6:.0f} MB per launch = "
